@@ -1,0 +1,464 @@
+"""CPU oracle — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding over oracle/libchoracle.so (the C restatement of the reference's hot path, oracle/ch_oracle.c)
+and, when present, oracle/_ref/libchref_hash.so (the reference's own Hash.h compiled in place).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product package (clickhouse_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# type tags (same numeric values as include/chgpu.h)
+I64, U32, U64, F64, U8, I32 = 0, 1, 2, 3, 4, 5
+EQ, NE, LT, GT, LE, GE = 0, 1, 2, 3, 4, 5
+AGG_COUNT, AGG_SUM, AGG_AVG = 0, 1, 2
+JOIN_INNER, JOIN_LEFT = 0, 1
+STRICT_ANY, STRICT_ALL, STRICT_SEMI, STRICT_ANTI = 0, 1, 2, 3
+DEFAULT_BLOCK_SIZE = 65409
+
+NP_OF = {I64: np.int64, U32: np.uint32, U64: np.uint64, F64: np.float64, U8: np.uint8, I32: np.int32}
+TAG_OF = {np.dtype(v): k for k, v in NP_OF.items()}
+
+
+def tag_of(arr: np.ndarray) -> int:
+    return TAG_OF[arr.dtype]
+
+
+def sum_result_dtype(tag: int):
+    """SumSimple result type (AggregateFunctionSum.cpp:19-28)."""
+    if tag in (I64, I32):
+        return np.int64
+    if tag in (U64, U32, U8):
+        return np.uint64
+    return np.float64
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle (and oracle/_ref when /root/reference is present)."""
+    so = os.path.join(_HERE, "libchoracle.so")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(
+        os.path.getmtime(os.path.join(_HERE, f)) for f in ("ch_oracle.c", "ch_oracle.h", "ch_hashtable.inc")
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "libchoracle.so"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+def _p(arr):
+    return arr.ctypes.data_as(C.c_void_p) if arr is not None else None
+
+
+_lib = None
+_ref = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        so = os.path.join(_HERE, "libchoracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        u64, sz, vp, i32 = C.c_uint64, C.c_size_t, C.c_void_p, C.c_int
+        sig = {
+            "cho_intHash64": (u64, [u64]),
+            "cho_intHashCRC32": (u64, [u64]),
+            "cho_intHashCRC32_seed": (u64, [u64, u64]),
+            "cho_intHashCRC32_soft": (u64, [u64, u64]),
+            "cho_intHash32": (C.c_uint32, [u64, u64]),
+            "cho_sql_intHash64": (u64, [u64]),
+            "cho_sql_intHash32": (C.c_uint32, [u64]),
+            "cho_hash_crc32_batch": (None, [i32, vp, sz, vp]),
+            "cho_weak_hash32": (None, [i32, vp, sz, vp]),
+            "cho_two_level_bucket": (C.c_uint32, [u64]),
+            "cho_crc32c_tables": (None, [vp, vp]),
+            "cho_cmp_const": (i32, [i32, vp, sz, i32, i32, vp, vp]),
+            "cho_bytes64MaskToBits64Mask": (u64, [vp]),
+            "cho_countBytesInFilter": (sz, [vp, sz, sz]),
+            "cho_filter": (C.c_int64, [i32, vp, sz, vp, sz, vp]),
+            "cho_filter_description_nullable": (None, [vp, vp, sz, vp]),
+            "cho_index": (None, [i32, vp, vp, sz, vp]),
+            "cho_replicate": (None, [i32, vp, sz, vp, vp]),
+            "cho_scatter": (None, [i32, vp, sz, vp, sz, vp, vp]),
+            "cho_sum_add_many": (None, [i32, vp, vp, sz, sz]),
+            "cho_sum_add_many_conditional": (None, [i32, vp, vp, vp, sz, sz]),
+            "cho_avg_divide": (C.c_double, [i32, vp, u64]),
+            "cho_filter_sum_pipeline": (i32, [i32, vp, vp, sz, i32, vp, sz, i32, vp, vp, vp, vp]),
+            "cho_hashmap_create": (vp, []),
+            "cho_hashmap_free": (None, [vp]),
+            "cho_hashmap_emplace": (i32, [vp, u64, C.POINTER(C.POINTER(u64))]),
+            "cho_hashmap_find": (C.POINTER(u64), [vp, u64]),
+            "cho_hashmap_reserve": (None, [vp, sz]),
+            "cho_hashmap_size": (sz, [vp]),
+            "cho_hashmap_buf_size": (sz, [vp]),
+            "cho_hashmap_has_zero": (i32, [vp]),
+            "cho_hashmap_dump": (sz, [vp, vp, vp]),
+            "cho_agg_create": (vp, [i32, i32, vp, vp, u64]),
+            "cho_agg_free": (None, [vp]),
+            "cho_agg_execute_on_block": (i32, [vp, vp, vp, sz, sz]),
+            "cho_agg_merge": (i32, [vp, vp]),
+            "cho_agg_size": (sz, [vp]),
+            "cho_agg_is_two_level": (i32, [vp]),
+            "cho_agg_convert_to_block": (sz, [vp, vp, vp]),
+            "cho_join_create": (vp, [i32, i32, i32]),
+            "cho_join_free": (None, [vp]),
+            "cho_join_add_block": (C.c_int64, [vp, vp, sz, vp, vp]),
+            "cho_join_total_rows": (sz, [vp]),
+            "cho_join_keys": (sz, [vp]),
+            "cho_join_probe": (sz, [vp, vp, sz, vp, sz, vp, vp, vp, vp, sz, vp]),
+            "cho_join_need_filter": (i32, [vp]),
+            "cho_join_need_replication": (i32, [vp]),
+            "cho_hash_to_selector": (None, [i32, vp, sz, sz, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def ref_hash():
+    """The reference's own Hash.h compiled in place (oracle/_ref); None when it was never built."""
+    global _ref
+    if _ref is None:
+        so = os.path.join(_HERE, "_ref", "libchref_hash.so")
+        if not os.path.exists(so):
+            return None
+        R = C.CDLL(so)
+        u64 = C.c_uint64
+        for name, res, args in [
+            ("ref_intHash64", u64, [u64]),
+            ("ref_intHashCRC32", u64, [u64]),
+            ("ref_intHashCRC32_seed", u64, [u64, u64]),
+            ("ref_intHash32_salt0", C.c_uint32, [u64]),
+            ("ref_intHash32_sql", C.c_uint32, [u64]),
+            ("ref_HashCRC32_UInt64", u64, [u64]),
+            ("ref_HashCRC32_UInt32", u64, [C.c_uint32]),
+            ("ref_HashCRC32_Int64", u64, [C.c_int64]),
+            ("ref_hashCRC32_UInt64_seed", u64, [u64, u64]),
+            ("ref_hashCRC32_UInt32_seed", u64, [C.c_uint32, u64]),
+            ("ref_intHashCRC32_batch", None, [C.c_void_p, u64, C.c_void_p]),
+            ("ref_intHash64_batch", None, [C.c_void_p, u64, C.c_void_p]),
+        ]:
+            fn = getattr(R, name)
+            fn.restype = res
+            fn.argtypes = args
+        _ref = R
+    return _ref
+
+
+# ---------------------------------------------------------------------------------------------
+# numpy-level helpers (what the tests call)
+# ---------------------------------------------------------------------------------------------
+
+def _scalar(tag: int, value):
+    return np.array([value], dtype=NP_OF[tag])
+
+
+def hash_crc32(keys: np.ndarray) -> np.ndarray:
+    keys = np.ascontiguousarray(keys)
+    out = np.empty(keys.shape[0], dtype=np.uint64)
+    lib().cho_hash_crc32_batch(tag_of(keys), _p(keys), keys.shape[0], _p(out))
+    return out
+
+
+def weak_hash32(data: np.ndarray, seed: np.ndarray | None = None) -> np.ndarray:
+    data = np.ascontiguousarray(data)
+    h = np.full(data.shape[0], 0xFFFFFFFF, dtype=np.uint32) if seed is None else seed.astype(np.uint32).copy()
+    lib().cho_weak_hash32(tag_of(data), _p(data), data.shape[0], _p(h))
+    return h
+
+
+def crc32c_tables():
+    t = np.zeros((8, 256), dtype=np.uint32)
+    c = np.zeros(1, dtype=np.uint32)
+    lib().cho_crc32c_tables(_p(t), _p(c))
+    return t, int(c[0])
+
+
+def cmp_const(a: np.ndarray, op: int, scalar, scalar_tag: int | None = None) -> np.ndarray:
+    a = np.ascontiguousarray(a)
+    st = tag_of(a) if scalar_tag is None else scalar_tag
+    s = _scalar(st, scalar)
+    out = np.empty(a.shape[0], dtype=np.uint8)
+    rc = lib().cho_cmp_const(tag_of(a), _p(a), a.shape[0], op, st, _p(s), _p(out))
+    assert rc == 0
+    return out
+
+
+def count_bytes_in_filter(filt: np.ndarray) -> int:
+    filt = np.ascontiguousarray(filt, dtype=np.uint8)
+    return int(lib().cho_countBytesInFilter(_p(filt), 0, filt.shape[0]))
+
+
+def filter_column(data: np.ndarray, filt: np.ndarray) -> np.ndarray:
+    data = np.ascontiguousarray(data)
+    filt = np.ascontiguousarray(filt, dtype=np.uint8)
+    out = np.empty(data.shape[0] + 64, dtype=data.dtype)
+    n = lib().cho_filter(data.dtype.itemsize, _p(data), data.shape[0], _p(filt), filt.shape[0], _p(out))
+    if n < 0:
+        raise ValueError("SIZES_OF_COLUMNS_DOESNT_MATCH")
+    return out[:n].copy()
+
+
+def index_column(data: np.ndarray, indexes: np.ndarray, limit: int | None = None) -> np.ndarray:
+    data = np.ascontiguousarray(data)
+    idx = np.ascontiguousarray(indexes, dtype=np.uint64)
+    limit = idx.shape[0] if limit is None else limit
+    out = np.empty(limit, dtype=data.dtype)
+    lib().cho_index(data.dtype.itemsize, _p(data), _p(idx), limit, _p(out))
+    return out
+
+
+def replicate(data: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+    data = np.ascontiguousarray(data)
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    total = int(off[-1]) if off.shape[0] else 0
+    out = np.empty(total, dtype=data.dtype)
+    lib().cho_replicate(data.dtype.itemsize, _p(data), data.shape[0], _p(off), _p(out))
+    return out
+
+
+def scatter(data: np.ndarray, selector: np.ndarray, num_columns: int):
+    data = np.ascontiguousarray(data)
+    sel = np.ascontiguousarray(selector, dtype=np.uint64)
+    out = np.empty(data.shape[0], dtype=data.dtype)
+    sizes = np.zeros(num_columns, dtype=np.uint64)
+    lib().cho_scatter(data.dtype.itemsize, _p(data), data.shape[0], _p(sel), num_columns, _p(out), _p(sizes))
+    res, pos = [], 0
+    for k in range(num_columns):
+        res.append(out[pos:pos + int(sizes[k])].copy())
+        pos += int(sizes[k])
+    return res
+
+
+def sum_add_many(data: np.ndarray, start: int = 0, end: int | None = None, state=None):
+    data = np.ascontiguousarray(data)
+    end = data.shape[0] if end is None else end
+    st = np.zeros(1, dtype=sum_result_dtype(tag_of(data))) if state is None else state
+    lib().cho_sum_add_many(tag_of(data), _p(st), _p(data), start, end)
+    return st
+
+
+def sum_add_many_conditional(data: np.ndarray, cond: np.ndarray, state=None):
+    data = np.ascontiguousarray(data)
+    cond = np.ascontiguousarray(cond, dtype=np.uint8)
+    st = np.zeros(1, dtype=sum_result_dtype(tag_of(data))) if state is None else state
+    lib().cho_sum_add_many_conditional(tag_of(data), _p(st), _p(data), _p(cond), 0, data.shape[0])
+    return st
+
+
+def filter_sum_pipeline(pred: np.ndarray, op: int, scalar, val: np.ndarray | None = None,
+                        block_rows: int = DEFAULT_BLOCK_SIZE, threads: int = 1):
+    """The C1/C2 query `SELECT sum(val), count() WHERE pred <op> scalar` through the per-Block pipeline."""
+    pred = np.ascontiguousarray(pred)
+    if val is not None:
+        val = np.ascontiguousarray(val)
+        assert val.dtype == pred.dtype and val.shape == pred.shape
+    t = tag_of(pred)
+    s = _scalar(t, scalar)
+    out = np.zeros(1, dtype=sum_result_dtype(t))
+    cnt = np.zeros(1, dtype=np.uint64)
+    dropped = np.zeros(1, dtype=np.uint64)
+    passed = np.zeros(1, dtype=np.uint64)
+    rc = lib().cho_filter_sum_pipeline(t, _p(pred), _p(val), pred.shape[0], op, _p(s), block_rows, threads,
+                                       _p(out), _p(cnt), _p(dropped), _p(passed))
+    assert rc == 0
+    return out[0], int(cnt[0]), int(dropped[0]), int(passed[0])
+
+
+class HashMap:
+    """HashMap<UInt64, UInt64, HashCRC32<UInt64>> restated (gtest_hash_table scenarios)."""
+
+    def __init__(self):
+        self._h = lib().cho_hashmap_create()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().cho_hashmap_free(self._h)
+            self._h = None
+
+    def emplace(self, key: int, value: int | None = None) -> bool:
+        mp = C.POINTER(C.c_uint64)()
+        ins = lib().cho_hashmap_emplace(self._h, key, C.byref(mp))
+        if ins and value is not None:
+            mp[0] = value
+        return bool(ins)
+
+    def add(self, key: int, delta: int):
+        mp = C.POINTER(C.c_uint64)()
+        lib().cho_hashmap_emplace(self._h, key, C.byref(mp))
+        mp[0] = (mp[0] + delta) & 0xFFFFFFFFFFFFFFFF
+
+    def find(self, key: int):
+        p = lib().cho_hashmap_find(self._h, key)
+        return int(p[0]) if p else None
+
+    def reserve(self, n: int):
+        lib().cho_hashmap_reserve(self._h, n)
+
+    def __len__(self):
+        return int(lib().cho_hashmap_size(self._h))
+
+    @property
+    def buf_size(self):
+        return int(lib().cho_hashmap_buf_size(self._h))
+
+    @property
+    def has_zero(self):
+        return bool(lib().cho_hashmap_has_zero(self._h))
+
+    def dump(self):
+        n = len(self)
+        k = np.empty(n, dtype=np.uint64)
+        v = np.empty(n, dtype=np.uint64)
+        m = lib().cho_hashmap_dump(self._h, _p(k), _p(v))
+        assert m == n
+        return k, v
+
+
+class Aggregator:
+    """Aggregator restated (executeOnBlock / merge / convertToBlocks). key_dtype None = without_key."""
+
+    def __init__(self, key_dtype, aggs, two_level_threshold: int = 100000):
+        # aggs: list of (kind, arg_dtype or None)
+        self.key_tag = -1 if key_dtype is None else TAG_OF[np.dtype(key_dtype)]
+        self.aggs = [(k, (TAG_OF[np.dtype(d)] if d is not None else I64)) for k, d in aggs]
+        kinds = np.array([k for k, _ in self.aggs], dtype=np.int32)
+        types = np.array([t for _, t in self.aggs], dtype=np.int32)
+        self._h = lib().cho_agg_create(self.key_tag, len(self.aggs), _p(kinds), _p(types), two_level_threshold)
+        assert self._h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().cho_agg_free(self._h)
+            self._h = None
+
+    def execute_on_block(self, keys, args, row_begin: int = 0, row_end: int | None = None):
+        n = (keys.shape[0] if keys is not None else next(a for a in args if a is not None).shape[0])
+        row_end = n if row_end is None else row_end
+        keep = [np.ascontiguousarray(a) if a is not None else None for a in args]
+        ptrs = (C.c_void_p * max(1, len(keep)))(*[(a.ctypes.data if a is not None else None) for a in keep])
+        k = np.ascontiguousarray(keys) if keys is not None else None
+        rc = lib().cho_agg_execute_on_block(self._h, _p(k), ptrs, row_begin, row_end)
+        assert rc == 0
+
+    def merge(self, other: "Aggregator"):
+        assert lib().cho_agg_merge(self._h, other._h) == 0
+
+    def __len__(self):
+        return int(lib().cho_agg_size(self._h))
+
+    @property
+    def is_two_level(self):
+        return bool(lib().cho_agg_is_two_level(self._h))
+
+    def result_dtypes(self):
+        out = []
+        for kind, t in self.aggs:
+            if kind == AGG_COUNT:
+                out.append(np.uint64)
+            elif kind == AGG_AVG:
+                out.append(np.float64)
+            else:
+                out.append(sum_result_dtype(t))
+        return out
+
+    def convert_to_block(self):
+        n = len(self)
+        keys = np.empty(n, dtype=NP_OF[self.key_tag]) if self.key_tag >= 0 else None
+        res = [np.zeros(n, dtype=d) for d in self.result_dtypes()]
+        ptrs = (C.c_void_p * max(1, len(res)))(*[r.ctypes.data for r in res])
+        m = lib().cho_agg_convert_to_block(self._h, _p(keys), ptrs)
+        assert m == n
+        return keys, res
+
+
+class HashJoin:
+    """HashJoin (key64) restated: addBlockToJoin / joinBlock's joinRightColumns."""
+
+    def __init__(self, kind: int, strictness: int, any_take_last_row: bool = False):
+        self._h = lib().cho_join_create(kind, strictness, int(any_take_last_row))
+        if not self._h:
+            raise NotImplementedError("unsupported join kind/strictness")
+        self.kind, self.strictness = kind, strictness
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().cho_join_free(self._h)
+            self._h = None
+
+    @property
+    def need_filter(self):
+        return bool(lib().cho_join_need_filter(self._h))
+
+    @property
+    def need_replication(self):
+        return bool(lib().cho_join_need_replication(self._h))
+
+    def add_block(self, keys, null_map=None, join_mask=None) -> int:
+        k = np.ascontiguousarray(keys).astype(np.uint64, copy=False)
+        nm = np.ascontiguousarray(null_map, dtype=np.uint8) if null_map is not None else None
+        jm = np.ascontiguousarray(join_mask, dtype=np.uint8) if join_mask is not None else None
+        return int(lib().cho_join_add_block(self._h, _p(k), k.shape[0], _p(nm), _p(jm)))
+
+    @property
+    def total_rows(self):
+        return int(lib().cho_join_total_rows(self._h))
+
+    @property
+    def n_keys(self):
+        return int(lib().cho_join_keys(self._h))
+
+    def probe(self, keys, null_map=None, max_joined_block_rows: int = 0):
+        """returns dict(consumed, filter, offsets, added_block, added_row)."""
+        k = np.ascontiguousarray(keys).astype(np.uint64, copy=False)
+        rows = k.shape[0]
+        nm = np.ascontiguousarray(null_map, dtype=np.uint8) if null_map is not None else None
+        filt = np.zeros(rows, dtype=np.uint8)
+        offs = np.zeros(rows, dtype=np.uint64)
+        cap = max(16, rows * 2)
+        while True:
+            ab = np.empty(cap, dtype=np.int64)
+            ar = np.empty(cap, dtype=np.int64)
+            n_added = C.c_size_t(0)
+            # non-ALL strictness appends <= rows entries < cap, so the (flag-mutating) INNER ANY probe never retries
+            consumed = lib().cho_join_probe(self._h, _p(k), rows, _p(nm), max_joined_block_rows, _p(filt), _p(offs),
+                                            _p(ab), _p(ar), cap, C.byref(n_added))
+            if n_added.value <= cap:
+                break
+            cap = n_added.value
+        n = n_added.value
+        return dict(consumed=int(consumed), filter=filt[:consumed] if self.need_filter else None,
+                    offsets=offs[:consumed] if self.need_replication else None,
+                    added_block=ab[:n].copy(), added_row=ar[:n].copy())
+
+    def joined_pairs(self, keys, null_map=None, max_joined_block_rows: int = 0):
+        """Canonical observable result: (left_row, right_block, right_row) per joined row, in output order."""
+        r = self.probe(keys, null_map, max_joined_block_rows)
+        c = r["consumed"]
+        if self.need_replication:
+            off = r["offsets"]
+            counts = np.diff(np.concatenate([[0], off])).astype(np.int64)
+            left = np.repeat(np.arange(c, dtype=np.int64), counts)
+        elif self.need_filter:
+            left = np.nonzero(r["filter"])[0].astype(np.int64)
+        else:
+            left = np.arange(c, dtype=np.int64)
+        assert left.shape[0] == r["added_block"].shape[0], (left.shape, r["added_block"].shape)
+        return left, r["added_block"], r["added_row"], c
+
+
+def hash_to_selector(keys: np.ndarray, num_shards: int) -> np.ndarray:
+    keys = np.ascontiguousarray(keys)
+    out = np.empty(keys.shape[0], dtype=np.uint64)
+    lib().cho_hash_to_selector(tag_of(keys), _p(keys), keys.shape[0], num_shards, _p(out))
+    return out

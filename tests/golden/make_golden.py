@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.json from the reference checkout (run in the build container only).
+
+What is committed are DATA fixtures: the expected-output rows of the reference's own stateless tests
+(tests/queries/0_stateless/*.reference) and known-answer vectors produced by running the reference's own
+Hash.h (compiled in place into oracle/_ref by oracle/Makefile).  No reference source or SQL text is stored;
+the queries are restated as Python input builders in tests/test_oracle_golden.py.
+
+Usage: python tests/golden/make_golden.py [/root/reference]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+
+def rows_of(ref_root, name, first=None, last=None):
+    path = os.path.join(ref_root, "tests/queries/0_stateless", name + ".reference")
+    with open(path) as f:
+        lines = [l.rstrip("\n") for l in f]
+    lines = lines[first:last]
+    return [l.split("\t") for l in lines]
+
+
+def main():
+    ref_root = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+    out = {}
+
+    # --- join semantics ---------------------------------------------------------------------
+    out["00049_any_left_join"] = dict(source="tests/queries/0_stateless/00049_any_left_join.reference",
+                                      rows=rows_of(ref_root, "00049_any_left_join"))
+    out["00050_any_left_join"] = dict(source="tests/queries/0_stateless/00050_any_left_join.reference",
+                                      rows=rows_of(ref_root, "00050_any_left_join"))
+    out["00051_any_inner_join"] = dict(source="tests/queries/0_stateless/00051_any_inner_join.reference",
+                                       rows=rows_of(ref_root, "00051_any_inner_join"))
+    out["00052_all_left_join"] = dict(source="tests/queries/0_stateless/00052_all_left_join.reference",
+                                      rows=rows_of(ref_root, "00052_all_left_join"))
+    out["00053_all_inner_join"] = dict(source="tests/queries/0_stateless/00053_all_inner_join.reference",
+                                       rows=rows_of(ref_root, "00053_all_inner_join"))
+    out["00055_join_two_numbers"] = dict(source="tests/queries/0_stateless/00055_join_two_numbers.reference",
+                                         rows=rows_of(ref_root, "00055_join_two_numbers"))
+    # join + group by + SQL intHash64/intHash32 KAT (first line of the .reference is the other query's empty row)
+    out["00120_join_and_group_by"] = dict(source="tests/queries/0_stateless/00120_join_and_group_by.reference",
+                                          rows=rows_of(ref_root, "00120_join_and_group_by", 1, None))
+    # --- group by / aggregate semantics -------------------------------------------------------
+    out["00041_aggregation_remap"] = dict(source="tests/queries/0_stateless/00041_aggregation_remap.reference",
+                                          rows=rows_of(ref_root, "00041_aggregation_remap"))
+    out["00266_read_overflow_mode"] = dict(source="tests/queries/0_stateless/00266_read_overflow_mode.reference",
+                                           rows=rows_of(ref_root, "00266_read_overflow_mode"))
+    # avg(-8e18) over 65535*2 rows: the value lines (the .reference echoes the queries in between)
+    avg_rows = [r for r in rows_of(ref_root, "02144_avg_ubsan") if len(r) == 1 and r[0] and r[0][0].isdigit()]
+    out["02144_avg_ubsan"] = dict(source="tests/queries/0_stateless/02144_avg_ubsan.reference", rows=avg_rows)
+    # sum(number) over numbers(1000000)
+    out["01091_sum_numbers_1e6"] = dict(source="tests/queries/0_stateless/01091_num_threads.reference",
+                                        rows=[rows_of(ref_root, "01091_num_threads")[2]])
+    # round(avg(log(2)*number), 6) GROUP BY number % 5 over numbers(1e7): lines 7..11 of the .reference
+    out["01300_avg_group_by_mod5"] = dict(source="tests/queries/0_stateless/01300_group_by_other_keys.reference",
+                                          rows=rows_of(ref_root, "01300_group_by_other_keys", 6, 11))
+
+    with open(os.path.join(HERE, "sql_reference_rows.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+    # --- hash KATs from the compiled reference Hash.h ---------------------------------------------
+    import oracle
+    oracle.build()
+    R = oracle.ref_hash()
+    assert R is not None, "oracle/_ref not built (reference checkout missing?)"
+    fixed = [0, 1, 2, 42, 1000000, 0xFFFFFFFF, 0x0123456789ABCDEF, 0xFFFFFFFFFFFFFFFF]
+    rng = np.random.Generator(np.random.PCG64(20250711))
+    rnd = [int(x) for x in rng.integers(0, 2**64, size=256, dtype=np.uint64)]
+    kat = []
+    for k in fixed + rnd:
+        crc = R.ref_intHashCRC32(k)
+        kat.append(dict(key=str(k), intHash64=str(R.ref_intHash64(k)), intHashCRC32=str(crc),
+                        two_level_bucket=(crc >> 24) & 0xFF, intHash32_salt0=str(R.ref_intHash32_salt0(k)),
+                        intHash32_sql=str(R.ref_intHash32_sql(k)),
+                        HashCRC32_UInt32=str(R.ref_HashCRC32_UInt32(k & 0xFFFFFFFF)),
+                        crc_seed_12345=str(R.ref_intHashCRC32_seed(k, 12345))))
+    with open(os.path.join(HERE, "hash_kat.json"), "w") as f:
+        json.dump(dict(source="src/Common/HashTable/Hash.h compiled in place (oracle/ref_hash_wrapper.cpp)", kat=kat), f, indent=1)
+    print("wrote", os.path.join(HERE, "sql_reference_rows.json"), "and hash_kat.json")
+
+
+if __name__ == "__main__":
+    main()

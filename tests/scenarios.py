@@ -1,0 +1,174 @@
+"""Restatements (as input builders) of the reference's stateless SQL tests that pin the hot path's semantics.
+
+Each scenario takes an `engine` exposing the mirror API shared by the CPU oracle (oracle.HashJoin / oracle.Aggregator)
+and the GPU host classes (clickhouse_amd.HashJoin / clickhouse_amd.Aggregator), and returns rows formatted like the
+reference's .reference files so they can be diffed against tests/golden/sql_reference_rows.json.
+"""
+import numpy as np
+
+I64, U32, U64, F64, U8, I32 = 0, 1, 2, 3, 4, 5
+AGG_COUNT, AGG_SUM, AGG_AVG = 0, 1, 2
+JOIN_INNER, JOIN_LEFT = 0, 1
+STRICT_ANY, STRICT_ALL, STRICT_SEMI, STRICT_ANTI = 0, 1, 2, 3
+
+
+def numbers(n, dtype=np.uint64):
+    return np.arange(n, dtype=dtype)
+
+
+def _gather_default(col, rrow):
+    """Right payload by row with type default 0 for missing rows (addNotFoundRow -> insertDefault)."""
+    out = np.zeros(rrow.shape[0], dtype=col.dtype)
+    ok = rrow >= 0
+    out[ok] = col[rrow[ok]]
+    return out
+
+
+def _fmt(*cols):
+    return [[str(int(v)) for v in row] for row in zip(*cols)]
+
+
+def q00049(engine):
+    # numbers ANY LEFT JOIN (number*2 AS number, number*10+1 AS joined LIMIT 10) USING number LIMIT 10
+    n = numbers(10)
+    j = engine.HashJoin(JOIN_LEFT, STRICT_ANY)
+    j.add_block(n * 2)
+    joined = (n * 2) * 10 + 1  # `number` in the 2nd expression resolves to the alias number*2 (expected row 2 -> 21)
+    left, _, rrow, _ = j.joined_pairs(n)
+    rows = _fmt(n[left], _gather_default(joined, rrow))
+    return sorted(rows, key=lambda r: [int(x) for x in r])
+
+
+def q00050(engine):
+    n = numbers(10)
+    j = engine.HashJoin(JOIN_LEFT, STRICT_ANY)
+    j.add_block(n * 2)
+    left, _, rrow, _ = j.joined_pairs(n)
+    bk = _gather_default(n * 2, rrow)
+    rows = _fmt(n[left], bk, _gather_default(n, rrow))
+    return sorted(rows, key=lambda r: int(r[0]))
+
+
+def q00051(engine):
+    n = numbers(10)
+    j = engine.HashJoin(JOIN_INNER, STRICT_ANY)
+    j.add_block(n * 2)
+    left, _, rrow, _ = j.joined_pairs(n)
+    rows = _fmt(n[left], _gather_default(n * 2, rrow), _gather_default(n, rrow))
+    return sorted(rows, key=lambda r: [int(x) for x in r])
+
+
+def q00052(engine):
+    n = numbers(10)
+    j = engine.HashJoin(JOIN_LEFT, STRICT_ALL)
+    j.add_block(n // 2)
+    left, _, rrow, _ = j.joined_pairs(n)
+    rows = _fmt(n[left], _gather_default(n, rrow))
+    return sorted(rows, key=lambda r: [int(x) for x in r])
+
+
+def q00053(engine):
+    n = numbers(10)
+    j = engine.HashJoin(JOIN_INNER, STRICT_ALL)
+    j.add_block(n // 2)
+    left, _, rrow, _ = j.joined_pairs(n)
+    rows = _fmt(n[left], _gather_default(n // 2, rrow), _gather_default(n, rrow))
+    return sorted(rows, key=lambda r: (int(r[0]), int(r[2])))
+
+
+def q00055(engine):
+    # two UInt8 keys packed into one fixed-width key (keys16-style packing); equality semantics identical
+    n = numbers(10)
+    lk = (n % 4) | ((n % 3) << 8)
+    rk = (n % 2) | ((n % 6) << 8)
+    j = engine.HashJoin(JOIN_LEFT, STRICT_ALL)
+    j.add_block(rk)
+    left, _, rrow, _ = j.joined_pairs(lk)
+    rows = _fmt(n[left], _gather_default(n, rrow))
+    return sorted(rows, key=lambda r: [int(x) for x in r])
+
+
+def q00120(engine, sql_intHash64, sql_intHash32):
+    # (number, intHash64(number)) ANY LEFT JOIN (number, intHash32(number)) USING number
+    # GROUP BY value1, value2 -> sum(number)
+    n = numbers(10)
+    v1 = np.array([sql_intHash64(int(x)) for x in n], dtype=np.uint64)
+    v2 = np.array([sql_intHash32(int(x)) for x in n], dtype=np.uint32)
+    j = engine.HashJoin(JOIN_LEFT, STRICT_ANY)
+    j.add_block(n)
+    left, _, rrow, _ = j.joined_pairs(n)
+    value1 = v1[left]
+    value2 = _gather_default(v2, rrow)
+    # group by (value1, value2): value1 is already unique per row; use it as the 64-bit key and carry value2
+    a = engine.Aggregator(np.uint64, [(AGG_SUM, np.uint64)], two_level_threshold=100000)
+    a.execute_on_block(value1, [n[left]])
+    keys, (sums,) = a.convert_to_block()
+    v2_of = {int(k): int(v) for k, v in zip(value1, value2)}
+    rows = [[str(int(k)), str(v2_of[int(k)]), str(int(s))] for k, s in zip(keys, sums)]
+    return sorted(rows, key=lambda r: (int(r[0]), int(r[1])))
+
+
+def q00041(engine):
+    # SELECT number, count() FROM numbers LIMIT 200000 GROUP BY number ORDER BY count(), number LIMIT 10
+    n = numbers(200000)
+    a = engine.Aggregator(np.uint64, [(AGG_COUNT, None)])
+    bs = 65409
+    for b in range(0, n.shape[0], bs):
+        a.execute_on_block(n[b:b + bs], [None])
+    keys, (cnt,) = a.convert_to_block()
+    assert keys.shape[0] == 200000
+    order = np.lexsort((keys, cnt))[:10]
+    return _fmt(keys[order], cnt[order])
+
+
+def q00266(engine):
+    n = numbers(110000)
+    a = engine.Aggregator(np.uint64, [(AGG_COUNT, None)])
+    bs = 65409
+    for b in range(0, n.shape[0], bs):
+        a.execute_on_block(n[b:b + bs], [None])
+    keys, _ = a.convert_to_block()
+    assert keys.shape[0] == 110000
+    return [[str(int(k))] for k in np.sort(keys)[:10]]
+
+
+def q02144(engine):
+    # avg(-8000000000000000000) over numbers(65535*2): (a) GROUP BY constant key 1, (b) without key
+    rows = 65535 * 2
+    v = np.full(rows, -8000000000000000000, dtype=np.int64)
+    out = []
+    a = engine.Aggregator(np.uint32, [(AGG_AVG, np.int64)])
+    bs = 65409
+    k = np.ones(rows, dtype=np.uint32)
+    for b in range(0, rows, bs):
+        a.execute_on_block(k[b:b + bs], [v[b:b + bs]])
+    _, (avg,) = a.convert_to_block()
+    out.append(float(avg[0]))
+    a = engine.Aggregator(None, [(AGG_AVG, np.int64)])
+    for b in range(0, rows, bs):
+        a.execute_on_block(None, [v[b:b + bs]])
+    _, (avg,) = a.convert_to_block()
+    out.append(float(avg[0]))
+    return out
+
+
+def q01091(engine):
+    n = numbers(1000000)
+    a = engine.Aggregator(None, [(AGG_SUM, np.uint64)])
+    bs = 65409
+    for b in range(0, n.shape[0], bs):
+        a.execute_on_block(None, [n[b:b + bs]])
+    _, (s,) = a.convert_to_block()
+    return [[str(int(s[0]))]]
+
+
+def q01300(engine, rows=10000000, block=65505):
+    # round(avg(log(2) * number), 6) FROM numbers(1e7) GROUP BY number % 5  ORDER BY k  (max_block_size = 65505)
+    n = numbers(rows)
+    val = np.log(2.0) * n.astype(np.float64)
+    key = (n % 5).astype(np.uint32)  # UInt8 in the reference; widened key, same grouping
+    a = engine.Aggregator(np.uint32, [(AGG_AVG, np.float64)])
+    for b in range(0, rows, block):
+        a.execute_on_block(key[b:b + block], [val[b:b + block]])
+    _, (avg,) = a.convert_to_block()
+    return sorted(float(x) for x in avg)
