@@ -1,0 +1,122 @@
+"""ctypes binding of libchgpu.so — exactly the symbols include/chgpu.h declares.
+
+The product path has NO CPU fallback: if the HIP library is missing or fails to load, importing raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libchgpu.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "chgpu.h")
+
+# enums of include/chgpu.h
+OK = 0
+ERR_SIZES_MISMATCH, ERR_NOT_IMPLEMENTED, ERR_OOM, ERR_LOGICAL, ERR_BAD_ARGUMENTS, ERR_DEVICE, ERR_TOO_MANY_ROWS = -1, -2, -3, -4, -5, -6, -7
+I64, U32, U64, F64, U8, I32 = 0, 1, 2, 3, 4, 5
+EQ, NE, LT, GT, LE, GE = 0, 1, 2, 3, 4, 5
+AGG_COUNT, AGG_SUM, AGG_AVG = 0, 1, 2
+JOIN_INNER, JOIN_LEFT = 0, 1
+STRICT_ANY, STRICT_ALL, STRICT_SEMI, STRICT_ANTI = 0, 1, 2, 3
+N_COUNTERS = 8
+
+_vp, _i, _u32, _u64, _i64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_int64
+_pp = C.POINTER(C.c_void_p)
+_pu64 = C.POINTER(C.c_uint64)
+
+SIGNATURES = {
+    "chgpu_abi_version": (_i, []),
+    "chgpu_last_error": (C.c_char_p, []),
+    "chgpu_ctx_create": (_i, [_i, _vp, _pp]),
+    "chgpu_ctx_destroy": (_i, [_vp]),
+    "chgpu_ctx_synchronize": (_i, [_vp]),
+    "chgpu_ctx_counters": (_i, [_vp, _pu64]),
+    "chgpu_timer_start": (_i, [_vp]),
+    "chgpu_timer_stop_ms": (_i, [_vp, C.POINTER(C.c_double)]),
+    "chgpu_col_upload": (_i, [_vp, _i, _vp, _u64, _pp]),
+    "chgpu_col_alloc": (_i, [_vp, _i, _u64, _pp]),
+    "chgpu_col_wrap": (_i, [_vp, _i, _vp, _u64, _pp]),
+    "chgpu_col_slice": (_i, [_vp, _vp, _u64, _u64, _pp]),
+    "chgpu_col_download": (_i, [_vp, _vp, _vp, _u64]),
+    "chgpu_col_rows": (_u64, [_vp]),
+    "chgpu_col_type": (_i, [_vp]),
+    "chgpu_col_device_ptr": (_vp, [_vp]),
+    "chgpu_col_free": (_i, [_vp]),
+    "chgpu_cmp_const": (_i, [_vp, _vp, _i, _i, _vp, _pp]),
+    "chgpu_count_bytes_in_filter": (_i, [_vp, _vp, _pu64]),
+    "chgpu_filter": (_i, [_vp, _vp, _vp, _i64, _pp, _pu64]),
+    "chgpu_filter_description_nullable": (_i, [_vp, _vp, _vp, _pp]),
+    "chgpu_sum_add_many": (_i, [_vp, _vp, _u64, _u64, _vp]),
+    "chgpu_sum_add_many_conditional": (_i, [_vp, _vp, _vp, _u64, _u64, _vp]),
+    "chgpu_filter_sum": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _pu64]),
+    "chgpu_filter_sum_async": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "chgpu_index": (_i, [_vp, _vp, _vp, _u64, _i, _pp]),
+    "chgpu_replicate": (_i, [_vp, _vp, _vp, _pp]),
+    "chgpu_weak_hash32": (_i, [_vp, _vp, _vp]),
+    "chgpu_hash_to_selector": (_i, [_vp, _vp, _u32, _pp]),
+    "chgpu_scatter": (_i, [_vp, _vp, _vp, _u32, _pp]),
+    "chgpu_partition_by_hash": (_i, [_vp, _vp, _u32, _u32, _pp, _pp, _pu64]),
+    "chgpu_agg_create": (_i, [_vp, _i, _u32, C.POINTER(_i), C.POINTER(_i), _u64, _pp]),
+    "chgpu_agg_add_block": (_i, [_vp, _vp, _pp, _u64, _u64]),
+    "chgpu_agg_merge": (_i, [_vp, _vp]),
+    "chgpu_agg_merge_states": (_i, [_vp, _vp, _pp, _u64]),
+    "chgpu_agg_size": (_i, [_vp, _pu64]),
+    "chgpu_agg_finalize": (_i, [_vp, _pp, _pp, _pu64]),
+    "chgpu_agg_export_states": (_i, [_vp, _pp, _pp, _pu64]),
+    "chgpu_agg_free": (_i, [_vp]),
+    "chgpu_join_create": (_i, [_vp, _i, _i, _i, _i, _u64, _pp]),
+    "chgpu_join_add_block": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_u32)]),
+    "chgpu_join_finish_build": (_i, [_vp]),
+    "chgpu_join_total_rows": (_i, [_vp, _pu64, _pu64]),
+    "chgpu_join_probe": (_i, [_vp, _vp, _vp, _u64, _pp, _pp, _pp, _pu64, _pu64]),
+    "chgpu_join_free": (_i, [_vp]),
+}
+
+
+def declared_symbols(header_path: str = HEADER_PATH):
+    """Every function name include/chgpu.h declares (used by the CPU test that checks the exports)."""
+    with open(header_path) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(chgpu_[a-z0-9_]+)\s*\(", text)))
+
+
+class ChgpuError(RuntimeError):
+    """Mirror of DB::Exception for this path: .code carries the CHGPU_ERR_* value."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"chgpu error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "There is no CPU fallback for the product path.")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7; when it is loaded first the dynamic
+        # loader satisfies libchgpu.so's NEEDED libamdhip64.so.7 with that copy.  The other order would bring a second
+        # runtime into the process (torch then fails with "no ROCm-capable device"), so import torch first when present.
+        try:
+            import torch  # noqa: F401  (plumbing only: device memory, streams, torch.distributed)
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here == the .so does not export what the header declares
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != OK:
+        raise ChgpuError(rc, lib().chgpu_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,90 @@
+"""Aggregator mirror (src/Interpreters/Aggregator.h:179-265) over the C ABI: one instance == one
+AggregatedDataVariants living in HBM.  execute_on_block / merge / convert_to_block follow executeOnBlock /
+mergeDataImpl / convertToBlockImplFinal."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as K
+from .columns import NP_OF, TAG_OF, Column, Context, sum_result_dtype
+
+
+class Aggregator:
+    def __init__(self, key_dtype, aggs, two_level_threshold: int = 100000, size_hint: int = 0, ctx: Context | None = None):
+        """aggs: list of (kind, arg_dtype or None).  key_dtype None = without_key.  two_level_threshold is accepted for
+        interface parity (Aggregator::Params) — the device table is single-level."""
+        self.ctx = ctx if ctx is not None else Context(0)
+        self.key_tag = -1 if key_dtype is None else TAG_OF[np.dtype(key_dtype)]
+        self.aggs = [(k, (TAG_OF[np.dtype(d)] if d is not None else K.U64)) for k, d in aggs]
+        kinds = (C.c_int * max(1, len(self.aggs)))(*[k for k, _ in self.aggs])
+        types = (C.c_int * max(1, len(self.aggs)))(*[t for _, t in self.aggs])
+        h = C.c_void_p()
+        K.check(K.lib().chgpu_agg_create(self.ctx._h, self.key_tag, len(self.aggs), kinds, types, size_hint, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            K.lib().chgpu_agg_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def execute_on_block(self, keys, args, row_begin: int = 0, row_end: int | None = None):
+        """Aggregator::executeOnBlock(columns, row_begin, row_end, result, key_columns, aggregate_columns, ...)"""
+        kcol = self.ctx.column(keys) if keys is not None else None
+        acols = [self.ctx.column(a) if a is not None else None for a in args]
+        n = kcol.size() if kcol is not None else next(a.size() for a in acols if a is not None)
+        row_end = n if row_end is None else row_end
+        ptrs = (C.c_void_p * max(1, len(acols)))(*[(a._h if a is not None else None) for a in acols])
+        K.check(K.lib().chgpu_agg_add_block(self._h, kcol._h if kcol is not None else None, ptrs, row_begin, row_end))
+
+    def merge(self, other: "Aggregator"):
+        K.check(K.lib().chgpu_agg_merge(self._h, other._h))
+
+    def merge_states(self, keys: Column | None, state_cols, rows: int):
+        ptrs = (C.c_void_p * max(1, len(state_cols)))(*[c._h for c in state_cols])
+        K.check(K.lib().chgpu_agg_merge_states(self._h, keys._h if keys is not None else None, ptrs, rows))
+
+    def __len__(self):
+        n = C.c_uint64(0)
+        K.check(K.lib().chgpu_agg_size(self._h, C.byref(n)))
+        return int(n.value)
+
+    @property
+    def n_words(self):
+        return sum(2 if k == K.AGG_AVG else 1 for k, _ in self.aggs)
+
+    def result_dtypes(self):
+        out = []
+        for kind, t in self.aggs:
+            out.append(np.uint64 if kind == K.AGG_COUNT else np.float64 if kind == K.AGG_AVG else sum_result_dtype(t))
+        return out
+
+    def finalize_columns(self):
+        """-> (keys Column or None, [result Columns]) resident in HBM."""
+        kh = C.c_void_p()
+        res = (C.c_void_p * max(1, len(self.aggs)))()
+        n = C.c_uint64(0)
+        K.check(K.lib().chgpu_agg_finalize(self._h, C.byref(kh), res, C.byref(n)))
+        keys = Column(self.ctx, kh) if kh.value else None
+        return keys, [Column(self.ctx, C.c_void_p(res[j])) for j in range(len(self.aggs))]
+
+    def export_state_columns(self):
+        kh = C.c_void_p()
+        nw = self.n_words
+        res = (C.c_void_p * max(1, nw))()
+        n = C.c_uint64(0)
+        K.check(K.lib().chgpu_agg_export_states(self._h, C.byref(kh), res, C.byref(n)))
+        keys = Column(self.ctx, kh) if kh.value else None
+        return keys, [Column(self.ctx, C.c_void_p(res[w])) for w in range(nw)], int(n.value)
+
+    def convert_to_block(self):
+        """Aggregator::convertToBlocks(final=true) downloaded: (keys ndarray or None, [result ndarrays])."""
+        keys, res = self.finalize_columns()
+        return (keys.numpy() if keys is not None else None), [r.numpy() for r in res]

@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's column / function / aggregate interfaces for the hot path, over the C ABI.
+
+Names and argument meaning follow the reference (src/Columns/IColumn.h, src/Functions/FunctionsComparison.h,
+src/AggregateFunctions/IAggregateFunction.h) so parity tests read like the reference's own tests.  Everything here
+runs on the MI355X through libchgpu.so; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as K
+
+NP_OF = {K.I64: np.int64, K.U32: np.uint32, K.U64: np.uint64, K.F64: np.float64, K.U8: np.uint8, K.I32: np.int32}
+TAG_OF = {np.dtype(v): k for k, v in NP_OF.items()}
+
+
+def sum_result_dtype(tag: int):
+    """SumSimple (src/AggregateFunctions/AggregateFunctionSum.cpp:19-28)."""
+    if tag in (K.I64, K.I32):
+        return np.int64
+    if tag in (K.U64, K.U32, K.U8):
+        return np.uint64
+    return np.float64
+
+
+class Context:
+    """One device + one HIP stream (one per pipeline thread, IProcessor.h:176-193)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        h = C.c_void_p()
+        K.check(K.lib().chgpu_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            K.lib().chgpu_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        K.check(K.lib().chgpu_ctx_synchronize(self._h))
+
+    def counters(self):
+        arr = (C.c_uint64 * K.N_COUNTERS)()
+        K.check(K.lib().chgpu_ctx_counters(self._h, arr))
+        names = ["FilterTransformPassedRows", "FilterTransformPassedBytes", "JoinBuildTableRowCount", "JoinProbeTableRowCount",
+                 "JoinResultRowCount", "AggregatedRows", "KernelLaunches", "TableRehashes"]
+        return dict(zip(names, [int(x) for x in arr]))
+
+    def timer_start(self):
+        K.check(K.lib().chgpu_timer_start(self._h))
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_double(0)
+        K.check(K.lib().chgpu_timer_stop_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    # -- column factories -------------------------------------------------------------------
+    def upload(self, arr: np.ndarray) -> "Column":
+        arr = np.ascontiguousarray(arr)
+        h = C.c_void_p()
+        K.check(K.lib().chgpu_col_upload(self._h, TAG_OF[arr.dtype], arr.ctypes.data_as(C.c_void_p), arr.shape[0], C.byref(h)))
+        return Column(self, h)
+
+    def alloc(self, dtype, rows: int) -> "Column":
+        h = C.c_void_p()
+        K.check(K.lib().chgpu_col_alloc(self._h, TAG_OF[np.dtype(dtype)], rows, C.byref(h)))
+        return Column(self, h)
+
+    def wrap(self, device_ptr: int, dtype, rows: int, keepalive=None) -> "Column":
+        """Non-owning view of HBM the caller manages (e.g. a torch tensor's data_ptr())."""
+        h = C.c_void_p()
+        K.check(K.lib().chgpu_col_wrap(self._h, TAG_OF[np.dtype(dtype)], C.c_void_p(device_ptr), rows, C.byref(h)))
+        c = Column(self, h)
+        c._keepalive = keepalive
+        return c
+
+    def column(self, x) -> "Column":
+        return x if isinstance(x, Column) else self.upload(x)
+
+
+class Column:
+    """ColumnVector<T> resident in HBM (src/Columns/ColumnVector.h:28-320)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx = ctx
+        self._h = handle
+        self._keepalive = None
+
+    def free(self):
+        if getattr(self, "_h", None):
+            K.lib().chgpu_col_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def size(self) -> int:
+        return int(K.lib().chgpu_col_rows(self._h))
+
+    __len__ = size
+
+    @property
+    def tag(self) -> int:
+        return int(K.lib().chgpu_col_type(self._h))
+
+    @property
+    def dtype(self):
+        return np.dtype(NP_OF[self.tag])
+
+    @property
+    def device_ptr(self) -> int:
+        return int(K.lib().chgpu_col_device_ptr(self._h) or 0)
+
+    def numpy(self, rows: int | None = None) -> np.ndarray:
+        rows = self.size() if rows is None else rows
+        out = np.empty(rows, dtype=self.dtype)
+        K.check(K.lib().chgpu_col_download(self.ctx._h, self._h, out.ctypes.data_as(C.c_void_p), rows))
+        return out
+
+    def cut(self, start: int, length: int) -> "Column":
+        """IColumn::cut (IColumn.h:118-121) as a non-owning view."""
+        h = C.c_void_p()
+        K.check(K.lib().chgpu_col_slice(self.ctx._h, self._h, start, length, C.byref(h)))
+        c = Column(self.ctx, h)
+        c._keepalive = self
+        return c
+
+    def filter(self, filt: "Column", result_size_hint: int = 0) -> "Column":
+        """IColumn::filter (IColumn.h:313-314)."""
+        h = C.c_void_p()
+        n = C.c_uint64(0)
+        K.check(K.lib().chgpu_filter(self.ctx._h, self._h, filt._h, result_size_hint, C.byref(h), C.byref(n)))
+        return Column(self.ctx, h)
+
+    def index(self, indexes: "Column", limit: int = 0, default_for_missing: bool = False) -> "Column":
+        """IColumn::index (IColumn.h:331)."""
+        h = C.c_void_p()
+        K.check(K.lib().chgpu_index(self.ctx._h, self._h, indexes._h, limit, int(default_for_missing), C.byref(h)))
+        return Column(self.ctx, h)
+
+    def replicate(self, offsets: "Column") -> "Column":
+        """IColumn::replicate (IColumn.h:440)."""
+        h = C.c_void_p()
+        K.check(K.lib().chgpu_replicate(self.ctx._h, self._h, offsets._h, C.byref(h)))
+        return Column(self.ctx, h)
+
+    def scatter(self, num_columns: int, selector: "Column"):
+        """IColumn::scatter (IColumn.h:448)."""
+        outs = (C.c_void_p * num_columns)()
+        K.check(K.lib().chgpu_scatter(self.ctx._h, self._h, selector._h, num_columns, outs))
+        return [Column(self.ctx, C.c_void_p(outs[i])) for i in range(num_columns)]
+
+    def get_weak_hash32(self, hash_col: "Column | None" = None) -> "Column":
+        """IColumn::getWeakHash32 (IColumn.h:302): CRC32-C chained over hash_col (initialised to 0xFFFFFFFF)."""
+        if hash_col is None:
+            hash_col = self.ctx.upload(np.full(self.size(), 0xFFFFFFFF, dtype=np.uint32))
+        K.check(K.lib().chgpu_weak_hash32(self.ctx._h, self._h, hash_col._h))
+        return hash_col
+
+
+def _scalar_buf(tag: int, value):
+    return np.array([value], dtype=NP_OF[tag])
+
+
+def cmp_const(col: Column, op: int, scalar, scalar_tag: int | None = None) -> Column:
+    """FunctionComparison with a constant right argument -> UInt8 column (FunctionsComparison.h:204-245)."""
+    st = col.tag if scalar_tag is None else scalar_tag
+    s = _scalar_buf(st, scalar)
+    h = C.c_void_p()
+    K.check(K.lib().chgpu_cmp_const(col.ctx._h, col._h, op, st, s.ctypes.data_as(C.c_void_p), C.byref(h)))
+    return Column(col.ctx, h)
+
+
+def count_bytes_in_filter(filt: Column) -> int:
+    n = C.c_uint64(0)
+    K.check(K.lib().chgpu_count_bytes_in_filter(filt.ctx._h, filt._h, C.byref(n)))
+    return int(n.value)
+
+
+def filter_description_nullable(data: Column, null_map: Column) -> Column:
+    h = C.c_void_p()
+    K.check(K.lib().chgpu_filter_description_nullable(data.ctx._h, data._h, null_map._h, C.byref(h)))
+    return Column(data.ctx, h)
+
+
+def sum_add_many(col: Column, row_begin: int = 0, row_end: int | None = None, state: np.ndarray | None = None) -> np.ndarray:
+    """IAggregateFunction::addBatchSinglePlace for sum (AggregateFunctionSum.h:494-512)."""
+    row_end = col.size() if row_end is None else row_end
+    st = np.zeros(1, dtype=sum_result_dtype(col.tag)) if state is None else state
+    K.check(K.lib().chgpu_sum_add_many(col.ctx._h, col._h, row_begin, row_end, st.ctypes.data_as(C.c_void_p)))
+    return st
+
+
+def sum_add_many_conditional(col: Column, cond: Column, row_begin: int = 0, row_end: int | None = None,
+                             state: np.ndarray | None = None) -> np.ndarray:
+    row_end = col.size() if row_end is None else row_end
+    st = np.zeros(1, dtype=sum_result_dtype(col.tag)) if state is None else state
+    K.check(K.lib().chgpu_sum_add_many_conditional(col.ctx._h, col._h, cond._h, row_begin, row_end, st.ctypes.data_as(C.c_void_p)))
+    return st
+
+
+def filter_sum(pred: Column, op: int, scalar, val: Column | None = None, scalar_tag: int | None = None):
+    """`SELECT sum(val), count() WHERE pred <op> scalar` fused in one HBM pass -> (sum, count)."""
+    val = pred if val is None else val
+    st = pred.tag if scalar_tag is None else scalar_tag
+    s = _scalar_buf(st, scalar)
+    out = np.zeros(1, dtype=sum_result_dtype(val.tag))
+    cnt = C.c_uint64(0)
+    K.check(K.lib().chgpu_filter_sum(pred.ctx._h, pred._h, op, st, s.ctypes.data_as(C.c_void_p), val._h,
+                                     out.ctypes.data_as(C.c_void_p), C.byref(cnt)))
+    return out[0], int(cnt.value)
+
+
+def filter_sum_async(pred: Column, op: int, scalar, val: Column | None, result: Column, scalar_tag: int | None = None):
+    """Same without host synchronisation: `result` is a 2-row UInt64 device column {sum bits, count}."""
+    val = pred if val is None else val
+    st = pred.tag if scalar_tag is None else scalar_tag
+    s = _scalar_buf(st, scalar)
+    K.check(K.lib().chgpu_filter_sum_async(pred.ctx._h, pred._h, op, st, s.ctypes.data_as(C.c_void_p), val._h, result._h))
+
+
+def hash_to_selector(keys: Column, num_shards: int) -> Column:
+    h = C.c_void_p()
+    K.check(K.lib().chgpu_hash_to_selector(keys.ctx._h, keys._h, num_shards, C.byref(h)))
+    return Column(keys.ctx, h)
+
+
+def partition_by_hash(keys: Column, num_shards: int, cols):
+    """-> (list of partitioned columns, counts[num_shards]); shard s occupies [sum(counts[:s]), +counts[s])."""
+    n = len(cols)
+    ins = (C.c_void_p * n)(*[c._h for c in cols])
+    outs = (C.c_void_p * n)()
+    counts = (C.c_uint64 * num_shards)()
+    K.check(K.lib().chgpu_partition_by_hash(keys.ctx._h, keys._h, num_shards, n, ins, outs, counts))
+    return [Column(keys.ctx, C.c_void_p(outs[i])) for i in range(n)], np.array(list(counts), dtype=np.uint64)

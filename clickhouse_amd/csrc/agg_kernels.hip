@@ -1,0 +1,941 @@
+// agg_kernels.hip — GROUP BY on the device: Aggregator::executeOnBlock / merge / convertToBlocks for one numeric key
+// and POD-state aggregate functions (count, sum, avg).
+//
+// Reference loops replaced (file:line in the reference checkout):
+//   k_agg_rows      Aggregator::executeImplBatch loops A+B (emplaceKey + addBatch)   src/Interpreters/Aggregator.cpp:1010-1206,
+//                   HashTable::emplace / findCell                                     src/Common/HashTable/HashTable.h:448-459,901-1027,
+//                   IAggregateFunctionHelper::addBatch                                src/AggregateFunctions/IAggregateFunction.h:428-452
+//   k_agg_tuples    mergeDataImpl / HashMap::mergeToViaEmplace, resize+reinsert       Aggregator.cpp:2468-2521, HashMap.h:203-233,
+//                                                                                     HashTable.h:504-593
+//   finalize        convertToBlockImplFinal / insertResultsIntoColumns                Aggregator.cpp:1948-2117
+//
+// Table geometry mirrors the reference's (HashTable.h:217-330,358-391): power-of-two capacity, linear probing,
+// max fill 1/2, growth x4 until 2^23 cells then x2, empty <=> key == 0, the zero key kept out of line (slot index
+// == capacity).  Layout is SoA in HBM: keys[capacity+1], then one u64/f64 array per state word, so probes touch only
+// 8-byte keys and state updates are single 64-bit atomics.  Placement hash = intHash64 (Hash.h:27-36); CRC32-C is
+// only needed where the hash is externally visible (partition_kernels.hip).
+//
+// Two row kernels: DIRECT (global atomics per row; large cardinalities) and LDS-STAGED (a per-workgroup open-addressing
+// table in LDS absorbs repeated keys — the device analogue of the consecutive-key cache, ColumnsHashingImpl.h:313-366 —
+// and is flushed once per workgroup).  Rows that would push the table over max fill are marked in a pending bitmap;
+// the host grows the table (rehash) and re-runs only those rows, which is the reference's resize-on-overflow
+// (HashTable.h:921-944) restructured for a device that cannot realloc inside a kernel.
+#include "chgpu_internal.h"
+
+static constexpr u32 AGG_MAX_AGGS = 8;
+static constexpr u32 AGG_MAX_WORDS = 16;
+static constexpr u64 AGG_MIN_CAPACITY = 1ull << 18; // keeps >= 128 Ki cells of slack for LDS flushes
+static constexpr u32 AGG_THREADS = 256;
+
+struct AggCtrl
+{
+    unsigned long long n_groups; // occupied cells incl. the zero key
+    u32 overflow;                // some row hit the max-fill limit and was left pending
+    u32 has_zero;
+    u32 fatal;                   // table completely full during a flush (cannot happen by construction)
+    u32 pad;
+};
+
+struct AggArg
+{
+    const void * ptr; // argument column (NULL for count)
+    int kind;
+    int arg_type;
+    u32 word;         // first state word
+};
+
+struct AggDesc
+{
+    u32 n_aggs;
+    u32 n_words;
+    AggArg a[AGG_MAX_AGGS];
+    u32 word_is_f64; // bit w set: state word w is Float64
+};
+
+struct AggTable
+{
+    u64 * keys;      // [capacity + 1]
+    u64 * words;     // [n_words][capacity + 1]
+    u64 capacity;    // power of two
+    u64 max_fill;    // capacity / 2
+    AggCtrl * ctrl;
+};
+
+struct chgpu_agg
+{
+    chgpu_ctx * ctx = nullptr;
+    int key_type = -1;
+    u32 n_aggs = 0, n_words = 0;
+    int kinds[AGG_MAX_AGGS];
+    int arg_types[AGG_MAX_AGGS];
+    u32 word_off[AGG_MAX_AGGS];
+    u32 word_is_f64 = 0;
+    u64 size_hint = 0;
+    AggTable t{nullptr, nullptr, 0, 0, nullptr};
+    void * table_mem = nullptr;
+    u64 n_groups = 0; // host copy, refreshed after every call
+    u64 host_words[AGG_MAX_WORDS]; // without_key states live on the host (8 B each)
+};
+
+// ---------------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 load_key_zext(const void * keys, int type, u64 i)
+{
+    // HashMethodOneNumber::getKeyHolder (ColumnsHashing/HashMethod.h:91): raw bits of the key, zero-extended to the
+    // UInt64 table key (AggregatedDataVariants.h:63-64)
+    switch (type)
+    {
+        case CHGPU_U32: case CHGPU_I32: return ((const u32 *)keys)[i];
+        case CHGPU_U8: return ((const u8 *)keys)[i];
+        default: return ((const u64 *)keys)[i];
+    }
+}
+
+__device__ __forceinline__ u64 load_arg_bits(const void * p, int type, u64 i)
+{
+    switch (type)
+    {
+        case CHGPU_I64: case CHGPU_U64: case CHGPU_F64: return ((const u64 *)p)[i];
+        case CHGPU_U32: return ((const u32 *)p)[i];
+        case CHGPU_I32: return (u64)(i64)((const i32 *)p)[i]; // sign-extend: wrap-around two's complement sum
+        case CHGPU_U8: return ((const u8 *)p)[i];
+        default: return 0;
+    }
+}
+
+__device__ __forceinline__ void global_add_word(u64 * p, u64 bits, bool is_f64)
+{
+    if (is_f64)
+        __hip_atomic_fetch_add((double *)p, __longlong_as_double((long long)bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        __hip_atomic_fetch_add((unsigned long long *)p, (unsigned long long)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Find-or-claim the cell of `key` (emplace).  Returns the slot, or ~0 when the row must wait for a bigger table.
+// soft_limit: refuse to claim new cells once n_groups >= max_fill (rows); flushes/rehash pass false and may use
+// the slack above max fill.  Every loop is bounded by the capacity, so the wave always exits.
+__device__ __forceinline__ u64 table_emplace(const AggTable & t, u64 key, bool soft_limit)
+{
+    if (key == 0)
+    {
+        // zero key lives out of line (HashTable.h:874-898)
+        if (__hip_atomic_load(&t.ctrl->has_zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            if (atomicExch(&t.ctrl->has_zero, 1u) == 0)
+                atomicAdd(&t.ctrl->n_groups, 1ull);
+        return t.capacity;
+    }
+    const u64 mask = t.capacity - 1;
+    u64 slot = dev_intHash64(key) & mask;
+    for (u64 step = 0; step < t.capacity; ++step)
+    {
+        u64 k = t.keys[slot];
+        if (k == key)
+            return slot;
+        if (k == 0)
+        {
+            if (soft_limit && __hip_atomic_load(&t.ctrl->n_groups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= t.max_fill)
+                return ~0ull;
+            const u64 prev = atomicCAS((unsigned long long *)&t.keys[slot], 0ull, (unsigned long long)key);
+            if (prev == 0)
+            {
+                atomicAdd(&t.ctrl->n_groups, 1ull);
+                return slot;
+            }
+            if (prev == key)
+                return slot;
+        }
+        slot = (slot + 1) & mask;
+    }
+    return ~0ull;
+}
+
+// add row i's contribution of every aggregate to the cell `slot` (IAggregateFunction::add per function)
+__device__ __forceinline__ void add_row_global(const AggTable & t, const AggDesc & d, u64 slot, u64 i)
+{
+    const u64 stride = t.capacity + 1;
+    for (u32 j = 0; j < d.n_aggs; ++j)
+    {
+        const AggArg & a = d.a[j];
+        u64 * w = t.words + (u64)a.word * stride + slot;
+        if (a.kind == CHGPU_AGG_COUNT)
+            global_add_word(w, 1, false);
+        else
+        {
+            global_add_word(w, load_arg_bits(a.ptr, a.arg_type, i), a.arg_type == CHGPU_F64);
+            if (a.kind == CHGPU_AGG_AVG)
+                global_add_word(w + stride, 1, false); // denominator
+        }
+    }
+}
+
+enum { AGG_MODE_ALL = 0, AGG_MODE_PENDING = 1 };
+
+// DIRECT kernel: one global emplace + one atomic per state word per row.
+template <int MODE>
+__global__ __launch_bounds__(AGG_THREADS) void k_agg_rows_direct(AggTable t, AggDesc d, const void * __restrict__ keys, int key_type,
+                                                                 u64 row_begin, u64 n, u64 * __restrict__ pending)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave0 = ((u64)blockIdx.x * AGG_THREADS + threadIdx.x) >> 6;
+    const u64 n_waves = ((u64)gridDim.x * AGG_THREADS) >> 6;
+    const u64 n_groups64 = (n + 63) / 64;
+    for (u64 g = wave0; g < n_groups64; g += n_waves)
+    {
+        const u64 r = g * 64 + lane;
+        bool active = r < n;
+        if (MODE == AGG_MODE_PENDING)
+        {
+            const u64 word = pending[g];
+            if (word == 0)
+                continue;
+            active = active && ((word >> lane) & 1);
+        }
+        bool failed = false;
+        if (active)
+        {
+            const u64 i = row_begin + r;
+            const u64 slot = table_emplace(t, load_key_zext(keys, key_type, i), true);
+            if (slot == ~0ull)
+                failed = true;
+            else
+                add_row_global(t, d, slot, i);
+        }
+        const u64 b = __ballot(failed);
+        if (lane == 0)
+            pending[g] = b;
+        if (b != 0 && lane == 0)
+            t.ctrl->overflow = 1; // benign race: every writer stores 1
+    }
+}
+
+// LDS-STAGED kernel.  Dynamic LDS: lkeys[S+1] then lwords[n_words][S+1]; cell S is the zero key's.
+__global__ __launch_bounds__(AGG_THREADS) void k_agg_rows_lds(AggTable t, AggDesc d, const void * __restrict__ keys, int key_type,
+                                                              u64 row_begin, u64 n, u64 * __restrict__ pending, u32 S)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    u64 * lkeys = (u64 *)lds_raw;
+    u64 * lwords = lkeys + (S + 1);
+    __shared__ u32 lzero;
+    const u32 lstride = S + 1;
+    for (u32 s = threadIdx.x; s < (d.n_words + 1) * lstride; s += AGG_THREADS)
+        lkeys[s] = 0;
+    if (threadIdx.x == 0)
+        lzero = 0;
+    __syncthreads();
+
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave0 = ((u64)blockIdx.x * AGG_THREADS + threadIdx.x) >> 6;
+    const u64 n_waves = ((u64)gridDim.x * AGG_THREADS) >> 6;
+    const u64 n_groups64 = (n + 63) / 64;
+    for (u64 g = wave0; g < n_groups64; g += n_waves)
+    {
+        const u64 r = g * 64 + lane;
+        const bool active = r < n;
+        bool failed = false;
+        if (active)
+        {
+            const u64 i = row_begin + r;
+            const u64 key = load_key_zext(keys, key_type, i);
+            // ---- LDS emplace: a few probes, then give up and go to HBM ----
+            u32 ls = ~0u;
+            if (key == 0)
+            {
+                ls = S;
+                lzero = 1;
+            }
+            else
+            {
+                u32 s = (u32)(dev_intHash64(key) >> 40) & (S - 1);
+#pragma unroll 1
+                for (int probe = 0; probe < 8; ++probe)
+                {
+                    u64 k = lkeys[s];
+                    if (k == 0)
+                        k = atomicCAS((unsigned long long *)&lkeys[s], 0ull, (unsigned long long)key), k = (k == 0) ? key : k;
+                    if (k == key)
+                    {
+                        ls = s;
+                        break;
+                    }
+                    s = (s + 1) & (S - 1);
+                }
+            }
+            if (ls != ~0u)
+            {
+                for (u32 j = 0; j < d.n_aggs; ++j)
+                {
+                    const AggArg & a = d.a[j];
+                    u64 * w = lwords + a.word * lstride + ls;
+                    if (a.kind == CHGPU_AGG_COUNT)
+                        atomicAdd((unsigned long long *)w, 1ull);
+                    else
+                    {
+                        const u64 bits = load_arg_bits(a.ptr, a.arg_type, i);
+                        if (a.arg_type == CHGPU_F64)
+                            atomicAdd((double *)w, __longlong_as_double((long long)bits));
+                        else
+                            atomicAdd((unsigned long long *)w, (unsigned long long)bits);
+                        if (a.kind == CHGPU_AGG_AVG)
+                            atomicAdd((unsigned long long *)(w + lstride), 1ull);
+                    }
+                }
+            }
+            else
+            {
+                const u64 slot = table_emplace(t, key, true);
+                if (slot == ~0ull)
+                    failed = true;
+                else
+                    add_row_global(t, d, slot, i);
+            }
+        }
+        const u64 b = __ballot(failed);
+        if (lane == 0)
+            pending[g] = b;
+        if (b != 0 && lane == 0)
+            t.ctrl->overflow = 1;
+    }
+    __syncthreads();
+
+    // ---- flush the workgroup's partial states: one emplace + n_words atomics per distinct key ----
+    const u64 gstride = t.capacity + 1;
+    for (u32 s = threadIdx.x; s <= S; s += AGG_THREADS)
+    {
+        const u64 key = lkeys[s];
+        const bool occupied = (s == S) ? (lzero != 0) : (key != 0);
+        if (!occupied)
+            continue;
+        const u64 slot = table_emplace(t, s == S ? 0 : key, false); // may use the slack above max fill
+        if (slot == ~0ull)
+        {
+            t.ctrl->fatal = 1;
+            continue;
+        }
+        for (u32 w = 0; w < d.n_words; ++w)
+        {
+            const u64 bits = lwords[w * lstride + s];
+            const bool f = (d.word_is_f64 >> w) & 1;
+            if (f ? (__longlong_as_double((long long)bits) != 0.0 || bits != 0) : (bits != 0))
+                global_add_word(t.words + (u64)w * gstride + slot, bits, f);
+        }
+    }
+}
+
+// Merge (key, state words) tuples into the table: mergeToViaEmplace, also the rehash of a grown table.
+// src_words[w] + i*1 ; src keys are u64; key==0 entries are skipped when skip_zero_keys (table arrays: empty cells),
+// zero_slot_index: index in the source arrays of the out-of-line zero key (or ~0).
+template <int MODE>
+__global__ __launch_bounds__(AGG_THREADS) void k_agg_tuples(AggTable t, u32 n_words, u32 word_is_f64, const u64 * __restrict__ src_keys,
+                                                            const u64 * __restrict__ src_words, u64 src_stride, u64 n, int skip_zero_keys,
+                                                            u64 zero_slot_index, int soft_limit, u64 * __restrict__ pending)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave0 = ((u64)blockIdx.x * AGG_THREADS + threadIdx.x) >> 6;
+    const u64 n_waves = ((u64)gridDim.x * AGG_THREADS) >> 6;
+    const u64 n_groups64 = (n + 63) / 64;
+    const u64 gstride = t.capacity + 1;
+    for (u64 g = wave0; g < n_groups64; g += n_waves)
+    {
+        const u64 i = g * 64 + lane;
+        bool active = i < n;
+        if (MODE == AGG_MODE_PENDING)
+        {
+            const u64 word = pending[g];
+            if (word == 0)
+                continue;
+            active = active && ((word >> lane) & 1);
+        }
+        bool failed = false;
+        if (active)
+        {
+            u64 key = src_keys[i];
+            const bool is_zero_cell = (i == zero_slot_index);
+            if (is_zero_cell)
+                key = 0;
+            if (!(skip_zero_keys && key == 0 && !is_zero_cell))
+            {
+                const u64 slot = table_emplace(t, key, soft_limit != 0);
+                if (slot == ~0ull)
+                    failed = true;
+                else
+                    for (u32 w = 0; w < n_words; ++w)
+                        global_add_word(t.words + (u64)w * gstride + slot, src_words[(u64)w * src_stride + i], (word_is_f64 >> w) & 1);
+            }
+        }
+        const u64 b = __ballot(failed);
+        if (pending && lane == 0)
+            pending[g] = b;
+        if (b != 0 && lane == 0)
+            t.ctrl->overflow = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_occupied_mask(const u64 * __restrict__ keys, u64 capacity, const AggCtrl * __restrict__ ctrl, u8 * __restrict__ mask)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i <= capacity; i += (u64)gridDim.x * 256)
+        mask[i] = (i == capacity) ? (ctrl->has_zero != 0) : (keys[i] != 0);
+}
+
+__global__ __launch_bounds__(256) void k_fix_zero_key(u64 * __restrict__ keys, u64 capacity)
+{
+    // the zero-key cell's key word is never written by emplace; make it read as 0 for the exported key column
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        keys[capacity] = 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_narrow_keys(const u64 * __restrict__ in, u64 n, T * __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+        out[i] = (T)in[i];
+}
+
+// AvgFraction::divide (AggregateFunctionAvg.h:61-67): Float64(numerator) / denominator
+__global__ __launch_bounds__(256) void k_avg_divide(const u64 * __restrict__ num, const u64 * __restrict__ den, u64 n, int num_type, double * __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        double x;
+        if (num_type == CHGPU_F64)
+            x = __longlong_as_double((long long)num[i]);
+        else if (num_type == CHGPU_I64)
+            x = (double)(i64)num[i];
+        else
+            x = (double)num[i];
+        out[i] = x / (double)den[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static u64 pow2_ceil(u64 x)
+{
+    u64 p = 1;
+    while (p < x)
+        p <<= 1;
+    return p;
+}
+
+static int agg_alloc_table(chgpu_agg * a, u64 capacity, AggTable * t, void ** mem)
+{
+    const size_t cells = capacity + 1;
+    const size_t bytes = cells * 8 * (1 + a->n_words) + 256;
+    void * m = nullptr;
+    CHGPU_HIP(hipMalloc(&m, bytes));
+    hipError_t e = hipMemsetAsync(m, 0, bytes, a->ctx->stream); // HashTableAllocator zero-fills (HashTableAllocator.h:11)
+    if (e != hipSuccess)
+    {
+        (void)hipFree(m);
+        return chgpu_set_error(CHGPU_ERR_DEVICE, "memset: %s", hipGetErrorString(e));
+    }
+    t->ctrl = (AggCtrl *)m;
+    t->keys = (u64 *)((char *)m + 256);
+    t->words = t->keys + cells;
+    t->capacity = capacity;
+    t->max_fill = capacity / 2;
+    *mem = m;
+    return CHGPU_OK;
+}
+
+static int agg_read_ctrl(chgpu_agg * a, AggCtrl * out)
+{
+    CHGPU_TRY(chgpu_read_back(a->ctx, a->t.ctrl, out, sizeof(AggCtrl)));
+    a->n_groups = out->n_groups;
+    CHGPU_REQUIRE(!out->fatal, CHGPU_ERR_LOGICAL, "aggregation table filled completely during a flush");
+    return CHGPU_OK;
+}
+
+// resize (HashTable.h:504-560): new capacity per the reference's grower, rehash every occupied cell
+static int agg_grow(chgpu_agg * a, u64 min_groups, bool has_zero)
+{
+    u64 cap = a->t.capacity;
+    do
+    {
+        // HashTableGrowerWithPrecalculation::increaseSize (HashTable.h:303): degree += degree >= 23 ? 1 : 2
+        cap = cap >= (1ull << 23) ? cap * 2 : cap * 4;
+    } while (cap / 2 <= min_groups);
+    AggTable nt;
+    void * nmem = nullptr;
+    CHGPU_TRY(agg_alloc_table(a, cap, &nt, &nmem));
+    // old cells [0, capacity) plus the out-of-line zero cell when it is set; no soft limit: the new table fits them all
+    const u64 n = a->t.capacity + (has_zero ? 1 : 0);
+    const u32 grid = chgpu_grid_for(a->ctx, n, AGG_THREADS, 8);
+    hipLaunchKernelGGL(k_agg_tuples<AGG_MODE_ALL>, dim3(grid), dim3(AGG_THREADS), 0, a->ctx->stream, nt, a->n_words, a->word_is_f64,
+                       a->t.keys, a->t.words, a->t.capacity + 1, n, 1, has_zero ? a->t.capacity : ~0ull, 0, (u64 *)nullptr);
+    a->ctx->counters[6] += 1;
+    a->ctx->counters[7] += 1;
+    CHGPU_HIP(hipGetLastError());
+    CHGPU_HIP(hipStreamSynchronize(a->ctx->stream));
+    CHGPU_HIP(hipFree(a->table_mem));
+    a->table_mem = nmem;
+    a->t = nt;
+    return CHGPU_OK;
+}
+
+static int agg_ensure_table(chgpu_agg * a)
+{
+    if (a->table_mem)
+        return CHGPU_OK;
+    u64 cap = pow2_ceil(a->size_hint * 2);
+    if (cap < AGG_MIN_CAPACITY)
+        cap = AGG_MIN_CAPACITY;
+    return agg_alloc_table(a, cap, &a->t, &a->table_mem);
+}
+
+extern "C" int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, const int * agg_kinds, const int * arg_types,
+                                uint64_t size_hint, chgpu_agg ** out)
+{
+    CHGPU_REQUIRE(ctx && out && (agg_kinds || n_aggs == 0), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(n_aggs <= AGG_MAX_AGGS, CHGPU_ERR_NOT_IMPLEMENTED, "more than %u aggregate functions: CPU path", AGG_MAX_AGGS);
+    CHGPU_REQUIRE(key_type < 0 || key_type == CHGPU_U32 || key_type == CHGPU_U64 || key_type == CHGPU_I64 || key_type == CHGPU_I32 || key_type == CHGPU_U8,
+                  CHGPU_ERR_NOT_IMPLEMENTED, "GROUP BY key type %d: CPU path", key_type);
+    chgpu_agg * a = new chgpu_agg();
+    a->ctx = ctx;
+    a->key_type = key_type;
+    a->n_aggs = n_aggs;
+    a->size_hint = size_hint;
+    u32 w = 0;
+    for (u32 j = 0; j < n_aggs; ++j)
+    {
+        const int kind = agg_kinds[j];
+        const int at = (kind == CHGPU_AGG_COUNT || !arg_types) ? CHGPU_U64 : arg_types[j];
+        if (kind != CHGPU_AGG_COUNT && kind != CHGPU_AGG_SUM && kind != CHGPU_AGG_AVG)
+        {
+            delete a;
+            return chgpu_set_error(CHGPU_ERR_NOT_IMPLEMENTED, "aggregate function kind %d has no device state: CPU path", kind);
+        }
+        if (kind != CHGPU_AGG_COUNT && !chgpu_type_size(at))
+        {
+            delete a;
+            return chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "bad argument type %d", at);
+        }
+        a->kinds[j] = kind;
+        a->arg_types[j] = at;
+        a->word_off[j] = w;
+        if (kind != CHGPU_AGG_COUNT && at == CHGPU_F64)
+            a->word_is_f64 |= 1u << w;
+        w += kind == CHGPU_AGG_AVG ? 2 : 1;
+    }
+    a->n_words = w;
+    memset(a->host_words, 0, sizeof(a->host_words));
+    *out = a;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_agg_free(chgpu_agg * a)
+{
+    if (!a)
+        return CHGPU_OK;
+    if (a->table_mem)
+        (void)hipFree(a->table_mem);
+    delete a;
+    return CHGPU_OK;
+}
+
+static void agg_fill_desc(const chgpu_agg * a, const chgpu_col * const * arg_cols, AggDesc * d)
+{
+    d->n_aggs = a->n_aggs;
+    d->n_words = a->n_words;
+    d->word_is_f64 = a->word_is_f64;
+    for (u32 j = 0; j < a->n_aggs; ++j)
+    {
+        d->a[j].ptr = (arg_cols && arg_cols[j]) ? arg_cols[j]->data : nullptr;
+        d->a[j].kind = a->kinds[j];
+        d->a[j].arg_type = a->arg_types[j];
+        d->a[j].word = a->word_off[j];
+    }
+}
+
+extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols,
+                                   uint64_t row_begin, uint64_t row_end)
+{
+    CHGPU_REQUIRE(a, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(row_begin <= row_end, CHGPU_ERR_BAD_ARGUMENTS, "row_begin > row_end");
+    chgpu_ctx * ctx = a->ctx;
+    const u64 n = row_end - row_begin;
+    for (u32 j = 0; j < a->n_aggs; ++j)
+    {
+        if (a->kinds[j] == CHGPU_AGG_COUNT)
+            continue;
+        CHGPU_REQUIRE(arg_cols && arg_cols[j], CHGPU_ERR_BAD_ARGUMENTS, "argument column %u is NULL", j);
+        CHGPU_REQUIRE(arg_cols[j]->type == a->arg_types[j], CHGPU_ERR_BAD_ARGUMENTS, "argument column %u has type %d, expected %d", j, arg_cols[j]->type, a->arg_types[j]);
+        CHGPU_REQUIRE(row_end <= arg_cols[j]->rows, CHGPU_ERR_SIZES_MISMATCH, "argument column %u has %llu rows, block ends at %llu", j,
+                      (unsigned long long)arg_cols[j]->rows, (unsigned long long)row_end);
+    }
+    if (a->key_type < 0)
+    {
+        // executeWithoutKeyImpl (Aggregator.cpp:1276-1321): addBatchSinglePlace per function
+        for (u32 j = 0; j < a->n_aggs; ++j)
+        {
+            u64 * st = &a->host_words[a->word_off[j]];
+            if (a->kinds[j] == CHGPU_AGG_COUNT)
+                st[0] += n;
+            else
+            {
+                CHGPU_TRY(chgpu_sum_add_many(ctx, arg_cols[j], row_begin, row_end, st));
+                if (a->kinds[j] == CHGPU_AGG_AVG)
+                    st[1] += n;
+            }
+        }
+        return CHGPU_OK;
+    }
+    CHGPU_REQUIRE(key_col, CHGPU_ERR_BAD_ARGUMENTS, "key column is NULL");
+    CHGPU_REQUIRE(key_col->type == a->key_type, CHGPU_ERR_BAD_ARGUMENTS, "key column has type %d, expected %d", key_col->type, a->key_type);
+    CHGPU_REQUIRE(row_end <= key_col->rows, CHGPU_ERR_SIZES_MISMATCH, "key column has %llu rows, block ends at %llu",
+                  (unsigned long long)key_col->rows, (unsigned long long)row_end);
+    if (n == 0)
+        return CHGPU_OK;
+    CHGPU_TRY(agg_ensure_table(a));
+    AggDesc d;
+    agg_fill_desc(a, arg_cols, &d);
+
+    const u64 n_words64 = (n + 63) / 64;
+    void * scratch = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, n_words64 * sizeof(u64) + 256, &scratch));
+    u64 * pending = (u64 *)scratch;
+
+    // strategy: LDS-staged unless the caller promised a large cardinality (where nearly every key misses the LDS table)
+    const bool use_lds = a->size_hint <= 65536;
+    if (use_lds)
+    {
+        // LDS cells per workgroup: keep (1 + n_words) * 8 * (S+1) <= 32 KiB so 4+ workgroups fit a CU
+        u32 S = 1024;
+        while ((size_t)(S + 1) * 8 * (1 + a->n_words) > 32 * 1024 && S > 64)
+            S >>= 1;
+        // flushes may claim up to grid * (S+1) cells above max fill: keep that inside the slack (capacity/2)
+        u64 max_grid = (a->t.capacity / 2) / (S + 1);
+        u32 grid = chgpu_grid_for(ctx, n, AGG_THREADS, 4);
+        if (grid > max_grid)
+            grid = (u32)(max_grid ? max_grid : 1);
+        const size_t lds = (size_t)(S + 1) * 8 * (1 + a->n_words);
+        hipLaunchKernelGGL(k_agg_rows_lds, dim3(grid), dim3(AGG_THREADS), lds, ctx->stream, a->t, d, key_col->data, a->key_type, row_begin, n, pending, S);
+    }
+    else
+    {
+        const u32 grid = chgpu_grid_for(ctx, n, AGG_THREADS, 8);
+        hipLaunchKernelGGL(k_agg_rows_direct<AGG_MODE_ALL>, dim3(grid), dim3(AGG_THREADS), 0, ctx->stream, a->t, d, key_col->data, a->key_type, row_begin, n, pending);
+    }
+    ctx->counters[6] += 1;
+    ctx->counters[5] += n;
+    CHGPU_HIP(hipGetLastError());
+
+    for (int round = 0; round < 64; ++round)
+    {
+        AggCtrl c;
+        CHGPU_TRY(agg_read_ctrl(a, &c));
+        if (!c.overflow && c.n_groups <= a->t.max_fill)
+            return CHGPU_OK;
+        // resize on overflow (HashTable.h:921-944), then re-run only the rows left pending
+        CHGPU_TRY(agg_grow(a, c.n_groups, c.has_zero != 0));
+        if (!c.overflow)
+            return CHGPU_OK;
+        const u32 grid = chgpu_grid_for(ctx, n, AGG_THREADS, 8);
+        hipLaunchKernelGGL(k_agg_rows_direct<AGG_MODE_PENDING>, dim3(grid), dim3(AGG_THREADS), 0, ctx->stream, a->t, d, key_col->data, a->key_type, row_begin, n, pending);
+        ctx->counters[6] += 1;
+        CHGPU_HIP(hipGetLastError());
+    }
+    return chgpu_set_error(CHGPU_ERR_LOGICAL, "aggregation table did not converge after 64 growth rounds");
+}
+
+// merge tuples (keys + state word columns) with overflow handling
+static int agg_merge_tuples(chgpu_agg * a, const u64 * src_keys, const u64 * src_words, u64 src_stride, u64 n, int skip_zero_keys, u64 zero_slot_index)
+{
+    chgpu_ctx * ctx = a->ctx;
+    if (n == 0)
+        return CHGPU_OK;
+    CHGPU_TRY(agg_ensure_table(a));
+    const u64 n_words64 = (n + 63) / 64;
+    void * scratch = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, n_words64 * sizeof(u64) + 256, &scratch));
+    u64 * pending = (u64 *)scratch;
+    const u32 grid = chgpu_grid_for(ctx, n, AGG_THREADS, 8);
+    hipLaunchKernelGGL(k_agg_tuples<AGG_MODE_ALL>, dim3(grid), dim3(AGG_THREADS), 0, ctx->stream, a->t, a->n_words, a->word_is_f64,
+                       src_keys, src_words, src_stride, n, skip_zero_keys, zero_slot_index, 1, pending);
+    ctx->counters[6] += 1;
+    CHGPU_HIP(hipGetLastError());
+    for (int round = 0; round < 64; ++round)
+    {
+        AggCtrl c;
+        CHGPU_TRY(agg_read_ctrl(a, &c));
+        if (!c.overflow)
+            return CHGPU_OK;
+        CHGPU_TRY(agg_grow(a, c.n_groups, c.has_zero != 0));
+        hipLaunchKernelGGL(k_agg_tuples<AGG_MODE_PENDING>, dim3(grid), dim3(AGG_THREADS), 0, ctx->stream, a->t, a->n_words, a->word_is_f64,
+                           src_keys, src_words, src_stride, n, skip_zero_keys, zero_slot_index, 1, pending);
+        ctx->counters[6] += 1;
+        CHGPU_HIP(hipGetLastError());
+    }
+    return chgpu_set_error(CHGPU_ERR_LOGICAL, "aggregation merge did not converge after 64 growth rounds");
+}
+
+static bool agg_same_shape(const chgpu_agg * x, const chgpu_agg * y)
+{
+    if (x->key_type != y->key_type || x->n_aggs != y->n_aggs)
+        return false;
+    for (u32 j = 0; j < x->n_aggs; ++j)
+        if (x->kinds[j] != y->kinds[j] || x->arg_types[j] != y->arg_types[j])
+            return false;
+    return true;
+}
+
+extern "C" int chgpu_agg_merge(chgpu_agg * dst, const chgpu_agg * src)
+{
+    CHGPU_REQUIRE(dst && src, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(agg_same_shape(dst, src), CHGPU_ERR_BAD_ARGUMENTS, "cannot merge aggregation states of different shape");
+    if (dst->key_type < 0)
+    {
+        // mergeWithoutKeyDataImpl (Aggregator.cpp:2584-2628)
+        for (u32 w = 0; w < dst->n_words; ++w)
+        {
+            if ((dst->word_is_f64 >> w) & 1)
+            {
+                double x, y;
+                memcpy(&x, &dst->host_words[w], 8);
+                memcpy(&y, &src->host_words[w], 8);
+                x += y;
+                memcpy(&dst->host_words[w], &x, 8);
+            }
+            else
+                dst->host_words[w] += src->host_words[w];
+        }
+        return CHGPU_OK;
+    }
+    if (!src->table_mem)
+        return CHGPU_OK;
+    // the source's zero cell participates only when it is set
+    AggCtrl sc;
+    CHGPU_TRY(chgpu_read_back(dst->ctx, src->t.ctrl, &sc, sizeof(sc)));
+    const u64 n = src->t.capacity + (sc.has_zero ? 1 : 0);
+    return agg_merge_tuples(dst, src->t.keys, src->t.words, src->t.capacity + 1, n, 1, sc.has_zero ? src->t.capacity : ~0ull);
+}
+
+extern "C" int chgpu_agg_merge_states(chgpu_agg * dst, const chgpu_col * key_col, const chgpu_col * const * state_cols, uint64_t rows)
+{
+    CHGPU_REQUIRE(dst && state_cols, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    chgpu_ctx * ctx = dst->ctx;
+    for (u32 w = 0; w < dst->n_words; ++w)
+    {
+        CHGPU_REQUIRE(state_cols[w], CHGPU_ERR_BAD_ARGUMENTS, "state column %u is NULL", w);
+        CHGPU_REQUIRE(chgpu_type_size(state_cols[w]->type) == 8, CHGPU_ERR_BAD_ARGUMENTS, "state column %u must be 8 bytes wide", w);
+        CHGPU_REQUIRE(state_cols[w]->rows >= rows, CHGPU_ERR_SIZES_MISMATCH, "state column %u shorter than %llu rows", w, (unsigned long long)rows);
+    }
+    if (dst->key_type < 0)
+    {
+        CHGPU_REQUIRE(rows <= 1, CHGPU_ERR_BAD_ARGUMENTS, "without_key states merge one row at a time");
+        if (rows == 0)
+            return CHGPU_OK;
+        for (u32 w = 0; w < dst->n_words; ++w)
+        {
+            u64 v;
+            CHGPU_TRY(chgpu_read_back(ctx, state_cols[w]->data, &v, 8));
+            if ((dst->word_is_f64 >> w) & 1)
+            {
+                double x, y;
+                memcpy(&x, &dst->host_words[w], 8);
+                memcpy(&y, &v, 8);
+                x += y;
+                memcpy(&dst->host_words[w], &x, 8);
+            }
+            else
+                dst->host_words[w] += v;
+        }
+        return CHGPU_OK;
+    }
+    CHGPU_REQUIRE(key_col && key_col->rows >= rows, CHGPU_ERR_SIZES_MISMATCH, "key column shorter than %llu rows", (unsigned long long)rows);
+    CHGPU_REQUIRE(key_col->type == dst->key_type, CHGPU_ERR_BAD_ARGUMENTS, "key column type mismatch");
+    if (rows == 0)
+        return CHGPU_OK;
+    // stage into one SoA buffer [keys u64][words...] so the tuple kernel sees a single stride
+    chgpu_col * stage = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U64, rows * (1 + dst->n_words), &stage));
+    u64 * sk = (u64 *)stage->data;
+    int rc = CHGPU_OK;
+    {
+        const u32 grid = chgpu_grid_for(ctx, rows, 256, 8);
+        // widen keys with the same zero-extension as the row path (reuse k_narrow in reverse via a tiny lambda kernel)
+        switch (chgpu_type_size(key_col->type))
+        {
+            case 8: rc = hipMemcpyAsync(sk, key_col->data, rows * 8, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; break;
+            default:
+            {
+                extern __global__ void k_widen_keys(const void *, int, u64, u64 *);
+                hipLaunchKernelGGL(k_widen_keys, dim3(grid), dim3(256), 0, ctx->stream, (const void *)key_col->data, key_col->type, (u64)rows, sk);
+                break;
+            }
+        }
+        for (u32 w = 0; w < dst->n_words && rc == CHGPU_OK; ++w)
+            rc = hipMemcpyAsync(sk + (u64)(w + 1) * rows, state_cols[w]->data, rows * 8, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
+    }
+    if (rc == CHGPU_OK)
+        rc = agg_merge_tuples(dst, sk, sk + rows, rows, rows, 0, ~0ull);
+    else
+        chgpu_set_error(CHGPU_ERR_DEVICE, "staging copy failed");
+    chgpu_col_free(stage);
+    return rc;
+}
+
+__global__ __launch_bounds__(256) void k_widen_keys(const void * keys, int type, u64 n, u64 * out)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+        out[i] = load_key_zext(keys, type, i);
+}
+
+extern "C" int chgpu_agg_size(chgpu_agg * a, uint64_t * groups)
+{
+    CHGPU_REQUIRE(a && groups, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    if (a->key_type < 0)
+    {
+        *groups = 1; // no-key aggregation always yields one row (AggregatingTransform.cpp:700-708)
+        return CHGPU_OK;
+    }
+    if (!a->table_mem)
+    {
+        *groups = 0;
+        return CHGPU_OK;
+    }
+    AggCtrl c;
+    CHGPU_TRY(agg_read_ctrl(a, &c));
+    *groups = c.n_groups;
+    return CHGPU_OK;
+}
+
+// keys + raw state words compacted out of the table (table order; the reference's order is unspecified too)
+static int agg_export(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** word_cols /* [n_words] */, u64 * groups)
+{
+    chgpu_ctx * ctx = a->ctx;
+    if (a->key_type < 0)
+    {
+        for (u32 w = 0; w < a->n_words; ++w)
+        {
+            CHGPU_TRY(chgpu_col_upload(ctx, ((a->word_is_f64 >> w) & 1) ? CHGPU_F64 : CHGPU_U64, &a->host_words[w], 1, &word_cols[w]));
+        }
+        if (keys_out)
+            *keys_out = nullptr;
+        *groups = 1;
+        return CHGPU_OK;
+    }
+    if (!a->table_mem)
+    {
+        if (keys_out)
+            CHGPU_TRY(chgpu_col_new(ctx, a->key_type, 0, keys_out));
+        for (u32 w = 0; w < a->n_words; ++w)
+            CHGPU_TRY(chgpu_col_new(ctx, ((a->word_is_f64 >> w) & 1) ? CHGPU_F64 : CHGPU_U64, 0, &word_cols[w]));
+        *groups = 0;
+        return CHGPU_OK;
+    }
+    const u64 cells = a->t.capacity + 1;
+    chgpu_col * mask = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U8, cells, &mask));
+    const u32 grid = chgpu_grid_for(ctx, cells, 256, 8);
+    hipLaunchKernelGGL(k_fix_zero_key, dim3(1), dim3(64), 0, ctx->stream, a->t.keys, a->t.capacity);
+    hipLaunchKernelGGL(k_occupied_mask, dim3(grid), dim3(256), 0, ctx->stream, a->t.keys, a->t.capacity, a->t.ctrl, (u8 *)mask->data);
+    ctx->counters[6] += 2;
+    int rc = CHGPU_OK;
+    u64 n_out = 0;
+    chgpu_col view;
+    view.ctx = ctx;
+    view.rows = cells;
+    view.owns = false;
+    // keys
+    chgpu_col * k64 = nullptr;
+    view.type = CHGPU_U64;
+    view.data = a->t.keys;
+    rc = chgpu_filter(ctx, &view, mask, 0, &k64, &n_out);
+    for (u32 w = 0; w < a->n_words && rc == CHGPU_OK; ++w)
+    {
+        view.type = ((a->word_is_f64 >> w) & 1) ? CHGPU_F64 : CHGPU_U64;
+        view.data = a->t.words + (u64)w * cells;
+        u64 nw = 0;
+        rc = chgpu_filter(ctx, &view, mask, 0, &word_cols[w], &nw);
+    }
+    chgpu_col_free(mask);
+    if (rc != CHGPU_OK)
+    {
+        chgpu_col_free(k64);
+        return rc;
+    }
+    if (keys_out)
+    {
+        if (chgpu_type_size(a->key_type) == 8)
+        {
+            k64->type = a->key_type;
+            *keys_out = k64;
+        }
+        else
+        {
+            // insertKeyIntoColumns casts the UInt64 table key back to the column type
+            chgpu_col * kn = nullptr;
+            rc = chgpu_col_new(ctx, a->key_type, n_out, &kn);
+            if (rc == CHGPU_OK && n_out)
+            {
+                const u32 g2 = chgpu_grid_for(ctx, n_out, 256, 8);
+                if (chgpu_type_size(a->key_type) == 4)
+                    hipLaunchKernelGGL(k_narrow_keys<u32>, dim3(g2), dim3(256), 0, ctx->stream, (const u64 *)k64->data, n_out, (u32 *)kn->data);
+                else
+                    hipLaunchKernelGGL(k_narrow_keys<u8>, dim3(g2), dim3(256), 0, ctx->stream, (const u64 *)k64->data, n_out, (u8 *)kn->data);
+                ctx->counters[6] += 1;
+            }
+            chgpu_col_free(k64); // hipFree synchronises: the narrow kernel has finished reading it
+            if (rc != CHGPU_OK)
+                return rc;
+            *keys_out = kn;
+        }
+    }
+    else
+        chgpu_col_free(k64);
+    *groups = n_out;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_agg_export_states(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** state_cols, uint64_t * groups)
+{
+    CHGPU_REQUIRE(a && state_cols && groups, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    return agg_export(a, keys_out, state_cols, groups);
+}
+
+extern "C" int chgpu_agg_finalize(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** res_cols, uint64_t * groups)
+{
+    CHGPU_REQUIRE(a && res_cols && groups, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    chgpu_ctx * ctx = a->ctx;
+    chgpu_col * words[AGG_MAX_WORDS] = {nullptr};
+    u64 n = 0;
+    CHGPU_TRY(agg_export(a, keys_out, words, &n));
+    int rc = CHGPU_OK;
+    for (u32 j = 0; j < a->n_aggs; ++j)
+    {
+        const u32 w = a->word_off[j];
+        if (a->kinds[j] == CHGPU_AGG_COUNT)
+        {
+            words[w]->type = CHGPU_U64;
+            res_cols[j] = words[w];
+            words[w] = nullptr;
+        }
+        else if (a->kinds[j] == CHGPU_AGG_SUM)
+        {
+            words[w]->type = chgpu_sum_result_type(a->arg_types[j]); // SumSimple: Int64 / UInt64 / Float64
+            res_cols[j] = words[w];
+            words[w] = nullptr;
+        }
+        else
+        {
+            chgpu_col * r = nullptr;
+            rc = chgpu_col_new(ctx, CHGPU_F64, n, &r);
+            if (rc != CHGPU_OK)
+                break;
+            if (n)
+            {
+                hipLaunchKernelGGL(k_avg_divide, dim3(chgpu_grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, (const u64 *)words[w]->data,
+                                   (const u64 *)words[w + 1]->data, n, chgpu_sum_result_type(a->arg_types[j]), (double *)r->data);
+                ctx->counters[6] += 1;
+            }
+            res_cols[j] = r;
+        }
+    }
+    for (u32 w = 0; w < a->n_words; ++w)
+        if (words[w])
+            chgpu_col_free(words[w]); // hipFree synchronises with k_avg_divide
+    *groups = n;
+    return rc;
+}

@@ -1,0 +1,277 @@
+// core.hip — context, device columns (PaddedPODArray pinned into HBM), scratch, error plumbing of libchgpu.so.
+// Reference surfaces: PaddedPODArray (src/Common/PODArray.h:51-57,94-98), IColumn::cut (src/Columns/IColumn.h:118-121),
+// ProfileEvents counters (src/Common/ProfileEvents.cpp:1034-1035,245-247), IProcessor::elapsed_ns (IProcessor.h:359-364).
+#include "chgpu_internal.h"
+
+static thread_local char g_last_error[512] = "";
+
+int chgpu_set_error(int code, const char * fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char * chgpu_last_error(void) { return g_last_error; }
+extern "C" int chgpu_abi_version(void) { return CHGPU_ABI_VERSION; }
+
+extern "C" int chgpu_ctx_create(int device_id, void * hip_stream, chgpu_ctx ** out)
+{
+    CHGPU_REQUIRE(out, CHGPU_ERR_BAD_ARGUMENTS, "chgpu_ctx_create: out is NULL");
+    int n_dev = 0;
+    CHGPU_HIP(hipGetDeviceCount(&n_dev));
+    CHGPU_REQUIRE(device_id >= 0 && device_id < n_dev, CHGPU_ERR_BAD_ARGUMENTS, "device %d out of range (%d devices)", device_id, n_dev);
+    CHGPU_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    CHGPU_HIP(hipGetDeviceProperties(&prop, device_id));
+    chgpu_ctx * ctx = new chgpu_ctx();
+    ctx->device = device_id;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hip_stream)
+    {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->owns_stream = false;
+    }
+    else
+    {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess)
+        {
+            delete ctx;
+            return chgpu_set_error(CHGPU_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        ctx->owns_stream = true;
+    }
+    (void)hipEventCreate(&ctx->ev_start);
+    (void)hipEventCreate(&ctx->ev_stop);
+    *out = ctx;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_ctx_destroy(chgpu_ctx * ctx)
+{
+    if (!ctx)
+        return CHGPU_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->crc_lut_dev) (void)hipFree(ctx->crc_lut_dev);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_ctx_synchronize(chgpu_ctx * ctx)
+{
+    CHGPU_REQUIRE(ctx, CHGPU_ERR_BAD_ARGUMENTS, "ctx is NULL");
+    CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_ctx_counters(chgpu_ctx * ctx, uint64_t out[CHGPU_N_COUNTERS])
+{
+    CHGPU_REQUIRE(ctx && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    memcpy(out, ctx->counters, sizeof(ctx->counters));
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_timer_start(chgpu_ctx * ctx)
+{
+    CHGPU_REQUIRE(ctx, CHGPU_ERR_BAD_ARGUMENTS, "ctx is NULL");
+    CHGPU_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_timer_stop_ms(chgpu_ctx * ctx, double * elapsed_ms)
+{
+    CHGPU_REQUIRE(ctx && elapsed_ms, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
+    CHGPU_HIP(hipEventSynchronize(ctx->ev_stop));
+    float ms = 0;
+    CHGPU_HIP(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    *elapsed_ms = ms;
+    return CHGPU_OK;
+}
+
+int chgpu_scratch(chgpu_ctx * ctx, size_t bytes, void ** out)
+{
+    if (bytes > ctx->scratch_bytes)
+    {
+        // growing frees the old buffer: earlier kernels on this stream may still read it -> drain first
+        CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch)
+            CHGPU_HIP(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        size_t want = bytes + bytes / 4 + (1 << 20);
+        CHGPU_HIP(hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return CHGPU_OK;
+}
+
+int chgpu_pinned(chgpu_ctx * ctx, size_t bytes, void ** out)
+{
+    if (bytes > ctx->pinned_bytes)
+    {
+        CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->pinned)
+            CHGPU_HIP(hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+        size_t want = bytes < 4096 ? 4096 : bytes;
+        CHGPU_HIP(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_bytes = want;
+    }
+    *out = ctx->pinned;
+    return CHGPU_OK;
+}
+
+int chgpu_read_back(chgpu_ctx * ctx, const void * dev, void * host, size_t bytes)
+{
+    void * stage = nullptr;
+    CHGPU_TRY(chgpu_pinned(ctx, bytes, &stage));
+    CHGPU_HIP(hipMemcpyAsync(stage, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(host, stage, bytes);
+    return CHGPU_OK;
+}
+
+int chgpu_col_new(chgpu_ctx * ctx, int type, u64 rows, chgpu_col ** out)
+{
+    size_t es = chgpu_type_size(type);
+    CHGPU_REQUIRE(es, CHGPU_ERR_BAD_ARGUMENTS, "unknown column type %d", type);
+    CHGPU_HIP(hipSetDevice(ctx->device));
+    size_t bytes = rows * es + 2 * CHGPU_PAD;
+    void * base = nullptr;
+    CHGPU_HIP(hipMalloc(&base, bytes));
+    chgpu_col * c = new chgpu_col();
+    c->ctx = ctx;
+    c->type = type;
+    c->rows = rows;
+    c->base = base;
+    c->data = (char *)base + CHGPU_PAD;
+    c->owns = true;
+    *out = c;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_col_alloc(chgpu_ctx * ctx, int type, uint64_t rows, chgpu_col ** out)
+{
+    CHGPU_REQUIRE(ctx && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    return chgpu_col_new(ctx, type, rows, out);
+}
+
+extern "C" int chgpu_col_upload(chgpu_ctx * ctx, int type, const void * host_ptr, uint64_t rows, chgpu_col ** out)
+{
+    CHGPU_REQUIRE(ctx && out && (host_ptr || rows == 0), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    chgpu_col * c = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, type, rows, &c));
+    if (rows)
+    {
+        hipError_t e = hipMemcpyAsync(c->data, host_ptr, rows * chgpu_type_size(type), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream); // the host buffer is the caller's: do not keep reading it
+        if (e != hipSuccess)
+        {
+            chgpu_col_free(c);
+            return chgpu_set_error(CHGPU_ERR_DEVICE, "upload: %s", hipGetErrorString(e));
+        }
+    }
+    *out = c;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_col_wrap(chgpu_ctx * ctx, int type, void * device_ptr, uint64_t rows, chgpu_col ** out)
+{
+    CHGPU_REQUIRE(ctx && out && (device_ptr || rows == 0), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(chgpu_type_size(type), CHGPU_ERR_BAD_ARGUMENTS, "unknown column type %d", type);
+    CHGPU_REQUIRE(((uintptr_t)device_ptr % chgpu_type_size(type)) == 0, CHGPU_ERR_BAD_ARGUMENTS, "device pointer not element-aligned");
+    chgpu_col * c = new chgpu_col();
+    c->ctx = ctx;
+    c->type = type;
+    c->rows = rows;
+    c->data = device_ptr;
+    c->owns = false;
+    *out = c;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_col_slice(chgpu_ctx * ctx, const chgpu_col * col, uint64_t start, uint64_t rows, chgpu_col ** out)
+{
+    CHGPU_REQUIRE(ctx && col && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(start <= col->rows && rows <= col->rows - start, CHGPU_ERR_BAD_ARGUMENTS,
+                  "cut(%llu,%llu) out of bounds of a column of %llu rows", (unsigned long long)start, (unsigned long long)rows, (unsigned long long)col->rows);
+    return chgpu_col_wrap(ctx, col->type, (char *)col->data + start * chgpu_type_size(col->type), rows, out);
+}
+
+extern "C" int chgpu_col_download(chgpu_ctx * ctx, const chgpu_col * col, void * host_ptr, uint64_t rows)
+{
+    CHGPU_REQUIRE(ctx && col && (host_ptr || rows == 0), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(rows <= col->rows, CHGPU_ERR_SIZES_MISMATCH, "download of %llu rows from a column of %llu", (unsigned long long)rows, (unsigned long long)col->rows);
+    if (rows)
+    {
+        CHGPU_HIP(hipMemcpyAsync(host_ptr, col->data, rows * chgpu_type_size(col->type), hipMemcpyDeviceToHost, ctx->stream));
+        CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return CHGPU_OK;
+}
+
+extern "C" uint64_t chgpu_col_rows(const chgpu_col * col) { return col ? col->rows : 0; }
+extern "C" int chgpu_col_type(const chgpu_col * col) { return col ? col->type : -1; }
+extern "C" void * chgpu_col_device_ptr(const chgpu_col * col) { return col ? col->data : nullptr; }
+
+extern "C" int chgpu_col_free(chgpu_col * col)
+{
+    if (!col)
+        return CHGPU_OK;
+    if (col->owns && col->base)
+    {
+        bool last = true;
+        if (col->shared_refs)
+        {
+            last = --*col->shared_refs == 0;
+            if (last)
+                delete col->shared_refs;
+        }
+        // hipFree synchronises the device: safe against kernels still reading the buffer
+        if (last)
+            (void)hipFree(col->base);
+    }
+    delete col;
+    return CHGPU_OK;
+}
+
+// CRC32-C slice-by-8 tables for the bit-exact shard/bucket hash (src/Common/HashTable/Hash.h:63-66).
+// lut[j*256+b] = crc(0, byte b at position j), lut[2048] = crc(-1, 0).
+int chgpu_crc_lut(chgpu_ctx * ctx, const u32 ** lut_dev)
+{
+    if (!ctx->crc_lut_dev)
+    {
+        std::vector<u32> lut(8 * 256 + 1);
+        auto soft = [](u64 x, u32 crc) {
+            for (int i = 0; i < 8; ++i)
+            {
+                crc ^= (u32)((x >> (8 * i)) & 0xFF);
+                for (int k = 0; k < 8; ++k)
+                    crc = (crc >> 1) ^ (0x82F63B78u & (0u - (crc & 1u)));
+            }
+            return crc;
+        };
+        for (int j = 0; j < 8; ++j)
+            for (int b = 0; b < 256; ++b)
+                lut[j * 256 + b] = soft((u64)b << (8 * j), 0);
+        lut[2048] = soft(0, 0xFFFFFFFFu);
+        CHGPU_HIP(hipMalloc((void **)&ctx->crc_lut_dev, lut.size() * sizeof(u32)));
+        CHGPU_HIP(hipMemcpyAsync(ctx->crc_lut_dev, lut.data(), lut.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+        CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *lut_dev = ctx->crc_lut_dev;
+    return CHGPU_OK;
+}

@@ -1,0 +1,901 @@
+// filter_kernels.hip — comparison masks, order-preserving stream compaction, no-key sum/count and the fused
+// predicate+sum kernel (configs C1/C2 of BASELINE.json).  gfx950: wave64 ballots, 16-B-per-lane coalesced loads.
+//
+// Reference loops replaced (file:line in the reference checkout):
+//   k_cmp_mask          NumComparisonImpl::vectorConstant        src/Functions/FunctionsComparison.h:204-245
+//   k_count_mask        countBytesInFilter                       src/Columns/ColumnsCommon.cpp:31-58
+//   k_filter_*          ColumnVector<T>::filter/doFilterAligned   src/Columns/ColumnVector.cpp:559-724
+//   k_filter_sum        FilterTransform::doTransform + AggregateFunctionSumData::addMany/Count
+//                                                                src/Processors/Transforms/FilterTransform.cpp:136-256,
+//                                                                src/AggregateFunctions/AggregateFunctionSum.h:62-103
+//   k_index/k_replicate ColumnVector<T>::indexImpl / replicate    src/Columns/ColumnVector.cpp:1121-1143, 879-907
+#include "chgpu_internal.h"
+
+#include <type_traits>
+
+// ---------------------------------------------------------------------------------------------
+// predicates
+// ---------------------------------------------------------------------------------------------
+
+// Integer comparison against a constant, for any op and any signedness mix, as ONE unsigned range test on an
+// order-preserving key: pass = ((key(a) - lo) <= span) != invert.  The host folds accurate::lessOp/equalsOp
+// (src/Core/AccurateComparison.h:20-130: mixed-sign operands compare mathematically) into lo/span/invert.
+struct IntRangePred
+{
+    u64 lo, span, flip;
+    u32 invert;
+    template <typename T>
+    __device__ __forceinline__ bool operator()(T a) const
+    {
+        u64 key;
+        if constexpr (std::is_signed<T>::value)
+            key = (u64)(i64)a ^ flip; // sign-extend, then flip the sign bit
+        else
+            key = (u64)a ^ flip;
+        return ((key - lo) <= span) != (invert != 0);
+    }
+};
+
+// Float64 column vs Float64 constant: IEEE semantics are exactly the reference's (any NaN -> false, != -> true)
+template <int OP>
+struct F64Pred
+{
+    double s;
+    __device__ __forceinline__ bool operator()(double a) const
+    {
+        if constexpr (OP == CHGPU_EQ) return a == s;
+        if constexpr (OP == CHGPU_NE) return a != s;
+        if constexpr (OP == CHGPU_LT) return a < s;
+        if constexpr (OP == CHGPU_GT) return a > s;
+        if constexpr (OP == CHGPU_LE) return a <= s;
+        return a >= s;
+    }
+};
+
+struct TruePred
+{
+    template <typename T>
+    __device__ __forceinline__ bool operator()(T) const { return true; }
+};
+
+struct CmpSpec
+{
+    bool is_f64 = false;
+    int op = 0;
+    double fs = 0;
+    IntRangePred ip{0, 0, 0, 0};
+};
+
+// Fold (column type, op, scalar) into a CmpSpec; CHGPU_ERR_NOT_IMPLEMENTED for unsupported type mixes.
+static int make_cmp_spec(int col_type, int op, int scalar_type, const void * scalar, CmpSpec * spec)
+{
+    CHGPU_REQUIRE(op >= CHGPU_EQ && op <= CHGPU_GE, CHGPU_ERR_BAD_ARGUMENTS, "unknown comparison op %d", op);
+    CHGPU_REQUIRE(scalar, CHGPU_ERR_BAD_ARGUMENTS, "scalar is NULL");
+    if (col_type == CHGPU_F64)
+    {
+        CHGPU_REQUIRE(scalar_type == CHGPU_F64, CHGPU_ERR_NOT_IMPLEMENTED, "Float64 column vs non-Float64 constant: CPU path");
+        spec->is_f64 = true;
+        spec->op = op;
+        spec->fs = *(const double *)scalar;
+        return CHGPU_OK;
+    }
+    CHGPU_REQUIRE(chgpu_type_is_int(col_type), CHGPU_ERR_BAD_ARGUMENTS, "unknown column type %d", col_type);
+    CHGPU_REQUIRE(chgpu_type_is_int(scalar_type), CHGPU_ERR_NOT_IMPLEMENTED, "integer column vs Float64 constant: CPU path");
+    __int128 s = 0;
+    switch (scalar_type)
+    {
+        case CHGPU_I64: s = *(const i64 *)scalar; break;
+        case CHGPU_U64: s = *(const u64 *)scalar; break;
+        case CHGPU_U32: s = *(const u32 *)scalar; break;
+        case CHGPU_I32: s = *(const i32 *)scalar; break;
+        case CHGPU_U8: s = *(const u8 *)scalar; break;
+        default: return chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "unknown scalar type %d", scalar_type);
+    }
+    const bool sgn = chgpu_type_is_signed(col_type);
+    // the 64-bit extension domain of the column's signedness class
+    const __int128 dmin = sgn ? -((__int128)1 << 63) : 0;
+    const __int128 dmax = sgn ? (((__int128)1 << 63) - 1) : (((__int128)1 << 64) - 1);
+    const u64 flip = sgn ? (1ull << 63) : 0;
+    auto key = [&](__int128 v) { return (u64)v ^ flip; }; // (u64) of an in-domain value is its two's complement
+    __int128 lo = dmin, hi = dmax;
+    bool none = false, invert = false;
+    switch (op)
+    {
+        case CHGPU_EQ: if (s < dmin || s > dmax) none = true; else lo = hi = s; break;
+        case CHGPU_NE: if (s < dmin || s > dmax) none = true; else lo = hi = s; invert = true; break;
+        case CHGPU_LT: if (s <= dmin) none = true; else if (s <= dmax) hi = s - 1; break;
+        case CHGPU_LE: if (s < dmin) none = true; else if (s < dmax) hi = s; break;
+        case CHGPU_GT: if (s >= dmax) none = true; else if (s >= dmin) lo = s + 1; break;
+        case CHGPU_GE: if (s > dmax) none = true; else if (s > dmin) lo = s; break;
+    }
+    if (none)
+    {
+        // empty range == full range inverted (for NE the inversion cancels: everything passes)
+        lo = dmin;
+        hi = dmax;
+        invert = !invert;
+    }
+    spec->is_f64 = false;
+    spec->op = op;
+    spec->ip.lo = key(lo);
+    spec->ip.span = key(hi) - key(lo);
+    spec->ip.flip = flip;
+    spec->ip.invert = invert ? 1u : 0u;
+    return CHGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// vector load helpers: 16 B per lane
+// ---------------------------------------------------------------------------------------------
+template <typename T, int N>
+struct alignas(sizeof(T) * N) Vec
+{
+    T v[N];
+};
+
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+// streaming (read-once) load: 16-B vectors go out as global_load_dwordx4 ... nt so an 8 GB scan does not churn L2/MALL
+template <typename V>
+__device__ __forceinline__ V load_stream(const V * p)
+{
+    if constexpr (sizeof(V) == 16)
+    {
+        u32x4 r = __builtin_nontemporal_load((const u32x4 *)p);
+        return __builtin_bit_cast(V, r);
+    }
+    else
+        return *p;
+}
+
+template <typename T>
+struct AccOf { typedef u64 type; };
+template <>
+struct AccOf<double> { typedef double type; };
+
+template <typename T>
+__device__ __forceinline__ typename AccOf<T>::type widen(T a)
+{
+    if constexpr (std::is_same<T, double>::value)
+        return a;
+    else if constexpr (std::is_signed<T>::value)
+        return (u64)(i64)a; // wrap-around two's complement sum (AggregateFunctionSum.h:36-39)
+    else
+        return (u64)a;
+}
+
+__device__ __forceinline__ u64 acc_bits(u64 v) { return v; }
+__device__ __forceinline__ u64 acc_bits(double v) { return (u64)__double_as_longlong(v); }
+__device__ __forceinline__ u64 wave_reduce_acc(u64 v) { return wave_reduce_add_u64(v); }
+__device__ __forceinline__ double wave_reduce_acc(double v) { return wave_reduce_add_f64(v); }
+
+// ---------------------------------------------------------------------------------------------
+// fused predicate -> sum(val), count()      (the dominant kernel of config C2: 8 B/row, one pass)
+// ---------------------------------------------------------------------------------------------
+static constexpr int FS_THREADS = 256;
+static constexpr int FS_UNROLL = 4;
+
+template <typename T, int VEC, bool SAME, bool HAS_COND, typename Pred>
+__global__ __launch_bounds__(FS_THREADS) void k_filter_sum(const T * __restrict__ pred_col, const T * __restrict__ val_col,
+                                                           const u8 * __restrict__ cond, u64 n, Pred p,
+                                                           u64 * __restrict__ part_sum, u64 * __restrict__ part_cnt)
+{
+    typedef typename AccOf<T>::type Acc;
+    typedef Vec<T, VEC> V;
+    typedef Vec<u8, VEC> CV;
+    const u64 nvec = n / VEC;
+    const u64 tid = (u64)blockIdx.x * FS_THREADS + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * FS_THREADS;
+    const V * __restrict__ pv = (const V *)pred_col;
+    const V * __restrict__ vv = (const V *)val_col;
+    const CV * __restrict__ cv = (const CV *)cond;
+    Acc s = 0;
+    u64 c = 0;
+
+    u64 i = tid;
+    // main loop: FS_UNROLL independent 16-B loads in flight per lane per column
+    for (; i + (FS_UNROLL - 1) * stride < nvec; i += FS_UNROLL * stride)
+    {
+        V a[FS_UNROLL], b[FS_UNROLL];
+        CV m[FS_UNROLL];
+#pragma unroll
+        for (int k = 0; k < FS_UNROLL; ++k)
+        {
+            a[k] = load_stream(&pv[i + k * stride]);
+            if constexpr (!SAME)
+                b[k] = load_stream(&vv[i + k * stride]);
+            if constexpr (HAS_COND)
+                m[k] = cv[i + k * stride];
+        }
+#pragma unroll
+        for (int k = 0; k < FS_UNROLL; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+            {
+                bool pass = p(a[k].v[e]);
+                if constexpr (HAS_COND)
+                    pass = pass && (m[k].v[e] != 0);
+                T x = SAME ? a[k].v[e] : b[k].v[e];
+                s += pass ? widen<T>(x) : Acc(0);
+                c += pass ? 1 : 0;
+            }
+    }
+    for (; i < nvec; i += stride)
+    {
+        V a = pv[i];
+        V b;
+        if constexpr (!SAME)
+            b = vv[i];
+        CV m;
+        if constexpr (HAS_COND)
+            m = cv[i];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+        {
+            bool pass = p(a.v[e]);
+            if constexpr (HAS_COND)
+                pass = pass && (m.v[e] != 0);
+            T x = SAME ? a.v[e] : b.v[e];
+            s += pass ? widen<T>(x) : Acc(0);
+            c += pass ? 1 : 0;
+        }
+    }
+    // scalar tail (n % VEC rows)
+    {
+        const u64 r = nvec * VEC + tid;
+        if (r < n)
+        {
+            bool pass = p(pred_col[r]);
+            if constexpr (HAS_COND)
+                pass = pass && (cond[r] != 0);
+            T x = SAME ? pred_col[r] : val_col[r];
+            s += pass ? widen<T>(x) : Acc(0);
+            c += pass ? 1 : 0;
+        }
+    }
+
+    // wave -> workgroup reduction; one partial per workgroup, folded in fixed order by k_filter_sum_finish
+    __shared__ u64 lds_s[FS_THREADS / WAVE];
+    __shared__ u64 lds_c[FS_THREADS / WAVE];
+    s = wave_reduce_acc(s);
+    c = wave_reduce_add_u64(c);
+    if ((threadIdx.x & 63) == 0)
+    {
+        lds_s[threadIdx.x >> 6] = acc_bits(s);
+        lds_c[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        u64 cc = 0;
+        if constexpr (std::is_same<Acc, double>::value)
+        {
+            double ss = 0;
+            for (int w = 0; w < FS_THREADS / WAVE; ++w)
+            {
+                ss += __longlong_as_double((long long)lds_s[w]);
+                cc += lds_c[w];
+            }
+            part_sum[blockIdx.x] = acc_bits(ss);
+        }
+        else
+        {
+            u64 ss = 0;
+            for (int w = 0; w < FS_THREADS / WAVE; ++w)
+            {
+                ss += lds_s[w];
+                cc += lds_c[w];
+            }
+            part_sum[blockIdx.x] = ss;
+        }
+        part_cnt[blockIdx.x] = cc;
+    }
+}
+
+template <bool IS_F64>
+__global__ __launch_bounds__(256) void k_filter_sum_finish(const u64 * __restrict__ part_sum, const u64 * __restrict__ part_cnt,
+                                                           u32 n_parts, u64 * __restrict__ result /* {sum bits, count} */)
+{
+    __shared__ u64 lds_s[4];
+    __shared__ u64 lds_c[4];
+    u64 c = 0;
+    u64 sb;
+    if constexpr (IS_F64)
+    {
+        double s = 0;
+        for (u32 i = threadIdx.x; i < n_parts; i += 256)
+        {
+            s += __longlong_as_double((long long)part_sum[i]);
+            c += part_cnt[i];
+        }
+        s = wave_reduce_add_f64(s);
+        sb = acc_bits(s);
+    }
+    else
+    {
+        u64 s = 0;
+        for (u32 i = threadIdx.x; i < n_parts; i += 256)
+        {
+            s += part_sum[i];
+            c += part_cnt[i];
+        }
+        sb = wave_reduce_add_u64(s);
+    }
+    c = wave_reduce_add_u64(c);
+    if ((threadIdx.x & 63) == 0)
+    {
+        lds_s[threadIdx.x >> 6] = sb;
+        lds_c[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        u64 cc = lds_c[0] + lds_c[1] + lds_c[2] + lds_c[3];
+        if constexpr (IS_F64)
+        {
+            double ss = 0;
+            for (int w = 0; w < 4; ++w)
+                ss += __longlong_as_double((long long)lds_s[w]);
+            result[0] = acc_bits(ss);
+        }
+        else
+            result[0] = lds_s[0] + lds_s[1] + lds_s[2] + lds_s[3];
+        result[1] = cc;
+    }
+}
+
+template <typename T, typename Pred>
+static int launch_filter_sum_t(chgpu_ctx * ctx, const void * pred, const void * val, const u8 * cond, u64 n, Pred p, u64 * result_dev)
+{
+    constexpr int VECW = 16 / sizeof(T);
+    const bool same = (pred == val);
+    const bool aligned = (((uintptr_t)pred | (uintptr_t)val) & 15) == 0 && (!cond || ((uintptr_t)cond % VECW) == 0);
+    // persistent-style grid: 8 workgroups of 256 per CU (2048 lanes = full occupancy at <= 64 VGPRs), grid-stride
+    const u32 grid = chgpu_grid_for(ctx, (n + VECW - 1) / VECW, FS_THREADS, 8);
+    void * scratch = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, (size_t)grid * 2 * sizeof(u64), &scratch));
+    u64 * part_sum = (u64 *)scratch;
+    u64 * part_cnt = part_sum + grid;
+    const T * pp = (const T *)pred;
+    const T * vp = (const T *)val;
+#define FS_LAUNCH(VEC, SAME, HC) \
+    hipLaunchKernelGGL((k_filter_sum<T, VEC, SAME, HC, Pred>), dim3(grid), dim3(FS_THREADS), 0, ctx->stream, pp, vp, cond, n, p, part_sum, part_cnt)
+    if (aligned)
+    {
+        if (cond) { if (same) FS_LAUNCH(VECW, true, true); else FS_LAUNCH(VECW, false, true); }
+        else      { if (same) FS_LAUNCH(VECW, true, false); else FS_LAUNCH(VECW, false, false); }
+    }
+    else
+    {
+        if (cond) { if (same) FS_LAUNCH(1, true, true); else FS_LAUNCH(1, false, true); }
+        else      { if (same) FS_LAUNCH(1, true, false); else FS_LAUNCH(1, false, false); }
+    }
+#undef FS_LAUNCH
+    hipLaunchKernelGGL((k_filter_sum_finish<std::is_same<T, double>::value>), dim3(1), dim3(256), 0, ctx->stream, part_sum, part_cnt, grid, result_dev);
+    ctx->counters[6] += 2;
+    CHGPU_HIP(hipGetLastError());
+    return CHGPU_OK;
+}
+
+template <typename Pred>
+static int launch_filter_sum_int(chgpu_ctx * ctx, int type, const void * pred, const void * val, const u8 * cond, u64 n, Pred p, u64 * result_dev)
+{
+    switch (type)
+    {
+        case CHGPU_I64: return launch_filter_sum_t<i64, Pred>(ctx, pred, val, cond, n, p, result_dev);
+        case CHGPU_U64: return launch_filter_sum_t<u64, Pred>(ctx, pred, val, cond, n, p, result_dev);
+        case CHGPU_U32: return launch_filter_sum_t<u32, Pred>(ctx, pred, val, cond, n, p, result_dev);
+        case CHGPU_I32: return launch_filter_sum_t<i32, Pred>(ctx, pred, val, cond, n, p, result_dev);
+        case CHGPU_U8: return launch_filter_sum_t<u8, Pred>(ctx, pred, val, cond, n, p, result_dev);
+        default: return chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "unsupported column type %d", type);
+    }
+}
+
+static int launch_filter_sum(chgpu_ctx * ctx, int type, const void * pred, const void * val, const u8 * cond, u64 n,
+                             const CmpSpec * spec /* NULL = no predicate */, u64 * result_dev)
+{
+    if (!spec)
+    {
+        if (type == CHGPU_F64)
+            return launch_filter_sum_t<double, TruePred>(ctx, pred, val, cond, n, TruePred(), result_dev);
+        return launch_filter_sum_int<TruePred>(ctx, type, pred, val, cond, n, TruePred(), result_dev);
+    }
+    if (spec->is_f64)
+    {
+        switch (spec->op)
+        {
+#define F64CASE(OP) case OP: return launch_filter_sum_t<double, F64Pred<OP>>(ctx, pred, val, cond, n, F64Pred<OP>{spec->fs}, result_dev);
+            F64CASE(CHGPU_EQ) F64CASE(CHGPU_NE) F64CASE(CHGPU_LT) F64CASE(CHGPU_GT) F64CASE(CHGPU_LE) F64CASE(CHGPU_GE)
+#undef F64CASE
+        }
+        return chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "bad op");
+    }
+    return launch_filter_sum_int<IntRangePred>(ctx, type, pred, val, cond, n, spec->ip, result_dev);
+}
+
+extern "C" int chgpu_filter_sum_async(chgpu_ctx * ctx, const chgpu_col * pred, int op, int scalar_type, const void * scalar,
+                                      const chgpu_col * val, chgpu_col * result)
+{
+    CHGPU_REQUIRE(ctx && pred && val && result, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(pred->rows == val->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of predicate column (%llu) doesn't match size of value column (%llu)",
+                  (unsigned long long)pred->rows, (unsigned long long)val->rows);
+    CHGPU_REQUIRE(pred->type == val->type, CHGPU_ERR_NOT_IMPLEMENTED, "fused filter+sum needs predicate and value columns of one type");
+    CHGPU_REQUIRE(result->type == CHGPU_U64 && result->rows >= 2, CHGPU_ERR_BAD_ARGUMENTS, "result must be a UInt64 column of 2 rows");
+    CmpSpec spec;
+    CHGPU_TRY(make_cmp_spec(pred->type, op, scalar_type, scalar, &spec));
+    ctx->counters[5] += pred->rows;
+    return launch_filter_sum(ctx, pred->type, pred->data, val->data, nullptr, pred->rows, &spec, (u64 *)result->data);
+}
+
+extern "C" int chgpu_filter_sum(chgpu_ctx * ctx, const chgpu_col * pred, int op, int scalar_type, const void * scalar,
+                                const chgpu_col * val, void * sum_out, uint64_t * count_out)
+{
+    CHGPU_REQUIRE(ctx && pred && val && sum_out && count_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(pred->rows == val->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of predicate column (%llu) doesn't match size of value column (%llu)",
+                  (unsigned long long)pred->rows, (unsigned long long)val->rows);
+    CHGPU_REQUIRE(pred->type == val->type, CHGPU_ERR_NOT_IMPLEMENTED, "fused filter+sum needs predicate and value columns of one type");
+    CmpSpec spec;
+    CHGPU_TRY(make_cmp_spec(pred->type, op, scalar_type, scalar, &spec));
+    void * scratch = nullptr;
+    // result slot lives behind the partials: ask for the partials' worth first so the pointer stays valid
+    const u32 grid_cap = (u32)ctx->num_cus * 8;
+    CHGPU_TRY(chgpu_scratch(ctx, (size_t)grid_cap * 2 * sizeof(u64) + 64, &scratch));
+    u64 * result_dev = (u64 *)((char *)scratch + (size_t)grid_cap * 2 * sizeof(u64));
+    CHGPU_TRY(launch_filter_sum(ctx, pred->type, pred->data, val->data, nullptr, pred->rows, &spec, result_dev));
+    u64 res[2];
+    CHGPU_TRY(chgpu_read_back(ctx, result_dev, res, sizeof(res)));
+    memcpy(sum_out, &res[0], 8);
+    *count_out = res[1];
+    ctx->counters[0] += res[1];
+    ctx->counters[1] += res[1] * chgpu_type_size(val->type);
+    ctx->counters[5] += pred->rows;
+    return CHGPU_OK;
+}
+
+static int sum_add_many_impl(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * cond, u64 row_begin, u64 row_end, void * state8)
+{
+    CHGPU_REQUIRE(ctx && col && state8, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(row_begin <= row_end && row_end <= col->rows, CHGPU_ERR_BAD_ARGUMENTS, "row range [%llu,%llu) out of bounds (%llu rows)",
+                  (unsigned long long)row_begin, (unsigned long long)row_end, (unsigned long long)col->rows);
+    if (cond)
+    {
+        CHGPU_REQUIRE(cond->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "condition column must be UInt8");
+        CHGPU_REQUIRE(cond->rows == col->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of condition column (%llu) doesn't match size of column (%llu)",
+                      (unsigned long long)cond->rows, (unsigned long long)col->rows);
+    }
+    const size_t es = chgpu_type_size(col->type);
+    const u64 n = row_end - row_begin;
+    const void * p = (const char *)col->data + row_begin * es;
+    const u8 * c = cond ? (const u8 *)cond->data + row_begin : nullptr;
+    void * scratch = nullptr;
+    const u32 grid_cap = (u32)ctx->num_cus * 8;
+    CHGPU_TRY(chgpu_scratch(ctx, (size_t)grid_cap * 2 * sizeof(u64) + 64, &scratch));
+    u64 * result_dev = (u64 *)((char *)scratch + (size_t)grid_cap * 2 * sizeof(u64));
+    CHGPU_TRY(launch_filter_sum(ctx, col->type, p, p, c, n, nullptr, result_dev));
+    u64 res[2];
+    CHGPU_TRY(chgpu_read_back(ctx, result_dev, res, sizeof(res)));
+    if (col->type == CHGPU_F64)
+    {
+        double batch, st;
+        memcpy(&batch, &res[0], 8);
+        memcpy(&st, state8, 8);
+        st += batch;
+        memcpy(state8, &st, 8);
+    }
+    else
+    {
+        u64 st;
+        memcpy(&st, state8, 8);
+        st += res[0];
+        memcpy(state8, &st, 8);
+    }
+    ctx->counters[5] += n;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_sum_add_many(chgpu_ctx * ctx, const chgpu_col * col, uint64_t row_begin, uint64_t row_end, void * state8)
+{
+    return sum_add_many_impl(ctx, col, nullptr, row_begin, row_end, state8);
+}
+
+extern "C" int chgpu_sum_add_many_conditional(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * cond_u8,
+                                              uint64_t row_begin, uint64_t row_end, void * state8)
+{
+    CHGPU_REQUIRE(cond_u8, CHGPU_ERR_BAD_ARGUMENTS, "condition column is NULL");
+    return sum_add_many_impl(ctx, col, cond_u8, row_begin, row_end, state8);
+}
+
+// ---------------------------------------------------------------------------------------------
+// comparison -> UInt8 mask
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC, typename Pred>
+__global__ __launch_bounds__(256) void k_cmp_mask(const T * __restrict__ a, u64 n, Pred p, u8 * __restrict__ c)
+{
+    typedef Vec<T, VEC> V;
+    typedef Vec<u8, VEC> CV;
+    const u64 nvec = n / VEC;
+    const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * 256;
+    const V * __restrict__ av = (const V *)a;
+    CV * __restrict__ cv = (CV *)c;
+    for (u64 i = tid; i < nvec; i += stride)
+    {
+        V x = av[i];
+        CV m;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            m.v[e] = p(x.v[e]) ? 1 : 0;
+        cv[i] = m;
+    }
+    const u64 r = nvec * VEC + tid;
+    if (r < n)
+        c[r] = p(a[r]) ? 1 : 0;
+}
+
+template <typename T, typename Pred>
+static int launch_cmp_t(chgpu_ctx * ctx, const void * a, u64 n, Pred p, u8 * c)
+{
+    constexpr int VECW = 16 / sizeof(T);
+    const bool aligned = ((uintptr_t)a & 15) == 0 && ((uintptr_t)c % VECW) == 0;
+    const u32 grid = chgpu_grid_for(ctx, (n + VECW - 1) / VECW, 256, 8);
+    if (aligned)
+        hipLaunchKernelGGL((k_cmp_mask<T, VECW, Pred>), dim3(grid), dim3(256), 0, ctx->stream, (const T *)a, n, p, c);
+    else
+        hipLaunchKernelGGL((k_cmp_mask<T, 1, Pred>), dim3(grid), dim3(256), 0, ctx->stream, (const T *)a, n, p, c);
+    ctx->counters[6] += 1;
+    CHGPU_HIP(hipGetLastError());
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_cmp_const(chgpu_ctx * ctx, const chgpu_col * col, int op, int scalar_type, const void * scalar, chgpu_col ** mask_out)
+{
+    CHGPU_REQUIRE(ctx && col && mask_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CmpSpec spec;
+    CHGPU_TRY(make_cmp_spec(col->type, op, scalar_type, scalar, &spec));
+    chgpu_col * m = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U8, col->rows, &m));
+    int rc = CHGPU_OK;
+    const u64 n = col->rows;
+    u8 * c = (u8 *)m->data;
+    if (n)
+    {
+        if (spec.is_f64)
+        {
+            switch (spec.op)
+            {
+#define F64CASE(OP) case OP: rc = launch_cmp_t<double, F64Pred<OP>>(ctx, col->data, n, F64Pred<OP>{spec.fs}, c); break;
+                F64CASE(CHGPU_EQ) F64CASE(CHGPU_NE) F64CASE(CHGPU_LT) F64CASE(CHGPU_GT) F64CASE(CHGPU_LE) F64CASE(CHGPU_GE)
+#undef F64CASE
+            }
+        }
+        else
+        {
+            switch (col->type)
+            {
+                case CHGPU_I64: rc = launch_cmp_t<i64, IntRangePred>(ctx, col->data, n, spec.ip, c); break;
+                case CHGPU_U64: rc = launch_cmp_t<u64, IntRangePred>(ctx, col->data, n, spec.ip, c); break;
+                case CHGPU_U32: rc = launch_cmp_t<u32, IntRangePred>(ctx, col->data, n, spec.ip, c); break;
+                case CHGPU_I32: rc = launch_cmp_t<i32, IntRangePred>(ctx, col->data, n, spec.ip, c); break;
+                case CHGPU_U8: rc = launch_cmp_t<u8, IntRangePred>(ctx, col->data, n, spec.ip, c); break;
+                default: rc = chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "unsupported column type");
+            }
+        }
+    }
+    if (rc != CHGPU_OK)
+    {
+        chgpu_col_free(m);
+        return rc;
+    }
+    *mask_out = m;
+    return CHGPU_OK;
+}
+
+__global__ __launch_bounds__(256) void k_and_not(const u8 * __restrict__ d, const u8 * __restrict__ nul, u64 n, u8 * __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+        out[i] = (d[i] && !nul[i]) ? 1 : 0;
+}
+
+extern "C" int chgpu_filter_description_nullable(chgpu_ctx * ctx, const chgpu_col * data, const chgpu_col * nul, chgpu_col ** out)
+{
+    CHGPU_REQUIRE(ctx && data && nul && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(data->type == CHGPU_U8 && nul->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "Nullable(UInt8) filter expected");
+    CHGPU_REQUIRE(data->rows == nul->rows, CHGPU_ERR_SIZES_MISMATCH, "null map size mismatch");
+    chgpu_col * m = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U8, data->rows, &m));
+    if (data->rows)
+    {
+        hipLaunchKernelGGL(k_and_not, dim3(chgpu_grid_for(ctx, data->rows, 256, 8)), dim3(256), 0, ctx->stream,
+                           (const u8 *)data->data, (const u8 *)nul->data, data->rows, (u8 *)m->data);
+        ctx->counters[6] += 1;
+    }
+    *out = m;
+    return CHGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter: order-preserving compaction.  Rows are cut into chunks of 1024; one wave owns one chunk.
+//   pass 1  k_mask_chunk_counts: non-zero mask bytes per chunk                    (1 B/row read)
+//   pass 2  exclusive scan of the chunk counts (scan.hip)                          (tiny)
+//   pass 3  k_filter_scatter: each lane takes R = 16/sizeof(T) consecutive rows (one 16-B load), wave ballots
+//           give every kept row its rank inside the chunk, stores land compacted    (1 + sizeof(T) + sizeof(T)*sel B/row)
+// ---------------------------------------------------------------------------------------------
+static constexpr u32 CHUNK_ROWS = 1024;
+
+__device__ __forceinline__ u32 count_nonzero_bytes16(const uint4 v)
+{
+    auto nz = [](u32 x) { return __popc((x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u); };
+    return nz(v.x) + nz(v.y) + nz(v.z) + nz(v.w);
+}
+
+__global__ __launch_bounds__(256) void k_mask_chunk_counts(const u8 * __restrict__ mask, u64 n, u32 * __restrict__ counts, u64 n_chunks)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave0 = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u64 n_waves = ((u64)gridDim.x * 256) >> 6;
+    const bool aligned = ((uintptr_t)mask & 15) == 0;
+    for (u64 chunk = wave0; chunk < n_chunks; chunk += n_waves)
+    {
+        const u64 base = chunk * CHUNK_ROWS + (u64)lane * 16;
+        u32 c = 0;
+        if (aligned && base + 16 <= n)
+            c = count_nonzero_bytes16(*(const uint4 *)(mask + base));
+        else
+            for (u32 k = 0; k < 16; ++k)
+                if (base + k < n)
+                    c += mask[base + k] != 0;
+        c = wave_reduce_add_u32(c);
+        if (lane == 0)
+            counts[chunk] = c;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_filter_scatter(const T * __restrict__ data, const u8 * __restrict__ mask, u64 n,
+                                                        const u64 * __restrict__ chunk_offsets, u64 n_chunks, T * __restrict__ out)
+{
+    constexpr int R = 16 / sizeof(T);        // rows per lane per group
+    constexpr u32 GROUP = 64 * R;            // rows per wave per group
+    constexpr int G = CHUNK_ROWS / GROUP;    // groups per chunk
+    typedef Vec<T, R> V;
+    typedef Vec<u8, R> MV;
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave0 = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u64 n_waves = ((u64)gridDim.x * 256) >> 6;
+    const bool aligned = (((uintptr_t)data) & 15) == 0 && (((uintptr_t)mask) % R) == 0;
+
+    for (u64 chunk = wave0; chunk < n_chunks; chunk += n_waves)
+    {
+        u64 pos = chunk_offsets[chunk];
+        const u64 cbase = chunk * CHUNK_ROWS;
+        if (aligned && cbase + CHUNK_ROWS <= n)
+        {
+            V x[G];
+            MV m[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+            {
+                const u64 row = cbase + (u64)g * GROUP + (u64)lane * R;
+                x[g] = *(const V *)(data + row);
+                m[g] = *(const MV *)(mask + row);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+            {
+                u32 before = 0, total = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                {
+                    const u64 b = __ballot(m[g].v[r] != 0);
+                    before += mbcnt(b);
+                    total += __popcll(b);
+                }
+                u64 o = pos + before;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (m[g].v[r] != 0)
+                        out[o++] = x[g].v[r];
+                pos += total;
+            }
+        }
+        else
+        {
+            // ragged tail chunk / unaligned view: same order, guarded scalar accesses
+            for (int g = 0; g < G; ++g)
+            {
+                const u64 row = cbase + (u64)g * GROUP + (u64)lane * R;
+                T xv[R];
+                bool keep[R];
+                u32 before = 0, total = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                {
+                    const bool in = row + r < n;
+                    keep[r] = in && mask[in ? row + r : 0] != 0;
+                    if (keep[r])
+                        xv[r] = data[row + r];
+                    const u64 b = __ballot(keep[r]);
+                    before += mbcnt(b);
+                    total += __popcll(b);
+                }
+                u64 o = pos + before;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (keep[r])
+                        out[o++] = xv[r];
+                pos += total;
+            }
+        }
+    }
+}
+
+extern "C" int chgpu_count_bytes_in_filter(chgpu_ctx * ctx, const chgpu_col * mask, uint64_t * count)
+{
+    CHGPU_REQUIRE(ctx && mask && count, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(mask->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "filter must be a UInt8 column");
+    // sum of the mask's "non-zero" indicator == conditional count: reuse the reduction kernel on the u8 column
+    CmpSpec spec;
+    const u8 zero = 0;
+    CHGPU_TRY(make_cmp_spec(CHGPU_U8, CHGPU_NE, CHGPU_U8, &zero, &spec));
+    void * scratch = nullptr;
+    const u32 grid_cap = (u32)ctx->num_cus * 8;
+    CHGPU_TRY(chgpu_scratch(ctx, (size_t)grid_cap * 2 * sizeof(u64) + 64, &scratch));
+    u64 * result_dev = (u64 *)((char *)scratch + (size_t)grid_cap * 2 * sizeof(u64));
+    CHGPU_TRY(launch_filter_sum(ctx, CHGPU_U8, mask->data, mask->data, nullptr, mask->rows, &spec, result_dev));
+    u64 res[2];
+    CHGPU_TRY(chgpu_read_back(ctx, result_dev, res, sizeof(res)));
+    *count = res[1];
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_filter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * mask, int64_t result_size_hint,
+                            chgpu_col ** out, uint64_t * out_rows)
+{
+    (void)result_size_hint; // the device path sizes the result exactly from the scan; the hint only matters for CPU reserve()
+    CHGPU_REQUIRE(ctx && col && mask && out && out_rows, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(mask->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "filter must be a UInt8 column");
+    CHGPU_REQUIRE(col->rows == mask->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of filter (%llu) doesn't match size of column (%llu)",
+                  (unsigned long long)mask->rows, (unsigned long long)col->rows);
+    const u64 n = col->rows;
+    const u64 n_chunks = (n + CHUNK_ROWS - 1) / CHUNK_ROWS;
+    if (n == 0)
+    {
+        CHGPU_TRY(chgpu_col_new(ctx, col->type, 0, out));
+        *out_rows = 0;
+        return CHGPU_OK;
+    }
+    // scratch layout: counts u32[n_chunks] | offsets u64[n_chunks] | total u64 | scan tmp
+    const size_t counts_b = ((n_chunks * sizeof(u32) + 255) / 256) * 256;
+    const size_t offs_b = ((n_chunks * sizeof(u64) + 255) / 256) * 256;
+    const size_t tmp_b = chgpu_scan_tmp_bytes(n_chunks);
+    void * scratch = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, counts_b + offs_b + 256 + tmp_b, &scratch));
+    u32 * counts = (u32 *)scratch;
+    u64 * offsets = (u64 *)((char *)scratch + counts_b);
+    u64 * total_dev = (u64 *)((char *)scratch + counts_b + offs_b);
+    void * tmp = (char *)scratch + counts_b + offs_b + 256;
+
+    const u32 grid = chgpu_grid_for(ctx, n_chunks * 64, 256, 8);
+    hipLaunchKernelGGL(k_mask_chunk_counts, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)mask->data, n, counts, n_chunks);
+    ctx->counters[6] += 1;
+    CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, n_chunks, total_dev, tmp, tmp_b));
+    u64 total = 0;
+    CHGPU_TRY(chgpu_read_back(ctx, total_dev, &total, sizeof(total)));
+
+    chgpu_col * res = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, col->type, total, &res));
+    if (total)
+    {
+        switch (chgpu_type_size(col->type))
+        {
+            case 8:
+                hipLaunchKernelGGL(k_filter_scatter<u64>, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)col->data, (const u8 *)mask->data, n, offsets, n_chunks, (u64 *)res->data);
+                break;
+            case 4:
+                hipLaunchKernelGGL(k_filter_scatter<u32>, dim3(grid), dim3(256), 0, ctx->stream, (const u32 *)col->data, (const u8 *)mask->data, n, offsets, n_chunks, (u32 *)res->data);
+                break;
+            default:
+                hipLaunchKernelGGL(k_filter_scatter<u8>, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)col->data, (const u8 *)mask->data, n, offsets, n_chunks, (u8 *)res->data);
+                break;
+        }
+        ctx->counters[6] += 1;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+        chgpu_col_free(res);
+        return chgpu_set_error(CHGPU_ERR_DEVICE, "filter launch: %s", hipGetErrorString(e));
+    }
+    ctx->counters[0] += total;
+    ctx->counters[1] += total * chgpu_type_size(col->type);
+    *out = res;
+    *out_rows = total;
+    return CHGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// index (gather) and replicate
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void k_index(const T * __restrict__ data, const I * __restrict__ idx, u64 limit, u64 rows,
+                                               int default_for_missing, T * __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < limit; i += (u64)gridDim.x * 256)
+    {
+        const I j = idx[i];
+        const bool missing = default_for_missing && j == (I)~(I)0;
+        // out-of-range indexes are a caller bug in the reference too (no bounds check, ColumnVector.cpp:1137-1140);
+        // here they read row 0 instead of faulting the GPU
+        out[i] = missing ? T(0) : data[(u64)j < rows ? (u64)j : 0];
+    }
+}
+
+extern "C" int chgpu_index(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * indexes, uint64_t limit,
+                           int default_for_missing, chgpu_col ** out)
+{
+    CHGPU_REQUIRE(ctx && col && indexes && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(indexes->type == CHGPU_U64 || indexes->type == CHGPU_U32, CHGPU_ERR_BAD_ARGUMENTS, "indexes must be UInt64 or UInt32");
+    if (limit == 0)
+        limit = indexes->rows;
+    CHGPU_REQUIRE(limit <= indexes->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of indexes (%llu) is less than required (%llu)",
+                  (unsigned long long)indexes->rows, (unsigned long long)limit); // ColumnVector.cpp:1126-1127
+    CHGPU_REQUIRE(col->rows > 0 || limit == 0 || default_for_missing, CHGPU_ERR_BAD_ARGUMENTS, "index into an empty column");
+    chgpu_col * res = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, col->type, limit, &res));
+    if (limit)
+    {
+        const u32 grid = chgpu_grid_for(ctx, limit, 256, 8);
+        const size_t es = chgpu_type_size(col->type);
+#define IDX_LAUNCH(T, I) hipLaunchKernelGGL((k_index<T, I>), dim3(grid), dim3(256), 0, ctx->stream, (const T *)col->data, (const I *)indexes->data, limit, col->rows, default_for_missing, (T *)res->data)
+        if (indexes->type == CHGPU_U64)
+        {
+            if (es == 8) IDX_LAUNCH(u64, u64); else if (es == 4) IDX_LAUNCH(u32, u64); else IDX_LAUNCH(u8, u64);
+        }
+        else
+        {
+            if (es == 8) IDX_LAUNCH(u64, u32); else if (es == 4) IDX_LAUNCH(u32, u32); else IDX_LAUNCH(u8, u32);
+        }
+#undef IDX_LAUNCH
+        ctx->counters[6] += 1;
+    }
+    *out = res;
+    return CHGPU_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_replicate(const T * __restrict__ data, const u64 * __restrict__ offsets, u64 n, T * __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        const u64 end = offsets[i];
+        const u64 begin = i ? offsets[i - 1] : 0;
+        const T v = data[i];
+        for (u64 o = begin; o < end; ++o)
+            out[o] = v;
+    }
+}
+
+extern "C" int chgpu_replicate(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * offsets, chgpu_col ** out)
+{
+    CHGPU_REQUIRE(ctx && col && offsets && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(offsets->type == CHGPU_U64, CHGPU_ERR_BAD_ARGUMENTS, "offsets must be UInt64");
+    CHGPU_REQUIRE(offsets->rows == col->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of offsets doesn't match size of column."); // ColumnVector.cpp:881-883
+    u64 total = 0;
+    if (col->rows)
+        CHGPU_TRY(chgpu_read_back(ctx, (const u64 *)offsets->data + (col->rows - 1), &total, sizeof(total)));
+    chgpu_col * res = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, col->type, total, &res));
+    if (total)
+    {
+        const u32 grid = chgpu_grid_for(ctx, col->rows, 256, 8);
+        switch (chgpu_type_size(col->type))
+        {
+            case 8: hipLaunchKernelGGL(k_replicate<u64>, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)col->data, (const u64 *)offsets->data, col->rows, (u64 *)res->data); break;
+            case 4: hipLaunchKernelGGL(k_replicate<u32>, dim3(grid), dim3(256), 0, ctx->stream, (const u32 *)col->data, (const u64 *)offsets->data, col->rows, (u32 *)res->data); break;
+            default: hipLaunchKernelGGL(k_replicate<u8>, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)col->data, (const u64 *)offsets->data, col->rows, (u8 *)res->data); break;
+        }
+        ctx->counters[6] += 1;
+    }
+    *out = res;
+    return CHGPU_OK;
+}

@@ -1,0 +1,624 @@
+// join_kernels.hip — hash join build and probe on the device for one numeric key (HashJoin key64 family).
+//
+// Reference loops replaced (file:line in the reference checkout):
+//   k_join_insert / k_join_fill   HashJoin::addBlockToJoin -> insertFromBlockImplTypeCase, Inserter::insertOne/insertAll,
+//                                 RowRefList::insert            src/Interpreters/HashJoin/HashJoin.cpp:556-768,
+//                                                               HashJoinMethodsImpl.h:220-281, HashJoinMethods.h:16-62, RowRefs.h:16-141
+//   k_join_probe_* / k_join_emit  HashJoin::joinBlock -> joinRightColumns (findKey, addFoundRowAll, addNotFoundRow,
+//                                 offsets_to_replicate, filter, max_joined_block_rows)
+//                                                               HashJoin.cpp:1036-1101, HashJoinMethodsImpl.h:402-549,
+//                                                               KnownRowsHolder.h:88-153, JoinFeatures.h:9-40
+//
+// Design (not a translation): RowRef{block*,row} becomes a 64-bit global row id (block_index << 32 | row); the
+// RowRefList's arena-allocated 7-slot batches become one CSR array (per-key count -> exclusive scan -> fill); the
+// serial "first row owns the cell" rule becomes atomicMin (atomicMax for any_take_last_row) on the cell's row id; the
+// INNER ANY "each right row joins its first left row only" flag (setUsedOnce) becomes atomicMin of a running left-row
+// sequence number.  The table is built once in chgpu_join_finish_build (IJoin::onBuildPhaseFinish), sized from the
+// number of build rows, so no kernel ever has to grow it.
+#include "chgpu_internal.h"
+
+#include <vector>
+
+static constexpr u32 JT = 256;
+static constexpr u64 NO_ROW = ~0ull;
+static constexpr u32 NO_SLOT = ~0u;
+
+struct JoinCtrl
+{
+    unsigned long long n_keys;
+    u32 has_zero;
+    u32 pad;
+    u64 consumed; // probe: left rows consumed
+    u64 n_out;    // probe: appended rows
+};
+
+struct JoinTable
+{
+    u64 * keys;      // [cap+1], 0 = empty, cell cap = the zero key
+    u64 * first_row; // [cap+1] global row id of the first (ANY: min or max) inserted row
+    u32 * cnt;       // [cap+1] rows per key (ALL)
+    u64 * start;     // [cap+1] CSR start (ALL)
+    u64 * used_by;   // [cap+1] left-row sequence that consumed this cell (INNER ANY)
+    u64 * rowids;    // [inserted] CSR payload (ALL)
+    u64 capacity;
+    JoinCtrl * ctrl;
+};
+
+struct BuildBlock
+{
+    u64 * keys = nullptr; // zero-extended keys on device
+    u8 * valid = nullptr; // NULL = all rows valid
+    u64 rows = 0;
+    u64 base = 0;         // running position of this block's first row in slot_of_row
+};
+
+struct chgpu_join
+{
+    chgpu_ctx * ctx = nullptr;
+    int key_type = CHGPU_U64;
+    int kind = CHGPU_JOIN_INNER, strictness = CHGPU_STRICT_ALL, any_take_last_row = 0;
+    std::vector<BuildBlock> blocks;
+    u64 total_rows = 0;
+    bool finished = false;
+    JoinTable t{};
+    void * table_mem = nullptr;
+    u64 n_keys = 0;
+    u64 inserted = 0;
+    u64 left_seq = 0; // running left-row sequence across joinBlock calls (INNER ANY)
+};
+
+static inline bool jf_need_replication(const chgpu_join * j) { return j->strictness == CHGPU_STRICT_ALL; } // JoinFeatures.h:29
+static inline bool jf_need_filter(const chgpu_join * j)
+{
+    return !jf_need_replication(j)
+        && (j->kind == CHGPU_JOIN_INNER || j->strictness == CHGPU_STRICT_SEMI || j->strictness == CHGPU_STRICT_ANTI); // JoinFeatures.h:32
+}
+static inline bool jf_add_missing(const chgpu_join * j) { return j->kind == CHGPU_JOIN_LEFT && j->strictness != CHGPU_STRICT_SEMI; } // :35
+
+// ---------------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 jload_key(const void * keys, int type, u64 i)
+{
+    switch (type)
+    {
+        case CHGPU_U32: case CHGPU_I32: return ((const u32 *)keys)[i];
+        case CHGPU_U8: return ((const u8 *)keys)[i];
+        default: return ((const u64 *)keys)[i];
+    }
+}
+
+__global__ __launch_bounds__(JT) void k_join_stage_keys(const void * __restrict__ keys, int type, const u8 * __restrict__ null_map,
+                                                        const u8 * __restrict__ join_mask, u64 n, u64 * __restrict__ out_keys, u8 * __restrict__ out_valid)
+{
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+    {
+        out_keys[i] = jload_key(keys, type, i);
+        if (out_valid)
+            out_valid[i] = !(null_map && null_map[i]) && !(join_mask && !join_mask[i]); // HashJoinMethodsImpl.h:261-272
+    }
+}
+
+__device__ __forceinline__ u32 jt_emplace(const JoinTable & t, u64 key)
+{
+    if (key == 0)
+    {
+        if (atomicExch(&t.ctrl->has_zero, 1u) == 0)
+            atomicAdd(&t.ctrl->n_keys, 1ull);
+        return (u32)t.capacity;
+    }
+    const u64 mask = t.capacity - 1;
+    u64 slot = dev_intHash64(key) & mask;
+    for (u64 step = 0; step < t.capacity; ++step)
+    {
+        u64 k = t.keys[slot];
+        if (k == 0)
+        {
+            k = atomicCAS((unsigned long long *)&t.keys[slot], 0ull, (unsigned long long)key);
+            if (k == 0)
+            {
+                atomicAdd(&t.ctrl->n_keys, 1ull);
+                return (u32)slot;
+            }
+        }
+        if (k == key)
+            return (u32)slot;
+        slot = (slot + 1) & mask;
+    }
+    return NO_SLOT; // unreachable: capacity >= 2 * rows
+}
+
+__device__ __forceinline__ u32 jt_find(const JoinTable & t, u64 key)
+{
+    if (key == 0)
+        return t.ctrl->has_zero ? (u32)t.capacity : NO_SLOT;
+    const u64 mask = t.capacity - 1;
+    u64 slot = dev_intHash64(key) & mask;
+    for (u64 step = 0; step < t.capacity; ++step)
+    {
+        const u64 k = t.keys[slot];
+        if (k == key)
+            return (u32)slot;
+        if (k == 0)
+            return NO_SLOT;
+        slot = (slot + 1) & mask;
+    }
+    return NO_SLOT;
+}
+
+// build pass 1: claim cells, count rows per key, record the owning row
+__global__ __launch_bounds__(JT) void k_join_insert(JoinTable t, const u64 * __restrict__ keys, const u8 * __restrict__ valid, u64 n,
+                                                    u64 block_index, int maps_all, int take_last, u32 * __restrict__ slot_of_row)
+{
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+    {
+        u32 slot = NO_SLOT;
+        if (!valid || valid[i])
+        {
+            slot = jt_emplace(t, keys[i]);
+            if (slot != NO_SLOT)
+            {
+                const u64 rowid = (block_index << 32) | i;
+                if (maps_all)
+                {
+                    atomicAdd(&t.cnt[slot], 1u);                                              // RowRefList::rows
+                    atomicMin((unsigned long long *)&t.first_row[slot], (unsigned long long)rowid); // the root RowRef = first inserted
+                }
+                else if (take_last)
+                    atomicMax((unsigned long long *)&t.first_row[slot], (unsigned long long)(rowid + 1)); // stored +1 so 0 == unset
+                else
+                    atomicMin((unsigned long long *)&t.first_row[slot], (unsigned long long)rowid);       // insertOne: first row wins
+            }
+        }
+        slot_of_row[i] = slot;
+    }
+}
+
+// build pass 3: CSR fill
+__global__ __launch_bounds__(JT) void k_join_fill(JoinTable t, const u32 * __restrict__ slot_of_row, u64 n, u64 block_index, u32 * __restrict__ cursor)
+{
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+    {
+        const u32 slot = slot_of_row[i];
+        if (slot == NO_SLOT)
+            continue;
+        const u32 k = atomicAdd(&cursor[slot], 1u);
+        t.rowids[t.start[slot] + k] = (block_index << 32) | i;
+    }
+}
+
+// build pass 4: put the first-inserted row at the head of each key's run (RowRefList iteration starts at the root)
+__global__ __launch_bounds__(JT) void k_join_root_first(JoinTable t)
+{
+    for (u64 s = (u64)blockIdx.x * JT + threadIdx.x; s <= t.capacity; s += (u64)gridDim.x * JT)
+    {
+        const u32 c = t.cnt[s];
+        if (c < 2)
+            continue;
+        u64 * run = t.rowids + t.start[s];
+        const u64 root = t.first_row[s];
+        for (u32 k = 0; k < c; ++k)
+            if (run[k] == root)
+            {
+                run[k] = run[0];
+                run[0] = root;
+                break;
+            }
+    }
+}
+
+__global__ __launch_bounds__(JT) void k_fill_u64(u64 * p, u64 n, u64 v)
+{
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+        p[i] = v;
+}
+
+enum { PV_ALL_INNER, PV_ALL_LEFT, PV_ANY_LEFT, PV_SEMI_LEFT, PV_ANTI_LEFT, PV_ANY_INNER };
+
+// probe pass 0 (INNER ANY only): every matching left row bids for its right cell with its sequence number
+__global__ __launch_bounds__(JT) void k_join_probe_bid(JoinTable t, const void * __restrict__ keys, int key_type, const u8 * __restrict__ null_map,
+                                                       u64 n, u64 seq_base, u32 * __restrict__ slot_of_left)
+{
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+    {
+        u32 slot = NO_SLOT;
+        if (!(null_map && null_map[i]))
+            slot = jt_find(t, jload_key(keys, key_type, i));
+        if (slot != NO_SLOT)
+            atomicMin((unsigned long long *)&t.used_by[slot], (unsigned long long)(seq_base + i));
+        slot_of_left[i] = slot;
+    }
+}
+
+// probe pass 1: per left row, how many right rows get appended (and the filter byte)
+__global__ __launch_bounds__(JT) void k_join_probe_count(JoinTable t, int variant, const void * __restrict__ keys, int key_type,
+                                                         const u8 * __restrict__ null_map, u64 n, u64 seq_base, int slots_known,
+                                                         u32 * __restrict__ slot_of_left, u32 * __restrict__ counts, u8 * __restrict__ filter)
+{
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+    {
+        u32 slot;
+        if (slots_known)
+            slot = slot_of_left[i];
+        else
+        {
+            slot = NO_SLOT;
+            if (!(null_map && null_map[i])) // HashJoinMethodsImpl.h:451-452
+                slot = jt_find(t, jload_key(keys, key_type, i));
+            slot_of_left[i] = slot;
+        }
+        const bool found = slot != NO_SLOT;
+        u32 c = 0;
+        u8 f = 0;
+        switch (variant)
+        {
+            case PV_ALL_INNER: c = found ? t.cnt[slot] : 0; break;
+            case PV_ALL_LEFT: c = found ? t.cnt[slot] : 1; break;                 // addNotFoundRow<add_missing>: ++current_offset
+            case PV_ANY_LEFT: c = 1; break;                                       // found row or default row
+            case PV_SEMI_LEFT: c = found ? 1 : 0; f = found; break;
+            case PV_ANTI_LEFT: c = found ? 0 : 1; f = !found; break;              // :515-519, :535-536
+            case PV_ANY_INNER: c = (found && t.used_by[slot] == seq_base + i) ? 1 : 0; f = (u8)c; break; // setUsedOnce, :498-510
+        }
+        counts[i] = c;
+        if (filter)
+            filter[i] = f;
+    }
+}
+
+// probe pass 2b: where does max_joined_block_rows cut?  offsets are inclusive cumulative counts.
+__global__ void k_join_cut(const u64 * __restrict__ offsets, u64 n, u64 max_rows, JoinCtrl * __restrict__ ctrl)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0)
+        return;
+    u64 consumed = n;
+    if (max_rows != 0 && n > 0)
+    {
+        // the loop stops BEFORE row i when the offset after row i-1 is already >= max (HashJoinMethodsImpl.h:436-444):
+        // consumed = 1 + (first index whose inclusive offset >= max), capped at n
+        u64 lo = 0, hi = n; // first idx in [0,n) with offsets[idx] >= max_rows
+        while (lo < hi)
+        {
+            const u64 mid = (lo + hi) / 2;
+            if (offsets[mid] >= max_rows)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        if (lo < n)
+            consumed = lo + 1;
+    }
+    ctrl->consumed = consumed;
+    ctrl->n_out = consumed ? offsets[consumed - 1] : 0;
+}
+
+// probe pass 3: write the appended right row ids
+__global__ __launch_bounds__(JT) void k_join_emit(JoinTable t, int variant, int take_last, const u32 * __restrict__ slot_of_left,
+                                                  const u32 * __restrict__ counts, const u64 * __restrict__ offsets, u64 consumed,
+                                                  u64 * __restrict__ right_rowid)
+{
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < consumed; i += (u64)gridDim.x * JT)
+    {
+        const u32 c = counts[i];
+        if (c == 0)
+            continue;
+        const u64 base = offsets[i] - c;
+        const u32 slot = slot_of_left[i];
+        if (slot == NO_SLOT)
+        {
+            right_rowid[base] = NO_ROW; // default row (addNotFoundRow -> insertDefault)
+            continue;
+        }
+        if (variant == PV_ALL_INNER || variant == PV_ALL_LEFT)
+        {
+            const u64 * run = t.rowids + t.start[slot];
+            for (u32 k = 0; k < c; ++k)
+                right_rowid[base + k] = run[k];
+        }
+        else if (variant == PV_ANTI_LEFT)
+            right_rowid[base] = NO_ROW;
+        else
+            right_rowid[base] = take_last ? t.first_row[slot] - 1 : t.first_row[slot];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+static u64 jpow2_ceil(u64 x)
+{
+    u64 p = 256;
+    while (p < x)
+        p <<= 1;
+    return p;
+}
+
+extern "C" int chgpu_join_create(chgpu_ctx * ctx, int key_type, int kind, int strictness, int any_take_last_row,
+                                 uint64_t size_hint, chgpu_join ** out)
+{
+    (void)size_hint;
+    CHGPU_REQUIRE(ctx && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(key_type == CHGPU_U64 || key_type == CHGPU_I64 || key_type == CHGPU_U32 || key_type == CHGPU_I32 || key_type == CHGPU_U8,
+                  CHGPU_ERR_NOT_IMPLEMENTED, "join key type %d: CPU path", key_type);
+    CHGPU_REQUIRE(kind == CHGPU_JOIN_INNER || kind == CHGPU_JOIN_LEFT, CHGPU_ERR_NOT_IMPLEMENTED, "join kind %d (RIGHT/FULL need non-joined rows): CPU path", kind);
+    CHGPU_REQUIRE(strictness >= CHGPU_STRICT_ANY && strictness <= CHGPU_STRICT_ANTI, CHGPU_ERR_NOT_IMPLEMENTED, "join strictness %d: CPU path", strictness);
+    CHGPU_REQUIRE(!((strictness == CHGPU_STRICT_SEMI || strictness == CHGPU_STRICT_ANTI) && kind != CHGPU_JOIN_LEFT), CHGPU_ERR_NOT_IMPLEMENTED,
+                  "only SEMI LEFT / ANTI LEFT are valid here (joinDispatch.h:52-64)");
+    chgpu_join * j = new chgpu_join();
+    j->ctx = ctx;
+    j->key_type = key_type;
+    j->kind = kind;
+    j->strictness = strictness;
+    j->any_take_last_row = any_take_last_row ? 1 : 0;
+    *out = j;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_join_free(chgpu_join * j)
+{
+    if (!j)
+        return CHGPU_OK;
+    for (auto & b : j->blocks)
+    {
+        if (b.keys) (void)hipFree(b.keys);
+        if (b.valid) (void)hipFree(b.valid);
+    }
+    if (j->table_mem)
+        (void)hipFree(j->table_mem);
+    delete j;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_join_add_block(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map, const chgpu_col * join_mask,
+                                    uint32_t * block_index_out)
+{
+    CHGPU_REQUIRE(j && key_col, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(!j->finished, CHGPU_ERR_LOGICAL, "addBlockToJoin after onBuildPhaseFinish");
+    CHGPU_REQUIRE(key_col->type == j->key_type, CHGPU_ERR_BAD_ARGUMENTS, "key column has type %d, expected %d", key_col->type, j->key_type);
+    CHGPU_REQUIRE(key_col->rows < 0xFFFFFFFFull, CHGPU_ERR_TOO_MANY_ROWS, "Too many rows in right table block for HashJoin: %llu", (unsigned long long)key_col->rows); // HashJoin.cpp:563-564
+    CHGPU_REQUIRE(j->blocks.size() < 0xFFFFFFFFull, CHGPU_ERR_TOO_MANY_ROWS, "too many right blocks");
+    if (null_map)
+        CHGPU_REQUIRE(null_map->type == CHGPU_U8 && null_map->rows == key_col->rows, CHGPU_ERR_SIZES_MISMATCH, "null map size mismatch");
+    if (join_mask)
+        CHGPU_REQUIRE(join_mask->type == CHGPU_U8 && join_mask->rows == key_col->rows, CHGPU_ERR_SIZES_MISMATCH, "join mask size mismatch");
+    chgpu_ctx * ctx = j->ctx;
+    BuildBlock b;
+    b.rows = key_col->rows;
+    b.base = j->total_rows;
+    if (b.rows)
+    {
+        // the right block stays alive for the join's lifetime (data->blocks, HashJoin.cpp:656-658): keep its keys in HBM
+        CHGPU_HIP(hipMalloc((void **)&b.keys, b.rows * sizeof(u64)));
+        if (null_map || join_mask)
+        {
+            hipError_t e = hipMalloc((void **)&b.valid, b.rows);
+            if (e != hipSuccess)
+            {
+                (void)hipFree(b.keys);
+                return chgpu_set_error(CHGPU_ERR_OOM, "hipMalloc: %s", hipGetErrorString(e));
+            }
+        }
+        hipLaunchKernelGGL(k_join_stage_keys, dim3(chgpu_grid_for(ctx, b.rows, JT, 8)), dim3(JT), 0, ctx->stream, (const void *)key_col->data, key_col->type,
+                           null_map ? (const u8 *)null_map->data : nullptr, join_mask ? (const u8 *)join_mask->data : nullptr, b.rows, b.keys, b.valid);
+        ctx->counters[6] += 1;
+        // the caller may free its column right after this call returns
+        CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (block_index_out)
+        *block_index_out = (u32)j->blocks.size();
+    j->blocks.push_back(b);
+    j->total_rows += b.rows;
+    ctx->counters[2] += b.rows;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_join_finish_build(chgpu_join * j)
+{
+    CHGPU_REQUIRE(j, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    if (j->finished)
+        return CHGPU_OK;
+    chgpu_ctx * ctx = j->ctx;
+    const bool maps_all = j->strictness == CHGPU_STRICT_ALL;
+    const bool flagged = j->kind == CHGPU_JOIN_INNER && j->strictness == CHGPU_STRICT_ANY;
+    const u64 cap = jpow2_ceil(j->total_rows * 2);
+    CHGPU_REQUIRE(cap + 1 < 0xFFFFFFFFull, CHGPU_ERR_NOT_IMPLEMENTED, "build side of %llu rows exceeds the 32-bit cell index", (unsigned long long)j->total_rows);
+    const u64 cells = cap + 1;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    size_t off_keys = 256, off_first = off_keys + al(cells * 8), off_cnt = off_first + al(cells * 8);
+    size_t off_start = off_cnt + (maps_all ? al(cells * 4) : 0);
+    size_t off_used = off_start + (maps_all ? al(cells * 8) : 0);
+    size_t off_rowids = off_used + (flagged ? al(cells * 8) : 0);
+    size_t total_b = off_rowids + (maps_all ? al(j->total_rows * 8) : 0) + 256;
+    void * m = nullptr;
+    CHGPU_HIP(hipMalloc(&m, total_b));
+    j->table_mem = m;
+    JoinTable & t = j->t;
+    t.ctrl = (JoinCtrl *)m;
+    t.keys = (u64 *)((char *)m + off_keys);
+    t.first_row = (u64 *)((char *)m + off_first);
+    t.cnt = maps_all ? (u32 *)((char *)m + off_cnt) : nullptr;
+    t.start = maps_all ? (u64 *)((char *)m + off_start) : nullptr;
+    t.used_by = flagged ? (u64 *)((char *)m + off_used) : nullptr;
+    t.rowids = maps_all ? (u64 *)((char *)m + off_rowids) : nullptr;
+    t.capacity = cap;
+    CHGPU_HIP(hipMemsetAsync(m, 0, off_first, ctx->stream)); // ctrl + keys
+    const bool take_last = !maps_all && j->any_take_last_row;
+    // first_row: ~0 for atomicMin, 0 for atomicMax(+1)
+    CHGPU_HIP(hipMemsetAsync(t.first_row, take_last ? 0x00 : 0xFF, cells * 8, ctx->stream));
+    if (maps_all)
+        CHGPU_HIP(hipMemsetAsync(t.cnt, 0, cells * 4, ctx->stream));
+    if (flagged)
+        CHGPU_HIP(hipMemsetAsync(t.used_by, 0xFF, cells * 8, ctx->stream));
+
+    // scratch: slot_of_row u32[total_rows] | cursor u32[cells] | total u64 | scan tmp
+    const size_t sor_b = al(j->total_rows * 4 + 4), cur_b = al(cells * 4), tmp_b = chgpu_scan_tmp_bytes(cells);
+    void * scratch = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, sor_b + cur_b + 256 + tmp_b, &scratch));
+    u32 * slot_of_row = (u32 *)scratch;
+    u32 * cursor = (u32 *)((char *)scratch + sor_b);
+    u64 * total_dev = (u64 *)((char *)scratch + sor_b + cur_b);
+    void * tmp = (char *)scratch + sor_b + cur_b + 256;
+
+    for (size_t bi = 0; bi < j->blocks.size(); ++bi)
+    {
+        const BuildBlock & b = j->blocks[bi];
+        if (!b.rows)
+            continue;
+        hipLaunchKernelGGL(k_join_insert, dim3(chgpu_grid_for(ctx, b.rows, JT, 8)), dim3(JT), 0, ctx->stream, t, (const u64 *)b.keys, (const u8 *)b.valid, b.rows,
+                           (u64)bi, maps_all ? 1 : 0, take_last ? 1 : 0, slot_of_row + b.base);
+        ctx->counters[6] += 1;
+    }
+    if (maps_all)
+    {
+        CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, t.cnt, t.start, cells, total_dev, tmp, tmp_b));
+        CHGPU_HIP(hipMemsetAsync(cursor, 0, cells * 4, ctx->stream));
+        for (size_t bi = 0; bi < j->blocks.size(); ++bi)
+        {
+            const BuildBlock & b = j->blocks[bi];
+            if (!b.rows)
+                continue;
+            hipLaunchKernelGGL(k_join_fill, dim3(chgpu_grid_for(ctx, b.rows, JT, 8)), dim3(JT), 0, ctx->stream, t, (const u32 *)(slot_of_row + b.base), b.rows, (u64)bi, cursor);
+            ctx->counters[6] += 1;
+        }
+        hipLaunchKernelGGL(k_join_root_first, dim3(chgpu_grid_for(ctx, cells, JT, 8)), dim3(JT), 0, ctx->stream, t);
+        ctx->counters[6] += 1;
+        CHGPU_TRY(chgpu_read_back(ctx, total_dev, &j->inserted, sizeof(u64)));
+    }
+    CHGPU_HIP(hipGetLastError());
+    JoinCtrl c;
+    CHGPU_TRY(chgpu_read_back(ctx, t.ctrl, &c, sizeof(c)));
+    j->n_keys = c.n_keys;
+    j->finished = true;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_join_total_rows(chgpu_join * j, uint64_t * rows, uint64_t * keys)
+{
+    CHGPU_REQUIRE(j, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    if (rows)
+        *rows = j->total_rows; // IJoin::getTotalRowCount
+    if (keys)
+    {
+        if (!j->finished)
+            CHGPU_TRY(chgpu_join_finish_build(j));
+        *keys = j->n_keys;
+    }
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map, uint64_t max_joined_block_rows,
+                                chgpu_col ** filter_out, chgpu_col ** offsets_out, chgpu_col ** right_rowid_out, uint64_t * n_out,
+                                uint64_t * n_left_consumed)
+{
+    CHGPU_REQUIRE(j && key_col && right_rowid_out && n_out && n_left_consumed, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(key_col->type == j->key_type, CHGPU_ERR_BAD_ARGUMENTS, "left key column has type %d, expected %d", key_col->type, j->key_type);
+    if (null_map)
+        CHGPU_REQUIRE(null_map->type == CHGPU_U8 && null_map->rows == key_col->rows, CHGPU_ERR_SIZES_MISMATCH, "null map size mismatch");
+    if (!j->finished)
+        CHGPU_TRY(chgpu_join_finish_build(j));
+    chgpu_ctx * ctx = j->ctx;
+    const u64 n = key_col->rows;
+    const bool need_filter = jf_need_filter(j), need_repl = jf_need_replication(j);
+    CHGPU_REQUIRE(!need_filter || filter_out, CHGPU_ERR_BAD_ARGUMENTS, "this join variant produces a filter: filter_u8 must not be NULL");
+    CHGPU_REQUIRE(!need_repl || offsets_out, CHGPU_ERR_BAD_ARGUMENTS, "this join variant produces offsets_to_replicate: offsets_u64 must not be NULL");
+    if (filter_out) *filter_out = nullptr;
+    if (offsets_out) *offsets_out = nullptr;
+    *right_rowid_out = nullptr;
+    int variant;
+    if (j->strictness == CHGPU_STRICT_ALL) variant = j->kind == CHGPU_JOIN_LEFT ? PV_ALL_LEFT : PV_ALL_INNER;
+    else if (j->strictness == CHGPU_STRICT_SEMI) variant = PV_SEMI_LEFT;
+    else if (j->strictness == CHGPU_STRICT_ANTI) variant = PV_ANTI_LEFT;
+    else variant = j->kind == CHGPU_JOIN_LEFT ? PV_ANY_LEFT : PV_ANY_INNER;
+    if (!need_repl)
+        max_joined_block_rows = 0; // the early stop only exists for need_replication (HashJoinMethodsImpl.h:434-444)
+
+    if (n == 0)
+    {
+        if (need_filter) CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U8, 0, filter_out));
+        if (need_repl) CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U64, 0, offsets_out));
+        CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U64, 0, right_rowid_out));
+        *n_out = 0;
+        *n_left_consumed = 0;
+        return CHGPU_OK;
+    }
+
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t sl_b = al(n * 4), cnt_b = al(n * 4), tmp_b = chgpu_scan_tmp_bytes(n);
+    void * scratch = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, sl_b + cnt_b + 256 + tmp_b, &scratch));
+    u32 * slot_of_left = (u32 *)scratch;
+    u32 * counts = (u32 *)((char *)scratch + sl_b);
+    u64 * total_dev = (u64 *)((char *)scratch + sl_b + cnt_b);
+    void * tmp = (char *)scratch + sl_b + cnt_b + 256;
+
+    chgpu_col * filter = nullptr;
+    chgpu_col * offsets = nullptr;
+    chgpu_col * rowid = nullptr;
+    int rc = CHGPU_OK;
+    auto fail = [&](int code) {
+        chgpu_col_free(filter);
+        chgpu_col_free(offsets);
+        chgpu_col_free(rowid);
+        return code;
+    };
+    if (need_filter && (rc = chgpu_col_new(ctx, CHGPU_U8, n, &filter)) != CHGPU_OK)
+        return fail(rc);
+    if ((rc = chgpu_col_new(ctx, CHGPU_U64, n, &offsets)) != CHGPU_OK)
+        return fail(rc);
+
+    const u32 grid = chgpu_grid_for(ctx, n, JT, 8);
+    const void * kp = key_col->data;
+    const u8 * nm = null_map ? (const u8 *)null_map->data : nullptr;
+    const u64 seq_base = j->left_seq;
+    if (variant == PV_ANY_INNER)
+    {
+        hipLaunchKernelGGL(k_join_probe_bid, dim3(grid), dim3(JT), 0, ctx->stream, j->t, kp, j->key_type, nm, n, seq_base, slot_of_left);
+        ctx->counters[6] += 1;
+    }
+    hipLaunchKernelGGL(k_join_probe_count, dim3(grid), dim3(JT), 0, ctx->stream, j->t, variant, kp, j->key_type, nm, n, seq_base,
+                       variant == PV_ANY_INNER ? 1 : 0, slot_of_left, counts, filter ? (u8 *)filter->data : nullptr);
+    ctx->counters[6] += 1;
+    if ((rc = chgpu_scan_inclusive_u32_u64(ctx, counts, (u64 *)offsets->data, n, total_dev, tmp, tmp_b)) != CHGPU_OK)
+        return fail(rc);
+    hipLaunchKernelGGL(k_join_cut, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)offsets->data, n, (u64)max_joined_block_rows, j->t.ctrl);
+    ctx->counters[6] += 1;
+    JoinCtrl c;
+    if ((rc = chgpu_read_back(ctx, j->t.ctrl, &c, sizeof(c))) != CHGPU_OK)
+        return fail(rc);
+    if ((rc = chgpu_col_new(ctx, CHGPU_U64, c.n_out, &rowid)) != CHGPU_OK)
+        return fail(rc);
+    if (c.n_out)
+    {
+        hipLaunchKernelGGL(k_join_emit, dim3(grid), dim3(JT), 0, ctx->stream, j->t, variant, (!need_repl && j->any_take_last_row) ? 1 : 0,
+                           (const u32 *)slot_of_left, (const u32 *)counts, (const u64 *)offsets->data, c.consumed, (u64 *)rowid->data);
+        ctx->counters[6] += 1;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+        chgpu_set_error(CHGPU_ERR_DEVICE, "join probe launch: %s", hipGetErrorString(e));
+        return fail(CHGPU_ERR_DEVICE);
+    }
+    // the scratch buffers (slot_of_left, counts) are reused by the next call on this context: finish reading them now
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+    {
+        chgpu_set_error(CHGPU_ERR_DEVICE, "join probe failed");
+        return fail(CHGPU_ERR_DEVICE);
+    }
+    j->left_seq += c.consumed; // rows not consumed are resubmitted by the caller and bid again
+    // outputs are cut to the consumed prefix (offsets_to_replicate->resize(i), filter.resize(i): :439-441)
+    if (filter)
+        filter->rows = c.consumed;
+    offsets->rows = c.consumed;
+    if (need_filter)
+        *filter_out = filter;
+    if (need_repl)
+        *offsets_out = offsets;
+    else
+        chgpu_col_free(offsets);
+    *right_rowid_out = rowid;
+    *n_out = c.n_out;
+    *n_left_consumed = c.consumed;
+    ctx->counters[3] += c.consumed;
+    ctx->counters[4] += c.n_out;
+    return CHGPU_OK;
+}

@@ -1,0 +1,110 @@
+"""HashJoin mirror (IJoin: src/Interpreters/IJoin.h:80-142; HashJoin key64) over the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as K
+from .columns import TAG_OF, Column, Context
+
+NO_ROW = 0xFFFFFFFFFFFFFFFF
+
+
+class HashJoin:
+    def __init__(self, kind: int, strictness: int, any_take_last_row: bool = False, key_dtype=np.uint64, ctx: Context | None = None):
+        self.ctx = ctx if ctx is not None else Context(0)
+        self.kind, self.strictness = kind, strictness
+        self.key_dtype = np.dtype(key_dtype)
+        h = C.c_void_p()
+        K.check(K.lib().chgpu_join_create(self.ctx._h, TAG_OF[self.key_dtype], kind, strictness, int(any_take_last_row), 0, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            K.lib().chgpu_join_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def need_replication(self):  # JoinFeatures.h:29
+        return self.strictness == K.STRICT_ALL
+
+    @property
+    def need_filter(self):  # JoinFeatures.h:32
+        return not self.need_replication and (self.kind == K.JOIN_INNER or self.strictness in (K.STRICT_SEMI, K.STRICT_ANTI))
+
+    def _col(self, x, dtype=None):
+        if isinstance(x, Column):
+            return x
+        x = np.ascontiguousarray(x)
+        if dtype is not None and x.dtype != dtype:
+            x = x.astype(dtype)
+        return self.ctx.upload(x)
+
+    def add_block(self, keys, null_map=None, join_mask=None) -> int:
+        """IJoin::addBlockToJoin"""
+        k = self._col(keys, self.key_dtype)
+        nm = self._col(null_map, np.uint8) if null_map is not None else None
+        jm = self._col(join_mask, np.uint8) if join_mask is not None else None
+        idx = C.c_uint32(0)
+        K.check(K.lib().chgpu_join_add_block(self._h, k._h, nm._h if nm else None, jm._h if jm else None, C.byref(idx)))
+        return int(idx.value)
+
+    def finish_build(self):
+        """IJoin::onBuildPhaseFinish"""
+        K.check(K.lib().chgpu_join_finish_build(self._h))
+
+    @property
+    def total_rows(self):
+        r = C.c_uint64(0)
+        K.check(K.lib().chgpu_join_total_rows(self._h, C.byref(r), None))
+        return int(r.value)
+
+    @property
+    def n_keys(self):
+        r, k = C.c_uint64(0), C.c_uint64(0)
+        K.check(K.lib().chgpu_join_total_rows(self._h, C.byref(r), C.byref(k)))
+        return int(k.value)
+
+    def probe_columns(self, keys, null_map=None, max_joined_block_rows: int = 0):
+        """joinBlock's joinRightColumns -> dict(consumed, n_out, filter, offsets, right_rowid) of device Columns."""
+        k = self._col(keys, self.key_dtype)
+        nm = self._col(null_map, np.uint8) if null_map is not None else None
+        fh, oh, rh = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n_out, consumed = C.c_uint64(0), C.c_uint64(0)
+        K.check(K.lib().chgpu_join_probe(self._h, k._h, nm._h if nm else None, max_joined_block_rows, C.byref(fh), C.byref(oh), C.byref(rh),
+                                         C.byref(n_out), C.byref(consumed)))
+        return dict(consumed=int(consumed.value), n_out=int(n_out.value),
+                    filter=Column(self.ctx, fh) if fh.value else None,
+                    offsets=Column(self.ctx, oh) if oh.value else None,
+                    right_rowid=Column(self.ctx, rh))
+
+    def probe(self, keys, null_map=None, max_joined_block_rows: int = 0):
+        r = self.probe_columns(keys, null_map, max_joined_block_rows)
+        rid = r["right_rowid"].numpy()
+        miss = rid == np.uint64(NO_ROW)
+        block = np.where(miss, -1, (rid >> np.uint64(32)).astype(np.int64))
+        row = np.where(miss, -1, (rid & np.uint64(0xFFFFFFFF)).astype(np.int64))
+        return dict(consumed=r["consumed"], filter=r["filter"].numpy() if r["filter"] is not None else None,
+                    offsets=r["offsets"].numpy() if r["offsets"] is not None else None,
+                    added_block=block.astype(np.int64), added_row=row.astype(np.int64))
+
+    def joined_pairs(self, keys, null_map=None, max_joined_block_rows: int = 0):
+        """Canonical observable result: (left_row, right_block, right_row) per joined row, in output order."""
+        r = self.probe(keys, null_map, max_joined_block_rows)
+        c = r["consumed"]
+        if self.need_replication:
+            counts = np.diff(np.concatenate([[0], r["offsets"]])).astype(np.int64)
+            left = np.repeat(np.arange(c, dtype=np.int64), counts)
+        elif self.need_filter:
+            left = np.nonzero(r["filter"])[0].astype(np.int64)
+        else:
+            left = np.arange(c, dtype=np.int64)
+        assert left.shape[0] == r["added_block"].shape[0]
+        return left, r["added_block"], r["added_row"], c

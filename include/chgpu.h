@@ -1,0 +1,231 @@
+/*
+ * chgpu.h — C ABI of the MI355X-native block-processing hot path (filter -> aggregate -> hash join).
+ *
+ * This is the drop-in boundary.  The reference (filimonov/ClickHouse) has no C ABI for this path; its extension
+ * points are C++ virtual interfaces.  Every entry point below names the reference interface it stands in for
+ * (file:line relative to the reference checkout); INTEGRATION.md shows the C++ shim a maintainer adds on the
+ * reference side (GpuFilterTransform : ISimpleTransform, GpuAggregator, GpuHashJoin : IJoin) that calls these.
+ *
+ * Conventions
+ *   - plain C, opaque handles, no torch/HIP types in signatures (a hipStream_t travels as void*);
+ *   - every call returns an int status: 0 = OK, negative = error mapped from the reference's error names;
+ *     chgpu_last_error() gives the message of the calling thread's last failure; nothing throws across the ABI;
+ *   - the caller owns host buffers; the library owns device buffers behind handles;
+ *   - a chgpu_ctx binds one device + one HIP stream; N host threads drive N contexts concurrently (the
+ *     threading contract of IProcessor::work(), src/Processors/IProcessor.h:176-193); one ctx is single-threaded;
+ *   - CHGPU_ERR_NOT_IMPLEMENTED means "fall back to the CPU path" (mirror of isCompilable() gating,
+ *     src/AggregateFunctions/AggregateFunctionSum.h:590-604).
+ */
+#ifndef CHGPU_H
+#define CHGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHGPU_ABI_VERSION 1
+
+/* ---- status codes (names follow src/Common/ErrorCodes.cpp) ---- */
+enum
+{
+    CHGPU_OK = 0,
+    CHGPU_ERR_SIZES_MISMATCH = -1,  /* SIZES_OF_COLUMNS_DOESNT_MATCH (ColumnVector.cpp:685-686) */
+    CHGPU_ERR_NOT_IMPLEMENTED = -2, /* NOT_IMPLEMENTED: caller falls back to CPU */
+    CHGPU_ERR_OOM = -3,             /* CANNOT_ALLOCATE_MEMORY */
+    CHGPU_ERR_LOGICAL = -4,         /* LOGICAL_ERROR */
+    CHGPU_ERR_BAD_ARGUMENTS = -5,   /* BAD_ARGUMENTS */
+    CHGPU_ERR_DEVICE = -6,          /* a HIP runtime call failed */
+    CHGPU_ERR_TOO_MANY_ROWS = -7    /* TOO_MANY_ROWS (HashJoin.cpp:563-564: block >= 2^32 rows) */
+};
+
+/* ---- column element types (the TypeIndex subset of the hot path, src/Core/TypeId.h) ---- */
+enum
+{
+    CHGPU_I64 = 0,
+    CHGPU_U32 = 1,
+    CHGPU_U64 = 2,
+    CHGPU_F64 = 3,
+    CHGPU_U8 = 4,
+    CHGPU_I32 = 5
+};
+
+/* ---- comparison functions (src/Functions/FunctionsComparison.h: equals..greaterOrEquals) ---- */
+enum { CHGPU_EQ = 0, CHGPU_NE = 1, CHGPU_LT = 2, CHGPU_GT = 3, CHGPU_LE = 4, CHGPU_GE = 5 };
+
+/* ---- aggregate functions with POD states the device can hold (src/AggregateFunctions/) ---- */
+enum { CHGPU_AGG_COUNT = 0, CHGPU_AGG_SUM = 1, CHGPU_AGG_AVG = 2 };
+
+/* ---- JoinKind / JoinStrictness subset (src/Core/Joins.h) ---- */
+enum { CHGPU_JOIN_INNER = 0, CHGPU_JOIN_LEFT = 1 };
+enum { CHGPU_STRICT_ANY = 0, CHGPU_STRICT_ALL = 1, CHGPU_STRICT_SEMI = 2, CHGPU_STRICT_ANTI = 3 };
+
+typedef struct chgpu_ctx chgpu_ctx;
+typedef struct chgpu_col chgpu_col;
+typedef struct chgpu_agg chgpu_agg;
+typedef struct chgpu_join chgpu_join;
+
+/* ================================================================================================
+ * context
+ * ============================================================================================== */
+int chgpu_abi_version(void);
+const char * chgpu_last_error(void);
+/* hip_stream: an existing hipStream_t to launch on (e.g. the host framework's stream), or NULL for a private one */
+int chgpu_ctx_create(int device_id, void * hip_stream, chgpu_ctx ** out);
+int chgpu_ctx_destroy(chgpu_ctx * ctx);
+int chgpu_ctx_synchronize(chgpu_ctx * ctx);
+/* ProfileEvents-style counters of this context (src/Common/ProfileEvents.cpp:1034-1035, 245-247):
+   [0] FilterTransformPassedRows [1] FilterTransformPassedBytes [2] JoinBuildTableRowCount
+   [3] JoinProbeTableRowCount [4] JoinResultRowCount [5] AggregatedRows [6] kernel launches [7] table rehashes */
+#define CHGPU_N_COUNTERS 8
+int chgpu_ctx_counters(chgpu_ctx * ctx, uint64_t out[CHGPU_N_COUNTERS]);
+/* HIP-event stopwatch on the context's stream (IProcessor::elapsed_ns analogue, IProcessor.h:359-364) */
+int chgpu_timer_start(chgpu_ctx * ctx);
+int chgpu_timer_stop_ms(chgpu_ctx * ctx, double * elapsed_ms); /* synchronizes on the stop event */
+
+/* ================================================================================================
+ * a1/a2 columns: PaddedPODArray<T> pinned into HBM (src/Common/PODArray.h:51-57; IColumn::Filter =
+ * PaddedPODArray<UInt8>, src/Columns/FilterDescription.h:14).  Device buffers are over-allocated by 64 B on both
+ * sides like the reference's pad so kernels may over-read a vector lane.
+ * ============================================================================================== */
+int chgpu_col_upload(chgpu_ctx * ctx, int type, const void * host_ptr, uint64_t rows, chgpu_col ** out);
+int chgpu_col_alloc(chgpu_ctx * ctx, int type, uint64_t rows, chgpu_col ** out);
+/* non-owning view of caller-managed HBM (columns already resident on the device) */
+int chgpu_col_wrap(chgpu_ctx * ctx, int type, void * device_ptr, uint64_t rows, chgpu_col ** out);
+/* IColumn::cut(start, length) as a non-owning view (src/Columns/IColumn.h:118-121) */
+int chgpu_col_slice(chgpu_ctx * ctx, const chgpu_col * col, uint64_t start, uint64_t rows, chgpu_col ** out);
+int chgpu_col_download(chgpu_ctx * ctx, const chgpu_col * col, void * host_ptr, uint64_t rows);
+uint64_t chgpu_col_rows(const chgpu_col * col);
+int chgpu_col_type(const chgpu_col * col);
+void * chgpu_col_device_ptr(const chgpu_col * col);
+int chgpu_col_free(chgpu_col * col);
+
+/* ================================================================================================
+ * a3 comparison  —  IFunction::executeImpl for less/greater/equals... with a constant right argument:
+ * NumComparisonImpl<A,B,Op>::vectorConstant (src/Functions/FunctionsComparison.h:204-245), semantics
+ * accurate::lessOp/equalsOp (src/Core/AccurateComparison.h:20-130).  mask[i] = Op(col[i], scalar) ? 1 : 0.
+ * Supported: integer column x integer scalar of any signedness (compared mathematically), F64 x F64.
+ * ============================================================================================== */
+int chgpu_cmp_const(chgpu_ctx * ctx, const chgpu_col * col, int op, int scalar_type, const void * scalar,
+                    chgpu_col ** mask_u8);
+
+/* ================================================================================================
+ * a4/a5 filter  —  IColumn::filter(const Filter &, ssize_t result_size_hint) (src/Columns/IColumn.h:313-314;
+ * ColumnVector<T>::filter, src/Columns/ColumnVector.cpp:682-724).  Order-preserving; any non-zero mask byte keeps
+ * the row; size mismatch -> CHGPU_ERR_SIZES_MISMATCH.  result_size_hint: <0 reserve rows, >0 reserve hint, 0 exact.
+ * ============================================================================================== */
+int chgpu_count_bytes_in_filter(chgpu_ctx * ctx, const chgpu_col * mask_u8, uint64_t * count); /* ColumnsCommon.cpp:31-58 */
+int chgpu_filter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * mask_u8, int64_t result_size_hint,
+                 chgpu_col ** out, uint64_t * out_rows);
+/* a6 FilterDescription for Nullable(UInt8): res = data && !null (src/Columns/FilterDescription.cpp:86-92) */
+int chgpu_filter_description_nullable(chgpu_ctx * ctx, const chgpu_col * data_u8, const chgpu_col * null_u8, chgpu_col ** out);
+
+/* ================================================================================================
+ * a8/a9 aggregate functions without key  —  IAggregateFunction::addBatchSinglePlace
+ * (src/AggregateFunctions/IAggregateFunction.h:254-260): AggregateFunctionSumData::addMany /
+ * addManyConditional (AggregateFunctionSum.h:62-236).  state8 is the 8-byte host-side state (Int64 for signed,
+ * UInt64 for unsigned, Float64 for floats: SumSimple, AggregateFunctionSum.cpp:19-28); the batch sum is ADDED to it.
+ * ============================================================================================== */
+int chgpu_sum_add_many(chgpu_ctx * ctx, const chgpu_col * col, uint64_t row_begin, uint64_t row_end, void * state8);
+int chgpu_sum_add_many_conditional(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * cond_u8,
+                                   uint64_t row_begin, uint64_t row_end, void * state8);
+
+/* Fused a3+a5+a8/a9 for `SELECT sum(val), count() WHERE pred <op> scalar` (FilterTransform::doTransform,
+ * src/Processors/Transforms/FilterTransform.cpp:136-256 -> Aggregator::executeWithoutKeyImpl,
+ * src/Interpreters/Aggregator.cpp:1276-1321): one pass over HBM, no mask, no filtered column.
+ * val may equal pred.  sum_out: 8 bytes typed like SumSimple(val type). */
+int chgpu_filter_sum(chgpu_ctx * ctx, const chgpu_col * pred, int op, int scalar_type, const void * scalar,
+                     const chgpu_col * val, void * sum_out, uint64_t * count_out);
+/* same, no host synchronisation: result_u64x2 is a 2-row CHGPU_U64 device column receiving {sum bits, count} */
+int chgpu_filter_sum_async(chgpu_ctx * ctx, const chgpu_col * pred, int op, int scalar_type, const void * scalar,
+                           const chgpu_col * val, chgpu_col * result_u64x2);
+
+/* ================================================================================================
+ * a22 data movement  —  IColumn::index / replicate (src/Columns/ColumnVector.cpp:1121-1143, 879-907)
+ * ============================================================================================== */
+/* out[i] = col[indexes[i]], i < limit (limit 0 = all); indexes: CHGPU_U64 or CHGPU_U32.
+   default_for_missing != 0: index == all-ones (-1) yields the type default 0 (join LEFT misses, insertDefault) */
+int chgpu_index(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * indexes, uint64_t limit,
+                int default_for_missing, chgpu_col ** out);
+/* offsets: CHGPU_U64 cumulative (IColumn::Offsets) */
+int chgpu_replicate(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * offsets_u64, chgpu_col ** out);
+
+/* ================================================================================================
+ * a11/a21 hashing & sharding  —  ColumnVector::getWeakHash32 (ColumnVector.cpp:78-95), ConcurrentHashJoin
+ * hashToSelector (src/Interpreters/ConcurrentHashJoin.cpp:426-440), IColumn::scatter (src/Columns/IColumn.cpp:245-269).
+ * Bit-exact CRC32-C (Hash.h:63-66): shard ids are externally visible.
+ * ============================================================================================== */
+/* hash_u32[i] = (u32) hashCRC32(col[i], hash_u32[i])  (in place; initialise to 0xFFFFFFFF like WeakHash32) */
+int chgpu_weak_hash32(chgpu_ctx * ctx, const chgpu_col * col, chgpu_col * hash_u32);
+/* selector[i] = ((crc32c(key) >> 24) & 0xFF) & (num_shards-1); num_shards power of two <= 256; out: CHGPU_U32 */
+int chgpu_hash_to_selector(chgpu_ctx * ctx, const chgpu_col * keys, uint32_t num_shards, chgpu_col ** selector_u32);
+/* stable split of col by selector into num_columns new columns (outs[num_columns]) */
+int chgpu_scatter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * selector_u32, uint32_t num_columns,
+                  chgpu_col ** outs);
+/* one-call hash partition of n_cols columns by keys (cols[0] must be the key column or any payload): computes the
+   selector once, returns per-shard row counts (host, counts[num_shards]) and for each input column ONE output column
+   holding the shards back to back (shard s occupies [sum(counts[:s]), +counts[s])) — the send buffer of an
+   all-to-all.  Stable within a shard. */
+int chgpu_partition_by_hash(chgpu_ctx * ctx, const chgpu_col * keys, uint32_t num_shards, uint32_t n_cols,
+                            const chgpu_col * const * cols, chgpu_col ** outs, uint64_t * counts);
+
+/* ================================================================================================
+ * a12-a17 GROUP BY  —  Aggregator::executeOnBlock / mergeOnBlock / convertToBlocks
+ * (src/Interpreters/Aggregator.h:179-190,227,253; Aggregator.cpp:1506-1627, 2468-2725, 2037-2117) with
+ * AggregatedDataVariants key32/key64 = HashMap<UInt64, AggregateDataPtr> (AggregatedData.h:38).
+ * One chgpu_agg == one AggregatedDataVariants (single writer).  key_type < 0: without_key.
+ * Device table: open addressing, linear probing, power-of-two capacity, max fill 1/2, growth x4 until 2^23 then x2,
+ * empty <=> key == 0 with the zero key kept out of line — the geometry of HashTable.h:217-330,358-391.
+ * ============================================================================================== */
+int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, const int * agg_kinds, const int * arg_types,
+                     uint64_t size_hint, chgpu_agg ** out);
+/* executeOnBlock over rows [row_begin,row_end) of the key column and the argument columns (arg_cols[j] may be NULL
+   for count()) */
+int chgpu_agg_add_block(chgpu_agg * agg, const chgpu_col * key_col, const chgpu_col * const * arg_cols,
+                        uint64_t row_begin, uint64_t row_end);
+/* mergeDataImpl: fold src's states into dst (src stays valid but should be freed) */
+int chgpu_agg_merge(chgpu_agg * dst, const chgpu_agg * src);
+/* merge partial states that arrive as columns (the ColumnAggregateFunction blocks of a distributed GROUP BY,
+   Aggregator::mergeOnBlock :227): keys + one state column per aggregate (avg: two columns numerator, denominator
+   passed consecutively in state_cols) */
+int chgpu_agg_merge_states(chgpu_agg * dst, const chgpu_col * key_col, const chgpu_col * const * state_cols, uint64_t rows);
+int chgpu_agg_size(chgpu_agg * agg, uint64_t * groups);
+/* convertToBlockImplFinal: key column + one result column per aggregate (count -> U64, sum -> SumSimple type,
+   avg -> F64).  Row order is table order (unspecified, as in the reference); keys_out may be NULL for without_key. */
+int chgpu_agg_finalize(chgpu_agg * agg, chgpu_col ** keys_out, chgpu_col ** res_cols, uint64_t * groups);
+/* convertToBlockImplNotFinal: raw states (sum/count 8 B; avg -> numerator, denominator as two columns) */
+int chgpu_agg_export_states(chgpu_agg * agg, chgpu_col ** keys_out, chgpu_col ** state_cols, uint64_t * groups);
+int chgpu_agg_free(chgpu_agg * agg);
+
+/* ================================================================================================
+ * a19/a20 hash join  —  IJoin::addBlockToJoin / onBuildPhaseFinish / joinBlock (src/Interpreters/IJoin.h:80-93,142)
+ * for HashJoin key64 (one numeric key up to 8 bytes; src/Interpreters/HashJoin/HashJoin.cpp:254-356,556-768,1036-1101;
+ * HashJoinMethodsImpl.h:220-281,402-549).  RowRef{block*,row} becomes a global build row id
+ * (block_index << 32 | row_in_block); RowRefList's linked 7-slot batches become one CSR array.
+ * ============================================================================================== */
+int chgpu_join_create(chgpu_ctx * ctx, int key_type, int kind, int strictness, int any_take_last_row,
+                      uint64_t size_hint, chgpu_join ** out);
+/* null_map_u8 / join_mask_u8 may be NULL (rows with null key or failed ON mask are not inserted, Impl.h:261-272).
+   block_index_out receives the index the block got (0,1,2...).  rows >= 2^32 -> CHGPU_ERR_TOO_MANY_ROWS. */
+int chgpu_join_add_block(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map_u8,
+                         const chgpu_col * join_mask_u8, uint32_t * block_index_out);
+int chgpu_join_finish_build(chgpu_join * j);
+int chgpu_join_total_rows(chgpu_join * j, uint64_t * rows, uint64_t * keys);
+/* joinRightColumns over the left key column.  Outputs (all device columns, caller frees; unused ones are NULL):
+     filter_u8        [n_left_consumed]  need_filter variants (INNER ANY, LEFT SEMI, LEFT ANTI)
+     offsets_u64      [n_left_consumed]  need_replication variants (ALL): cumulative offsets_to_replicate
+     right_rowid_u64  [n_out]            one entry per appended right row: (block<<32|row), all-ones = default row
+   max_joined_block_rows: 0 = unlimited; else processing stops BEFORE the first left row at which the running
+   output count is already >= max (HashJoinMethodsImpl.h:436-444) and n_left_consumed < rows tells the caller to
+   resubmit the tail (JoiningTransform.cpp:220-260). */
+int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map_u8,
+                     uint64_t max_joined_block_rows, chgpu_col ** filter_u8, chgpu_col ** offsets_u64,
+                     chgpu_col ** right_rowid_u64, uint64_t * n_out, uint64_t * n_left_consumed);
+int chgpu_join_free(chgpu_join * j);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHGPU_H */

@@ -1,0 +1,305 @@
+"""GPU parity, GROUP BY / hash join / sharding: HIP kernels through the C ABI vs the CPU
+oracle and vs the reference's golden SQL outputs (tests/golden/sql_reference_rows.json)."""
+import numpy as np
+import pytest
+
+import scenarios as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ch():
+    import clickhouse_amd
+    return clickhouse_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(ch):
+    c = ch.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def engine(ch, ctx):
+    class Engine:
+        @staticmethod
+        def HashJoin(kind, strictness, any_take_last_row=False):
+            return ch.HashJoin(kind, strictness, any_take_last_row, ctx=ctx)
+
+        @staticmethod
+        def Aggregator(key_dtype, aggs, two_level_threshold=100000, size_hint=0):
+            return ch.Aggregator(key_dtype, aggs, two_level_threshold, size_hint, ctx=ctx)
+    return Engine
+
+
+# ---- the reference's own expected rows, through the GPU path --------------------------------------
+@pytest.mark.parametrize("name,fn", [
+    ("00049_any_left_join", S.q00049), ("00050_any_left_join", S.q00050), ("00051_any_inner_join", S.q00051),
+    ("00052_all_left_join", S.q00052), ("00053_all_inner_join", S.q00053), ("00055_join_two_numbers", S.q00055),
+    ("00041_aggregation_remap", S.q00041), ("00266_read_overflow_mode", S.q00266), ("01091_sum_numbers_1e6", S.q01091),
+])
+def test_sql_reference_rows_on_gpu(engine, golden, name, fn):
+    assert fn(engine) == golden["rows"][name]["rows"]
+
+
+def test_00120_join_group_by_on_gpu(engine, golden, oracle_mod):
+    L = oracle_mod.lib()  # only the SQL hash *input columns* come from the oracle's (KAT-pinned) hash functions
+    got = S.q00120(engine, L.cho_sql_intHash64, L.cho_sql_intHash32)
+    assert got == golden["rows"]["00120_join_and_group_by"]["rows"]
+
+
+def test_02144_avg_wraps_like_reference_on_gpu(engine, golden):
+    want = float(golden["rows"]["02144_avg_ubsan"]["rows"][0][0])
+    for got in S.q02144(engine):
+        assert f"{got:.2f}" == f"{want:.2f}"
+
+
+def test_01300_avg_float64_group_by_on_gpu(engine, golden):
+    want = sorted(float(r[0]) for r in golden["rows"]["01300_avg_group_by_mod5"]["rows"])
+    got = S.q01300(engine)
+    assert [round(g, 6) for g in got] == want
+
+
+# ---- randomized parity against the oracle ------------------------------------------------------------
+def _group_ref(k, cols):
+    uk, inv = np.unique(k, return_inverse=True)
+    return uk, inv
+
+
+@pytest.mark.parametrize("key_dtype,groups,size_hint", [
+    (np.uint32, 1000, 0), (np.uint32, 200_000, 0), (np.uint64, 50_000, 1_000_000), (np.int64, 3000, 0), (np.int32, 70_000, 100_000),
+])
+def test_group_by_sum_count_avg_matches_oracle(ch, engine, oracle_mod, key_dtype, groups, size_hint):
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(groups))
+    n = 600_000
+    if np.dtype(key_dtype).kind == "i":
+        k = rng.integers(-groups // 2, groups // 2, size=n).astype(key_dtype)
+    else:
+        k = rng.integers(0, groups, size=n).astype(key_dtype)
+    k[:7] = 0
+    v = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)          # sums wrap modulo 2^64
+    u = rng.integers(0, 2**32, size=n, dtype=np.uint32)
+    f = rng.random(n)
+    aggs = [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None), (ch.AGG_AVG, np.float64), (ch.AGG_SUM, np.uint32), (ch.AGG_AVG, np.int64)]
+    g = engine.Aggregator(key_dtype, aggs, size_hint=size_hint)
+    o = O.Aggregator(key_dtype, aggs)
+    for b in range(0, n, 65409 * 3):
+        e = min(n, b + 65409 * 3)
+        g.execute_on_block(k[b:e], [v[b:e], None, f[b:e], u[b:e], v[b:e]])
+        o.execute_on_block(k[b:e], [v[b:e], None, f[b:e], u[b:e], v[b:e]])
+    assert len(g) == len(o)
+    gk, gr = g.convert_to_block()
+    ok, orr = o.convert_to_block()
+    gi, oi = np.argsort(gk, kind="stable"), np.argsort(ok, kind="stable")
+    assert gk.dtype == ok.dtype and np.array_equal(gk[gi], ok[oi])
+    for j, (kind, dt) in enumerate(aggs):
+        a, b = gr[j][gi], orr[j][oi]
+        assert a.dtype == b.dtype
+        if a.dtype == np.float64:
+            assert np.allclose(a, b, rtol=1e-6, atol=0), j   # north_star tolerance for sum/avg(Float64)
+        else:
+            assert np.array_equal(a, b), j                   # integer sums / counts bit-exact
+
+
+def test_group_by_growth_from_small_hint_and_row_ranges(ch, engine, oracle_mod):
+    # far more groups than the initial table (2^18 cells): exercises pending rows + rehash (resize on overflow)
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(77))
+    n = 1_500_000
+    k = rng.integers(0, 2**40, size=n, dtype=np.uint64)
+    v = rng.integers(-1000, 1000, size=n, dtype=np.int64)
+    g = engine.Aggregator(np.uint64, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], size_hint=100_000)
+    g.execute_on_block(k, [v, None], 0, 700_001)
+    g.execute_on_block(k, [v, None], 700_001, n)
+    assert g.ctx.counters()["TableRehashes"] >= 1
+    gk, (gs, gc) = g.convert_to_block()
+    uk, inv = np.unique(k, return_inverse=True)
+    ws = np.zeros(uk.shape[0], dtype=np.int64)
+    np.add.at(ws, inv, v)
+    gi = np.argsort(gk)
+    assert np.array_equal(gk[gi], uk) and np.array_equal(gs[gi], ws) and np.array_equal(gc[gi], np.bincount(inv).astype(np.uint64))
+
+
+def test_group_by_skew_single_hot_key_and_merge(ch, engine, oracle_mod):
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 2_000_000
+    k = (rng.zipf(1.1, size=n) % 1_000_000).astype(np.uint32)
+    v = rng.integers(-2**31, 2**31, size=n, dtype=np.int64)
+    aggs = [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)]
+    parts = []
+    for lo, hi in ((0, 900_000), (900_000, n)):
+        g = engine.Aggregator(np.uint32, aggs)
+        g.execute_on_block(k[lo:hi], [v[lo:hi], None])
+        parts.append(g)
+    parts[0].merge(parts[1])                       # mergeDataImpl on the device
+    keys_c, states, rows = parts[1].export_state_columns()
+    third = engine.Aggregator(np.uint32, aggs)     # mergeOnBlock-style: states arriving as columns
+    third.merge_states(keys_c, states, rows)
+    third.execute_on_block(k[:900_000], [v[:900_000], None])
+    o = O.Aggregator(np.uint32, aggs)
+    o.execute_on_block(k, [v, None])
+    ok, (os_, oc) = o.convert_to_block()
+    oi = np.argsort(ok)
+    for g in (parts[0], third):
+        gk, (gs, gc) = g.convert_to_block()
+        gi = np.argsort(gk)
+        assert np.array_equal(gk[gi], ok[oi]) and np.array_equal(gs[gi], os_[oi]) and np.array_equal(gc[gi], oc[oi])
+
+
+def test_without_key_and_empty_input(ch, engine, oracle_mod):
+    a = engine.Aggregator(None, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None), (ch.AGG_AVG, np.float64)])
+    keys, (s, c, avg) = a.convert_to_block()
+    # no-key aggregation over an empty input still yields ONE row (AggregatingTransform.cpp:700-708); avg = 0/0 = NaN
+    assert keys is None and s.tolist() == [0] and c.tolist() == [0] and np.isnan(avg[0])
+    v = np.arange(100_000, dtype=np.int64)
+    f = np.linspace(0, 1, 100_000)
+    a.execute_on_block(None, [v, None, f])
+    b = engine.Aggregator(None, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None), (ch.AGG_AVG, np.float64)])
+    b.execute_on_block(None, [v, None, f], 10, 20)
+    a.merge(b)
+    _, (s, c, avg) = a.convert_to_block()
+    assert int(s[0]) == int(v.sum()) + int(v[10:20].sum()) and int(c[0]) == 100_010
+    assert abs(avg[0] - (f.sum() + f[10:20].sum()) / 100_010) < 1e-9
+    g = engine.Aggregator(np.uint32, [(ch.AGG_COUNT, None)])
+    assert len(g) == 0
+    gk, (gc,) = g.convert_to_block()
+    assert gk.shape[0] == 0 and gc.shape[0] == 0
+
+
+def _pairs(left, block, row):
+    return sorted(zip(left.tolist(), block.tolist(), row.tolist()))
+
+
+@pytest.mark.parametrize("kind,strict,kw", [
+    ("INNER", "ALL", {}), ("LEFT", "ALL", {}), ("LEFT", "ANY", {}), ("LEFT", "ANY", {"any_take_last_row": True}),
+    ("INNER", "ANY", {}), ("LEFT", "SEMI", {}), ("LEFT", "ANTI", {}),
+])
+def test_join_matrix_matches_oracle(ch, engine, oracle_mod, kind, strict, kw):
+    O = oracle_mod
+    K_ = {"INNER": ch.JOIN_INNER, "LEFT": ch.JOIN_LEFT}[kind]
+    S_ = {"ALL": ch.STRICT_ALL, "ANY": ch.STRICT_ANY, "SEMI": ch.STRICT_SEMI, "ANTI": ch.STRICT_ANTI}[strict]
+    rng = np.random.Generator(np.random.PCG64(31))
+    rb = [rng.integers(0, 5000, size=n, dtype=np.uint64) for n in (20_000, 1, 30_001)]   # duplicates + key 0
+    lb = [rng.integers(0, 10_000, size=n, dtype=np.uint64) for n in (50_000, 777)]
+    rnull = (rng.integers(0, 50, size=20_000) == 0).astype(np.uint8)
+    rmask = (rng.integers(0, 20, size=30_001) != 0).astype(np.uint8)
+    lnull = (rng.integers(0, 40, size=50_000) == 0).astype(np.uint8)
+    g, o = engine.HashJoin(K_, S_, **kw), O.HashJoin(K_, S_, **kw)
+    for j in (g, o):
+        j.add_block(rb[0], null_map=rnull)
+        j.add_block(rb[1])
+        j.add_block(rb[2], join_mask=rmask)
+    assert g.total_rows == o.total_rows and g.n_keys == o.n_keys
+    for keys, nm in ((lb[0], lnull), (lb[1], None)):
+        gl, gb, gr, gc = g.joined_pairs(keys, nm)
+        ol, ob, orow, oc = o.joined_pairs(keys, nm)
+        assert gc == oc
+        if strict == "ALL":
+            # per left row the matches are a multiset (RowRefList order is an implementation detail) but the first
+            # match of a left row is the first-inserted right row in both
+            assert _pairs(gl, gb, gr) == _pairs(ol, ob, orow)
+            first_g = np.concatenate([[True], gl[1:] != gl[:-1]])
+            first_o = np.concatenate([[True], ol[1:] != ol[:-1]])
+            assert np.array_equal(gb[first_g], ob[first_o]) and np.array_equal(gr[first_g], orow[first_o])
+            rg, ro = g.probe(keys, nm), o.probe(keys, nm)
+            assert np.array_equal(rg["offsets"], ro["offsets"])          # offsets_to_replicate bit-exact
+        else:
+            assert np.array_equal(gl, ol) and np.array_equal(gb, ob) and np.array_equal(gr, orow)   # bit-exact, in order
+
+
+def test_join_max_joined_block_rows_resubmission(ch, engine, oracle_mod):
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(8))
+    right = rng.integers(0, 300, size=5000, dtype=np.uint64)
+    left = rng.integers(0, 400, size=3000, dtype=np.uint64)
+    g, o = engine.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL), O.HashJoin(O.JOIN_INNER, O.STRICT_ALL)
+    g.add_block(right)
+    o.add_block(right)
+    pos, total_g, total_o = 0, [], []
+    while pos < left.shape[0]:                      # JoiningTransform::readExecute resubmits the not_processed tail
+        gl, gb, gr, gc = g.joined_pairs(left[pos:], max_joined_block_rows=65)
+        ol, ob, orow, oc = o.joined_pairs(left[pos:], max_joined_block_rows=65)
+        assert gc == oc and gc > 0
+        total_g += _pairs(gl + pos, gb, gr)
+        total_o += _pairs(ol + pos, ob, orow)
+        pos += gc
+    assert total_g == total_o and len(total_g) > 10_000
+
+
+def test_join_empty_sides_and_errors(ch, engine):
+    j = engine.HashJoin(ch.JOIN_LEFT, ch.STRICT_ALL)
+    l, b, r, c = j.joined_pairs(np.array([1, 2, 3], dtype=np.uint64))     # empty right table: LEFT keeps rows with defaults
+    assert l.tolist() == [0, 1, 2] and b.tolist() == [-1, -1, -1] and c == 3
+    j = engine.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL)
+    j.add_block(np.array([5], dtype=np.uint64))
+    l, b, r, c = j.joined_pairs(np.array([], dtype=np.uint64))
+    assert l.shape[0] == 0 and c == 0
+    with pytest.raises(ch.ChgpuError) as e:
+        j.add_block(np.array([6], dtype=np.uint64))                         # addBlockToJoin after the build phase finished
+    assert e.value.code == ch._capi.ERR_LOGICAL
+    with pytest.raises(ch.ChgpuError) as e:
+        ch.HashJoin(2, ch.STRICT_ALL)                                       # RIGHT join: explicit CPU fallback signal
+    assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED
+
+
+def test_join_payload_gather_and_replicate_end_to_end(ch, ctx, engine, oracle_mod):
+    # SELECT pk, bv FROM probe INNER JOIN build ON pk = bk  (C4 shape, small) — materialised on the device
+    rng = np.random.Generator(np.random.PCG64(5))
+    nb, npb = 200_000, 1_000_000
+    bk = (rng.permutation(nb).astype(np.uint64) + 1) * np.uint64(2654435761)
+    bv = rng.integers(-2**40, 2**40, size=nb, dtype=np.int64)
+    pk = np.where(rng.integers(0, 2, size=npb) == 0, bk[rng.integers(0, nb, size=npb)], rng.integers(0, 2**63, size=npb, dtype=np.uint64))
+    j = engine.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL)
+    j.add_block(bk)
+    pk_col = ctx.upload(pk)
+    r = j.probe_columns(pk_col)
+    out_bv = ctx.upload(bv).index(r["right_rowid"], default_for_missing=True)   # fillFromBlocksAndRowNumbers (single block: rowid == row)
+    out_pk = pk_col.replicate(r["offsets"])                                      # columns[i]->replicate(offsets)
+    assert r["consumed"] == npb
+    lut = dict(zip(bk.tolist(), bv.tolist()))
+    hit = np.array([x in lut for x in pk.tolist()])
+    assert r["n_out"] == int(hit.sum())
+    assert np.array_equal(out_pk.numpy(), pk[hit])
+    assert np.array_equal(out_bv.numpy(), np.array([lut[x] for x in pk[hit].tolist()], dtype=np.int64))
+    s, c = ch.filter_sum(out_bv, ch.GE, -2**62)                                 # count(), sum(bv) checksum form
+    assert c == int(hit.sum()) and int(s) == int(np.array([lut[x] for x in pk[hit].tolist()], dtype=np.int64).sum())
+
+
+def test_selector_weak_hash_scatter_partition(ch, ctx, oracle_mod):
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 300_007
+    for dtype in (np.uint64, np.uint32, np.int64):
+        keys = rng.integers(0, 2**31, size=n).astype(dtype)
+        keys[:3] = 0
+        kc = ctx.upload(keys)
+        assert np.array_equal(kc.get_weak_hash32().numpy(), O.weak_hash32(keys))               # bit-exact CRC32-C
+        seed = rng.integers(0, 2**32, size=n, dtype=np.uint32)
+        assert np.array_equal(kc.get_weak_hash32(ctx.upload(seed)).numpy(), O.weak_hash32(keys, seed))
+        for shards in (1, 2, 8, 64, 256):
+            sel = ch.hash_to_selector(kc, shards)
+            want = O.hash_to_selector(keys, shards)
+            assert np.array_equal(sel.numpy().astype(np.uint64), want)
+            if shards in (8, 256):
+                parts = kc.scatter(shards, sel)
+                wparts = O.scatter(keys, want, shards)
+                for s in range(shards):
+                    assert np.array_equal(parts[s].numpy(), wparts[s])                          # stable, bit-exact
+    keys = rng.integers(0, 2**63, size=n, dtype=np.uint64)
+    pay = rng.integers(-5, 5, size=n).astype(np.int64)
+    pay32 = rng.integers(0, 100, size=n).astype(np.uint32)
+    kc = ctx.upload(keys)
+    outs, counts = ch.partition_by_hash(kc, 8, [kc, ctx.upload(pay), ctx.upload(pay32)])
+    want_sel = O.hash_to_selector(keys, 8)
+    assert counts.tolist() == np.bincount(want_sel.astype(np.int64), minlength=8).tolist()
+    order = np.argsort(want_sel, kind="stable")
+    assert np.array_equal(outs[0].numpy(), keys[order]) and np.array_equal(outs[1].numpy(), pay[order]) and np.array_equal(outs[2].numpy(), pay32[order])
+    # non-power-of-two scatter with an arbitrary selector
+    sel3 = rng.integers(0, 3, size=n).astype(np.uint32)
+    parts = ctx.upload(pay).scatter(3, ctx.upload(sel3))
+    for s in range(3):
+        assert np.array_equal(parts[s].numpy(), pay[sel3 == s])

@@ -1,0 +1,208 @@
+"""GPU parity, filter path: HIP kernels through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ch():
+    import clickhouse_amd
+    return clickhouse_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(ch):
+    c = ch.Context(0)
+    yield c
+    c.close()
+
+
+DTYPES = [np.int64, np.uint64, np.uint32, np.int32, np.float64, np.uint8]
+
+
+def _rand(rng, dtype, n, lo=0, hi=255):
+    if np.dtype(dtype) == np.float64:
+        return rng.random(n) * (hi - lo) + lo
+    return rng.integers(lo, hi, size=n).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_filter_property_like_gtest_column_vector(ch, ctx, oracle_mod, dtype):
+    rng = np.random.Generator(np.random.PCG64(11))
+    for ratio in (1, 2, 5, 11, 32, 64, 100, 1000):
+        for _ in range(3):
+            rows = int(rng.integers(1, 10000))
+            data = _rand(rng, dtype, rows)
+            filt = ((rng.integers(0, ratio, size=rows) == 0) * rng.integers(1, 255, size=rows)).astype(np.uint8)
+            got = ctx.upload(data).filter(ctx.upload(filt)).numpy()
+            want = oracle_mod.filter_column(data, filt)
+            assert got.dtype == want.dtype and np.array_equal(got, want)
+            assert ch.count_bytes_in_filter(ctx.upload(filt)) == oracle_mod.count_bytes_in_filter(filt)
+
+
+@pytest.mark.parametrize("rows", [0, 1, 63, 64, 65, 1023, 1024, 1025, 65409, 1_000_003])
+def test_filter_ragged_sizes_and_unaligned_views(ch, ctx, oracle_mod, rows):
+    rng = np.random.Generator(np.random.PCG64(rows + 1))
+    data = rng.integers(-2**62, 2**62, size=rows + 3, dtype=np.int64)
+    filt = (rng.integers(0, 10, size=rows + 3) == 0).astype(np.uint8)
+    col, m = ctx.upload(data), ctx.upload(filt)
+    for start in (0, 1, 3):  # views that are 8-B but not 16-B aligned
+        n = rows
+        got = col.cut(start, n).filter(m.cut(start, n)).numpy()
+        assert np.array_equal(got, oracle_mod.filter_column(data[start:start + n], filt[start:start + n]))
+
+
+def test_filter_size_mismatch_is_an_error(ch, ctx):
+    col = ctx.upload(np.arange(10, dtype=np.int64))
+    m = ctx.upload(np.ones(9, dtype=np.uint8))
+    with pytest.raises(ch.ChgpuError) as e:
+        col.filter(m)
+    assert e.value.code == ch._capi.ERR_SIZES_MISMATCH and "doesn't match" in str(e.value)
+
+
+def test_cmp_const_all_ops_and_mixed_signedness(ch, ctx, oracle_mod):
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(5))
+    ops = [ch.EQ, ch.NE, ch.LT, ch.GT, ch.LE, ch.GE]
+    a64 = np.concatenate([rng.integers(-50, 50, size=5000), np.array([-2**63, 2**63 - 1, 0, -1, 1])]).astype(np.int64)
+    u64 = np.concatenate([rng.integers(0, 100, size=5000).astype(np.uint64), np.array([0, 2**64 - 1, 2**63], dtype=np.uint64)])
+    u32 = rng.integers(0, 2**32, size=5001, dtype=np.uint32)
+    i32 = rng.integers(-2**31, 2**31, size=5003).astype(np.int32)
+    cases = [
+        (a64, O.I64, [0, -7, 49, -2**63, 2**63 - 1]), (a64, O.U64, [0, 7, 2**63, 2**64 - 1]),
+        (u64, O.U64, [0, 50, 2**63, 2**64 - 1]), (u64, O.I64, [-1, 0, 50, -2**63, 2**63 - 1]),
+        (u32, O.U64, [0, 2**31, 2**32 - 1, 2**40]), (u32, O.I64, [-5, 2**31]),
+        (i32, O.I64, [-2**31, 0, 2**31 - 1, -2**40, 2**40]), (i32, O.U64, [0, 5, 2**63]),
+    ]
+    for arr, stag, scalars in cases:
+        col = ctx.upload(arr)
+        for s in scalars:
+            for op in ops:
+                got = ch.cmp_const(col, op, s, stag).numpy()
+                want = O.cmp_const(arr, op, s, stag)
+                assert np.array_equal(got, want), (arr.dtype, stag, s, op)
+    f = np.concatenate([rng.standard_normal(4099), np.array([np.nan, np.inf, -np.inf, 0.0, -0.0])])
+    fc = ctx.upload(f)
+    for s in (0.0, 0.5, np.nan, np.inf):
+        for op in ops:
+            assert np.array_equal(ch.cmp_const(fc, op, s).numpy(), O.cmp_const(f, op, s)), (s, op)
+    with pytest.raises(ch.ChgpuError) as e:  # int column vs float constant: explicit CPU fallback signal
+        ch.cmp_const(ctx.upload(a64), ch.LT, 1.5, ch.F64)
+    assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.uint64, np.uint32, np.int32, np.uint8])
+def test_sum_integers_bit_exact_with_wraparound(ch, ctx, oracle_mod, dtype):
+    rng = np.random.Generator(np.random.PCG64(6))
+    info = np.iinfo(dtype)
+    for n in (0, 1, 7, 1000, 65409, 300_001):
+        a = rng.integers(info.min, info.max, size=n, dtype=dtype, endpoint=True)
+        col = ctx.upload(a)
+        got = ch.sum_add_many(col)
+        want = oracle_mod.sum_add_many(a)
+        assert got.dtype == want.dtype and got[0] == want[0]
+        if n > 10:
+            st = np.array([123], dtype=got.dtype)
+            assert ch.sum_add_many(col, 3, n - 2, st)[0] == oracle_mod.sum_add_many(a, 3, n - 2, np.array([123], dtype=got.dtype))[0]
+            cond = (rng.integers(0, 3, size=n) == 0).astype(np.uint8) * 7
+            assert ch.sum_add_many_conditional(col, ctx.upload(cond))[0] == oracle_mod.sum_add_many_conditional(a, cond)[0]
+
+
+def test_sum_float64_within_1e6_relative(ch, ctx, oracle_mod):
+    rng = np.random.Generator(np.random.PCG64(4))
+    for n in (1, 1000, 65409, 2_000_003):
+        a = rng.random(n)
+        got = float(ch.sum_add_many(ctx.upload(a))[0])
+        want = float(oracle_mod.sum_add_many(a)[0])
+        assert abs(got - want) <= 1e-6 * abs(want)  # BASELINE.json north_star tolerance for sum/avg(Float64)
+    # run-to-run reproducible (fixed grid, fixed fold order)
+    col = ctx.upload(rng.standard_normal(1_000_000) * 1e6)
+    assert len({float(ch.sum_add_many(col)[0]) for _ in range(3)}) == 1
+    a = np.array([1.0, np.nan, 2.0])
+    assert np.isnan(ch.sum_add_many(ctx.upload(a))[0])
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 1000, 65409, 10_000_000])
+def test_fused_filter_sum_matches_block_pipeline_c1(ch, ctx, oracle_mod, n):
+    # BASELINE.json configs[0] shape: Int64 uniform [0,2^31), seed 1, a < 214748365 (~10 %)
+    rng = np.random.Generator(np.random.PCG64(1))
+    a = rng.integers(0, 2**31, size=n, dtype=np.int64)
+    s, c = ch.filter_sum(ctx.upload(a), ch.LT, 214748365)
+    so, co, _, _ = oracle_mod.filter_sum_pipeline(a, oracle_mod.LT, 214748365)
+    assert (int(s), c) == (int(so), co)
+
+
+def test_fused_filter_sum_two_columns_types_and_views(ch, ctx, oracle_mod):
+    rng = np.random.Generator(np.random.PCG64(2))
+    n = 1_000_001
+    for dtype in (np.int64, np.uint64, np.uint32, np.int32):
+        info = np.iinfo(dtype)
+        b = rng.integers(info.min, info.max, size=n, dtype=dtype, endpoint=True)
+        a = rng.integers(info.min, info.max, size=n, dtype=dtype, endpoint=True)
+        thr = int(np.quantile(b.astype(np.float64), 0.1))
+        bc, ac = ctx.upload(b), ctx.upload(a)
+        for op in (ch.LT, ch.GE, ch.EQ, ch.NE):
+            s, c = ch.filter_sum(bc, op, thr, ac)
+            so, co, _, _ = oracle_mod.filter_sum_pipeline(b, op, thr, a)
+            assert (int(s), c) == (int(so), co), (dtype, op)
+        # 8-byte-but-not-16-byte aligned views take the scalar-load kernel; same answer
+        s, c = ch.filter_sum(bc.cut(1, n - 2), ch.LT, thr, ac.cut(1, n - 2))
+        so, co, _, _ = oracle_mod.filter_sum_pipeline(b[1:n - 1], oracle_mod.LT, thr, a[1:n - 1])
+        assert (int(s), c) == (int(so), co)
+    f = rng.random(n)
+    s, c = ch.filter_sum(ctx.upload(f), ch.LT, 0.1)
+    so, co, _, _ = oracle_mod.filter_sum_pipeline(f, oracle_mod.LT, 0.1)
+    assert c == co and abs(float(s) - float(so)) <= 1e-6 * abs(float(so))
+    with pytest.raises(ch.ChgpuError) as e:
+        ch.filter_sum(ctx.upload(a[:10]), ch.LT, 1, ctx.upload(a[:9]))
+    assert e.value.code == ch._capi.ERR_SIZES_MISMATCH
+
+
+def test_filter_description_nullable(ch, ctx, oracle_mod):
+    rng = np.random.Generator(np.random.PCG64(3))
+    d = rng.integers(0, 3, size=10007).astype(np.uint8)
+    nm = rng.integers(0, 2, size=10007).astype(np.uint8)
+    got = ch.filter_description_nullable(ctx.upload(d), ctx.upload(nm)).numpy()
+    want = np.zeros_like(d)
+    oracle_mod.lib().cho_filter_description_nullable(d.ctypes.data, nm.ctypes.data, d.shape[0], want.ctypes.data)
+    assert np.array_equal(got, want)
+
+
+def test_index_and_replicate(ch, ctx, oracle_mod):
+    rng = np.random.Generator(np.random.PCG64(9))
+    for dtype in (np.int64, np.uint32, np.uint8, np.float64):
+        data = _rand(rng, dtype, 10000)
+        col = ctx.upload(data)
+        idx = rng.integers(0, 10000, size=5000, dtype=np.uint64)
+        assert np.array_equal(col.index(ctx.upload(idx)).numpy(), oracle_mod.index_column(data, idx))
+        assert np.array_equal(col.index(ctx.upload(idx.astype(np.uint32)), limit=100).numpy(), oracle_mod.index_column(data, idx, 100))
+        cnt = rng.integers(0, 4, size=10000)
+        off = np.cumsum(cnt).astype(np.uint64)
+        assert np.array_equal(col.replicate(ctx.upload(off)).numpy(), oracle_mod.replicate(data, off))
+    miss = np.array([0, 2**64 - 1, 5], dtype=np.uint64)
+    got = ctx.upload(np.arange(1, 11, dtype=np.int64)).index(ctx.upload(miss), default_for_missing=True).numpy()
+    assert got.tolist() == [1, 0, 6]
+
+
+def test_size_independent_properties_at_scale(ch, ctx):
+    # 2^27 rows: linearity of sum over a split, count(p) + count(!p) == n, filter keeps order and sums match
+    import torch
+    n = 1 << 27
+    g = torch.Generator(device="cuda").manual_seed(1)
+    t = torch.randint(0, 2**31, (n,), dtype=torch.int64, device="cuda", generator=g)
+    torch.cuda.synchronize()
+    col = ctx.wrap(t.data_ptr(), np.int64, n, keepalive=t)
+    thr = 214748365
+    s_lt, c_lt = ch.filter_sum(col, ch.LT, thr)
+    s_ge, c_ge = ch.filter_sum(col, ch.GE, thr)
+    total = ch.sum_add_many(col)[0]
+    assert c_lt + c_ge == n and int(s_lt) + int(s_ge) == int(total) == int(t.sum().item())
+    half = n // 2 + 1
+    assert int(ch.sum_add_many(col, 0, half)[0]) + int(ch.sum_add_many(col, half, n)[0]) == int(total)
+    mask = ch.cmp_const(col, ch.LT, thr)
+    assert ch.count_bytes_in_filter(mask) == c_lt
+    kept = col.filter(mask)
+    assert kept.size() == c_lt and int(ch.sum_add_many(kept)[0]) == int(s_lt)
+    # order preserved: equals torch's boolean-mask selection
+    assert np.array_equal(kept.numpy(), t[t < thr].cpu().numpy())
