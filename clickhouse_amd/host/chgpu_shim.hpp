@@ -1,0 +1,497 @@
+// chgpu_shim.hpp — C++ host side above the C ABI (include/chgpu.h), shaped like the reference's plugin surfaces for
+// the hot path so the GPU path is a drop-in under the existing query pipeline:
+//
+//   reference interface (file:line)                                            mirror here
+//   -------------------------------------------------------------------------  ---------------------------------------
+//   DB::Exception + ErrorCodes                                                 chgpu::Exception
+//   IColumn / ColumnVector<T>   src/Columns/IColumn.h:80, ColumnVector.h:28    chgpu::ColumnVector (HBM-resident)
+//   IColumn::Filter             src/Columns/FilterDescription.h:14             chgpu::ColumnVector of UInt8
+//   Chunk                       src/Processors/Chunk.h:55-128                  chgpu::Chunk
+//   IProcessor / ISimpleTransform  src/Processors/IProcessor.h:119-376,        chgpu::IProcessor, chgpu::ISimpleTransform
+//                               ISimpleTransform.h:42
+//   FilterTransform             src/Processors/Transforms/FilterTransform.cpp:136-256   chgpu::GpuFilterTransform
+//   IFunction (less, ...)       src/Functions/IFunction.h:426-434              chgpu::FunctionComparisonConst
+//   IAggregateFunction          src/AggregateFunctions/IAggregateFunction.h:55-399      chgpu::AggregateDescription (closed POD set)
+//   Aggregator                  src/Interpreters/Aggregator.h:179-265          chgpu::GpuAggregator
+//   AggregatingTransform        src/Processors/Transforms/AggregatingTransform.cpp:640-840   chgpu::GpuAggregatingTransform
+//   IJoin / HashJoin            src/Interpreters/IJoin.h:80-142                chgpu::GpuHashJoin
+//   JoiningTransform            src/Processors/Transforms/JoiningTransform.cpp:176-260       chgpu::GpuJoiningTransform
+//
+// Host Blocks (65 409 rows) are far too small per kernel launch, so host-side sources batch many Blocks into one HBM
+// stripe (StripeBuilder) before the device operators run; device-resident Chunks flow between the GPU transforms.
+// Header-only, C++17, no dependency besides include/chgpu.h.  Errors from the C ABI become chgpu::Exception with the
+// reference's error-code meaning; CHGPU_ERR_NOT_IMPLEMENTED is the signal to fall back to the CPU operator.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "../../include/chgpu.h"
+
+namespace chgpu
+{
+
+class Exception : public std::runtime_error
+{
+public:
+    Exception(int code_, const std::string & msg) : std::runtime_error(msg), code_v(code_) {}
+    int code() const { return code_v; }
+    bool isNotImplemented() const { return code_v == CHGPU_ERR_NOT_IMPLEMENTED; }
+
+private:
+    int code_v;
+};
+
+inline void check(int rc)
+{
+    if (rc != CHGPU_OK)
+        throw Exception(rc, chgpu_last_error());
+}
+
+template <typename T> struct TypeTag;
+template <> struct TypeTag<int64_t> { static constexpr int value = CHGPU_I64; };
+template <> struct TypeTag<uint64_t> { static constexpr int value = CHGPU_U64; };
+template <> struct TypeTag<uint32_t> { static constexpr int value = CHGPU_U32; };
+template <> struct TypeTag<int32_t> { static constexpr int value = CHGPU_I32; };
+template <> struct TypeTag<uint8_t> { static constexpr int value = CHGPU_U8; };
+template <> struct TypeTag<double> { static constexpr int value = CHGPU_F64; };
+
+/// One device + one HIP stream: create one per pipeline thread (IProcessor::work() of different processors runs
+/// concurrently, src/Processors/IProcessor.h:176-193).
+class Context
+{
+public:
+    explicit Context(int device = 0, void * hip_stream = nullptr) { check(chgpu_ctx_create(device, hip_stream, &h)); }
+    ~Context() { chgpu_ctx_destroy(h); }
+    Context(const Context &) = delete;
+    Context & operator=(const Context &) = delete;
+    chgpu_ctx * get() const { return h; }
+    void synchronize() const { check(chgpu_ctx_synchronize(h)); }
+
+private:
+    chgpu_ctx * h = nullptr;
+};
+using ContextPtr = std::shared_ptr<Context>;
+
+class ColumnVector;
+using ColumnPtr = std::shared_ptr<const ColumnVector>;
+using MutableColumnPtr = std::shared_ptr<ColumnVector>;
+using Columns = std::vector<ColumnPtr>;
+
+/// ColumnVector<T> pinned into HBM.  Immutable once shared, like the reference's COW columns.
+class ColumnVector
+{
+public:
+    ColumnVector(ContextPtr ctx_, chgpu_col * h_, std::shared_ptr<const void> keepalive_ = nullptr)
+        : ctx(std::move(ctx_)), h(h_), keepalive(std::move(keepalive_)) {}
+    ~ColumnVector() { chgpu_col_free(h); }
+    ColumnVector(const ColumnVector &) = delete;
+
+    template <typename T>
+    static MutableColumnPtr fromHost(const ContextPtr & ctx, const T * data, size_t rows)
+    {
+        chgpu_col * c = nullptr;
+        check(chgpu_col_upload(ctx->get(), TypeTag<T>::value, data, rows, &c));
+        return std::make_shared<ColumnVector>(ctx, c);
+    }
+
+    size_t size() const { return chgpu_col_rows(h); }
+    int getDataType() const { return chgpu_col_type(h); }
+    chgpu_col * handle() const { return h; }
+    const ContextPtr & context() const { return ctx; }
+
+    template <typename T>
+    std::vector<T> getData() const
+    {
+        if (TypeTag<T>::value != getDataType())
+            throw Exception(CHGPU_ERR_BAD_ARGUMENTS, "ColumnVector::getData: type mismatch");
+        std::vector<T> out(size());
+        check(chgpu_col_download(ctx->get(), h, out.data(), out.size()));
+        return out;
+    }
+
+    /// IColumn::filter (IColumn.h:313-314)
+    ColumnPtr filter(const ColumnVector & filt, ssize_t result_size_hint) const
+    {
+        chgpu_col * out = nullptr;
+        uint64_t n = 0;
+        check(chgpu_filter(ctx->get(), h, filt.h, result_size_hint, &out, &n));
+        return std::make_shared<ColumnVector>(ctx, out);
+    }
+    /// IColumn::cut (IColumn.h:118-121); the view keeps its parent alive
+    ColumnPtr cut(size_t start, size_t length, const ColumnPtr & self) const
+    {
+        chgpu_col * out = nullptr;
+        check(chgpu_col_slice(ctx->get(), h, start, length, &out));
+        return std::make_shared<ColumnVector>(ctx, out, self);
+    }
+    /// IColumn::index (IColumn.h:331)
+    ColumnPtr index(const ColumnVector & indexes, size_t limit, bool default_for_missing = false) const
+    {
+        chgpu_col * out = nullptr;
+        check(chgpu_index(ctx->get(), h, indexes.h, limit, default_for_missing ? 1 : 0, &out));
+        return std::make_shared<ColumnVector>(ctx, out);
+    }
+    /// IColumn::replicate (IColumn.h:440)
+    ColumnPtr replicate(const ColumnVector & offsets) const
+    {
+        chgpu_col * out = nullptr;
+        check(chgpu_replicate(ctx->get(), h, offsets.h, &out));
+        return std::make_shared<ColumnVector>(ctx, out);
+    }
+    /// IColumn::scatter (IColumn.h:448)
+    std::vector<ColumnPtr> scatter(uint32_t num_columns, const ColumnVector & selector) const
+    {
+        std::vector<chgpu_col *> outs(num_columns, nullptr);
+        check(chgpu_scatter(ctx->get(), h, selector.h, num_columns, outs.data()));
+        std::vector<ColumnPtr> res;
+        for (auto * c : outs)
+            res.push_back(std::make_shared<ColumnVector>(ctx, c));
+        return res;
+    }
+
+private:
+    ContextPtr ctx;
+    chgpu_col * h;
+    std::shared_ptr<const void> keepalive;
+};
+
+/// Chunk (src/Processors/Chunk.h:55-128): columns + row count, move-only in spirit.
+struct Chunk
+{
+    Columns columns;
+    size_t num_rows = 0;
+    bool empty() const { return num_rows == 0; }
+    void clear() { columns.clear(); num_rows = 0; }
+    explicit operator bool() const { return !columns.empty() || num_rows; }
+};
+
+/// Batches host Blocks into one HBM stripe per column: a 65 409-row Block is ~0.5 MB, far below what fills 256 CUs.
+template <typename T>
+class StripeBuilder
+{
+public:
+    explicit StripeBuilder(ContextPtr ctx_, size_t reserve_rows = 0) : ctx(std::move(ctx_)) { staging.reserve(reserve_rows); }
+    void appendBlock(const T * data, size_t rows) { staging.insert(staging.end(), data, data + rows); }
+    size_t rows() const { return staging.size(); }
+    ColumnPtr flush()
+    {
+        auto col = ColumnVector::fromHost<T>(ctx, staging.data(), staging.size());
+        staging.clear();
+        return col;
+    }
+
+private:
+    ContextPtr ctx;
+    std::vector<T> staging;
+};
+
+/// IFunction for `col <op> constant` (FunctionsComparison.h:204-245): executeImpl -> UInt8 column.
+class FunctionComparisonConst
+{
+public:
+    template <typename S>
+    FunctionComparisonConst(int op_, S scalar_) : op(op_), scalar_type(TypeTag<S>::value)
+    {
+        static_assert(sizeof(S) <= 8);
+        std::memcpy(scalar, &scalar_, sizeof(S));
+    }
+    ColumnPtr executeImpl(const ColumnVector & arg) const
+    {
+        chgpu_col * out = nullptr;
+        check(chgpu_cmp_const(arg.context()->get(), arg.handle(), op, scalar_type, scalar, &out));
+        return std::make_shared<ColumnVector>(arg.context(), out);
+    }
+    int op;
+    int scalar_type;
+    unsigned char scalar[8] = {0};
+};
+
+/// IProcessor (src/Processors/IProcessor.h:119-376), reduced to the synchronous part the hot path needs.
+class IProcessor
+{
+public:
+    enum class Status { NeedData, PortFull, Finished, Ready };
+    virtual ~IProcessor() = default;
+    virtual std::string getName() const = 0;
+    virtual void work() = 0;
+    uint64_t elapsed_ns = 0; // IProcessor.h:359
+};
+
+/// ISimpleTransform (ISimpleTransform.h:42): transform(Chunk &) consumes one chunk, may produce one.
+class ISimpleTransform : public IProcessor
+{
+public:
+    void setInput(Chunk c) { input = std::move(c); has_input = true; }
+    bool hasOutput() const { return has_output; }
+    Chunk pullOutput() { has_output = false; return std::move(output); }
+    void work() override
+    {
+        if (!has_input)
+            return;
+        Chunk c = std::move(input);
+        has_input = false;
+        transform(c);
+        if (c.num_rows != 0) // ISimpleTransform.cpp:101-107: empty chunks are skipped
+        {
+            output = std::move(c);
+            has_output = true;
+        }
+    }
+
+protected:
+    virtual void transform(Chunk & chunk) = 0;
+    Chunk input, output;
+    bool has_input = false, has_output = false;
+};
+
+/// FilterTransform::doTransform (FilterTransform.cpp:136-256): expression -> filter column -> filter every column.
+class GpuFilterTransform : public ISimpleTransform
+{
+public:
+    GpuFilterTransform(size_t filter_arg_position_, FunctionComparisonConst predicate_)
+        : filter_arg_position(filter_arg_position_), predicate(std::move(predicate_)) {}
+    std::string getName() const override { return "GpuFilterTransform"; }
+    uint64_t passed_rows = 0; // ProfileEvents::FilterTransformPassedRows
+
+protected:
+    void transform(Chunk & chunk) override
+    {
+        const auto & arg = *chunk.columns.at(filter_arg_position);
+        auto mask = predicate.executeImpl(arg); // :146-147
+        uint64_t num_filtered_rows = 0;
+        check(chgpu_count_bytes_in_filter(arg.context()->get(), mask->handle(), &num_filtered_rows)); // :192-216
+        if (num_filtered_rows == 0)
+        {
+            chunk.clear(); // :221-226: the chunk is dropped
+            return;
+        }
+        if (num_filtered_rows == chunk.num_rows) // :229-235: all rows pass, columns untouched
+        {
+            passed_rows += num_filtered_rows;
+            return;
+        }
+        for (auto & col : chunk.columns) // :238-252
+            col = col->filter(*mask, static_cast<ssize_t>(num_filtered_rows));
+        chunk.num_rows = num_filtered_rows;
+        passed_rows += num_filtered_rows;
+    }
+
+private:
+    size_t filter_arg_position;
+    FunctionComparisonConst predicate;
+};
+
+/// AggregateDescription (src/Interpreters/AggregateDescription.h): function + argument position.
+struct AggregateDescription
+{
+    int kind;              // CHGPU_AGG_*
+    int argument_type;     // CHGPU_* (ignored for count)
+    size_t argument = 0;   // position in the chunk
+};
+
+/// Aggregator + AggregatedDataVariants (Aggregator.h:179-265) for one numeric key or no key.
+class GpuAggregator
+{
+public:
+    GpuAggregator(ContextPtr ctx_, int key_type_, std::vector<AggregateDescription> aggregates_, uint64_t size_hint = 0)
+        : ctx(std::move(ctx_)), key_type(key_type_), aggregates(std::move(aggregates_))
+    {
+        std::vector<int> kinds, types;
+        for (auto & a : aggregates)
+        {
+            kinds.push_back(a.kind);
+            types.push_back(a.argument_type);
+        }
+        check(chgpu_agg_create(ctx->get(), key_type, static_cast<uint32_t>(aggregates.size()), kinds.data(), types.data(), size_hint, &h));
+    }
+    ~GpuAggregator() { chgpu_agg_free(h); }
+    GpuAggregator(const GpuAggregator &) = delete;
+
+    /// Aggregator::executeOnBlock(columns, row_begin, row_end, ...): returns false to stop reading (never here)
+    bool executeOnBlock(const Columns & columns, size_t row_begin, size_t row_end, std::optional<size_t> key_position)
+    {
+        std::vector<const chgpu_col *> args;
+        for (auto & a : aggregates)
+            args.push_back(a.kind == CHGPU_AGG_COUNT ? nullptr : columns.at(a.argument)->handle());
+        const chgpu_col * key = key_position ? columns.at(*key_position)->handle() : nullptr;
+        check(chgpu_agg_add_block(h, key, args.data(), row_begin, row_end));
+        return true;
+    }
+    /// mergeDataImpl
+    void merge(const GpuAggregator & other) { check(chgpu_agg_merge(h, other.h)); }
+    /// convertToBlocks(final = true): [key column,] one column per aggregate
+    Chunk convertToBlock() const
+    {
+        chgpu_col * keys = nullptr;
+        std::vector<chgpu_col *> res(aggregates.size(), nullptr);
+        uint64_t groups = 0;
+        check(chgpu_agg_finalize(h, &keys, res.data(), &groups));
+        Chunk out;
+        out.num_rows = groups;
+        if (keys)
+            out.columns.push_back(std::make_shared<ColumnVector>(ctx, keys));
+        for (auto * r : res)
+            out.columns.push_back(std::make_shared<ColumnVector>(ctx, r));
+        return out;
+    }
+    size_t size() const
+    {
+        uint64_t n = 0;
+        check(chgpu_agg_size(h, &n));
+        return n;
+    }
+
+private:
+    ContextPtr ctx;
+    int key_type;
+    std::vector<AggregateDescription> aggregates;
+    chgpu_agg * h = nullptr;
+};
+
+/// AggregatingTransform (AggregatingTransform.cpp:640-840): consume() per chunk, then generate the result once.
+class GpuAggregatingTransform : public IProcessor
+{
+public:
+    GpuAggregatingTransform(std::shared_ptr<GpuAggregator> aggregator_, std::optional<size_t> key_position_)
+        : aggregator(std::move(aggregator_)), key_position(key_position_) {}
+    std::string getName() const override { return "GpuAggregatingTransform"; }
+    void consume(Chunk chunk)
+    {
+        if (chunk.num_rows == 0)
+            return;
+        src_rows += chunk.num_rows;
+        aggregator->executeOnBlock(chunk.columns, 0, chunk.num_rows, key_position); // :664-693
+    }
+    void work() override {}
+    Chunk generate() { return aggregator->convertToBlock(); } // initGenerate :695 (single variant: nothing to merge)
+    uint64_t src_rows = 0;
+
+private:
+    std::shared_ptr<GpuAggregator> aggregator;
+    std::optional<size_t> key_position;
+};
+
+/// IJoin (IJoin.h:80-142) for HashJoin key64.
+class GpuHashJoin
+{
+public:
+    GpuHashJoin(ContextPtr ctx_, int key_type, int kind_, int strictness_, bool any_take_last_row = false)
+        : ctx(std::move(ctx_)), kind(kind_), strictness(strictness_)
+    {
+        check(chgpu_join_create(ctx->get(), key_type, kind, strictness, any_take_last_row ? 1 : 0, 0, &h));
+    }
+    ~GpuHashJoin() { chgpu_join_free(h); }
+    GpuHashJoin(const GpuHashJoin &) = delete;
+
+    /// addBlockToJoin(block): key column at key_position; the other columns are kept as the right payload
+    bool addBlockToJoin(const Chunk & block, size_t key_position)
+    {
+        uint32_t idx = 0;
+        check(chgpu_join_add_block(h, block.columns.at(key_position)->handle(), nullptr, nullptr, &idx));
+        right_blocks.push_back(block);
+        return true;
+    }
+    void onBuildPhaseFinish() { check(chgpu_join_finish_build(h)); }
+    size_t getTotalRowCount() const
+    {
+        uint64_t r = 0;
+        check(chgpu_join_total_rows(h, &r, nullptr));
+        return r;
+    }
+    bool needReplication() const { return strictness == CHGPU_STRICT_ALL; }
+    bool needFilter() const
+    {
+        return !needReplication() && (kind == CHGPU_JOIN_INNER || strictness == CHGPU_STRICT_SEMI || strictness == CHGPU_STRICT_ANTI);
+    }
+
+    /// joinBlock(block, not_processed): the left chunk is replaced by [left columns..., right payload columns...];
+    /// the unprocessed tail (max_joined_block_rows) comes back in not_processed (HashJoin.cpp:1090-1093).
+    /// Single right block payloads are gathered on the device (fillFromBlocksAndRowNumbers, IColumn.cpp:515-526).
+    void joinBlock(Chunk & block, size_t key_position, std::shared_ptr<Chunk> & not_processed, uint64_t max_joined_block_rows = 0)
+    {
+        if (right_blocks.size() > 1)
+            throw Exception(CHGPU_ERR_NOT_IMPLEMENTED, "payload gather across several right blocks: concatenate the build side first");
+        chgpu_col *filter = nullptr, *offsets = nullptr, *rowid = nullptr;
+        uint64_t n_out = 0, consumed = 0;
+        check(chgpu_join_probe(h, block.columns.at(key_position)->handle(), nullptr, max_joined_block_rows, &filter, &offsets, &rowid, &n_out, &consumed));
+        auto filter_c = filter ? std::make_shared<ColumnVector>(ctx, filter) : nullptr;
+        auto offsets_c = offsets ? std::make_shared<ColumnVector>(ctx, offsets) : nullptr;
+        auto rowid_c = std::make_shared<ColumnVector>(ctx, rowid);
+        not_processed.reset();
+        if (consumed < block.num_rows)
+        {
+            not_processed = std::make_shared<Chunk>();
+            for (auto & col : block.columns)
+                not_processed->columns.push_back(col->cut(consumed, block.num_rows - consumed, col));
+            not_processed->num_rows = block.num_rows - consumed;
+        }
+        Chunk res;
+        for (auto & col : block.columns)
+        {
+            ColumnPtr c = consumed < block.num_rows ? col->cut(0, consumed, col) : col;
+            if (offsets_c)
+                c = c->replicate(*offsets_c); // HashJoinMethodsImpl.h:182-197
+            else if (filter_c)
+                c = c->filter(*filter_c, -1); // :122-123
+            res.columns.push_back(c);
+        }
+        if (!right_blocks.empty())
+            for (size_t i = 0; i < right_blocks[0].columns.size(); ++i)
+                res.columns.push_back(right_blocks[0].columns[i]->index(*rowid_c, 0, /*default_for_missing*/ true));
+        res.num_rows = n_out;
+        block = std::move(res);
+    }
+
+private:
+    ContextPtr ctx;
+    int kind, strictness;
+    chgpu_join * h = nullptr;
+    std::vector<Chunk> right_blocks; // data->blocks (HashJoin.cpp:656-658)
+};
+
+/// FillingRightJoinSideTransform + JoiningTransform (JoiningTransform.cpp:176-260, 347-357)
+class GpuJoiningTransform : public ISimpleTransform
+{
+public:
+    GpuJoiningTransform(std::shared_ptr<GpuHashJoin> join_, size_t left_key_position_, uint64_t max_joined_block_rows_ = 0)
+        : join(std::move(join_)), left_key_position(left_key_position_), max_joined_block_rows(max_joined_block_rows_) {}
+    std::string getName() const override { return "GpuJoiningTransform"; }
+    /// readExecute: keeps resubmitting the not_processed tail; outputs are collected in order
+    std::vector<Chunk> transformAll(Chunk chunk)
+    {
+        std::vector<Chunk> out;
+        std::shared_ptr<Chunk> rest;
+        for (;;)
+        {
+            join->joinBlock(chunk, left_key_position, rest, max_joined_block_rows);
+            if (chunk.num_rows)
+                out.push_back(std::move(chunk));
+            if (!rest)
+                break;
+            chunk = std::move(*rest);
+        }
+        return out;
+    }
+
+protected:
+    void transform(Chunk & chunk) override
+    {
+        std::shared_ptr<Chunk> rest;
+        join->joinBlock(chunk, left_key_position, rest, 0);
+    }
+
+private:
+    std::shared_ptr<GpuHashJoin> join;
+    size_t left_key_position;
+    uint64_t max_joined_block_rows;
+};
+
+} // namespace chgpu
