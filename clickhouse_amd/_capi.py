@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libchgpu.so")
+LIB_PATH = os.environ.get("CHGPU_LIB", os.path.join(_HERE, "libchgpu.so"))  # CHGPU_LIB: developer override for A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "chgpu.h")
 
 # enums of include/chgpu.h

@@ -173,7 +173,17 @@ __device__ __forceinline__ double wave_reduce_acc(double v) { return wave_reduce
 // fused predicate -> sum(val), count()      (the dominant kernel of config C2: 8 B/row, one pass)
 // ---------------------------------------------------------------------------------------------
 static constexpr int FS_THREADS = 256;
-static constexpr int FS_UNROLL = 4;
+// Launch geometry, measured on MI355X (tools/tune_filter_sum.hip: 1e9 Int64 rows, variants interleaved in one process):
+//   8 workgroups/CU x 4 loads/lane, grid-strided (the textbook shape)            6.1 TB/s
+//   FS_WG_PER_CU workgroups/CU, each reading one CONTIGUOUS chunk of FS_UNROLL x 256 16-B vectors per iteration
+//   with nontemporal loads (24-32 KiB in flight per CU)                             7.0-7.2 TB/s
+// i.e. few waves with deep, contiguous, streaming loads beat many waves.  Plain (non-nt) loads cost ~10 %.
+// Two workgroups per CU rather than one: the second hides the first's reduce phase without relying on hipcc to
+// software-pipeline the loop (it sinks loads below waits when asked to double-buffer in registers).
+static constexpr int FS_WG_PER_CU = 2;
+#ifndef FS_UNROLL_SAME
+#define FS_UNROLL_SAME 4
+#endif
 
 template <typename T, int VEC, bool SAME, bool HAS_COND, typename Pred>
 __global__ __launch_bounds__(FS_THREADS) void k_filter_sum(const T * __restrict__ pred_col, const T * __restrict__ val_col,
@@ -183,32 +193,35 @@ __global__ __launch_bounds__(FS_THREADS) void k_filter_sum(const T * __restrict_
     typedef typename AccOf<T>::type Acc;
     typedef Vec<T, VEC> V;
     typedef Vec<u8, VEC> CV;
+    constexpr int UNROLL = SAME ? FS_UNROLL_SAME : (FS_UNROLL_SAME + 1) / 2;
     const u64 nvec = n / VEC;
-    const u64 tid = (u64)blockIdx.x * FS_THREADS + threadIdx.x;
-    const u64 stride = (u64)gridDim.x * FS_THREADS;
     const V * __restrict__ pv = (const V *)pred_col;
     const V * __restrict__ vv = (const V *)val_col;
     const CV * __restrict__ cv = (const CV *)cond;
     Acc s = 0;
     u64 c = 0;
 
-    u64 i = tid;
-    // main loop: FS_UNROLL independent 16-B loads in flight per lane per column
-    for (; i + (FS_UNROLL - 1) * stride < nvec; i += FS_UNROLL * stride)
+    // main loop: the workgroup reads UNROLL * 256 consecutive vectors per iteration; every load is issued before the
+    // first use (sched_barrier pins that order)
+    constexpr u64 CHUNK = (u64)UNROLL * FS_THREADS;
+    const u64 n_chunks = nvec / CHUNK;
+    for (u64 ch = blockIdx.x; ch < n_chunks; ch += gridDim.x)
     {
-        V a[FS_UNROLL], b[FS_UNROLL];
-        CV m[FS_UNROLL];
+        const u64 base = ch * CHUNK + threadIdx.x;
+        V a[UNROLL], b[UNROLL];
+        CV m[UNROLL];
 #pragma unroll
-        for (int k = 0; k < FS_UNROLL; ++k)
+        for (int k = 0; k < UNROLL; ++k)
         {
-            a[k] = load_stream(&pv[i + k * stride]);
+            a[k] = load_stream(&pv[base + (u64)k * FS_THREADS]);
             if constexpr (!SAME)
-                b[k] = load_stream(&vv[i + k * stride]);
+                b[k] = load_stream(&vv[base + (u64)k * FS_THREADS]);
             if constexpr (HAS_COND)
-                m[k] = cv[i + k * stride];
+                m[k] = cv[base + (u64)k * FS_THREADS];
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < FS_UNROLL; ++k)
+        for (int k = 0; k < UNROLL; ++k)
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
             {
@@ -220,7 +233,10 @@ __global__ __launch_bounds__(FS_THREADS) void k_filter_sum(const T * __restrict_
                 c += pass ? 1 : 0;
             }
     }
-    for (; i < nvec; i += stride)
+    // remainder vectors (< one chunk per workgroup), grid-strided
+    const u64 tid = (u64)blockIdx.x * FS_THREADS + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * FS_THREADS;
+    for (u64 i = n_chunks * CHUNK + tid; i < nvec; i += stride)
     {
         V a = pv[i];
         V b;
@@ -350,8 +366,8 @@ static int launch_filter_sum_t(chgpu_ctx * ctx, const void * pred, const void * 
     constexpr int VECW = 16 / sizeof(T);
     const bool same = (pred == val);
     const bool aligned = (((uintptr_t)pred | (uintptr_t)val) & 15) == 0 && (!cond || ((uintptr_t)cond % VECW) == 0);
-    // persistent-style grid: 8 workgroups of 256 per CU (2048 lanes = full occupancy at <= 64 VGPRs), grid-stride
-    const u32 grid = chgpu_grid_for(ctx, (n + VECW - 1) / VECW, FS_THREADS, 8);
+    // persistent grid: FS_WG_PER_CU 256-thread workgroups per CU (see the measurement note above k_filter_sum)
+    const u32 grid = chgpu_grid_for(ctx, (n + VECW - 1) / VECW, FS_THREADS, FS_WG_PER_CU);
     void * scratch = nullptr;
     CHGPU_TRY(chgpu_scratch(ctx, (size_t)grid * 2 * sizeof(u64), &scratch));
     u64 * part_sum = (u64 *)scratch;
