@@ -1,0 +1,103 @@
+"""N>1 path on CPU: world_size-2 gloo runs of the sharding orchestration in clickhouse_amd/distributed.py (the local
+operators are replaced by the oracle-backed CPU engine; on the GPU box the same code drives the HIP kernels)."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, init_file, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle as O
+    from clickhouse_amd import distributed as D
+    from cpu_engine import CpuEngine
+
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        eng = CpuEngine()
+        rng = np.random.Generator(np.random.PCG64(123))
+        n = 40_000
+        keys_all = rng.integers(0, 5000, size=n, dtype=np.uint64)
+        keys_all[:5] = 0
+        vals_all = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
+        lo, hi = rank * n // world, (rank + 1) * n // world
+
+        # 1. no-key states: mergeWithoutKeyDataImpl == one all-reduce (integer sum wraps modulo 2^64)
+        local = vals_all[lo:hi]
+        st = torch.from_numpy(np.array([local[local < 0].sum(), (local < 0).sum()], dtype=np.int64))
+        D.merge_without_key(st)
+        want = np.array([vals_all[vals_all < 0].sum(), (vals_all < 0).sum()], dtype=np.int64)
+        assert np.array_equal(st.numpy(), want)
+
+        # 2. sharded GROUP BY: rows split by range, partial states routed to owner = bucket & (world-1)
+        g = D.ShardedGroupBy(eng, np.uint64, [(O.AGG_SUM, np.int64), (O.AGG_COUNT, None)])
+        for b in range(lo, hi, 7001):
+            e = min(hi, b + 7001)
+            g.add_block(torch.from_numpy(keys_all[b:e].view(np.int64)), [torch.from_numpy(vals_all[b:e]), None])
+        k, (s, c) = g.finish()
+        owners = O.hash_to_selector(np.ascontiguousarray(k), world)
+        assert (owners == rank).all(), "a rank holds groups it does not own"
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (k, s, c))
+        if rank == 0:
+            kk = np.concatenate([x[0] for x in gathered])
+            ss = np.concatenate([x[1] for x in gathered])
+            cc = np.concatenate([x[2] for x in gathered])
+            assert len(set(kk.tolist())) == kk.shape[0], "a group lives on two ranks"
+            uk, inv = np.unique(keys_all, return_inverse=True)
+            ws = np.zeros(uk.shape[0], dtype=np.int64)
+            np.add.at(ws, inv, vals_all)
+            order = np.argsort(kk)
+            assert np.array_equal(kk[order], uk) and np.array_equal(ss[order].view(np.int64), ws)
+            assert np.array_equal(cc[order], np.bincount(inv).astype(np.uint64))
+
+        # 3. sharded hash join (parallel_hash routing): union of per-rank results == the single-node join
+        bk_all = rng.integers(0, 3000, size=9000, dtype=np.uint64)
+        pk_all = rng.integers(0, 4000, size=20_000, dtype=np.uint64)
+        j = D.ShardedHashJoin(eng, O.JOIN_INNER, O.STRICT_ALL)
+        blo, bhi = rank * 9000 // world, (rank + 1) * 9000 // world
+        plo, phi = rank * 20_000 // world, (rank + 1) * 20_000 // world
+        j.add_build_rows(torch.from_numpy(bk_all[blo:bhi].view(np.int64)))
+        left, right = j.probe(torch.from_numpy(pk_all[plo:phi].view(np.int64)))
+        # ids travel as (origin rank << 40 | origin row); rank 0 maps them back to global row numbers
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (left, right))
+        if rank == 0:
+            def glob(ids, split_total):
+                r = ids >> 40
+                row = ids & ((1 << 40) - 1)
+                return np.array([int(rr) * split_total // world for rr in r]) + row
+            pairs = set()
+            for l, r_ in gathered:
+                pairs |= set(zip(glob(l, 20_000).tolist(), glob(r_, 9000).tolist()))
+            one = O.HashJoin(O.JOIN_INNER, O.STRICT_ALL)
+            one.add_block(bk_all)
+            ol, ob, orow, _ = one.joined_pairs(pk_all)
+            assert pairs == set(zip(ol.tolist(), orow.tolist()))
+            assert sum(x[0].shape[0] for x in gathered) == ol.shape[0]
+        dist.barrier()
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_gloo_sharded_groupby_join_and_state_merge():
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "rendezvous")
+        mp.spawn(_worker, args=(world, init_file, d), nprocs=world, join=True)
+        assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(world))
+
+
+def test_non_power_of_two_world_is_rejected():
+    from clickhouse_amd import distributed as D
+    assert D.world_is_power_of_two(8) and not D.world_is_power_of_two(6)
