@@ -110,15 +110,15 @@ def test_group_by_sum_count_avg_matches_oracle(ch, engine, oracle_mod, key_dtype
 
 
 def test_group_by_growth_from_small_hint_and_row_ranges(ch, engine, oracle_mod):
-    # far more groups than the initial table (2^18 cells): exercises pending rows + rehash (resize on overflow)
+    # more groups than half the initial table (2^22 cells): exercises pending rows + rehash (resize on overflow)
     O = oracle_mod
     rng = np.random.Generator(np.random.PCG64(77))
-    n = 1_500_000
+    n = 5_000_000
     k = rng.integers(0, 2**40, size=n, dtype=np.uint64)
     v = rng.integers(-1000, 1000, size=n, dtype=np.int64)
     g = engine.Aggregator(np.uint64, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], size_hint=100_000)
-    g.execute_on_block(k, [v, None], 0, 700_001)
-    g.execute_on_block(k, [v, None], 700_001, n)
+    g.execute_on_block(k, [v, None], 0, 1_700_001)
+    g.execute_on_block(k, [v, None], 1_700_001, n)
     assert g.ctx.counters()["TableRehashes"] >= 1
     gk, (gs, gc) = g.convert_to_block()
     uk, inv = np.unique(k, return_inverse=True)
@@ -308,3 +308,36 @@ def test_selector_weak_hash_scatter_partition(ch, ctx, oracle_mod):
     parts = ctx.upload(pay).scatter(3, ctx.upload(sel3))
     for s in range(3):
         assert np.array_equal(parts[s].numpy(), pay[sel3 == s])
+
+
+@pytest.mark.parametrize("aggs_name", ["sum_count", "avg_f64", "two_args"])
+def test_group_by_partitioned_path_large_cardinality(ch, engine, oracle_mod, aggs_name):
+    # >= 4 Mi rows with a large size hint take the partition -> LDS-aggregate path
+    rng = np.random.Generator(np.random.PCG64(99))
+    n, groups = 6_000_000, 300_000
+    k = rng.integers(0, groups, size=n).astype(np.uint32)
+    k[:3] = 0
+    v = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
+    f = rng.random(n)
+    if aggs_name == "sum_count":
+        aggs, args = [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], [v, None]
+    elif aggs_name == "avg_f64":
+        aggs, args = [(ch.AGG_AVG, np.float64)], [f]
+    else:
+        aggs, args = [(ch.AGG_SUM, np.int64), (ch.AGG_SUM, np.float64), (ch.AGG_COUNT, None)], [v, f, None]
+    g = engine.Aggregator(np.uint32, aggs, size_hint=groups)
+    before = g.ctx.counters()["KernelLaunches"]
+    g.execute_on_block(k, args, 1, n)          # odd row_begin on purpose
+    assert g.ctx.counters()["KernelLaunches"] - before >= 6   # hist + scan(3) + scatter + aggregate
+    o = oracle_mod.Aggregator(np.uint32, aggs)
+    o.execute_on_block(k, args, 1, n)
+    gk, gr = g.convert_to_block()
+    ok, orr = o.convert_to_block()
+    gi, oi = np.argsort(gk), np.argsort(ok)
+    assert np.array_equal(gk[gi], ok[oi])
+    for j in range(len(aggs)):
+        a, b = gr[j][gi], orr[j][oi]
+        if a.dtype == np.float64:
+            assert np.allclose(a, b, rtol=1e-6, atol=0)
+        else:
+            assert np.array_equal(a, b)

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Ad-hoc timings of the non-headline operators through the C ABI on device-resident inputs (configs C3/C4 shapes).
+usage: bench_ops.py [groupby|join|filter|all] [rows]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import clickhouse_amd as ch
+
+what = sys.argv[1] if len(sys.argv) > 1 else "all"
+rows = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000_000
+dev = torch.device("cuda", 0)
+st = torch.cuda.Stream(device=dev)
+torch.cuda.set_stream(st)
+ctx = ch.Context(0, st.cuda_stream)
+
+
+def timed(fn, reps=3):
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best, r
+
+
+if what in ("groupby", "all"):
+    for groups, hint in ((1_000_000, 1_000_000), (1000, 0), (1_000_000, 0)):
+        g = torch.Generator(device=dev).manual_seed(2)
+        k = torch.randint(0, groups, (rows,), dtype=torch.int32, device=dev, generator=g)
+        v = torch.randint(-2**31, 2**31, (rows,), dtype=torch.int64, device=dev, generator=g)
+        kc = ctx.wrap(k.data_ptr(), np.uint32, rows, keepalive=k)
+        vc = ctx.wrap(v.data_ptr(), np.int64, rows, keepalive=v)
+
+        def run():
+            a = ch.Aggregator(np.uint32, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], size_hint=hint, ctx=ctx)
+            a.execute_on_block(kc, [vc, None])
+            n = len(a)
+            a.close()
+            return n
+        dt, n = timed(run)
+        print(f"groupby rows={rows} groups={groups} hint={hint}: {dt*1e3:.2f} ms  {rows/dt:.3e} rows/s  {12*rows/dt/1e9:.1f} GB/s algorithmic (12 B/row)  groups_out={n}", flush=True)
+        del k, v, kc, vc
+
+if what in ("join", "all"):
+    nb, npb = 10_000_000, min(rows, 100_000_000)
+    g = torch.Generator(device=dev).manual_seed(5)
+    bk = (torch.randperm(nb, device=dev, generator=g).to(torch.int64) + 1) * 2654435761
+    pk = torch.where(torch.rand(npb, device=dev, generator=g) < 0.5, bk[torch.randint(0, nb, (npb,), device=dev, generator=g)],
+                     torch.randint(0, 2**62, (npb,), dtype=torch.int64, device=dev, generator=g))
+    bv = torch.randint(-2**40, 2**40, (nb,), dtype=torch.int64, device=dev, generator=g)
+    bkc = ctx.wrap(bk.data_ptr(), np.uint64, nb, keepalive=bk)
+    pkc = ctx.wrap(pk.data_ptr(), np.uint64, npb, keepalive=pk)
+    bvc = ctx.wrap(bv.data_ptr(), np.int64, nb, keepalive=bv)
+
+    def build():
+        j = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, ctx=ctx)
+        j.add_block(bkc)
+        j.finish_build()
+        return j
+    dt, j = timed(build)
+    print(f"join build rows={nb}: {dt*1e3:.2f} ms  {nb/dt:.3e} rows/s", flush=True)
+
+    def probe():
+        r = j.probe_columns(pkc)
+        out = bvc.index(r["right_rowid"], default_for_missing=True)
+        return r["n_out"], out.size()
+    dt, (n_out, _) = timed(probe)
+    print(f"join probe+gather rows={npb} matches={n_out}: {dt*1e3:.2f} ms  {npb/dt:.3e} probe rows/s  {(8*npb+16*n_out)/dt/1e9:.1f} GB/s algorithmic", flush=True)
+
+if what in ("filter", "all"):
+    g = torch.Generator(device=dev).manual_seed(1)
+    a = torch.randint(0, 2**31, (rows,), dtype=torch.int64, device=dev, generator=g)
+    col = ctx.wrap(a.data_ptr(), np.int64, rows, keepalive=a)
+    dt, mask = timed(lambda: ch.cmp_const(col, ch.LT, 214748365))
+    print(f"cmp_const rows={rows}: {dt*1e3:.2f} ms  {9*rows/dt/1e9:.1f} GB/s (9 B/row)", flush=True)
+    dt, out = timed(lambda: col.filter(mask))
+    sel = out.size() / rows
+    print(f"filter rows={rows} sel={sel:.3f}: {dt*1e3:.2f} ms  {(10 + 8*sel)*rows/dt/1e9:.1f} GB/s (8+1+1+8s B/row)", flush=True)
