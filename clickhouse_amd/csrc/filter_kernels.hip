@@ -11,6 +11,7 @@
 //   k_index/k_replicate ColumnVector<T>::indexImpl / replicate    src/Columns/ColumnVector.cpp:1121-1143, 879-907
 #include "chgpu_internal.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
@@ -529,12 +530,36 @@ __global__ __launch_bounds__(256) void k_cmp_mask(const T * __restrict__ a, u64 
 {
     typedef Vec<T, VEC> V;
     typedef Vec<u8, VEC> CV;
+    constexpr int UNROLL = 4;
     const u64 nvec = n / VEC;
-    const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x;
-    const u64 stride = (u64)gridDim.x * 256;
     const V * __restrict__ av = (const V *)a;
     CV * __restrict__ cv = (CV *)c;
-    for (u64 i = tid; i < nvec; i += stride)
+    // Same streaming geometry as k_filter_sum: contiguous 16 KiB chunk per workgroup iteration, nontemporal loads.
+    // (Giving each lane UNROLL consecutive vectors so it could store 8 mask bytes at once was measured 20 % SLOWER:
+    // the 64-B-strided loads cost more than the 2-byte-per-lane stores.)
+    constexpr u64 CHUNK = (u64)UNROLL * 256;
+    const u64 n_chunks = nvec / CHUNK;
+    for (u64 ch = blockIdx.x; ch < n_chunks; ch += gridDim.x)
+    {
+        const u64 base = ch * CHUNK + threadIdx.x;
+        V x[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k)
+            x[k] = load_stream(&av[base + (u64)k * 256]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k)
+        {
+            CV m;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                m.v[e] = p(x[k].v[e]) ? 1 : 0;
+            cv[base + (u64)k * 256] = m;
+        }
+    }
+    const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 i = n_chunks * CHUNK + tid; i < nvec; i += stride)
     {
         V x = av[i];
         CV m;
@@ -548,12 +573,19 @@ __global__ __launch_bounds__(256) void k_cmp_mask(const T * __restrict__ a, u64 
         c[r] = p(a[r]) ? 1 : 0;
 }
 
+static u32 tune_env(const char * name, u32 dflt)
+{
+    const char * v = getenv(name); // developer knob for A/B runs; unset in production
+    return v ? (u32)atoi(v) : dflt;
+}
+
 template <typename T, typename Pred>
 static int launch_cmp_t(chgpu_ctx * ctx, const void * a, u64 n, Pred p, u8 * c)
 {
     constexpr int VECW = 16 / sizeof(T);
     const bool aligned = ((uintptr_t)a & 15) == 0 && ((uintptr_t)c % VECW) == 0;
-    const u32 grid = chgpu_grid_for(ctx, (n + VECW - 1) / VECW, 256, 8);
+    static const u32 wg_per_cu = tune_env("CHGPU_TUNE_CMP_WG", 2);
+    const u32 grid = chgpu_grid_for(ctx, (n + VECW - 1) / VECW, 256, wg_per_cu);
     if (aligned)
         hipLaunchKernelGGL((k_cmp_mask<T, VECW, Pred>), dim3(grid), dim3(256), 0, ctx->stream, (const T *)a, n, p, c);
     else
@@ -791,8 +823,10 @@ extern "C" int chgpu_filter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_
     u64 * total_dev = (u64 *)((char *)scratch + counts_b + offs_b);
     void * tmp = (char *)scratch + counts_b + offs_b + 256;
 
-    const u32 grid = chgpu_grid_for(ctx, n_chunks * 64, 256, 8);
-    hipLaunchKernelGGL(k_mask_chunk_counts, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)mask->data, n, counts, n_chunks);
+    static const u32 wg_cnt = tune_env("CHGPU_TUNE_FCOUNT_WG", 8), wg_sc = tune_env("CHGPU_TUNE_FSCATTER_WG", 8);
+    const u32 grid_cnt = chgpu_grid_for(ctx, n_chunks * 64, 256, wg_cnt);
+    const u32 grid = chgpu_grid_for(ctx, n_chunks * 64, 256, wg_sc);
+    hipLaunchKernelGGL(k_mask_chunk_counts, dim3(grid_cnt), dim3(256), 0, ctx->stream, (const u8 *)mask->data, n, counts, n_chunks);
     ctx->counters[6] += 1;
     CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, n_chunks, total_dev, tmp, tmp_b));
     u64 total = 0;
