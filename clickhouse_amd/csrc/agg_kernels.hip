@@ -118,14 +118,23 @@ __device__ __forceinline__ void global_add_word(u64 * p, u64 bits, bool is_f64)
 // Find-or-claim the cell of `key` (emplace).  Returns the slot, or ~0 when the row must wait for a bigger table.
 // soft_limit: refuse to claim new cells once n_groups >= max_fill (rows); flushes/rehash pass false and may use
 // the slack above max fill.  Every loop is bounded by the capacity, so the wave always exits.
-__device__ __forceinline__ u64 table_emplace(const AggTable & t, u64 key, bool soft_limit)
+__device__ __forceinline__ void count_claim(const AggTable & t, bool claimed)
 {
+    // one atomic per wave on the shared group counter (a per-lane atomicAdd on one address serialises the kernel)
+    const u64 cb = __ballot(claimed);
+    if (claimed && mbcnt(cb) == 0)
+        atomicAdd(&t.ctrl->n_groups, (unsigned long long)__popcll(cb));
+}
+
+__device__ __forceinline__ u64 table_emplace_impl(const AggTable & t, u64 key, bool soft_limit, bool & claimed)
+{
+    claimed = false;
     if (key == 0)
     {
         // zero key lives out of line (HashTable.h:874-898)
         if (__hip_atomic_load(&t.ctrl->has_zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
             if (atomicExch(&t.ctrl->has_zero, 1u) == 0)
-                atomicAdd(&t.ctrl->n_groups, 1ull);
+                claimed = true;
         return t.capacity;
     }
     const u64 mask = t.capacity - 1;
@@ -142,7 +151,7 @@ __device__ __forceinline__ u64 table_emplace(const AggTable & t, u64 key, bool s
             const u64 prev = atomicCAS((unsigned long long *)&t.keys[slot], 0ull, (unsigned long long)key);
             if (prev == 0)
             {
-                atomicAdd(&t.ctrl->n_groups, 1ull);
+                claimed = true;
                 return slot;
             }
             if (prev == key)
@@ -151,6 +160,14 @@ __device__ __forceinline__ u64 table_emplace(const AggTable & t, u64 key, bool s
         slot = (slot + 1) & mask;
     }
     return ~0ull;
+}
+
+__device__ __forceinline__ u64 table_emplace(const AggTable & t, u64 key, bool soft_limit)
+{
+    bool claimed;
+    const u64 slot = table_emplace_impl(t, key, soft_limit, claimed);
+    count_claim(t, claimed);
+    return slot;
 }
 
 // add row i's contribution of every aggregate to the cell `slot` (IAggregateFunction::add per function)

@@ -99,12 +99,15 @@ __global__ __launch_bounds__(JT) void k_join_stage_keys(const void * __restrict_
     }
 }
 
-__device__ __forceinline__ u32 jt_emplace(const JoinTable & t, u64 key)
+// `claimed` tells the caller a new cell was taken; callers add the per-wave total to ctrl->n_keys with ONE atomic (a
+// per-lane atomicAdd on that single address serialised the whole build: 6.3 ms for 1e7 rows).
+__device__ __forceinline__ u32 jt_emplace(const JoinTable & t, u64 key, bool & claimed)
 {
+    claimed = false;
     if (key == 0)
     {
-        if (atomicExch(&t.ctrl->has_zero, 1u) == 0)
-            atomicAdd(&t.ctrl->n_keys, 1ull);
+        if (t.ctrl->has_zero == 0 && atomicExch(&t.ctrl->has_zero, 1u) == 0)
+            claimed = true;
         return (u32)t.capacity;
     }
     const u64 mask = t.capacity - 1;
@@ -117,7 +120,7 @@ __device__ __forceinline__ u32 jt_emplace(const JoinTable & t, u64 key)
             k = atomicCAS((unsigned long long *)&t.keys[slot], 0ull, (unsigned long long)key);
             if (k == 0)
             {
-                atomicAdd(&t.ctrl->n_keys, 1ull);
+                claimed = true;
                 return (u32)slot;
             }
         }
@@ -153,9 +156,10 @@ __global__ __launch_bounds__(JT) void k_join_insert(JoinTable t, const u64 * __r
     for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
     {
         u32 slot = NO_SLOT;
+        bool claimed = false;
         if (!valid || valid[i])
         {
-            slot = jt_emplace(t, keys[i]);
+            slot = jt_emplace(t, keys[i], claimed);
             if (slot != NO_SLOT)
             {
                 const u64 rowid = (block_index << 32) | i;
@@ -171,6 +175,9 @@ __global__ __launch_bounds__(JT) void k_join_insert(JoinTable t, const u64 * __r
             }
         }
         slot_of_row[i] = slot;
+        const u64 cb = __ballot(claimed);
+        if (claimed && mbcnt(cb) == 0)
+            atomicAdd(&t.ctrl->n_keys, (unsigned long long)__popcll(cb));
     }
 }
 
@@ -324,6 +331,9 @@ __global__ __launch_bounds__(JT) void k_join_emit(JoinTable t, int variant, int 
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
+// Table capacity for `rows` build rows: a power of two with load factor in (0.35, 0.7].  Denser than the reference's
+// 0.5 cap on purpose: the table is immutable after the build and a 1e7-row build then needs 2^24 cells (134 MB of keys),
+// which stays resident in the 256 MB Infinity Cache, where 2^25 cells would not.
 static u64 jpow2_ceil(u64 x)
 {
     u64 p = 256;
@@ -419,7 +429,7 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
     chgpu_ctx * ctx = j->ctx;
     const bool maps_all = j->strictness == CHGPU_STRICT_ALL;
     const bool flagged = j->kind == CHGPU_JOIN_INNER && j->strictness == CHGPU_STRICT_ANY;
-    const u64 cap = jpow2_ceil(j->total_rows * 2);
+    const u64 cap = jpow2_ceil(j->total_rows + j->total_rows * 3 / 7 + 1);
     CHGPU_REQUIRE(cap + 1 < 0xFFFFFFFFull, CHGPU_ERR_NOT_IMPLEMENTED, "build side of %llu rows exceeds the 32-bit cell index", (unsigned long long)j->total_rows);
     const u64 cells = cap + 1;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
