@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU (default: the 1 B rows of configs[1])")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (rehearsal of the N>1 code path on one GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -46,13 +47,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
+    if args.backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())  # rehearsal only: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     n = args.rows
     K, W = args.steps, args.warmup
@@ -73,10 +79,21 @@ def main():
 
     works = []
 
+    def merge_states(i):
+        """mergeWithoutKeyDataImpl across ranks: one 16-byte all-reduce, asynchronous under RCCL"""
+        if dist is None:
+            return
+        if args.backend == "nccl":
+            works.append(dist.all_reduce(results[i], op=dist.ReduceOp.SUM, async_op=True))
+        else:  # gloo rehearsal: stage through the host
+            stream.synchronize()
+            h = results[i].cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            results[i].copy_(h)
+
     def step(i):
         ch.filter_sum_async(col, ch.LT, THRESHOLD, None, slots[i])  # HIP kernels via the C ABI, no host sync
-        if dist is not None:
-            works.append(dist.all_reduce(results[i], op=dist.ReduceOp.SUM, async_op=True))  # merge of no-key states
+        merge_states(i)
 
     for i in range(W):
         step(i)
@@ -94,8 +111,7 @@ def main():
         ev[i][0].record(stream)
         ch.filter_sum_async(col, ch.LT, THRESHOLD, None, slots[W + i])
         ev[i][1].record(stream)
-        if dist is not None:
-            works.append(dist.all_reduce(results[W + i], op=dist.ReduceOp.SUM, async_op=True))
+        merge_states(W + i)
     for w in works:
         w.wait()
     torch.cuda.synchronize()
@@ -108,12 +124,10 @@ def main():
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        kt = torch.tensor([kern_avg_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
-        kern_avg_ms = float(kt.item())
+        red_dev = dev if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed, kern_avg_ms], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # MAX over ranks
+        elapsed, kern_avg_ms = float(t[0].item()), float(t[1].item())
 
     # ---- sanity: every step produced the same, correct state (checked outside the timed region) ----
     res = results.cpu().numpy()
@@ -198,12 +212,12 @@ def cpu_baseline(a, sample_rows, ctx, ch):
     cores = max(1, min(16, len(os.sched_getaffinity(0))))
     best1, bestN = None, None
     r1 = rN = None
-    for _ in range(3):
+    for _ in range(5):
         t0 = time.perf_counter()
         r1 = oracle.filter_sum_pipeline(host, oracle.LT, THRESHOLD, threads=1)
         dt = time.perf_counter() - t0
         best1 = dt if best1 is None else min(best1, dt)
-    for _ in range(5):
+    for _ in range(20):
         t0 = time.perf_counter()
         rN = oracle.filter_sum_pipeline(host, oracle.LT, THRESHOLD, threads=cores)
         dt = time.perf_counter() - t0
@@ -216,8 +230,8 @@ def cpu_baseline(a, sample_rows, ctx, ch):
         "unit": "rows/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"first {m} rows of the same column, Blocks of 65409 rows, best of 5 ({cores} threads) ; "
-                  f"single thread: {m / best1:.4g} rows/s (best of 3)",
+        "sample": f"first {m} rows of the same column, Blocks of 65409 rows, best of 20 ({cores} threads) ; "
+                  f"single thread: {m / best1:.4g} rows/s (best of 5); about 7 s of CPU work in all",
         "single_thread_value": m / best1,
     }
 

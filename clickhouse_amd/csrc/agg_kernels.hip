@@ -230,7 +230,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_rows_direct(AggTable t, Agg
 }
 
 // LDS-STAGED kernel.  Dynamic LDS: lkeys[S+1] then lwords[n_words][S+1]; cell S is the zero key's.
-__global__ __launch_bounds__(AGG_THREADS) void k_agg_rows_lds(AggTable t, AggDesc d, const void * __restrict__ keys, int key_type,
+__global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, const void * __restrict__ keys, int key_type,
                                                               u64 row_begin, u64 n, u64 * __restrict__ pending, u32 S)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -238,90 +238,117 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_rows_lds(AggTable t, AggDes
     u64 * lwords = lkeys + (S + 1);
     __shared__ u32 lzero;
     const u32 lstride = S + 1;
-    for (u32 s = threadIdx.x; s < (d.n_words + 1) * lstride; s += AGG_THREADS)
+    for (u32 s = threadIdx.x; s < (d.n_words + 1) * lstride; s += blockDim.x)
         lkeys[s] = 0;
     if (threadIdx.x == 0)
         lzero = 0;
     __syncthreads();
 
     const u32 lane = threadIdx.x & 63;
-    const u64 wave0 = ((u64)blockIdx.x * AGG_THREADS + threadIdx.x) >> 6;
-    const u64 n_waves = ((u64)gridDim.x * AGG_THREADS) >> 6;
+    const u64 wave0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u64 n_waves = ((u64)gridDim.x * blockDim.x) >> 6;
     const u64 n_groups64 = (n + 63) / 64;
-    for (u64 g = wave0; g < n_groups64; g += n_waves)
+    // Each wave takes LDS_R consecutive 64-row groups per iteration and issues ALL their key/argument loads before
+    // touching LDS: with one row per lane per iteration only ~24 KiB of 4-8-byte loads were in flight per CU and the
+    // kernel was latency-bound (measured 18.6 -> 10.2 ms from more waves alone).
+    constexpr int LDS_R = 4;
+    constexpr u32 PRE = 3; // argument columns preloaded per row (further ones are loaded on use)
+    for (u64 g0 = wave0 * LDS_R; g0 < n_groups64; g0 += n_waves * LDS_R)
     {
-        const u64 r = g * 64 + lane;
-        const bool active = r < n;
-        bool failed = false;
-        if (active)
+        u64 keyv[LDS_R];
+        u64 argv[LDS_R][PRE];
+        bool act[LDS_R];
+#pragma unroll
+        for (int q = 0; q < LDS_R; ++q)
         {
-            const u64 i = row_begin + r;
-            const u64 key = load_key_zext(keys, key_type, i);
-            // ---- LDS emplace: a few probes, then give up and go to HBM ----
-            u32 ls = ~0u;
-            if (key == 0)
-            {
-                ls = S;
-                lzero = 1;
-            }
-            else
-            {
-                u32 s = (u32)(dev_intHash64(key) >> 40) & (S - 1);
-                // linear probing; give up after 32 cells (a nearly full LDS table) and send the row to HBM instead
-#pragma unroll 1
-                for (int probe = 0; probe < 32; ++probe)
-                {
-                    u64 k = lkeys[s];
-                    if (k == 0)
-                        k = atomicCAS((unsigned long long *)&lkeys[s], 0ull, (unsigned long long)key), k = (k == 0) ? key : k;
-                    if (k == key)
-                    {
-                        ls = s;
-                        break;
-                    }
-                    s = (s + 1) & (S - 1);
-                }
-            }
-            if (ls != ~0u)
-            {
-                for (u32 j = 0; j < d.n_aggs; ++j)
-                {
-                    const AggArg & a = d.a[j];
-                    u64 * w = lwords + a.word * lstride + ls;
-                    if (a.kind == CHGPU_AGG_COUNT)
-                        atomicAdd((unsigned long long *)w, 1ull);
-                    else
-                    {
-                        const u64 bits = load_arg_bits(a.ptr, a.arg_type, i);
-                        if (a.arg_type == CHGPU_F64)
-                            atomicAdd((double *)w, __longlong_as_double((long long)bits));
-                        else
-                            atomicAdd((unsigned long long *)w, (unsigned long long)bits);
-                        if (a.kind == CHGPU_AGG_AVG)
-                            atomicAdd((unsigned long long *)(w + lstride), 1ull);
-                    }
-                }
-            }
-            else
-            {
-                const u64 slot = table_emplace(t, key, true);
-                if (slot == ~0ull)
-                    failed = true;
-                else
-                    add_row_global(t, d, slot, i);
-            }
+            const u64 r = (g0 + q) * 64 + lane;
+            act[q] = r < n;
+            const u64 i = row_begin + (act[q] ? r : 0);
+            keyv[q] = act[q] ? load_key_zext(keys, key_type, i) : 0;
+#pragma unroll
+            for (u32 j = 0; j < PRE; ++j)
+                argv[q][j] = (act[q] && j < d.n_aggs && d.a[j].kind != CHGPU_AGG_COUNT) ? load_arg_bits(d.a[j].ptr, d.a[j].arg_type, i) : 0;
         }
-        const u64 b = __ballot(failed);
-        if (lane == 0)
-            pending[g] = b;
-        if (b != 0 && lane == 0)
-            t.ctrl->overflow = 1;
+#pragma unroll
+        for (int q = 0; q < LDS_R; ++q)
+        {
+            const u64 g = g0 + q;
+            if (g >= n_groups64)
+                break;
+            bool failed = false;
+            if (act[q])
+            {
+                const u64 i = row_begin + g * 64 + lane;
+                const u64 key = keyv[q];
+                // ---- LDS emplace: linear probing, give up after 32 cells (a nearly full LDS table) -> HBM path ----
+                u32 ls = ~0u;
+                if (key == 0)
+                {
+                    ls = S;
+                    lzero = 1;
+                }
+                else
+                {
+                    u32 s = (u32)(dev_intHash64(key) >> 40) & (S - 1);
+#pragma unroll 1
+                    for (int probe = 0; probe < 32; ++probe)
+                    {
+                        u64 k = lkeys[s];
+                        if (k == 0)
+                            k = atomicCAS((unsigned long long *)&lkeys[s], 0ull, (unsigned long long)key), k = (k == 0) ? key : k;
+                        if (k == key)
+                        {
+                            ls = s;
+                            break;
+                        }
+                        s = (s + 1) & (S - 1);
+                    }
+                }
+                if (ls != ~0u)
+                {
+                    for (u32 j = 0; j < d.n_aggs; ++j)
+                    {
+                        const AggArg & a = d.a[j];
+                        u64 * w = lwords + a.word * lstride + ls;
+                        if (a.kind == CHGPU_AGG_COUNT)
+                            atomicAdd((unsigned long long *)w, 1ull);
+                        else
+                        {
+                            u64 bits;
+                            if (j == 0) bits = argv[q][0];
+                            else if (j == 1) bits = argv[q][1];
+                            else if (j == 2) bits = argv[q][2];
+                            else bits = load_arg_bits(a.ptr, a.arg_type, i);
+                            if (a.arg_type == CHGPU_F64)
+                                atomicAdd((double *)w, __longlong_as_double((long long)bits));
+                            else
+                                atomicAdd((unsigned long long *)w, (unsigned long long)bits);
+                            if (a.kind == CHGPU_AGG_AVG)
+                                atomicAdd((unsigned long long *)(w + lstride), 1ull);
+                        }
+                    }
+                }
+                else
+                {
+                    const u64 slot = table_emplace(t, key, true);
+                    if (slot == ~0ull)
+                        failed = true;
+                    else
+                        add_row_global(t, d, slot, i);
+                }
+            }
+            const u64 b = __ballot(failed);
+            if (lane == 0)
+                pending[g] = b;
+            if (b != 0 && lane == 0)
+                t.ctrl->overflow = 1;
+        }
     }
     __syncthreads();
 
     // ---- flush the workgroup's partial states: one emplace + n_words atomics per distinct key ----
     const u64 gstride = t.capacity + 1;
-    for (u32 s = threadIdx.x; s <= S; s += AGG_THREADS)
+    for (u32 s = threadIdx.x; s <= S; s += blockDim.x)
     {
         const u64 key = lkeys[s];
         const bool occupied = (s == S) ? (lzero != 0) : (key != 0);
@@ -1008,11 +1035,12 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
             S >>= 1;
         // flushes may claim up to grid * (S+1) cells above max fill: keep that inside the slack (capacity/2)
         u64 max_grid = (a->t.capacity / 2) / (S + 1);
-        u32 grid = chgpu_grid_for(ctx, n, AGG_THREADS, 4);
+        static const u32 lds_threads = getenv("CHGPU_TUNE_AGG_LDS_THREADS") ? (u32)atoi(getenv("CHGPU_TUNE_AGG_LDS_THREADS")) : 512;
+        u32 grid = chgpu_grid_for(ctx, n, lds_threads, lds_threads >= 1024 ? 2 : 4);
         if (grid > max_grid)
             grid = (u32)(max_grid ? max_grid : 1);
         const size_t lds = (size_t)(S + 1) * 8 * (1 + a->n_words);
-        hipLaunchKernelGGL(k_agg_rows_lds, dim3(grid), dim3(AGG_THREADS), lds, ctx->stream, a->t, d, key_col->data, a->key_type, row_begin, n, pending, S);
+        hipLaunchKernelGGL(k_agg_rows_lds, dim3(grid), dim3(lds_threads), lds, ctx->stream, a->t, d, key_col->data, a->key_type, row_begin, n, pending, S);
     }
     else
     {
