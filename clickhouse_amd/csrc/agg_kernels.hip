@@ -45,6 +45,7 @@ struct AggArg
     int kind;
     int arg_type;
     u32 word;         // first state word
+    u32 pre;          // partitioned path: index of this argument's word column in the partition buffers
 };
 
 struct AggDesc
@@ -416,7 +417,19 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_hist(const void * __restrict
     __syncthreads();
     const u64 r0 = (u64)blockIdx.x * rows_per_wg;
     const u64 r1 = r0 + rows_per_wg < n ? r0 + rows_per_wg : n;
-    for (u64 i = r0 + threadIdx.x; i < r1; i += GBP_THREADS)
+    constexpr int HU = 8; // independent key loads in flight per lane
+    u64 i = r0 + threadIdx.x;
+    for (; i + (u64)(HU - 1) * GBP_THREADS < r1; i += (u64)HU * GBP_THREADS)
+    {
+        u64 k[HU];
+#pragma unroll
+        for (int q = 0; q < HU; ++q)
+            k[q] = load_key_zext(keys, key_type, row_begin + i + (u64)q * GBP_THREADS);
+#pragma unroll
+        for (int q = 0; q < HU; ++q)
+            atomicAdd(&cnt[gbp_part_of(k[q], P - 1)], 1u);
+    }
+    for (; i < r1; i += GBP_THREADS)
         atomicAdd(&cnt[gbp_part_of(load_key_zext(keys, key_type, row_begin + i), P - 1)], 1u);
     __syncthreads();
     for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
@@ -446,11 +459,26 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
     const u64 r0 = (u64)blockIdx.x * rows_per_wg;
     const u64 r1 = r0 + rows_per_wg < n ? r0 + rows_per_wg : n;
     constexpr u32 RPT = GBP_TILE / GBP_THREADS; // rows per thread per tile
+    u64 key[RPT], argw[RPT][GBP_MAX_K];
+    // rows of a tile are held in registers; the NEXT tile's loads are issued right after the current tile has been
+    // staged to LDS, so their latency hides behind the write-out phase (one workgroup per CU: nothing else would)
+    auto load_tile = [&](u64 tb) {
+#pragma unroll
+        for (u32 j = 0; j < RPT; ++j)
+        {
+            const u64 i = tb + (u64)j * GBP_THREADS + threadIdx.x;
+            const bool in = i < r1;
+            key[j] = in ? load_key_zext(keys, key_type, row_begin + i) : 0;
+            argw[j][0] = (in && cols.k > 0) ? load_arg_bits(cols.src[0], cols.type[0], row_begin + i) : 0;
+            argw[j][1] = (in && cols.k > 1) ? load_arg_bits(cols.src[1], cols.type[1], row_begin + i) : 0;
+        }
+    };
+    if (r0 < r1)
+        load_tile(r0);
     for (u64 tbase = r0; tbase < r1; tbase += GBP_TILE)
     {
-        u64 key[RPT];
         u32 part[RPT], rank[RPT];
-        // 1. load keys (coalesced), take a rank inside the tile's partition bucket
+        // 1. take a rank inside the tile's partition bucket
 #pragma unroll
         for (u32 j = 0; j < RPT; ++j)
         {
@@ -458,7 +486,6 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
             part[j] = ~0u;
             if (i < r1)
             {
-                key[j] = load_key_zext(keys, key_type, row_begin + i);
                 part[j] = gbp_part_of(key[j], P - 1);
                 rank[j] = atomicAdd(&tile_cnt[part[j]], 1u);
             }
@@ -496,13 +523,16 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
         {
             if (part[j] == ~0u)
                 continue;
-            const u64 i = tbase + (u64)j * GBP_THREADS + threadIdx.x;
             const u32 pos = tile_off[part[j]] + rank[j];
             stage_key[pos] = key[j];
             stage_part[pos] = (unsigned short)part[j];
-            for (u32 c = 0; c < cols.k; ++c)
-                stage_word[(size_t)c * GBP_TILE + pos] = load_arg_bits(cols.src[c], cols.type[c], row_begin + i);
+            if (cols.k > 0)
+                stage_word[pos] = argw[j][0];
+            if (cols.k > 1)
+                stage_word[(size_t)GBP_TILE + pos] = argw[j][1];
         }
+        if (tbase + GBP_TILE < r1)
+            load_tile(tbase + GBP_TILE); // prefetch: lands while this tile is written out
         __syncthreads();
         // 4. write the partition runs: consecutive lanes -> consecutive addresses inside a run
         const u32 tile_rows = (u32)(r1 - tbase < GBP_TILE ? r1 - tbase : GBP_TILE);
@@ -510,9 +540,13 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
         {
             const u32 p = stage_part[pos];
             const u64 dst = cursor[p] + (pos - tile_off[p]);
+#if !defined(GBP_ABLATE) || GBP_ABLATE != 1
             out_keys[dst] = stage_key[pos];
             for (u32 c = 0; c < cols.k; ++c)
                 cols.dst[c][dst] = stage_word[(size_t)c * GBP_TILE + pos];
+#else
+            if (dst == ~0ull) out_keys[0] = stage_key[pos] + stage_word[pos];
+#endif
         }
         __syncthreads();
         for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
@@ -528,7 +562,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
 // partition buffers (n for the last).  Rows whose key cannot be placed in LDS go to the HBM table directly; rows that hit
 // the max-fill limit there are marked pending (atomicOr: 64-row groups straddle partition boundaries).
 __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const u64 * __restrict__ keys, const u64 * __restrict__ offsets, u32 G,
-                                                       u32 P, u64 n, u64 * __restrict__ pending, u32 S)
+                                                       u32 P, u64 n, u64 * __restrict__ pending, u32 S, u32 K)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u64 * lkeys = (u64 *)lds_raw;
@@ -547,70 +581,91 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
         const u64 begin = offsets[(u64)p * G];
         const u64 end = p + 1 < P ? offsets[(u64)(p + 1) * G] : n;
         const u64 g0 = begin / 64, g1 = (end + 63) / 64;
-        for (u64 g = g0 + wave; g < g1; g += n_waves)
+        constexpr int PR = 4;  // 64-row groups per wave iteration: all their loads are issued before LDS is touched
+        constexpr u32 PPRE = 2; // argument words preloaded per row (GBP_MAX_K)
+        for (u64 gb = g0 + (u64)wave * PR; gb < g1; gb += (u64)n_waves * PR)
         {
-            const u64 i = g * 64 + lane;
-            bool failed = false;
-            if (i >= begin && i < end)
+            u64 keyv[PR], argv[PR][PPRE];
+            bool act[PR];
+#pragma unroll
+            for (int q = 0; q < PR; ++q)
             {
-                const u64 key = keys[i];
-                u32 ls = ~0u;
-                if (key == 0)
-                {
-                    ls = S;
-                    lzero = 1;
-                }
-                else
-                {
-                    u32 s = (u32)(dev_intHash64(key) >> 28) & (S - 1); // bits disjoint from the partition id (>> 52)
-#pragma unroll 1
-                    for (int probe = 0; probe < 64; ++probe)
-                    {
-                        u64 k = lkeys[s];
-                        if (k == 0)
-                            k = atomicCAS((unsigned long long *)&lkeys[s], 0ull, (unsigned long long)key), k = (k == 0) ? key : k;
-                        if (k == key)
-                        {
-                            ls = s;
-                            break;
-                        }
-                        s = (s + 1) & (S - 1);
-                    }
-                }
-                if (ls != ~0u)
-                {
-                    for (u32 j = 0; j < d.n_aggs; ++j)
-                    {
-                        const AggArg & a = d.a[j];
-                        u64 * w = lwords + a.word * lstride + ls;
-                        if (a.kind == CHGPU_AGG_COUNT)
-                            atomicAdd((unsigned long long *)w, 1ull);
-                        else
-                        {
-                            const u64 bits = ((const u64 *)a.ptr)[i];
-                            if (a.arg_type == CHGPU_F64)
-                                atomicAdd((double *)w, __longlong_as_double((long long)bits));
-                            else
-                                atomicAdd((unsigned long long *)w, (unsigned long long)bits);
-                            if (a.kind == CHGPU_AGG_AVG)
-                                atomicAdd((unsigned long long *)(w + lstride), 1ull);
-                        }
-                    }
-                }
-                else
-                {
-                    const u64 slot = table_emplace(t, key, true);
-                    if (slot == ~0ull)
-                        failed = true;
-                    else
-                        add_row_global(t, d, slot, i);
-                }
+                const u64 i = (gb + q) * 64 + lane;
+                act[q] = i >= begin && i < end;
+                keyv[q] = act[q] ? keys[i] : 0;
+                // the K argument word columns follow the key column in the partition buffers, n rows apart
+                argv[q][0] = (act[q] && K > 0) ? keys[n + i] : 0;
+                argv[q][1] = (act[q] && K > 1) ? keys[2 * n + i] : 0;
             }
-            const u64 b = __ballot(failed);
-            if (b != 0 && lane == 0)
+#pragma unroll
+            for (int q = 0; q < PR; ++q)
             {
-                atomicOr((unsigned long long *)&pending[g], (unsigned long long)b);
-                t.ctrl->overflow = 1;
+                const u64 g = gb + q;
+                if (g >= g1)
+                    break;
+                const u64 i = g * 64 + lane;
+                bool failed = false;
+                if (act[q])
+                {
+                    const u64 key = keyv[q];
+                    u32 ls = ~0u;
+                    if (key == 0)
+                    {
+                        ls = S;
+                        lzero = 1;
+                    }
+                    else
+                    {
+                        u32 s = (u32)(dev_intHash64(key) >> 28) & (S - 1); // bits disjoint from the partition id (>> 52)
+#pragma unroll 1
+                        for (int probe = 0; probe < 64; ++probe)
+                        {
+                            u64 k = lkeys[s];
+                            if (k == 0)
+                                k = atomicCAS((unsigned long long *)&lkeys[s], 0ull, (unsigned long long)key), k = (k == 0) ? key : k;
+                            if (k == key)
+                            {
+                                ls = s;
+                                break;
+                            }
+                            s = (s + 1) & (S - 1);
+                        }
+                    }
+                    if (ls != ~0u)
+                    {
+                        for (u32 j = 0; j < d.n_aggs; ++j)
+                        {
+                            const AggArg & a = d.a[j];
+                            u64 * w = lwords + a.word * lstride + ls;
+                            if (a.kind == CHGPU_AGG_COUNT)
+                                atomicAdd((unsigned long long *)w, 1ull);
+                            else
+                            {
+                                const u64 bits = a.pre == 0 ? argv[q][0] : argv[q][1];
+                                if (a.arg_type == CHGPU_F64)
+                                    atomicAdd((double *)w, __longlong_as_double((long long)bits));
+                                else
+                                    atomicAdd((unsigned long long *)w, (unsigned long long)bits);
+                                if (a.kind == CHGPU_AGG_AVG)
+                                    atomicAdd((unsigned long long *)(w + lstride), 1ull);
+                            }
+                        }
+                    }
+                    else
+                    {
+                        const u64 slot = table_emplace(t, key, true);
+                        if (slot == ~0ull)
+                            failed = true;
+                        else
+                            add_row_global(t, d, slot, i);
+                    }
+                }
+                const u64 b = __ballot(failed);
+                if (b != 0 && lane == 0)
+                {
+                    atomicOr((unsigned long long *)&pending[g], (unsigned long long)b);
+                    t.ctrl->overflow = 1;
+                }
             }
         }
         __syncthreads();
@@ -860,6 +915,7 @@ static void agg_fill_desc(const chgpu_agg * a, const chgpu_col * const * arg_col
         d->a[j].kind = a->kinds[j];
         d->a[j].arg_type = a->arg_types[j];
         d->a[j].word = a->word_off[j];
+        d->a[j].pre = 0;
     }
 }
 
@@ -925,6 +981,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         // the aggregate pass reads widened 8-byte words: integers were sign/zero-extended, Float64 kept its bits
         d.a[j].ptr = gc.dst[kk];
         d.a[j].arg_type = a->arg_types[j] == CHGPU_F64 ? CHGPU_F64 : CHGPU_U64;
+        d.a[j].pre = kk;
         ++kk;
     }
 
@@ -948,7 +1005,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         u32 grid = P < (u32)ctx->num_cus ? P : (u32)ctx->num_cus;
         // flush slack: grid concurrent flushes of up to S+1 new cells each must stay below the capacity
         if (rc == CHGPU_OK)
-            hipLaunchKernelGGL(k_agg_part_lds, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const u64 *)offsets, G, P, n, pending, S);
+            hipLaunchKernelGGL(k_agg_part_lds, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const u64 *)offsets, G, P, n, pending, S, K);
     }
     ctx->counters[6] += 3;
     ctx->counters[5] += n;
