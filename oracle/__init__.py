@@ -282,9 +282,12 @@ class HashMap:
         self._h = lib().cho_hashmap_create()
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().cho_hashmap_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().cho_hashmap_free(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     def emplace(self, key: int, value: int | None = None) -> bool:
         mp = C.POINTER(C.c_uint64)()
@@ -338,9 +341,12 @@ class Aggregator:
         assert self._h
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().cho_agg_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().cho_agg_free(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     def execute_on_block(self, keys, args, row_begin: int = 0, row_end: int | None = None):
         n = (keys.shape[0] if keys is not None else next(a for a in args if a is not None).shape[0])
@@ -392,9 +398,12 @@ class HashJoin:
         self.kind, self.strictness = kind, strictness
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().cho_join_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().cho_join_free(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     @property
     def need_filter(self):
