@@ -245,3 +245,18 @@ def partition_by_hash(keys: Column, num_shards: int, cols):
     counts = (C.c_uint64 * num_shards)()
     K.check(K.lib().chgpu_partition_by_hash(keys.ctx._h, keys._h, num_shards, n, ins, outs, counts))
     return [Column(keys.ctx, C.c_void_p(outs[i])) for i in range(n)], np.array(list(counts), dtype=np.uint64)
+
+
+def pack_fixed_keys(cols) -> Column:
+    """packFixed<UInt64> over several fixed-width key columns (AggregationCommon.h:91-158): one UInt64 key per row."""
+    n = len(cols)
+    ins = (C.c_void_p * n)(*[c._h for c in cols])
+    h = C.c_void_p()
+    K.check(K.lib().chgpu_pack_fixed_keys(cols[0].ctx._h, n, ins, C.byref(h)))
+    return Column(cols[0].ctx, h)
+
+
+def unpack_fixed_key(packed: Column, byte_offset: int, dtype) -> Column:
+    h = C.c_void_p()
+    K.check(K.lib().chgpu_unpack_fixed_key(packed.ctx._h, packed._h, byte_offset, TAG_OF[np.dtype(dtype)], C.byref(h)))
+    return Column(packed.ctx, h)

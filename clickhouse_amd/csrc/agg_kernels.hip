@@ -1371,7 +1371,7 @@ static int agg_export(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** word_co
                     hipLaunchKernelGGL(k_narrow_keys<u8>, dim3(g2), dim3(256), 0, ctx->stream, (const u64 *)k64->data, n_out, (u8 *)kn->data);
                 ctx->counters[6] += 1;
             }
-            chgpu_col_free(k64); // hipFree synchronises: the narrow kernel has finished reading it
+            chgpu_col_free(k64); // pooled: any reuse is stream-ordered behind the narrow kernel
             if (rc != CHGPU_OK)
                 return rc;
             *keys_out = kn;
@@ -1429,7 +1429,7 @@ extern "C" int chgpu_agg_finalize(chgpu_agg * a, chgpu_col ** keys_out, chgpu_co
     }
     for (u32 w = 0; w < a->n_words; ++w)
         if (words[w])
-            chgpu_col_free(words[w]); // hipFree synchronises with k_avg_divide
+            chgpu_col_free(words[w]); // pooled: reuse is stream-ordered behind k_avg_divide
     *groups = n;
     return rc;
 }

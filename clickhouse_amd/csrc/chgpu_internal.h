@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "../../include/chgpu.h"
@@ -67,6 +68,12 @@ struct chgpu_ctx
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     u64 counters[CHGPU_N_COUNTERS] = {0};
     u32 * crc_lut_dev = nullptr; // 8x256 slice tables + constant (CRC32-C, Hash.h:63-66)
+    // Column memory pool: freed column buffers are kept (binned by size class) and handed to later allocations on the
+    // SAME stream, which orders reuse after the last kernel that touched them.  hipMalloc/hipFree of multi-GB buffers
+    // cost 10-400 ms and synchronise the device; an operator pipeline allocates one result column per call.
+    std::multimap<size_t, void *> pool_free;
+    size_t pool_cached_bytes = 0;
+    size_t pool_limit_bytes = (size_t)96 << 30;
 };
 
 struct chgpu_col
@@ -77,6 +84,7 @@ struct chgpu_col
     void * data = nullptr; // first element
     void * base = nullptr; // allocation base when owning (data - CHGPU_PAD)
     bool owns = false;
+    size_t alloc_bytes = 0; // size class of `base` when it came from the context's pool
     int * shared_refs = nullptr; // several owning columns carved out of one allocation (scatter outputs)
 };
 
@@ -101,6 +109,8 @@ static inline int chgpu_sum_result_type(int t)
 }
 
 int chgpu_scratch(chgpu_ctx * ctx, size_t bytes, void ** out);           // >= bytes, 256-B aligned
+int chgpu_pool_alloc(chgpu_ctx * ctx, size_t bytes, void ** out, size_t * class_bytes);
+void chgpu_pool_free(chgpu_ctx * ctx, void * p, size_t class_bytes);
 int chgpu_pinned(chgpu_ctx * ctx, size_t bytes, void ** out);
 int chgpu_col_new(chgpu_ctx * ctx, int type, u64 rows, chgpu_col ** out); // owning, padded
 int chgpu_read_back(chgpu_ctx * ctx, const void * dev, void * host, size_t bytes); // async copy + stream sync

@@ -57,6 +57,9 @@ extern "C" int chgpu_ctx_destroy(chgpu_ctx * ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (auto & kv : ctx->pool_free)
+        (void)hipFree(kv.second);
+    ctx->pool_free.clear();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->crc_lut_dev) (void)hipFree(ctx->crc_lut_dev);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
@@ -143,6 +146,63 @@ int chgpu_read_back(chgpu_ctx * ctx, const void * dev, void * host, size_t bytes
     return CHGPU_OK;
 }
 
+// size classes {1, 1.25, 1.5, 1.75} x 2^k: at most 25 % internal waste, few distinct classes
+static size_t pool_class(size_t bytes)
+{
+    if (bytes < 4096)
+        return 4096;
+    size_t p = 4096;
+    while (p * 2 <= bytes)
+        p *= 2;
+    for (int q = 4; q <= 8; ++q)
+        if (p / 4 * q >= bytes)
+            return p / 4 * q;
+    return p * 2;
+}
+
+int chgpu_pool_alloc(chgpu_ctx * ctx, size_t bytes, void ** out, size_t * class_bytes)
+{
+    const size_t cls = pool_class(bytes);
+    auto it = ctx->pool_free.lower_bound(cls);
+    if (it != ctx->pool_free.end() && it->first <= cls + cls / 2)
+    {
+        *out = it->second;
+        *class_bytes = it->first;
+        ctx->pool_cached_bytes -= it->first;
+        ctx->pool_free.erase(it);
+        return CHGPU_OK;
+    }
+    hipError_t e = hipMalloc(out, cls);
+    if (e == hipErrorOutOfMemory && !ctx->pool_free.empty())
+    {
+        // give the cached blocks back and retry once
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto & kv : ctx->pool_free)
+            (void)hipFree(kv.second);
+        ctx->pool_free.clear();
+        ctx->pool_cached_bytes = 0;
+        e = hipMalloc(out, cls);
+    }
+    if (e != hipSuccess)
+        return chgpu_set_error(e == hipErrorOutOfMemory ? CHGPU_ERR_OOM : CHGPU_ERR_DEVICE, "hipMalloc(%zu): %s", cls, hipGetErrorString(e));
+    *class_bytes = cls;
+    return CHGPU_OK;
+}
+
+void chgpu_pool_free(chgpu_ctx * ctx, void * p, size_t class_bytes)
+{
+    if (!p)
+        return;
+    if (ctx->pool_cached_bytes + class_bytes > ctx->pool_limit_bytes)
+    {
+        (void)hipFree(p); // synchronises
+        return;
+    }
+    ctx->pool_free.emplace(class_bytes, p);
+    ctx->pool_cached_bytes += class_bytes;
+}
+
 int chgpu_col_new(chgpu_ctx * ctx, int type, u64 rows, chgpu_col ** out)
 {
     size_t es = chgpu_type_size(type);
@@ -150,7 +210,8 @@ int chgpu_col_new(chgpu_ctx * ctx, int type, u64 rows, chgpu_col ** out)
     CHGPU_HIP(hipSetDevice(ctx->device));
     size_t bytes = rows * es + 2 * CHGPU_PAD;
     void * base = nullptr;
-    CHGPU_HIP(hipMalloc(&base, bytes));
+    size_t cls = 0;
+    CHGPU_TRY(chgpu_pool_alloc(ctx, bytes, &base, &cls));
     chgpu_col * c = new chgpu_col();
     c->ctx = ctx;
     c->type = type;
@@ -158,6 +219,7 @@ int chgpu_col_new(chgpu_ctx * ctx, int type, u64 rows, chgpu_col ** out)
     c->base = base;
     c->data = (char *)base + CHGPU_PAD;
     c->owns = true;
+    c->alloc_bytes = cls;
     *out = c;
     return CHGPU_OK;
 }
@@ -240,9 +302,14 @@ extern "C" int chgpu_col_free(chgpu_col * col)
             if (last)
                 delete col->shared_refs;
         }
-        // hipFree synchronises the device: safe against kernels still reading the buffer
+        // back to the context's pool: reuse is stream-ordered behind every kernel already enqueued on ctx->stream
         if (last)
-            (void)hipFree(col->base);
+        {
+            if (col->alloc_bytes && col->ctx)
+                chgpu_pool_free(col->ctx, col->base, col->alloc_bytes);
+            else
+                (void)hipFree(col->base);
+        }
     }
     delete col;
     return CHGPU_OK;

@@ -278,7 +278,7 @@ extern "C" int chgpu_partition_by_hash(chgpu_ctx * ctx, const chgpu_col * keys, 
     chgpu_col * sel = nullptr;
     CHGPU_TRY(chgpu_hash_to_selector(ctx, keys, num_shards, &sel));
     int rc = partition_core(ctx, (const u32 *)sel->data, keys->rows, num_shards, n_cols, cols, outs, counts);
-    chgpu_col_free(sel); // hipFree synchronises
+    chgpu_col_free(sel); // back to the pool; reuse is ordered behind the kernels above on this stream
     return rc;
 }
 
@@ -310,6 +310,7 @@ extern "C" int chgpu_scatter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu
         v->data = (char *)cat->data + pos * es;
         v->base = cat->base;
         v->owns = true;
+        v->alloc_bytes = cat->alloc_bytes; // the shared allocation goes back to the pool with the last view
         v->shared_refs = refs;
         ++*refs;
         outs[s] = v;

@@ -179,6 +179,12 @@ int chgpu_partition_by_hash(chgpu_ctx * ctx, const chgpu_col * keys, uint32_t nu
  * Device table: open addressing, linear probing, power-of-two capacity, max fill 1/2, growth x4 until 2^23 then x2,
  * empty <=> key == 0 with the zero key kept out of line — the geometry of HashTable.h:217-330,358-391.
  * ============================================================================================== */
+/* a15 multi-column fixed-width keys: packFixed<UInt64> (src/Interpreters/AggregationCommon.h:91-158) — the keys16/32/64
+   variants of chooseAggregationMethod (Aggregator.cpp:773-778).  Columns are laid out consecutively (little endian) in one
+   UInt64 per row; more than 8 key bytes -> CHGPU_ERR_NOT_IMPLEMENTED (keys128/256 stay on the CPU).  unpack is the
+   inverse used when the key column(s) of the result block are produced (insertKeyIntoColumns). */
+int chgpu_pack_fixed_keys(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, chgpu_col ** packed_u64);
+int chgpu_unpack_fixed_key(chgpu_ctx * ctx, const chgpu_col * packed_u64, uint32_t byte_offset, int type, chgpu_col ** out);
 int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, const int * agg_kinds, const int * arg_types,
                      uint64_t size_hint, chgpu_agg ** out);
 /* executeOnBlock over rows [row_begin,row_end) of the key column and the argument columns (arg_cols[j] may be NULL

@@ -1,0 +1,139 @@
+"""SSB Q4.1-style query (BASELINE.json configs[4]) composed from the hot-path operators, once over the C ABI (GPU) and once
+over the oracle (CPU restatement, per Block) — used by tests/test_gpu_ssb.py and tools/bench_ssb.py.
+
+    SELECT d_year, c_nation, sum(lo_revenue - lo_supplycost) AS profit
+    FROM lineorder JOIN supplier ON lo_suppkey = s_suppkey JOIN part ON lo_partkey = p_partkey
+                   JOIN customer ON lo_custkey = c_custkey JOIN date ON lo_orderdate = d_datekey
+    WHERE c_region = AMERICA AND s_region = AMERICA AND p_mfgr <= 2          -- MFGR#1 or MFGR#2, dictionary-encoded
+    GROUP BY d_year, c_nation
+
+Plan (the reference's shape: filtered dimension tables become the right sides of hash joins, the fact table streams through
+JoiningTransforms, then AggregatingTransform).  sum(a - b) is evaluated as sum(a) - sum(b) — identical for
+wrap-around integer sums — so no arithmetic function is needed yet (expression fusion is SURVEY §8f rank 1).
+"""
+import numpy as np
+
+AMERICA = 1
+N_DATES = 2556
+
+
+def gen_dims(customers, suppliers, parts, seed=7):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c_nation = rng.integers(0, 25, size=customers).astype(np.uint8)
+    dims = dict(
+        c_custkey=np.arange(1, customers + 1, dtype=np.uint32), c_nation=c_nation, c_region=(c_nation // 5).astype(np.uint8),
+        s_suppkey=np.arange(1, suppliers + 1, dtype=np.uint32), s_region=rng.integers(0, 5, size=suppliers).astype(np.uint8),
+        p_partkey=np.arange(1, parts + 1, dtype=np.uint32), p_mfgr=rng.integers(1, 6, size=parts).astype(np.uint8),
+        d_datekey=(np.arange(N_DATES, dtype=np.uint32) + 19920101), d_year=(1992 + np.arange(N_DATES) // 366).astype(np.uint32),
+    )
+    return dims
+
+
+def gen_lineorder_numpy(rows, customers, suppliers, parts, seed=11):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return dict(
+        lo_custkey=rng.integers(1, customers + 1, size=rows).astype(np.uint32),
+        lo_suppkey=rng.integers(1, suppliers + 1, size=rows).astype(np.uint32),
+        lo_partkey=rng.integers(1, parts + 1, size=rows).astype(np.uint32),
+        lo_orderdate=(rng.integers(0, N_DATES, size=rows).astype(np.uint32) + 19920101),
+        lo_revenue=rng.integers(0, 1_000_000, size=rows).astype(np.uint32),
+        lo_supplycost=rng.integers(0, 100_000, size=rows).astype(np.uint32),
+    )
+
+
+def gen_lineorder_torch(rows, customers, suppliers, parts, device, seed=11):
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+
+    def ri(lo, hi):
+        return torch.randint(lo, hi, (rows,), dtype=torch.int32, device=device, generator=g)
+    return dict(lo_custkey=ri(1, customers + 1), lo_suppkey=ri(1, suppliers + 1), lo_partkey=ri(1, parts + 1),
+                lo_orderdate=ri(0, N_DATES) + 19920101, lo_revenue=ri(0, 1_000_000), lo_supplycost=ri(0, 100_000))
+
+
+def q41_gpu(ch, ctx, dims, lo):
+    """dims: numpy arrays; lo: dict of device Columns (UInt32).  Returns {(year, nation): profit}."""
+    up = ctx.upload
+    # ---- right sides: filtered dimension tables -> hash tables (FillingRightJoinSideTransform) ----
+    c_region, c_custkey, c_nation = up(dims["c_region"]), up(dims["c_custkey"]), up(dims["c_nation"])
+    cm = ch.cmp_const(c_region, ch.EQ, AMERICA)
+    ck, cn = c_custkey.filter(cm), c_nation.filter(cm)
+    j_c = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, key_dtype=np.uint32, ctx=ctx)
+    j_c.add_block(ck)
+    sm = ch.cmp_const(up(dims["s_region"]), ch.EQ, AMERICA)
+    j_s = ch.HashJoin(ch.JOIN_LEFT, ch.STRICT_SEMI, key_dtype=np.uint32, ctx=ctx)
+    j_s.add_block(up(dims["s_suppkey"]).filter(sm))
+    pm = ch.cmp_const(up(dims["p_mfgr"]), ch.LE, 2)
+    j_p = ch.HashJoin(ch.JOIN_LEFT, ch.STRICT_SEMI, key_dtype=np.uint32, ctx=ctx)
+    j_p.add_block(up(dims["p_partkey"]).filter(pm))
+    d_year = up(dims["d_year"])
+    j_d = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, key_dtype=np.uint32, ctx=ctx)
+    j_d.add_block(up(dims["d_datekey"]))
+    for j in (j_c, j_s, j_p, j_d):
+        j.finish_build()
+    # ---- the fact table through the joins (JoiningTransform x4), most selective first ----
+    r = j_s.probe_columns(lo["lo_suppkey"])
+    f = r["filter"]
+    cust, part, date, rev, cost = (lo[k].filter(f) for k in ("lo_custkey", "lo_partkey", "lo_orderdate", "lo_revenue", "lo_supplycost"))
+    r = j_p.probe_columns(part)
+    f = r["filter"]
+    cust, date, rev, cost = (c.filter(f) for c in (cust, date, rev, cost))
+    r = j_c.probe_columns(cust)
+    off = r["offsets"]
+    date, rev, cost = (c.replicate(off) for c in (date, rev, cost))
+    nation = cn.index(r["right_rowid"], default_for_missing=True)
+    r = j_d.probe_columns(date)
+    off = r["offsets"]
+    rev, cost, nation = (c.replicate(off) for c in (rev, cost, nation))
+    year = d_year.index(r["right_rowid"], default_for_missing=True)
+    # ---- GROUP BY d_year, c_nation (keys64: packFixed) ----
+    key = ch.pack_fixed_keys([year, nation])
+    agg = ch.Aggregator(np.uint64, [(ch.AGG_SUM, np.uint32), (ch.AGG_SUM, np.uint32), (ch.AGG_COUNT, None)], ctx=ctx)
+    agg.execute_on_block(key, [rev, cost, None])
+    keys_c, (s_rev, s_cost, cnt) = agg.finalize_columns()
+    yy = ch.unpack_fixed_key(keys_c, 0, np.uint32).numpy()
+    nn = ch.unpack_fixed_key(keys_c, 4, np.uint8).numpy()
+    s_rev, s_cost, cnt = s_rev.numpy(), s_cost.numpy(), cnt.numpy()
+    return {(int(y), int(n)): (int(a) - int(b), int(c)) for y, n, a, b, c in zip(yy, nn, s_rev, s_cost, cnt)}
+
+
+def q41_cpu(O, dims, lo, block_rows=65409):
+    """Same plan over the oracle, fact table in Blocks of `block_rows` (lo: dict of numpy arrays)."""
+    cm = O.cmp_const(dims["c_region"], O.EQ, AMERICA)
+    ck, cn = O.filter_column(dims["c_custkey"], cm), O.filter_column(dims["c_nation"], cm)
+    j_c = O.HashJoin(O.JOIN_INNER, O.STRICT_ALL)
+    j_c.add_block(ck)
+    j_s = O.HashJoin(O.JOIN_LEFT, O.STRICT_SEMI)
+    j_s.add_block(O.filter_column(dims["s_suppkey"], O.cmp_const(dims["s_region"], O.EQ, AMERICA)))
+    j_p = O.HashJoin(O.JOIN_LEFT, O.STRICT_SEMI)
+    j_p.add_block(O.filter_column(dims["p_partkey"], O.cmp_const(dims["p_mfgr"], O.LE, 2)))
+    j_d = O.HashJoin(O.JOIN_INNER, O.STRICT_ALL)
+    j_d.add_block(dims["d_datekey"])
+    agg = O.Aggregator(np.uint64, [(O.AGG_SUM, np.uint32), (O.AGG_SUM, np.uint32), (O.AGG_COUNT, None)])
+    n = lo["lo_custkey"].shape[0]
+    for b in range(0, n, block_rows):
+        e = min(n, b + block_rows)
+        blk = {k: v[b:e] for k, v in lo.items()}
+        f = j_s.probe(blk["lo_suppkey"])["filter"]
+        if not f.any():
+            continue
+        cust, part, date, rev, cost = (O.filter_column(blk[k], f) for k in ("lo_custkey", "lo_partkey", "lo_orderdate", "lo_revenue", "lo_supplycost"))
+        f = j_p.probe(part)["filter"]
+        if not f.any():
+            continue
+        cust, date, rev, cost = (O.filter_column(c, f) for c in (cust, date, rev, cost))
+        r = j_c.probe(cust)
+        off = r["offsets"]
+        if off.shape[0] == 0 or off[-1] == 0:
+            continue
+        date, rev, cost = (O.replicate(c, off) for c in (date, rev, cost))
+        nation = cn[r["added_row"]]
+        r = j_d.probe(date)
+        off = r["offsets"]
+        rev, cost, nation = (O.replicate(c, off) for c in (rev, cost, nation))
+        year = dims["d_year"][r["added_row"]]
+        key = year.astype(np.uint64) | (nation.astype(np.uint64) << np.uint64(32))   # packFixed<UInt64>: 4 bytes year, 1 byte nation
+        agg.execute_on_block(key, [rev, cost, None])
+    keys, (s_rev, s_cost, cnt) = agg.convert_to_block()
+    return {(int(k & np.uint64(0xFFFFFFFF)), int((k >> np.uint64(32)) & np.uint64(0xFF))): (int(a) - int(b), int(c))
+            for k, a, b, c in zip(keys, s_rev, s_cost, cnt)}
