@@ -21,6 +21,7 @@ AGG_COUNT, AGG_SUM, AGG_AVG = 0, 1, 2
 JOIN_INNER, JOIN_LEFT = 0, 1
 STRICT_ANY, STRICT_ALL, STRICT_SEMI, STRICT_ANTI = 0, 1, 2, 3
 N_COUNTERS = 8
+VAL_COL, VAL_MUL, VAL_PLUS, VAL_MINUS = 0, 1, 2, 3
 
 _vp, _i, _u32, _u64, _i64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_int64
 _pp = C.POINTER(C.c_void_p)
@@ -52,6 +53,9 @@ SIGNATURES = {
     "chgpu_sum_add_many_conditional": (_i, [_vp, _vp, _vp, _u64, _u64, _vp]),
     "chgpu_filter_sum": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _pu64]),
     "chgpu_filter_sum_async": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "chgpu_and": (_i, [_vp, _vp, _vp, _pp]),
+    "chgpu_arith": (_i, [_vp, _i, _vp, _vp, _pp]),
+    "chgpu_expr_filter_sum": (_i, [_vp, _u32, _pp, _u32, C.POINTER(_u32), C.POINTER(_i), C.POINTER(_i), _pu64, _i, _u32, _u32, C.POINTER(_i), _vp, _pu64]),
     "chgpu_index": (_i, [_vp, _vp, _vp, _u64, _i, _pp]),
     "chgpu_replicate": (_i, [_vp, _vp, _vp, _pp]),
     "chgpu_weak_hash32": (_i, [_vp, _vp, _vp]),

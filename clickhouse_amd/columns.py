@@ -260,3 +260,39 @@ def unpack_fixed_key(packed: Column, byte_offset: int, dtype) -> Column:
     h = C.c_void_p()
     K.check(K.lib().chgpu_unpack_fixed_key(packed.ctx._h, packed._h, byte_offset, TAG_OF[np.dtype(dtype)], C.byref(h)))
     return Column(packed.ctx, h)
+
+
+def and_(a: Column, b: Column) -> Column:
+    """FunctionAnd over two UInt8 columns (FunctionsLogical.h:82-96)."""
+    h = C.c_void_p()
+    K.check(K.lib().chgpu_and(a.ctx._h, a._h, b._h, C.byref(h)))
+    return Column(a.ctx, h)
+
+
+def arith(value_op: int, a: Column, b: Column) -> Column:
+    """multiply / plus / minus with NumberTraits result types (multiply.cpp:10-28, NumberTraits.h:73-87)."""
+    h = C.c_void_p()
+    K.check(K.lib().chgpu_arith(a.ctx._h, value_op, a._h, b._h, C.byref(h)))
+    return Column(a.ctx, h)
+
+
+def scalar_bits(tag: int, value) -> int:
+    return int.from_bytes(np.array([value], dtype=NP_OF[tag]).tobytes().ljust(8, b"\0"), "little")
+
+
+def expr_filter_sum(cols, preds, value_op: int, val_a: int, val_b: int = 0):
+    """Fused `SELECT sum(value), count() WHERE p0 AND p1 ...`; preds: (col_index, op, scalar[, scalar_tag]) -> (sum, count)."""
+    n = len(cols)
+    cp = (C.c_void_p * n)(*[c._h for c in cols])
+    m = len(preds)
+    pc = (C.c_uint32 * max(1, m))(*[p[0] for p in preds])
+    po = (C.c_int * max(1, m))(*[p[1] for p in preds])
+    tags = [(p[3] if len(p) > 3 and p[3] is not None else cols[p[0]].tag) for p in preds]
+    ps = (C.c_int * max(1, m))(*tags)
+    pb = (C.c_uint64 * max(1, m))(*[scalar_bits(t, p[2]) for p, t in zip(preds, tags)])
+    rt = C.c_int(0)
+    out = np.zeros(1, dtype=np.uint64)
+    cnt = C.c_uint64(0)
+    K.check(K.lib().chgpu_expr_filter_sum(cols[0].ctx._h, n, cp, m, pc, po, ps, pb, value_op, val_a, val_b, C.byref(rt),
+                                          out.ctypes.data_as(C.c_void_p), C.byref(cnt)))
+    return out.view(NP_OF[rt.value])[0], int(cnt.value)

@@ -949,3 +949,365 @@ extern "C" int chgpu_replicate(chgpu_ctx * ctx, const chgpu_col * col, const chg
     *out = res;
     return CHGPU_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// and / arithmetic columns, and the fused multi-predicate filter + value expression + sum
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_and_u8(const u8 * __restrict__ a, const u8 * __restrict__ b, u64 n, u8 * __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+        out[i] = a[i] & b[i]; // AndImpl::apply
+}
+
+extern "C" int chgpu_and(chgpu_ctx * ctx, const chgpu_col * a, const chgpu_col * b, chgpu_col ** out)
+{
+    CHGPU_REQUIRE(ctx && a && b && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(a->type == CHGPU_U8 && b->type == CHGPU_U8, CHGPU_ERR_NOT_IMPLEMENTED, "and() over non-UInt8 arguments: CPU path");
+    CHGPU_REQUIRE(a->rows == b->rows, CHGPU_ERR_SIZES_MISMATCH, "arguments of function and have different sizes");
+    chgpu_col * m = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U8, a->rows, &m));
+    if (a->rows)
+    {
+        hipLaunchKernelGGL(k_and_u8, dim3(chgpu_grid_for(ctx, a->rows, 256, 8)), dim3(256), 0, ctx->stream, (const u8 *)a->data, (const u8 *)b->data, a->rows, (u8 *)m->data);
+        ctx->counters[6] += 1;
+    }
+    *out = m;
+    return CHGPU_OK;
+}
+
+static int arith_result_type(int value_op, int a_type, int b_type)
+{
+    if (!chgpu_type_is_int(a_type) || !chgpu_type_is_int(b_type))
+        return -1;
+    if (value_op == CHGPU_VAL_MINUS)
+        return CHGPU_I64; // ResultOfSubtraction: always signed (NumberTraits.h:81-87)
+    if (value_op == CHGPU_VAL_MUL || value_op == CHGPU_VAL_PLUS)
+        return (chgpu_type_is_signed(a_type) || chgpu_type_is_signed(b_type)) ? CHGPU_I64 : CHGPU_U64; // :73-79
+    return -1;
+}
+
+template <typename T>
+__device__ __forceinline__ u64 ext64(T v)
+{
+    if constexpr (std::is_signed<T>::value)
+        return (u64)(i64)v;
+    else
+        return (u64)v;
+}
+
+__device__ __forceinline__ u64 apply_val(int op, u64 x, u64 y)
+{
+    return op == CHGPU_VAL_MUL ? x * y : (op == CHGPU_VAL_PLUS ? x + y : x - y); // static_cast<Result>(a) OP b, wrap-around
+}
+
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void k_arith(const TA * __restrict__ a, const TB * __restrict__ b, u64 n, int op, u64 * __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+        out[i] = apply_val(op, ext64(a[i]), ext64(b[i]));
+}
+
+extern "C" int chgpu_arith(chgpu_ctx * ctx, int value_op, const chgpu_col * a, const chgpu_col * b, chgpu_col ** out)
+{
+    CHGPU_REQUIRE(ctx && a && b && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    const int rt = arith_result_type(value_op, a->type, b->type);
+    CHGPU_REQUIRE(rt >= 0, CHGPU_ERR_NOT_IMPLEMENTED, "arithmetic on these types/operator: CPU path");
+    CHGPU_REQUIRE(a->rows == b->rows, CHGPU_ERR_SIZES_MISMATCH, "arguments of an arithmetic function have different sizes");
+    CHGPU_REQUIRE(a->type == b->type, CHGPU_ERR_NOT_IMPLEMENTED, "mixed-type arithmetic: CPU path");
+    chgpu_col * r = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, rt, a->rows, &r));
+    const u64 n = a->rows;
+    if (n)
+    {
+        const u32 grid = chgpu_grid_for(ctx, n, 256, 8);
+#define AR(T) hipLaunchKernelGGL((k_arith<T, T>), dim3(grid), dim3(256), 0, ctx->stream, (const T *)a->data, (const T *)b->data, n, value_op, (u64 *)r->data)
+        switch (a->type)
+        {
+            case CHGPU_I64: AR(i64); break;
+            case CHGPU_U64: AR(u64); break;
+            case CHGPU_U32: AR(u32); break;
+            case CHGPU_I32: AR(i32); break;
+            default: AR(u8); break;
+        }
+#undef AR
+        ctx->counters[6] += 1;
+    }
+    *out = r;
+    return CHGPU_OK;
+}
+
+static constexpr u32 EX_MAX_COLS = 4;
+static constexpr u32 EX_MAX_PREDS = 8;
+
+// range predicate in the column's own width: 3 VALU ops per element for 4-byte columns (xor, sub, cmp) instead of the
+// ~8 a 64-bit key costs; lo/span/flip are folded on the host exactly like IntRangePred's
+struct ExprPred
+{
+    u64 lo, span, flip;
+    u32 invert;
+    u32 col;
+};
+
+struct ExprSpec
+{
+    u32 n_cols, n_preds;
+    const void * col[EX_MAX_COLS];
+    ExprPred pred[EX_MAX_PREDS];
+    int value_op;
+    u32 val_a, val_b;
+};
+
+template <typename T>
+__device__ __forceinline__ bool expr_pass(const ExprPred & p, T x)
+{
+    if constexpr (sizeof(T) <= 4)
+    {
+        const u32 key = (u32)x ^ (u32)p.flip; // the sign flip for signed 4-byte types is folded to bit 31
+        return ((key - (u32)p.lo) <= (u32)p.span) != (p.invert != 0);
+    }
+    else
+    {
+        const u64 key = (u64)x ^ p.flip;
+        return ((key - p.lo) <= p.span) != (p.invert != 0);
+    }
+}
+
+// One pass: up to 4 columns of one element type, <= 8 range predicates and-ed, value = column or a binary op of two columns.
+// Work is ordered column-major: for column k (static) loop over the predicates that test it (wave-uniform branch), apply each
+// to all E elements held in registers — the predicate constants are read once per (column, predicate), no runtime-indexed
+// register arrays (they would go to scratch) and no select chains.
+template <typename T>
+__global__ __launch_bounds__(FS_THREADS) void k_expr_filter_sum(ExprSpec sp, u64 n, u64 * __restrict__ part_sum, u64 * __restrict__ part_cnt)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    typedef Vec<T, VEC> V;
+    constexpr int UNROLL = 2;
+    constexpr int E = VEC * UNROLL; // elements per lane per iteration
+    const u64 nvec = n / VEC;
+    u64 s = 0, c = 0;
+
+    auto reduce_rows = [&](const T (&x0)[E], const T (&x1)[E], const T (&x2)[E], const T (&x3)[E], int n_elem) {
+        bool pass[E];
+        u64 va[E], vb[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+        {
+            pass[e] = e < n_elem;
+            va[e] = 0;
+            vb[e] = 0;
+        }
+        auto column = [&](u32 k, const T (&x)[E]) {
+            for (u32 q = 0; q < sp.n_preds; ++q)
+                if (sp.pred[q].col == k)
+                {
+                    const ExprPred pr = sp.pred[q];
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        pass[e] = pass[e] && expr_pass<T>(pr, x[e]);
+                }
+            if (sp.val_a == k)
+            {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    va[e] = ext64(x[e]);
+            }
+            if (sp.value_op != CHGPU_VAL_COL && sp.val_b == k)
+            {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    vb[e] = ext64(x[e]);
+            }
+        };
+        column(0, x0);
+        if (sp.n_cols > 1) column(1, x1);
+        if (sp.n_cols > 2) column(2, x2);
+        if (sp.n_cols > 3) column(3, x3);
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+        {
+            const u64 v = sp.value_op == CHGPU_VAL_COL ? va[e] : apply_val(sp.value_op, va[e], vb[e]);
+            s += pass[e] ? v : 0;
+            c += pass[e] ? 1 : 0;
+        }
+    };
+
+    constexpr u64 CHUNK = (u64)UNROLL * FS_THREADS;
+    const u64 n_chunks = nvec / CHUNK;
+    const V * __restrict__ c0 = (const V *)sp.col[0];
+    const V * __restrict__ c1 = (const V *)sp.col[1];
+    const V * __restrict__ c2 = (const V *)sp.col[2];
+    const V * __restrict__ c3 = (const V *)sp.col[3];
+    for (u64 ch = blockIdx.x; ch < n_chunks; ch += gridDim.x)
+    {
+        const u64 base = ch * CHUNK + threadIdx.x;
+        V y0[UNROLL], y1[UNROLL], y2[UNROLL], y3[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k)
+        {
+            const u64 i = base + (u64)k * FS_THREADS;
+            y0[k] = load_stream(&c0[i]);
+            if (sp.n_cols > 1) y1[k] = load_stream(&c1[i]);
+            if (sp.n_cols > 2) y2[k] = load_stream(&c2[i]);
+            if (sp.n_cols > 3) y3[k] = load_stream(&c3[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        T x0[E], x1[E], x2[E], x3[E];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+            {
+                x0[k * VEC + e] = y0[k].v[e];
+                x1[k * VEC + e] = y1[k].v[e];
+                x2[k * VEC + e] = y2[k].v[e];
+                x3[k * VEC + e] = y3[k].v[e];
+            }
+        reduce_rows(x0, x1, x2, x3, E);
+    }
+    const u64 tid = (u64)blockIdx.x * FS_THREADS + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * FS_THREADS;
+    const T * s0 = (const T *)sp.col[0];
+    const T * s1 = (const T *)sp.col[1];
+    const T * s2 = (const T *)sp.col[2];
+    const T * s3 = (const T *)sp.col[3];
+    for (u64 r = n_chunks * CHUNK * VEC + tid; r < n; r += stride)
+    {
+        T x0[E] = {}, x1[E] = {}, x2[E] = {}, x3[E] = {};
+        x0[0] = s0[r];
+        x1[0] = s1[r];
+        x2[0] = s2[r];
+        x3[0] = s3[r];
+        reduce_rows(x0, x1, x2, x3, 1);
+    }
+
+    __shared__ u64 lds_s[FS_THREADS / WAVE];
+    __shared__ u64 lds_c[FS_THREADS / WAVE];
+    s = wave_reduce_add_u64(s);
+    c = wave_reduce_add_u64(c);
+    if ((threadIdx.x & 63) == 0)
+    {
+        lds_s[threadIdx.x >> 6] = s;
+        lds_c[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        u64 ss = 0, cc = 0;
+        for (int w = 0; w < FS_THREADS / WAVE; ++w)
+        {
+            ss += lds_s[w];
+            cc += lds_c[w];
+        }
+        part_sum[blockIdx.x] = ss;
+        part_cnt[blockIdx.x] = cc;
+    }
+}
+
+extern "C" int chgpu_expr_filter_sum(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, uint32_t n_preds,
+                                     const uint32_t * pred_col, const int * pred_op, const int * pred_scalar_type,
+                                     const uint64_t * pred_scalar_bits, int value_op, uint32_t val_a, uint32_t val_b,
+                                     int * result_type_out, void * sum_out, uint64_t * count_out)
+{
+    CHGPU_REQUIRE(ctx && cols && sum_out && count_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(n_cols >= 1 && n_cols <= EX_MAX_COLS, CHGPU_ERR_NOT_IMPLEMENTED, "fused expression over more than %u columns: CPU path", EX_MAX_COLS);
+    CHGPU_REQUIRE(n_preds <= EX_MAX_PREDS, CHGPU_ERR_NOT_IMPLEMENTED, "more than %u predicates: CPU path", EX_MAX_PREDS);
+    CHGPU_REQUIRE(n_preds == 0 || (pred_col && pred_op && pred_scalar_type && pred_scalar_bits), CHGPU_ERR_BAD_ARGUMENTS, "NULL predicate arrays");
+    CHGPU_REQUIRE(value_op >= CHGPU_VAL_COL && value_op <= CHGPU_VAL_MINUS, CHGPU_ERR_BAD_ARGUMENTS, "unknown value operator %d", value_op);
+    CHGPU_REQUIRE(val_a < n_cols && (value_op == CHGPU_VAL_COL || val_b < n_cols), CHGPU_ERR_BAD_ARGUMENTS, "value column index out of range");
+    ExprSpec sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.n_cols = n_cols;
+    sp.n_preds = n_preds;
+    const int type = cols[0] ? cols[0]->type : -1;
+    u64 n = cols[0] ? cols[0]->rows : 0;
+    bool aligned = true;
+    for (u32 k = 0; k < EX_MAX_COLS; ++k)
+    {
+        const chgpu_col * cc = cols[k < n_cols ? k : 0];
+        CHGPU_REQUIRE(cc, CHGPU_ERR_BAD_ARGUMENTS, "column %u is NULL", k);
+        CHGPU_REQUIRE(cc->type == type, CHGPU_ERR_NOT_IMPLEMENTED, "fused expression needs columns of one type");
+        CHGPU_REQUIRE(cc->rows == n, CHGPU_ERR_SIZES_MISMATCH, "Sizes of columns doesn't match");
+        sp.col[k] = cc->data;
+        aligned = aligned && (((uintptr_t)cc->data) & 15) == 0;
+    }
+    CHGPU_REQUIRE(chgpu_type_is_int(type), CHGPU_ERR_NOT_IMPLEMENTED, "fused expression over Float64: CPU path");
+    CHGPU_REQUIRE(aligned, CHGPU_ERR_NOT_IMPLEMENTED, "fused expression needs 16-byte aligned columns");
+    for (u32 k = 0; k < n_preds; ++k)
+    {
+        CHGPU_REQUIRE(pred_col[k] < n_cols, CHGPU_ERR_BAD_ARGUMENTS, "predicate %u refers to column %u of %u", k, pred_col[k], n_cols);
+        CmpSpec cs;
+        CHGPU_TRY(make_cmp_spec(type, pred_op[k], pred_scalar_type[k], &pred_scalar_bits[k], &cs));
+        // make_cmp_spec folds the comparison over the 64-bit extension of the column's signedness class; a 4-byte (or
+        // 1-byte) column only ever presents values of its own range, so clamping the key range to that sub-range and
+        // dropping the upper bits gives the same test in 32-bit arithmetic
+        ExprPred ep;
+        ep.col = pred_col[k];
+        ep.invert = cs.ip.invert;
+        if (chgpu_type_size(type) == 8)
+        {
+            ep.lo = cs.ip.lo;
+            ep.span = cs.ip.span;
+            ep.flip = cs.ip.flip;
+        }
+        else
+        {
+            const bool sgn = chgpu_type_is_signed(type);
+            // 64-bit key space: signed -> value + 2^63, unsigned -> value.  The column's values occupy [vmin, vmax] there.
+            const u64 vmin = sgn ? (1ull << 63) - (1ull << 31) : 0;
+            const u64 vmax = sgn ? (1ull << 63) + ((1ull << 31) - 1) : (chgpu_type_size(type) == 4 ? 0xFFFFFFFFull : 0xFFull);
+            u64 lo = cs.ip.lo, hi = cs.ip.lo + cs.ip.span; // inclusive key range (no wrap: span <= max - lo)
+            bool empty = hi < vmin || lo > vmax;
+            if (lo < vmin) lo = vmin;
+            if (hi > vmax) hi = vmax;
+            if (empty)
+            {
+                // nothing in range: full 32-bit range with the inversion flipped
+                ep.lo = 0;
+                ep.span = 0xFFFFFFFFull;
+                ep.invert = cs.ip.invert ? 0u : 1u;
+            }
+            else
+            {
+                // 32-bit key = value ^ 0x80000000 for signed (order-preserving), value for unsigned
+                ep.lo = sgn ? (lo - vmin) : lo;
+                ep.span = hi - lo;
+            }
+            ep.flip = sgn ? 0x80000000ull : 0;
+        }
+        sp.pred[k] = ep;
+    }
+    sp.value_op = value_op;
+    sp.val_a = val_a;
+    sp.val_b = val_b;
+    const int rt = value_op == CHGPU_VAL_COL ? chgpu_sum_result_type(type) : arith_result_type(value_op, type, type);
+    CHGPU_REQUIRE(rt >= 0, CHGPU_ERR_NOT_IMPLEMENTED, "value expression: CPU path");
+    if (result_type_out)
+        *result_type_out = rt;
+
+    const u32 vecw = 16 / (u32)chgpu_type_size(type);
+    const u32 grid = chgpu_grid_for(ctx, (n + vecw - 1) / vecw, FS_THREADS, FS_WG_PER_CU);
+    void * scratch = nullptr;
+    const u32 grid_cap = (u32)ctx->num_cus * 8;
+    CHGPU_TRY(chgpu_scratch(ctx, (size_t)grid_cap * 2 * sizeof(u64) + 64, &scratch));
+    u64 * part_sum = (u64 *)scratch;
+    u64 * part_cnt = part_sum + grid;
+    u64 * result_dev = (u64 *)((char *)scratch + (size_t)grid_cap * 2 * sizeof(u64));
+    switch (type)
+    {
+        case CHGPU_I64: hipLaunchKernelGGL(k_expr_filter_sum<i64>, dim3(grid), dim3(FS_THREADS), 0, ctx->stream, sp, n, part_sum, part_cnt); break;
+        case CHGPU_U64: hipLaunchKernelGGL(k_expr_filter_sum<u64>, dim3(grid), dim3(FS_THREADS), 0, ctx->stream, sp, n, part_sum, part_cnt); break;
+        case CHGPU_U32: hipLaunchKernelGGL(k_expr_filter_sum<u32>, dim3(grid), dim3(FS_THREADS), 0, ctx->stream, sp, n, part_sum, part_cnt); break;
+        case CHGPU_I32: hipLaunchKernelGGL(k_expr_filter_sum<i32>, dim3(grid), dim3(FS_THREADS), 0, ctx->stream, sp, n, part_sum, part_cnt); break;
+        default: hipLaunchKernelGGL(k_expr_filter_sum<u8>, dim3(grid), dim3(FS_THREADS), 0, ctx->stream, sp, n, part_sum, part_cnt); break;
+    }
+    hipLaunchKernelGGL(k_filter_sum_finish<false>, dim3(1), dim3(256), 0, ctx->stream, part_sum, part_cnt, grid, result_dev);
+    ctx->counters[6] += 2;
+    ctx->counters[5] += n;
+    CHGPU_HIP(hipGetLastError());
+    u64 res[2];
+    CHGPU_TRY(chgpu_read_back(ctx, result_dev, res, sizeof(res)));
+    memcpy(sum_out, &res[0], 8);
+    *count_out = res[1];
+    ctx->counters[0] += res[1];
+    return CHGPU_OK;
+}

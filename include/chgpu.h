@@ -143,6 +143,26 @@ int chgpu_filter_sum_async(chgpu_ctx * ctx, const chgpu_col * pred, int op, int 
                            const chgpu_col * val, chgpu_col * result_u64x2);
 
 /* ================================================================================================
+ * SURVEY §8(f) rank 1 — pieces of the expression DAG an SSB Q1.1-style query needs, and their fusion.
+ * `and`: FunctionAnd over UInt8 columns (AndImpl::apply = a & b, src/Functions/FunctionsLogical.h:82-96).
+ * multiply / plus / minus: FunctionBinaryArithmetic (src/Functions/multiply.cpp:10-28) with NumberTraits result types
+ * (src/DataTypes/NumberTraits.h:73-87): integer operands of <= 8 bytes give a 64-bit result, unsigned only for
+ * multiply/plus of two unsigned operands; wrap-around arithmetic.  Float operands -> CHGPU_ERR_NOT_IMPLEMENTED.
+ * ============================================================================================== */
+enum { CHGPU_VAL_COL = 0, CHGPU_VAL_MUL = 1, CHGPU_VAL_PLUS = 2, CHGPU_VAL_MINUS = 3 };
+int chgpu_and(chgpu_ctx * ctx, const chgpu_col * a_u8, const chgpu_col * b_u8, chgpu_col ** out_u8);
+int chgpu_arith(chgpu_ctx * ctx, int value_op, const chgpu_col * a, const chgpu_col * b, chgpu_col ** out);
+/* Fused `SELECT sum(<value>), count() WHERE p_0 AND p_1 ...` in ONE pass over HBM (ExpressionActions::execute +
+ * FilterTransform + AggregatingTransform without key).  cols[n_cols] are the distinct columns touched (<= 4, all of one
+ * element width); predicate k is `cols[pred_col[k]] pred_op[k] constant` (constant = 8 raw bytes in pred_scalar_bits[k], typed
+ * pred_scalar_type[k]; <= 8 predicates, and-ed); value = cols[val_a] (CHGPU_VAL_COL) or cols[val_a] <op> cols[val_b].
+ * sum_out: 8 bytes, Int64 or UInt64 per the result type rules above (*result_type_out tells which). */
+int chgpu_expr_filter_sum(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, uint32_t n_preds,
+                          const uint32_t * pred_col, const int * pred_op, const int * pred_scalar_type,
+                          const uint64_t * pred_scalar_bits, int value_op, uint32_t val_a, uint32_t val_b,
+                          int * result_type_out, void * sum_out, uint64_t * count_out);
+
+/* ================================================================================================
  * a22 data movement  —  IColumn::index / replicate (src/Columns/ColumnVector.cpp:1121-1143, 879-907)
  * ============================================================================================== */
 /* out[i] = col[indexes[i]], i < limit (limit 0 = all); indexes: CHGPU_U64 or CHGPU_U32.

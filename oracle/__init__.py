@@ -91,6 +91,10 @@ def lib() -> C.CDLL:
             "cho_sum_add_many_conditional": (None, [i32, vp, vp, vp, sz, sz]),
             "cho_avg_divide": (C.c_double, [i32, vp, u64]),
             "cho_filter_sum_pipeline": (i32, [i32, vp, vp, sz, i32, vp, sz, i32, vp, vp, vp, vp]),
+            "cho_and_u8": (None, [vp, vp, sz, vp]),
+            "cho_arith_result_type": (i32, [i32, i32, i32]),
+            "cho_arith": (i32, [i32, i32, vp, i32, vp, sz, vp]),
+            "cho_expr_filter_sum_pipeline": (i32, [sz, vp, vp, sz, sz, vp, vp, vp, vp, i32, C.c_uint32, C.c_uint32, sz, i32, vp, vp]),
             "cho_hashmap_create": (vp, []),
             "cho_hashmap_free": (None, [vp]),
             "cho_hashmap_emplace": (i32, [vp, u64, C.POINTER(C.POINTER(u64))]),
@@ -273,6 +277,51 @@ def filter_sum_pipeline(pred: np.ndarray, op: int, scalar, val: np.ndarray | Non
                                        _p(out), _p(cnt), _p(dropped), _p(passed))
     assert rc == 0
     return out[0], int(cnt[0]), int(dropped[0]), int(passed[0])
+
+
+VAL_COL, VAL_MUL, VAL_PLUS, VAL_MINUS = 0, 1, 2, 3
+
+
+def and_u8(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    out = np.empty_like(a)
+    lib().cho_and_u8(_p(a), _p(b), a.shape[0], _p(out))
+    return out
+
+
+def arith(value_op, a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    rt = lib().cho_arith_result_type(value_op, tag_of(a), tag_of(b))
+    assert rt >= 0
+    out = np.empty(a.shape[0], dtype=NP_OF[rt])
+    assert lib().cho_arith(value_op, tag_of(a), _p(a), tag_of(b), _p(b), a.shape[0], _p(out)) == 0
+    return out
+
+
+def scalar_bits(tag, value) -> int:
+    """the 8 raw little-endian bytes of `value` typed as `tag` (how constants cross the C boundary)"""
+    return int.from_bytes(np.array([value], dtype=NP_OF[tag]).tobytes().ljust(8, b"\0"), "little")
+
+
+def expr_filter_sum_pipeline(cols, preds, value_op, val_a, val_b=0, block_rows=DEFAULT_BLOCK_SIZE, threads=1):
+    """cols: list of ndarrays; preds: list of (col_index, op, scalar, scalar_tag or None) and-ed together."""
+    cols = [np.ascontiguousarray(c) for c in cols]
+    n = cols[0].shape[0]
+    types = np.array([tag_of(c) for c in cols], dtype=np.int32)
+    ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+    pc = np.array([p[0] for p in preds], dtype=np.uint32)
+    po = np.array([p[1] for p in preds], dtype=np.int32)
+    ps = np.array([(p[3] if len(p) > 3 and p[3] is not None else tag_of(cols[p[0]])) for p in preds], dtype=np.int32)
+    pb = np.array([scalar_bits(int(t), p[2]) for p, t in zip(preds, ps)], dtype=np.uint64)
+    ta = tag_of(cols[val_a])
+    rt = sum_result_dtype(ta) if value_op == VAL_COL else NP_OF[lib().cho_arith_result_type(value_op, ta, tag_of(cols[val_b]))]
+    out = np.zeros(1, dtype=rt)
+    cnt = np.zeros(1, dtype=np.uint64)
+    rc = lib().cho_expr_filter_sum_pipeline(len(cols), _p(types), ptrs, n, len(preds), _p(pc), _p(po), _p(ps), _p(pb), value_op, val_a, val_b,
+                                            block_rows, threads, _p(out), _p(cnt))
+    assert rc == 0
+    return out[0], int(cnt[0])
 
 
 class HashMap:

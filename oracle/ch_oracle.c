@@ -684,6 +684,196 @@ int cho_filter_sum_pipeline(int type, const void * pred, const void * val, size_
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * §8(f)-1  and / multiply / plus / minus and the Q1.1-style pipeline
+ * ---------------------------------------------------------------------------------------------- */
+
+void cho_and_u8(const uint8_t * a, const uint8_t * b, size_t n, uint8_t * out)
+{
+    for (size_t i = 0; i < n; ++i) /* AndImpl::apply (FunctionsLogical.h:94) */
+        out[i] = a[i] & b[i];
+}
+
+int cho_arith_result_type(int value_op, int a_type, int b_type)
+{
+    if (a_type == CHO_F64 || b_type == CHO_F64 || !type_size(a_type) || !type_size(b_type))
+        return -1;
+    const int sgn_a = a_type == CHO_I64 || a_type == CHO_I32, sgn_b = b_type == CHO_I64 || b_type == CHO_I32;
+    /* NumberTraits.h:73-87: every size this path handles (1, 4, 8 bytes) promotes to at most 8 bytes */
+    if (value_op == CHO_VAL_MINUS)
+        return CHO_I64;
+    if (value_op == CHO_VAL_MUL || value_op == CHO_VAL_PLUS)
+        return (sgn_a || sgn_b) ? CHO_I64 : CHO_U64;
+    return -1;
+}
+
+static inline uint64_t load_int_as_u64(int type, const void * p, size_t i)
+{
+    switch (type)
+    {
+        case CHO_I64: return (uint64_t)((const int64_t *)p)[i];
+        case CHO_U64: return ((const uint64_t *)p)[i];
+        case CHO_U32: return ((const uint32_t *)p)[i];
+        case CHO_I32: return (uint64_t)(int64_t)((const int32_t *)p)[i];
+        case CHO_U8: return ((const uint8_t *)p)[i];
+        default: return 0;
+    }
+}
+
+int cho_arith(int value_op, int a_type, const void * a, int b_type, const void * b, size_t n, void * out)
+{
+    if (cho_arith_result_type(value_op, a_type, b_type) < 0)
+        return -1;
+    uint64_t * o = (uint64_t *)out;
+    for (size_t i = 0; i < n; ++i)
+    {
+        /* static_cast<Result>(a) OP b in the 64-bit result type; two's complement wrap (NO_SANITIZE_UNDEFINED) */
+        const uint64_t x = load_int_as_u64(a_type, a, i), y = load_int_as_u64(b_type, b, i);
+        o[i] = value_op == CHO_VAL_MUL ? x * y : value_op == CHO_VAL_PLUS ? x + y : x - y;
+    }
+    return 0;
+}
+
+typedef struct
+{
+    size_t n_cols;
+    const int * cols_type;
+    const void * const * cols;
+    size_t begin, end;
+    size_t n_preds;
+    const uint32_t * pred_col;
+    const int * pred_op;
+    const int * pred_stype;
+    const uint64_t * pred_scalar_bits;
+    int value_op;
+    uint32_t val_a, val_b;
+    size_t block_rows;
+    uint64_t sum_state, count;
+} ex_stream;
+
+static void * expr_stream(void * arg)
+{
+    ex_stream * s = (ex_stream *)arg;
+    const size_t br = s->block_rows;
+    uint8_t * mask = (uint8_t *)malloc(br + 64);
+    uint8_t * tmp = (uint8_t *)malloc(br + 64);
+    char * fa = (char *)malloc((br + 64) * 8);
+    char * fb = (char *)malloc((br + 64) * 8);
+    uint64_t * val = (uint64_t *)malloc((br + 64) * 8);
+    s->sum_state = 0;
+    s->count = 0;
+    for (size_t b = s->begin; b < s->end; b += br)
+    {
+        const size_t rows = s->end - b < br ? s->end - b : br;
+        /* WHERE: one comparison function per predicate, combined by `and` (ExpressionActions::execute) */
+        for (size_t k = 0; k < s->n_preds; ++k)
+        {
+            const int t = s->cols_type[s->pred_col[k]];
+            const char * col = (const char *)s->cols[s->pred_col[k]] + b * type_size(t);
+            uint8_t * dst = k == 0 ? mask : tmp;
+            cho_cmp_const(t, col, rows, s->pred_op[k], s->pred_stype[k], &s->pred_scalar_bits[k], dst);
+            if (k > 0)
+                cho_and_u8(mask, tmp, rows, mask);
+        }
+        if (s->n_preds == 0)
+            memset(mask, 1, rows);
+        const size_t kept = cho_countBytesInFilter(mask, 0, rows);
+        if (kept == 0)
+            continue; /* FilterTransform drops the chunk */
+        /* FilterTransform filters the columns the projection needs; then the value expression runs on the filtered Block */
+        const int ta = s->cols_type[s->val_a];
+        const char * ca = (const char *)s->cols[s->val_a] + b * type_size(ta);
+        const void * pa = ca;
+        if (kept != rows)
+        {
+            cho_filter((int)type_size(ta), ca, rows, mask, rows, fa);
+            pa = fa;
+        }
+        if (s->value_op == CHO_VAL_COL)
+            cho_sum_add_many(ta, &s->sum_state, pa, 0, kept);
+        else
+        {
+            const int tb = s->cols_type[s->val_b];
+            const char * cb = (const char *)s->cols[s->val_b] + b * type_size(tb);
+            const void * pb = cb;
+            if (kept != rows)
+            {
+                cho_filter((int)type_size(tb), cb, rows, mask, rows, fb);
+                pb = fb;
+            }
+            cho_arith(s->value_op, ta, pa, tb, pb, kept, val);
+            cho_sum_add_many(cho_arith_result_type(s->value_op, ta, tb), &s->sum_state, val, 0, kept);
+        }
+        s->count += kept;
+    }
+    free(mask);
+    free(tmp);
+    free(fa);
+    free(fb);
+    free(val);
+    return NULL;
+}
+
+int cho_expr_filter_sum_pipeline(size_t n_cols, const int * cols_type, const void * const * cols, size_t n,
+                                 size_t n_preds, const uint32_t * pred_col, const int * pred_op, const int * pred_stype,
+                                 const uint64_t * pred_scalar_bits, int value_op, uint32_t val_a, uint32_t val_b,
+                                 size_t block_rows, int threads, void * sum_out, uint64_t * count_out)
+{
+    if (val_a >= n_cols || (value_op != CHO_VAL_COL && val_b >= n_cols))
+        return -1;
+    for (size_t k = 0; k < n_preds; ++k)
+        if (pred_col[k] >= n_cols)
+            return -1;
+    for (size_t c = 0; c < n_cols; ++c)
+        if (cols_type[c] == CHO_F64 || !type_size(cols_type[c]))
+            return -1;
+    if (threads < 1)
+        threads = 1;
+    if (!block_rows)
+        block_rows = CHO_DEFAULT_BLOCK_SIZE;
+    ex_stream * st = (ex_stream *)calloc((size_t)threads, sizeof(ex_stream));
+    pthread_t * th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    const size_t n_blocks = (n + block_rows - 1) / block_rows;
+    for (int t = 0; t < threads; ++t)
+    {
+        const size_t b0 = n_blocks * (size_t)t / (size_t)threads, b1 = n_blocks * (size_t)(t + 1) / (size_t)threads;
+        st[t].n_cols = n_cols;
+        st[t].cols_type = cols_type;
+        st[t].cols = cols;
+        st[t].begin = b0 * block_rows > n ? n : b0 * block_rows;
+        st[t].end = b1 * block_rows > n ? n : b1 * block_rows;
+        st[t].n_preds = n_preds;
+        st[t].pred_col = pred_col;
+        st[t].pred_op = pred_op;
+        st[t].pred_stype = pred_stype;
+        st[t].pred_scalar_bits = pred_scalar_bits;
+        st[t].value_op = value_op;
+        st[t].val_a = val_a;
+        st[t].val_b = val_b;
+        st[t].block_rows = block_rows;
+    }
+    if (threads == 1)
+        expr_stream(&st[0]);
+    else
+    {
+        for (int t = 0; t < threads; ++t)
+            pthread_create(&th[t], NULL, expr_stream, &st[t]);
+        for (int t = 0; t < threads; ++t)
+            pthread_join(th[t], NULL);
+    }
+    uint64_t sum = 0, cnt = 0;
+    for (int t = 0; t < threads; ++t)
+    {
+        sum += st[t].sum_state; /* integer states: wrap-around merge */
+        cnt += st[t].count;
+    }
+    memcpy(sum_out, &sum, 8);
+    *count_out = cnt;
+    free(st);
+    free(th);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * a12/a13  hash tables
  * ---------------------------------------------------------------------------------------------- */
 

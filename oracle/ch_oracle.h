@@ -91,6 +91,25 @@ int cho_filter_sum_pipeline(int type, const void * pred, const void * val, size_
                             size_t block_rows, int threads, void * sum_out, uint64_t * count_out,
                             uint64_t * chunks_dropped, uint64_t * chunks_passthrough);
 
+/* ---- §8(f) rank 1: expression DAG pieces for SSB Q1.1-style queries ---- */
+/* value expressions: FunctionBinaryArithmetic with NumberTraits result types (src/DataTypes/NumberTraits.h:73-87):
+   multiply/plus -> next size up, signed if either side is; minus -> next size up, always signed; 8-byte inputs stay 8 bytes
+   and wrap (MultiplyImpl::apply, src/Functions/multiply.cpp:10-28: static_cast<Result>(a) * b). */
+enum { CHO_VAL_COL = 0, CHO_VAL_MUL = 1, CHO_VAL_PLUS = 2, CHO_VAL_MINUS = 3 };
+/* and(a, b) over UInt8 0/1 columns: AndImpl::apply = a & b (src/Functions/FunctionsLogical.h:82-96) */
+void cho_and_u8(const uint8_t * a, const uint8_t * b, size_t n, uint8_t * out);
+/* out type = cho_arith_result_type(op, a_type, b_type) (CHO_I64 or CHO_U64 here); integer inputs only */
+int cho_arith_result_type(int value_op, int a_type, int b_type);
+int cho_arith(int value_op, int a_type, const void * a, int b_type, const void * b, size_t n, void * out);
+/* `SELECT sum(<value>), count() WHERE p1 AND p2 ...` through the per-Block pipeline: every predicate is a comparison of a
+   column with a constant (a3), the masks are and-ed, FilterTransform filters the columns the projection needs, the value
+   expression runs on the filtered Block (ExpressionActions order), sum/count states accumulate (a8/a9).
+   cols[n_cols] typed cols_type[]; predicate k tests cols[pred_col[k]] pred_op[k] scalar (8 raw bytes, typed pred_stype[k]). */
+int cho_expr_filter_sum_pipeline(size_t n_cols, const int * cols_type, const void * const * cols, size_t n,
+                                 size_t n_preds, const uint32_t * pred_col, const int * pred_op, const int * pred_stype,
+                                 const uint64_t * pred_scalar_bits, int value_op, uint32_t val_a, uint32_t val_b,
+                                 size_t block_rows, int threads, void * sum_out, uint64_t * count_out);
+
 /* ---- a12/a13 hash tables (exposed for the gtest_hash_table scenarios) ---- */
 typedef struct cho_hashmap cho_hashmap; /* HashMap<UInt64, UInt64, HashCRC32<UInt64>> */
 cho_hashmap * cho_hashmap_create(void);
