@@ -33,6 +33,7 @@ SIGNATURES = {
     "chgpu_ctx_create": (_i, [_i, _vp, _pp]),
     "chgpu_ctx_destroy": (_i, [_vp]),
     "chgpu_ctx_synchronize": (_i, [_vp]),
+    "chgpu_ctx_trim": (_i, [_vp]),
     "chgpu_ctx_counters": (_i, [_vp, _pu64]),
     "chgpu_timer_start": (_i, [_vp]),
     "chgpu_timer_stop_ms": (_i, [_vp, C.POINTER(C.c_double)]),

@@ -48,6 +48,10 @@ class Context:
     def synchronize(self):
         K.check(K.lib().chgpu_ctx_synchronize(self._h))
 
+    def trim(self):
+        """release the cached column pool and scratch arena"""
+        K.check(K.lib().chgpu_ctx_trim(self._h))
+
     def counters(self):
         arr = (C.c_uint64 * K.N_COUNTERS)()
         K.check(K.lib().chgpu_ctx_counters(self._h, arr))

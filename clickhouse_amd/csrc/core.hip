@@ -76,6 +76,21 @@ extern "C" int chgpu_ctx_synchronize(chgpu_ctx * ctx)
     return CHGPU_OK;
 }
 
+extern "C" int chgpu_ctx_trim(chgpu_ctx * ctx)
+{
+    CHGPU_REQUIRE(ctx, CHGPU_ERR_BAD_ARGUMENTS, "ctx is NULL");
+    CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto & kv : ctx->pool_free)
+        (void)hipFree(kv.second);
+    ctx->pool_free.clear();
+    ctx->pool_cached_bytes = 0;
+    if (ctx->scratch)
+        (void)hipFree(ctx->scratch);
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    return CHGPU_OK;
+}
+
 extern "C" int chgpu_ctx_counters(chgpu_ctx * ctx, uint64_t out[CHGPU_N_COUNTERS])
 {
     CHGPU_REQUIRE(ctx && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");

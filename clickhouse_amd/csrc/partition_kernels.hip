@@ -160,7 +160,6 @@ extern "C" int chgpu_weak_hash32(chgpu_ctx * ctx, const chgpu_col * col, chgpu_c
     CHGPU_REQUIRE(hash->type == CHGPU_U32, CHGPU_ERR_BAD_ARGUMENTS, "WeakHash32 data must be UInt32");
     CHGPU_REQUIRE(hash->rows == col->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of WeakHash32 does not match size of column: column size is %llu, hash size is %llu",
                   (unsigned long long)col->rows, (unsigned long long)hash->rows);
-    CHGPU_REQUIRE(col->type != CHGPU_F64 || true, CHGPU_ERR_BAD_ARGUMENTS, "");
     const u32 * lut = nullptr;
     CHGPU_TRY(chgpu_crc_lut(ctx, &lut));
     if (col->rows)

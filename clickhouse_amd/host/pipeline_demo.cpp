@@ -4,7 +4,9 @@
 // build: g++ -std=c++17 -O2 pipeline_demo.cpp -L.. -lchgpu -Wl,-rpath,'$ORIGIN/..' -o pipeline_demo
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <map>
+#include <thread>
 #include <unordered_map>
 
 #include "chgpu_shim.hpp"
@@ -157,6 +159,50 @@ int main(int argc, char ** argv)
             got_rows += c.num_rows;
         }
         REQUIRE(got_rows == want_rows && got_chk == want_chk);
+
+        // ---- threading contract: work() of different processors runs concurrently, each thread with its own Context ----
+        {
+            std::atomic<int> bad{0};
+            std::vector<std::thread> pool;
+            for (int t = 0; t < 4; ++t)
+                pool.emplace_back([&, t] {
+                    try
+                    {
+                        auto tctx = std::make_shared<Context>(0);
+                        const size_t lo = n * t / 4, hi = n * (t + 1) / 4;
+                        Chunk part;
+                        part.columns = {ColumnVector::fromHost<int64_t>(tctx, a.data() + lo, hi - lo)};
+                        part.num_rows = hi - lo;
+                        GpuFilterTransform f(0, FunctionComparisonConst(CHGPU_LT, thr));
+                        auto ag = std::make_shared<GpuAggregator>(tctx, -1, std::vector<AggregateDescription>{{CHGPU_AGG_SUM, CHGPU_I64, 0}, {CHGPU_AGG_COUNT, CHGPU_U64, 0}});
+                        GpuAggregatingTransform at(ag, std::nullopt);
+                        for (int rep = 0; rep < 5; ++rep)
+                        {
+                            f.setInput(part);
+                            f.work();
+                            if (f.hasOutput())
+                                at.consume(f.pullOutput());
+                        }
+                        Chunk r = at.generate();
+                        uint64_t ws = 0, wc = 0;
+                        for (size_t i = lo; i < hi; ++i)
+                            if (a[i] < thr)
+                            {
+                                ws += static_cast<uint64_t>(a[i]);
+                                ++wc;
+                            }
+                        if (static_cast<uint64_t>(r.columns[0]->getData<int64_t>()[0]) != 5 * ws || r.columns[1]->getData<uint64_t>()[0] != 5 * wc)
+                            ++bad;
+                    }
+                    catch (...)
+                    {
+                        ++bad;
+                    }
+                });
+            for (auto & th : pool)
+                th.join();
+            REQUIRE(bad == 0);
+        }
 
         // unsupported surface -> NOT_IMPLEMENTED (CPU fallback signal), not a crash
         bool fell_back = false;

@@ -76,6 +76,8 @@ const char * chgpu_last_error(void);
 int chgpu_ctx_create(int device_id, void * hip_stream, chgpu_ctx ** out);
 int chgpu_ctx_destroy(chgpu_ctx * ctx);
 int chgpu_ctx_synchronize(chgpu_ctx * ctx);
+/* give the context's cached device memory (column pool + scratch arena) back to the driver; synchronizes */
+int chgpu_ctx_trim(chgpu_ctx * ctx);
 /* ProfileEvents-style counters of this context (src/Common/ProfileEvents.cpp:1034-1035, 245-247):
    [0] FilterTransformPassedRows [1] FilterTransformPassedBytes [2] JoinBuildTableRowCount
    [3] JoinProbeTableRowCount [4] JoinResultRowCount [5] AggregatedRows [6] kernel launches [7] table rehashes */

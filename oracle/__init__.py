@@ -62,7 +62,7 @@ _ref = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        so = os.path.join(_HERE, "libchoracle.so")
+        so = os.environ.get("CHO_LIB", os.path.join(_HERE, "libchoracle.so"))  # CHO_LIB: sanitizer builds of the oracle
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)
