@@ -78,6 +78,7 @@ struct chgpu_agg
     AggTable t{nullptr, nullptr, 0, 0, nullptr};
     void * table_mem = nullptr;
     u64 n_groups = 0; // host copy, refreshed after every call
+    bool hint_probed = false; // the cardinality of a hint-less aggregation was sampled on its first large block
     u64 host_words[AGG_MAX_WORDS]; // without_key states live on the host (8 B each)
 };
 
@@ -947,7 +948,9 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     }
     const u32 G = (u32)ctx->num_cus * GBP_WG_PER_CU;
     u64 rows_per_wg = (n + G - 1) / G;
-    const u32 tile = K <= 1 ? GBP_TILE_MAX : GBP_TILE_MAX / 2;
+    // the scatter's LDS image is tile*(8*(1+K)+2) + 16*P bytes and must stay under ~150 KiB
+    const bool big_tile = (size_t)GBP_TILE_MAX * (8 * (1 + K) + 2) + (size_t)P * 16 <= 150 * 1024;
+    const u32 tile = big_tile ? GBP_TILE_MAX : GBP_TILE_MAX / 2;
     rows_per_wg = (rows_per_wg + tile - 1) / tile * tile;
 
     // partition buffers (8-byte keys + K 8-byte words per row) and bookkeeping
@@ -990,7 +993,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     if (rc == CHGPU_OK)
     {
         const size_t lds_sc = (size_t)tile * 8 * (1 + K) + (size_t)P * 16 + (size_t)tile * 2;
-        auto kern = K <= 1 ? k_gb_scatter<GBP_TILE_MAX> : k_gb_scatter<GBP_TILE_MAX / 2>;
+        auto kern = big_tile ? k_gb_scatter<GBP_TILE_MAX> : k_gb_scatter<GBP_TILE_MAX / 2>;
         rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
         if (rc == CHGPU_OK)
             hipLaunchKernelGGL(kern, dim3(G), dim3(GBP_THREADS), lds_sc, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P,
@@ -1061,6 +1064,21 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
     if (n == 0)
         return CHGPU_OK;
     CHGPU_TRY(agg_ensure_table(a));
+    // Adaptive strategy for callers that gave no size hint (the reference adapts too: consecutive-key cache hit rate,
+    // Aggregator.cpp:944-958; two-level conversion, :83-89): aggregate the first 4 Mi rows through the LDS-staged kernel,
+    // look at how many groups they produced, and let the remaining rows take the partitioned path when the cardinality is
+    // clearly beyond what per-workgroup LDS tables can absorb.
+    if (a->size_hint <= 65536 && a->n_groups > 65536)
+        a->size_hint = a->n_groups * 2;
+    if (a->size_hint == 0 && !a->hint_probed && n >= (8ull << 20))
+    {
+        a->hint_probed = true;
+        const u64 probe_rows = 4ull << 20;
+        CHGPU_TRY(chgpu_agg_add_block(a, key_col, arg_cols, row_begin, row_begin + probe_rows));
+        if (a->n_groups > 65536)
+            a->size_hint = a->n_groups >= probe_rows / 2 ? a->n_groups * 8 : a->n_groups * 2;
+        return chgpu_agg_add_block(a, key_col, arg_cols, row_begin + probe_rows, row_end);
+    }
     AggDesc d;
     agg_fill_desc(a, arg_cols, &d);
 

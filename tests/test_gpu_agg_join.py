@@ -341,3 +341,19 @@ def test_group_by_partitioned_path_large_cardinality(ch, engine, oracle_mod, agg
             assert np.allclose(a, b, rtol=1e-6, atol=0)
         else:
             assert np.array_equal(a, b)
+
+
+def test_group_by_without_hint_adapts_to_high_cardinality(ch, engine):
+    # no size hint, >= 8 Mi rows: the first 4 Mi rows are probed through the LDS-staged kernel, the rest is partitioned
+    rng = np.random.Generator(np.random.PCG64(123))
+    n = 9_000_000
+    k = rng.integers(0, 700_000, size=n).astype(np.uint32)
+    v = rng.integers(-2**40, 2**40, size=n, dtype=np.int64)
+    g = engine.Aggregator(np.uint32, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)])
+    g.execute_on_block(k, [v, None])
+    gk, (gs, gc) = g.convert_to_block()
+    uk, inv = np.unique(k, return_inverse=True)
+    ws = np.zeros(uk.shape[0], dtype=np.int64)
+    np.add.at(ws, inv, v)
+    gi = np.argsort(gk)
+    assert np.array_equal(gk[gi], uk) and np.array_equal(gs[gi], ws) and np.array_equal(gc[gi], np.bincount(inv).astype(np.uint64))
