@@ -542,6 +542,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
             const u32 p = stage_part[pos];
             const u64 dst = cursor[p] + (pos - tile_off[p]);
 #if !defined(GBP_ABLATE) || GBP_ABLATE != 1
+            // plain stores: runs are 64-128 B, L2 write-combining completes the lines (nontemporal stores: 4.7 -> 8.1 ms)
             out_keys[dst] = stage_key[pos];
             for (u32 c = 0; c < cols.k; ++c)
                 cols.dst[c][dst] = stage_word[(size_t)c * GBP_TILE + pos];

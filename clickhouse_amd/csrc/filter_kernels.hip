@@ -14,6 +14,12 @@
 #include <cstdlib>
 #include <type_traits>
 
+static u32 tune_env(const char * name, u32 dflt)
+{
+    const char * v = getenv(name); // developer knob for A/B runs; unset in production
+    return v ? (u32)atoi(v) : dflt;
+}
+
 // ---------------------------------------------------------------------------------------------
 // predicates
 // ---------------------------------------------------------------------------------------------
@@ -147,6 +153,20 @@ __device__ __forceinline__ V load_stream(const V * p)
     }
     else
         return *p;
+}
+
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+
+// streaming (write-once) store of 8 or 16 bytes
+template <typename V>
+__device__ __forceinline__ void store_stream(V * p, const V & v)
+{
+    if constexpr (sizeof(V) == 16)
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), (u32x4 *)p);
+    else if constexpr (sizeof(V) == 8)
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, v), (u32x2 *)p);
+    else
+        *p = v;
 }
 
 template <typename T>
@@ -368,7 +388,8 @@ static int launch_filter_sum_t(chgpu_ctx * ctx, const void * pred, const void * 
     const bool same = (pred == val);
     const bool aligned = (((uintptr_t)pred | (uintptr_t)val) & 15) == 0 && (!cond || ((uintptr_t)cond % VECW) == 0);
     // persistent grid: FS_WG_PER_CU 256-thread workgroups per CU (see the measurement note above k_filter_sum)
-    const u32 grid = chgpu_grid_for(ctx, (n + VECW - 1) / VECW, FS_THREADS, FS_WG_PER_CU);
+    static const u32 wg_same = tune_env("CHGPU_TUNE_FS_WG", FS_WG_PER_CU), wg_two = tune_env("CHGPU_TUNE_FS2_WG", FS_WG_PER_CU);
+    const u32 grid = chgpu_grid_for(ctx, (n + VECW - 1) / VECW, FS_THREADS, same ? wg_same : wg_two);
     void * scratch = nullptr;
     CHGPU_TRY(chgpu_scratch(ctx, (size_t)grid * 2 * sizeof(u64), &scratch));
     u64 * part_sum = (u64 *)scratch;
@@ -534,27 +555,53 @@ __global__ __launch_bounds__(256) void k_cmp_mask(const T * __restrict__ a, u64 
     const u64 nvec = n / VEC;
     const V * __restrict__ av = (const V *)a;
     CV * __restrict__ cv = (CV *)c;
-    // Same streaming geometry as k_filter_sum: contiguous 16 KiB chunk per workgroup iteration, nontemporal loads.
-    // (Giving each lane UNROLL consecutive vectors so it could store 8 mask bytes at once was measured 20 % SLOWER:
-    // the 64-B-strided loads cost more than the 2-byte-per-lane stores.)
+    // Same streaming geometry as k_filter_sum: contiguous 16 KiB chunk per workgroup iteration, nontemporal loads; inside the
+    // chunk each WAVE owns UNROLL*64 consecutive vectors.  The 2-4 mask bytes a lane produces per vector are transposed
+    // through a wave-private LDS strip so every lane stores UNROLL*VEC (8 or 16) CONTIGUOUS mask bytes: one wide store per
+    // iteration instead of UNROLL narrow ones.  (Giving each lane UNROLL consecutive vectors to the same end was measured
+    // 20 % slower: the 64-B-strided loads cost more than the narrow stores.)
     constexpr u64 CHUNK = (u64)UNROLL * 256;
     const u64 n_chunks = nvec / CHUNK;
+    constexpr int OB = VEC * UNROLL; // mask bytes per lane per iteration
+    constexpr bool TRANSPOSE = (VEC == 2 || VEC == 4);
+    __shared__ __attribute__((aligned(16))) u8 lds_m[4][64 * (TRANSPOSE ? OB : 1)];
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (u64 ch = blockIdx.x; ch < n_chunks; ch += gridDim.x)
     {
-        const u64 base = ch * CHUNK + threadIdx.x;
+        const u64 wbase = ch * CHUNK + (u64)wave * (64 * UNROLL); // first vector of this wave's strip
         V x[UNROLL];
 #pragma unroll
         for (int k = 0; k < UNROLL; ++k)
-            x[k] = load_stream(&av[base + (u64)k * 256]);
+            x[k] = load_stream(&av[wbase + (u64)k * 64 + lane]);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < UNROLL; ++k)
+        if constexpr (TRANSPOSE)
         {
-            CV m;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e)
-                m.v[e] = p(x[k].v[e]) ? 1 : 0;
-            cv[base + (u64)k * 256] = m;
+            for (int k = 0; k < UNROLL; ++k)
+            {
+                CV m;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    m.v[e] = p(x[k].v[e]) ? 1 : 0;
+                *(CV *)&lds_m[wave][(k * 64 + lane) * VEC] = m;
+            }
+            __builtin_amdgcn_wave_barrier();
+            typedef Vec<u8, OB> OV;
+            const OV o = *(const OV *)&lds_m[wave][lane * OB]; // LDS ops of one wave complete in order
+            store_stream((OV *)(c + wbase * VEC + (u64)lane * OB), o);
+            __builtin_amdgcn_wave_barrier();
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k)
+            {
+                CV m;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    m.v[e] = p(x[k].v[e]) ? 1 : 0;
+                cv[wbase + (u64)k * 64 + lane] = m;
+            }
         }
     }
     const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -571,12 +618,6 @@ __global__ __launch_bounds__(256) void k_cmp_mask(const T * __restrict__ a, u64 
     const u64 r = nvec * VEC + tid;
     if (r < n)
         c[r] = p(a[r]) ? 1 : 0;
-}
-
-static u32 tune_env(const char * name, u32 dflt)
-{
-    const char * v = getenv(name); // developer knob for A/B runs; unset in production
-    return v ? (u32)atoi(v) : dflt;
 }
 
 template <typename T, typename Pred>
@@ -742,7 +783,7 @@ __global__ __launch_bounds__(256) void k_filter_scatter(const T * __restrict__ d
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     if (m[g].v[r] != 0)
-                        out[o++] = x[g].v[r];
+                        out[o++] = x[g].v[r]; // plain store: L2 merges the partial lines (nontemporal stores here: +25 % time)
                 pos += total;
             }
         }
@@ -1079,9 +1120,12 @@ __device__ __forceinline__ bool expr_pass(const ExprPred & p, T x)
 template <typename T>
 __global__ __launch_bounds__(FS_THREADS) void k_expr_filter_sum(ExprSpec sp, u64 n, u64 * __restrict__ part_sum, u64 * __restrict__ part_cnt)
 {
+#ifndef EX_UNROLL
+#define EX_UNROLL 4 // measured with 3 workgroups/CU on the 4-column Q1.1 shape: U=1 4.3, U=2 6.1, U=3 6.6, U=4 6.7 TB/s
+#endif
     constexpr int VEC = 16 / sizeof(T);
     typedef Vec<T, VEC> V;
-    constexpr int UNROLL = 2;
+    constexpr int UNROLL = EX_UNROLL;
     constexpr int E = VEC * UNROLL; // elements per lane per iteration
     const u64 nvec = n / VEC;
     u64 s = 0, c = 0;
@@ -1285,7 +1329,8 @@ extern "C" int chgpu_expr_filter_sum(chgpu_ctx * ctx, uint32_t n_cols, const chg
         *result_type_out = rt;
 
     const u32 vecw = 16 / (u32)chgpu_type_size(type);
-    const u32 grid = chgpu_grid_for(ctx, (n + vecw - 1) / vecw, FS_THREADS, FS_WG_PER_CU);
+    static const u32 ex_wg = tune_env("CHGPU_TUNE_EXPR_WG", 3);
+    const u32 grid = chgpu_grid_for(ctx, (n + vecw - 1) / vecw, FS_THREADS, ex_wg);
     void * scratch = nullptr;
     const u32 grid_cap = (u32)ctx->num_cus * 8;
     CHGPU_TRY(chgpu_scratch(ctx, (size_t)grid_cap * 2 * sizeof(u64) + 64, &scratch));
