@@ -67,8 +67,14 @@ class LocalEngine:
     def __init__(self, ctx=None, device_index: int = 0):
         import clickhouse_amd as ch
         self.ch = ch
-        self.ctx = ctx if ctx is not None else ch.Context(device_index)
         self.device = torch.device("cuda", device_index)
+        if ctx is None:
+            # one stream for both worlds: the C-ABI context launches on a torch stream that is made current, so torch's
+            # copies/collectives and the HIP kernels are ordered without host synchronisation
+            self.stream = torch.cuda.Stream(device=self.device)
+            torch.cuda.set_stream(self.stream)
+            ctx = ch.Context(device_index, self.stream.cuda_stream)
+        self.ctx = ctx
 
     # -- tensors <-> device columns (zero copy both ways) ---------------------------------------
     def col(self, t: torch.Tensor, dtype):
