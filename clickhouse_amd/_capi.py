@@ -41,6 +41,7 @@ SIGNATURES = {
     "chgpu_col_alloc": (_i, [_vp, _i, _u64, _pp]),
     "chgpu_col_wrap": (_i, [_vp, _i, _vp, _u64, _pp]),
     "chgpu_col_slice": (_i, [_vp, _vp, _u64, _u64, _pp]),
+    "chgpu_col_concat": (_i, [_vp, _u32, _pp, _pp]),
     "chgpu_col_download": (_i, [_vp, _vp, _vp, _u64]),
     "chgpu_col_rows": (_u64, [_vp]),
     "chgpu_col_type": (_i, [_vp]),
@@ -78,6 +79,7 @@ SIGNATURES = {
     "chgpu_join_finish_build": (_i, [_vp]),
     "chgpu_join_total_rows": (_i, [_vp, _pu64, _pu64]),
     "chgpu_join_probe": (_i, [_vp, _vp, _vp, _u64, _pp, _pp, _pp, _pu64, _pu64]),
+    "chgpu_join_flatten_rowids": (_i, [_vp, _vp, _pp]),
     "chgpu_join_free": (_i, [_vp]),
 }
 

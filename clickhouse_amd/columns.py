@@ -300,3 +300,12 @@ def expr_filter_sum(cols, preds, value_op: int, val_a: int, val_b: int = 0):
     K.check(K.lib().chgpu_expr_filter_sum(cols[0].ctx._h, n, cp, m, pc, po, ps, pb, value_op, val_a, val_b, C.byref(rt),
                                           out.ctypes.data_as(C.c_void_p), C.byref(cnt)))
     return out.view(NP_OF[rt.value])[0], int(cnt.value)
+
+
+def concat(cols) -> Column:
+    """glue columns of one type end to end (right-side Blocks -> one payload column)"""
+    n = len(cols)
+    ins = (C.c_void_p * n)(*[c._h for c in cols])
+    h = C.c_void_p()
+    K.check(K.lib().chgpu_col_concat(cols[0].ctx._h, n, ins, C.byref(h)))
+    return Column(cols[0].ctx, h)

@@ -288,6 +288,37 @@ extern "C" int chgpu_col_slice(chgpu_ctx * ctx, const chgpu_col * col, uint64_t 
     return chgpu_col_wrap(ctx, col->type, (char *)col->data + start * chgpu_type_size(col->type), rows, out);
 }
 
+extern "C" int chgpu_col_concat(chgpu_ctx * ctx, uint32_t n, const chgpu_col * const * cols, chgpu_col ** out)
+{
+    CHGPU_REQUIRE(ctx && cols && out && n >= 1, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    u64 total = 0;
+    for (u32 k = 0; k < n; ++k)
+    {
+        CHGPU_REQUIRE(cols[k], CHGPU_ERR_BAD_ARGUMENTS, "column %u is NULL", k);
+        CHGPU_REQUIRE(cols[k]->type == cols[0]->type, CHGPU_ERR_BAD_ARGUMENTS, "columns of different types cannot be concatenated");
+        total += cols[k]->rows;
+    }
+    chgpu_col * r = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, cols[0]->type, total, &r));
+    const size_t es = chgpu_type_size(cols[0]->type);
+    u64 pos = 0;
+    for (u32 k = 0; k < n; ++k)
+    {
+        if (cols[k]->rows)
+        {
+            hipError_t e = hipMemcpyAsync((char *)r->data + pos * es, cols[k]->data, cols[k]->rows * es, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess)
+            {
+                chgpu_col_free(r);
+                return chgpu_set_error(CHGPU_ERR_DEVICE, "concat copy: %s", hipGetErrorString(e));
+            }
+        }
+        pos += cols[k]->rows;
+    }
+    *out = r;
+    return CHGPU_OK;
+}
+
 extern "C" int chgpu_col_download(chgpu_ctx * ctx, const chgpu_col * col, void * host_ptr, uint64_t rows)
 {
     CHGPU_REQUIRE(ctx && col && (host_ptr || rows == 0), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");

@@ -501,6 +501,43 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
     return CHGPU_OK;
 }
 
+__global__ __launch_bounds__(JT) void k_join_flatten(const u64 * __restrict__ rowid, u64 n, const u64 * __restrict__ block_base, u64 n_blocks, u64 * __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+    {
+        const u64 r = rowid[i];
+        const u64 b = r >> 32;
+        out[i] = (r == NO_ROW || b >= n_blocks) ? NO_ROW : block_base[b] + (r & 0xFFFFFFFFull);
+    }
+}
+
+extern "C" int chgpu_join_flatten_rowids(chgpu_join * j, const chgpu_col * rowids, chgpu_col ** flat)
+{
+    CHGPU_REQUIRE(j && rowids && flat, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(chgpu_type_size(rowids->type) == 8, CHGPU_ERR_BAD_ARGUMENTS, "row ids must be a 64-bit column");
+    chgpu_ctx * ctx = j->ctx;
+    const u64 nb = j->blocks.size();
+    std::vector<u64> bases(nb ? nb : 1, 0);
+    for (u64 b = 0; b < nb; ++b)
+        bases[b] = j->blocks[b].base;
+    void * scratch = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, bases.size() * sizeof(u64), &scratch));
+    CHGPU_HIP(hipMemcpyAsync(scratch, bases.data(), bases.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    CHGPU_HIP(hipStreamSynchronize(ctx->stream)); // `bases` is a host temporary
+    chgpu_col * out = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U64, rowids->rows, &out));
+    if (rowids->rows)
+    {
+        hipLaunchKernelGGL(k_join_flatten, dim3(chgpu_grid_for(ctx, rowids->rows, JT, 8)), dim3(JT), 0, ctx->stream, (const u64 *)rowids->data, rowids->rows,
+                           (const u64 *)scratch, nb, (u64 *)out->data);
+        ctx->counters[6] += 1;
+        // the scratch holding block_base is reused by the next call on this context
+        CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *flat = out;
+    return CHGPU_OK;
+}
+
 extern "C" int chgpu_join_total_rows(chgpu_join * j, uint64_t * rows, uint64_t * keys)
 {
     CHGPU_REQUIRE(j, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");

@@ -85,6 +85,12 @@ class HashJoin:
                     offsets=Column(self.ctx, oh) if oh.value else None,
                     right_rowid=Column(self.ctx, rh))
 
+    def flatten_rowids(self, right_rowid: Column) -> Column:
+        """(block << 32 | row) -> ordinal over all right blocks (index into concatenated payload columns)"""
+        h = C.c_void_p()
+        K.check(K.lib().chgpu_join_flatten_rowids(self._h, right_rowid._h, C.byref(h)))
+        return Column(self.ctx, h)
+
     def probe(self, keys, null_map=None, max_joined_block_rows: int = 0):
         r = self.probe_columns(keys, null_map, max_joined_block_rows)
         rid = r["right_rowid"].numpy()

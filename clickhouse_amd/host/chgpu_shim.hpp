@@ -399,7 +399,28 @@ public:
         right_blocks.push_back(block);
         return true;
     }
-    void onBuildPhaseFinish() { check(chgpu_join_finish_build(h)); }
+    void onBuildPhaseFinish()
+    {
+        check(chgpu_join_finish_build(h));
+        // glue the payload columns of all right Blocks once; probes gather from them by running row ordinal
+        right_payload.clear();
+        if (right_blocks.empty())
+            return;
+        for (size_t c = 0; c < right_blocks[0].columns.size(); ++c)
+        {
+            if (right_blocks.size() == 1)
+            {
+                right_payload.push_back(right_blocks[0].columns[c]);
+                continue;
+            }
+            std::vector<const chgpu_col *> parts;
+            for (auto & b : right_blocks)
+                parts.push_back(b.columns.at(c)->handle());
+            chgpu_col * cat = nullptr;
+            check(chgpu_col_concat(ctx->get(), static_cast<uint32_t>(parts.size()), parts.data(), &cat));
+            right_payload.push_back(std::make_shared<ColumnVector>(ctx, cat));
+        }
+    }
     size_t getTotalRowCount() const
     {
         uint64_t r = 0;
@@ -414,17 +435,23 @@ public:
 
     /// joinBlock(block, not_processed): the left chunk is replaced by [left columns..., right payload columns...];
     /// the unprocessed tail (max_joined_block_rows) comes back in not_processed (HashJoin.cpp:1090-1093).
-    /// Single right block payloads are gathered on the device (fillFromBlocksAndRowNumbers, IColumn.cpp:515-526).
+    /// Right payloads are gathered on the device (fillFromBlocksAndRowNumbers, IColumn.cpp:515-526) from the glued columns.
     void joinBlock(Chunk & block, size_t key_position, std::shared_ptr<Chunk> & not_processed, uint64_t max_joined_block_rows = 0)
     {
-        if (right_blocks.size() > 1)
-            throw Exception(CHGPU_ERR_NOT_IMPLEMENTED, "payload gather across several right blocks: concatenate the build side first");
+        if (right_payload.empty() && !right_blocks.empty())
+            onBuildPhaseFinish();
         chgpu_col *filter = nullptr, *offsets = nullptr, *rowid = nullptr;
         uint64_t n_out = 0, consumed = 0;
         check(chgpu_join_probe(h, block.columns.at(key_position)->handle(), nullptr, max_joined_block_rows, &filter, &offsets, &rowid, &n_out, &consumed));
         auto filter_c = filter ? std::make_shared<ColumnVector>(ctx, filter) : nullptr;
         auto offsets_c = offsets ? std::make_shared<ColumnVector>(ctx, offsets) : nullptr;
         auto rowid_c = std::make_shared<ColumnVector>(ctx, rowid);
+        if (right_blocks.size() > 1)
+        {
+            chgpu_col * flat = nullptr; // (block, row) -> ordinal in the concatenated payload
+            check(chgpu_join_flatten_rowids(h, rowid, &flat));
+            rowid_c = std::make_shared<ColumnVector>(ctx, flat);
+        }
         not_processed.reset();
         if (consumed < block.num_rows)
         {
@@ -443,9 +470,8 @@ public:
                 c = c->filter(*filter_c, -1); // :122-123
             res.columns.push_back(c);
         }
-        if (!right_blocks.empty())
-            for (size_t i = 0; i < right_blocks[0].columns.size(); ++i)
-                res.columns.push_back(right_blocks[0].columns[i]->index(*rowid_c, 0, /*default_for_missing*/ true));
+        for (auto & payload : right_payload)
+            res.columns.push_back(payload->index(*rowid_c, 0, /*default_for_missing*/ true));
         res.num_rows = n_out;
         block = std::move(res);
     }
@@ -455,6 +481,7 @@ private:
     int kind, strictness;
     chgpu_join * h = nullptr;
     std::vector<Chunk> right_blocks; // data->blocks (HashJoin.cpp:656-658)
+    Columns right_payload;           // the same columns glued end to end for the device gather
 };
 
 /// FillingRightJoinSideTransform + JoiningTransform (JoiningTransform.cpp:176-260, 347-357)

@@ -116,11 +116,15 @@ int main(int argc, char ** argv)
         std::vector<uint64_t> pk(200000);
         for (size_t i = 0; i < pk.size(); ++i)
             pk[i] = (i * 2654435761ull) % (nb * 7);
-        Chunk right;
-        right.columns = {ColumnVector::fromHost<uint64_t>(ctx, bk.data(), nb), ColumnVector::fromHost<int64_t>(ctx, bv.data(), nb)};
-        right.num_rows = nb;
         auto join = std::make_shared<GpuHashJoin>(ctx, CHGPU_U64, CHGPU_JOIN_INNER, CHGPU_STRICT_ALL);
-        join->addBlockToJoin(right, 0);
+        for (size_t b = 0; b < nb; b += 16384) // FillingRightJoinSideTransform: the build side arrives Block by Block
+        {
+            const size_t rows = std::min<size_t>(16384, nb - b);
+            Chunk right;
+            right.columns = {ColumnVector::fromHost<uint64_t>(ctx, bk.data() + b, rows), ColumnVector::fromHost<int64_t>(ctx, bv.data() + b, rows)};
+            right.num_rows = rows;
+            join->addBlockToJoin(right, 0);
+        }
         join->onBuildPhaseFinish();
         REQUIRE(join->getTotalRowCount() == nb);
         Chunk left;

@@ -98,6 +98,9 @@ int chgpu_col_alloc(chgpu_ctx * ctx, int type, uint64_t rows, chgpu_col ** out);
 int chgpu_col_wrap(chgpu_ctx * ctx, int type, void * device_ptr, uint64_t rows, chgpu_col ** out);
 /* IColumn::cut(start, length) as a non-owning view (src/Columns/IColumn.h:118-121) */
 int chgpu_col_slice(chgpu_ctx * ctx, const chgpu_col * col, uint64_t start, uint64_t rows, chgpu_col ** out);
+/* concatenation of n columns of one type (the way right-side Blocks are glued into one payload column: ColumnVector::insertRangeFrom,
+   src/Columns/ColumnVector.cpp:511-526) */
+int chgpu_col_concat(chgpu_ctx * ctx, uint32_t n, const chgpu_col * const * cols, chgpu_col ** out);
 int chgpu_col_download(chgpu_ctx * ctx, const chgpu_col * col, void * host_ptr, uint64_t rows);
 uint64_t chgpu_col_rows(const chgpu_col * col);
 int chgpu_col_type(const chgpu_col * col);
@@ -251,6 +254,10 @@ int chgpu_join_total_rows(chgpu_join * j, uint64_t * rows, uint64_t * keys);
 int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map_u8,
                      uint64_t max_joined_block_rows, chgpu_col ** filter_u8, chgpu_col ** offsets_u64,
                      chgpu_col ** right_rowid_u64, uint64_t * n_out, uint64_t * n_left_consumed);
+/* (block_index << 32 | row) ids -> running ordinal of the row over all right blocks in insertion order (all-ones stays
+   all-ones): the index into payload columns concatenated with chgpu_col_concat, i.e. fillFromBlocksAndRowNumbers
+   (src/Columns/IColumn.cpp:515-526) for many right Blocks */
+int chgpu_join_flatten_rowids(chgpu_join * j, const chgpu_col * right_rowid_u64, chgpu_col ** flat_u64);
 int chgpu_join_free(chgpu_join * j);
 
 #ifdef __cplusplus

@@ -357,3 +357,30 @@ def test_group_by_without_hint_adapts_to_high_cardinality(ch, engine):
     np.add.at(ws, inv, v)
     gi = np.argsort(gk)
     assert np.array_equal(gk[gi], uk) and np.array_equal(gs[gi], ws) and np.array_equal(gc[gi], np.bincount(inv).astype(np.uint64))
+
+
+def test_join_payload_across_many_right_blocks(ch, ctx, engine):
+    # the build side arrives Block by Block (FillingRightJoinSideTransform); payload = concatenated columns + flattened row ids
+    rng = np.random.Generator(np.random.PCG64(17))
+    blocks_k = [rng.integers(0, 50_000, size=n, dtype=np.uint64) for n in (65_409, 1, 30_000, 65_409, 12_345)]
+    blocks_v = [rng.integers(-2**50, 2**50, size=b.shape[0], dtype=np.int64) for b in blocks_k]
+    j = engine.HashJoin(ch.JOIN_LEFT, ch.STRICT_ALL)
+    for b in blocks_k:
+        j.add_block(b)
+    payload = ch.concat([ctx.upload(v) for v in blocks_v])
+    left = rng.integers(0, 60_000, size=200_000, dtype=np.uint64)
+    r = j.probe_columns(ctx.upload(left))
+    flat = j.flatten_rowids(r["right_rowid"])
+    got_v = payload.index(flat, default_for_missing=True).numpy()
+    got_l = ctx.upload(left).replicate(r["offsets"]).numpy()
+    all_k, all_v = np.concatenate(blocks_k), np.concatenate(blocks_v)
+    order = np.argsort(all_k, kind="stable")
+    sk, sv = all_k[order], all_v[order]
+    lo, hi = np.searchsorted(sk, left, "left"), np.searchsorted(sk, left, "right")
+    cnt = np.maximum(hi - lo, 1)                       # LEFT: unmatched rows appear once with the default 0
+    assert got_l.shape[0] == int(cnt.sum()) and np.array_equal(got_l, np.repeat(left, cnt))
+    pos = 0
+    for i in range(0, left.shape[0], 997):             # spot-check rows: multiset of payloads per left row
+        start = int(cnt[:i].sum())
+        want = sorted(sv[lo[i]:hi[i]].tolist()) if hi[i] > lo[i] else [0]
+        assert sorted(got_v[start:start + int(cnt[i])].tolist()) == want
