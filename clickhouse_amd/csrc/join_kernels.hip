@@ -22,6 +22,10 @@
 static constexpr u32 JT = 256;
 static constexpr u64 NO_ROW = ~0ull;
 static constexpr u32 NO_SLOT = ~0u;
+// packed probe value of a cell with several rows: bit 63 | min(count, SAT) << 40 | CSR start (40 bits)
+static constexpr u64 JV_MULTI = 1ull << 63;
+static constexpr u64 JV_CNT_SAT = (1ull << 23) - 1;
+static constexpr u64 JV_START_MASK = (1ull << 40) - 1;
 
 struct JoinCtrl
 {
@@ -40,6 +44,7 @@ struct JoinTable
     u64 * start;     // [cap+1] CSR start (ALL)
     u64 * used_by;   // [cap+1] left-row sequence that consumed this cell (INNER ANY)
     u64 * rowids;    // [inserted] CSR payload (ALL)
+    u64 * value;     // [cap+1] what a probe needs in ONE read: the row id itself (unique key / ANY), or MULTI | count | CSR start
     u64 capacity;
     JoinCtrl * ctrl;
 };
@@ -214,6 +219,30 @@ __global__ __launch_bounds__(JT) void k_join_root_first(JoinTable t)
     }
 }
 
+// build pass 5: one 8-byte word per cell that answers a probe without touching cnt/start/rowids for unique keys
+__global__ __launch_bounds__(JT) void k_join_finalize_values(JoinTable t, int maps_all, int take_last)
+{
+    for (u64 s = (u64)blockIdx.x * JT + threadIdx.x; s <= t.capacity; s += (u64)gridDim.x * JT)
+    {
+        const bool occupied = s == t.capacity ? (t.ctrl->has_zero != 0) : (t.keys[s] != 0);
+        u64 v = NO_ROW;
+        if (occupied)
+        {
+            if (!maps_all)
+                v = take_last ? t.first_row[s] - 1 : t.first_row[s];
+            else
+            {
+                const u32 c = t.cnt[s];
+                if (c == 1)
+                    v = t.rowids[t.start[s]];
+                else
+                    v = JV_MULTI | ((u64)(c < JV_CNT_SAT ? c : JV_CNT_SAT) << 40) | (t.start[s] & JV_START_MASK);
+            }
+        }
+        t.value[s] = v;
+    }
+}
+
 __global__ __launch_bounds__(JT) void k_fill_u64(u64 * p, u64 n, u64 v)
 {
     for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
@@ -237,10 +266,12 @@ __global__ __launch_bounds__(JT) void k_join_probe_bid(JoinTable t, const void *
     }
 }
 
-// probe pass 1: per left row, how many right rows get appended (and the filter byte)
+// probe pass 1: per left row, how many right rows get appended (and the filter byte).  A hit costs two random reads (the
+// key cell and its packed value word); the value is kept per left row so the emit pass streams instead of re-probing.
 __global__ __launch_bounds__(JT) void k_join_probe_count(JoinTable t, int variant, const void * __restrict__ keys, int key_type,
                                                          const u8 * __restrict__ null_map, u64 n, u64 seq_base, int slots_known,
-                                                         u32 * __restrict__ slot_of_left, u32 * __restrict__ counts, u8 * __restrict__ filter)
+                                                         u32 * __restrict__ slot_of_left, u64 * __restrict__ val_of_left,
+                                                         u32 * __restrict__ counts, u8 * __restrict__ filter)
 {
     for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
     {
@@ -252,21 +283,33 @@ __global__ __launch_bounds__(JT) void k_join_probe_count(JoinTable t, int varian
             slot = NO_SLOT;
             if (!(null_map && null_map[i])) // HashJoinMethodsImpl.h:451-452
                 slot = jt_find(t, jload_key(keys, key_type, i));
-            slot_of_left[i] = slot;
         }
         const bool found = slot != NO_SLOT;
+        const u64 v = found ? t.value[slot] : NO_ROW;
+        u32 rows_here = 0; // RowRefList::rows of the matched cell
+        if (found)
+        {
+            if (!(v & JV_MULTI))
+                rows_here = 1;
+            else
+            {
+                const u64 c = (v >> 40) & JV_CNT_SAT;
+                rows_here = c < JV_CNT_SAT ? (u32)c : t.cnt[slot];
+            }
+        }
         u32 c = 0;
         u8 f = 0;
         switch (variant)
         {
-            case PV_ALL_INNER: c = found ? t.cnt[slot] : 0; break;
-            case PV_ALL_LEFT: c = found ? t.cnt[slot] : 1; break;                 // addNotFoundRow<add_missing>: ++current_offset
+            case PV_ALL_INNER: c = rows_here; break;
+            case PV_ALL_LEFT: c = found ? rows_here : 1; break;                   // addNotFoundRow<add_missing>: ++current_offset
             case PV_ANY_LEFT: c = 1; break;                                       // found row or default row
             case PV_SEMI_LEFT: c = found ? 1 : 0; f = found; break;
             case PV_ANTI_LEFT: c = found ? 0 : 1; f = !found; break;              // :515-519, :535-536
             case PV_ANY_INNER: c = (found && t.used_by[slot] == seq_base + i) ? 1 : 0; f = (u8)c; break; // setUsedOnce, :498-510
         }
         counts[i] = c;
+        val_of_left[i] = v;
         if (filter)
             filter[i] = f;
     }
@@ -298,8 +341,8 @@ __global__ void k_join_cut(const u64 * __restrict__ offsets, u64 n, u64 max_rows
     ctrl->n_out = consumed ? offsets[consumed - 1] : 0;
 }
 
-// probe pass 3: write the appended right row ids
-__global__ __launch_bounds__(JT) void k_join_emit(JoinTable t, int variant, int take_last, const u32 * __restrict__ slot_of_left,
+// probe pass 3: write the appended right row ids (streams counts/offsets/values; touches rowids only for duplicate keys)
+__global__ __launch_bounds__(JT) void k_join_emit(JoinTable t, int variant, const u64 * __restrict__ val_of_left,
                                                   const u32 * __restrict__ counts, const u64 * __restrict__ offsets, u64 consumed,
                                                   u64 * __restrict__ right_rowid)
 {
@@ -309,22 +352,20 @@ __global__ __launch_bounds__(JT) void k_join_emit(JoinTable t, int variant, int 
         if (c == 0)
             continue;
         const u64 base = offsets[i] - c;
-        const u32 slot = slot_of_left[i];
-        if (slot == NO_SLOT)
+        const u64 v = val_of_left[i];
+        if (v == NO_ROW || variant == PV_ANTI_LEFT)
         {
             right_rowid[base] = NO_ROW; // default row (addNotFoundRow -> insertDefault)
             continue;
         }
-        if (variant == PV_ALL_INNER || variant == PV_ALL_LEFT)
+        if (!(v & JV_MULTI))
         {
-            const u64 * run = t.rowids + t.start[slot];
-            for (u32 k = 0; k < c; ++k)
-                right_rowid[base + k] = run[k];
+            right_rowid[base] = v;
+            continue;
         }
-        else if (variant == PV_ANTI_LEFT)
-            right_rowid[base] = NO_ROW;
-        else
-            right_rowid[base] = take_last ? t.first_row[slot] - 1 : t.first_row[slot];
+        const u64 * run = t.rowids + (v & JV_START_MASK);
+        for (u32 k = 0; k < c; ++k)
+            right_rowid[base + k] = run[k];
     }
 }
 
@@ -385,7 +426,7 @@ extern "C" int chgpu_join_add_block(chgpu_join * j, const chgpu_col * key_col, c
     CHGPU_REQUIRE(!j->finished, CHGPU_ERR_LOGICAL, "addBlockToJoin after onBuildPhaseFinish");
     CHGPU_REQUIRE(key_col->type == j->key_type, CHGPU_ERR_BAD_ARGUMENTS, "key column has type %d, expected %d", key_col->type, j->key_type);
     CHGPU_REQUIRE(key_col->rows < 0xFFFFFFFFull, CHGPU_ERR_TOO_MANY_ROWS, "Too many rows in right table block for HashJoin: %llu", (unsigned long long)key_col->rows); // HashJoin.cpp:563-564
-    CHGPU_REQUIRE(j->blocks.size() < 0xFFFFFFFFull, CHGPU_ERR_TOO_MANY_ROWS, "too many right blocks");
+    CHGPU_REQUIRE(j->blocks.size() < 0x7FFFFFFFull, CHGPU_ERR_TOO_MANY_ROWS, "too many right blocks"); // bit 63 of a row id tags packed multi-row values
     if (null_map)
         CHGPU_REQUIRE(null_map->type == CHGPU_U8 && null_map->rows == key_col->rows, CHGPU_ERR_SIZES_MISMATCH, "null map size mismatch");
     if (join_mask)
@@ -436,7 +477,8 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
     size_t off_keys = 256, off_first = off_keys + al(cells * 8), off_cnt = off_first + al(cells * 8);
     size_t off_start = off_cnt + (maps_all ? al(cells * 4) : 0);
     size_t off_used = off_start + (maps_all ? al(cells * 8) : 0);
-    size_t off_rowids = off_used + (flagged ? al(cells * 8) : 0);
+    size_t off_value = off_used + (flagged ? al(cells * 8) : 0);
+    size_t off_rowids = off_value + al(cells * 8);
     size_t total_b = off_rowids + (maps_all ? al(j->total_rows * 8) : 0) + 256;
     void * m = nullptr;
     CHGPU_HIP(hipMalloc(&m, total_b));
@@ -448,6 +490,7 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
     t.cnt = maps_all ? (u32 *)((char *)m + off_cnt) : nullptr;
     t.start = maps_all ? (u64 *)((char *)m + off_start) : nullptr;
     t.used_by = flagged ? (u64 *)((char *)m + off_used) : nullptr;
+    t.value = (u64 *)((char *)m + off_value);
     t.rowids = maps_all ? (u64 *)((char *)m + off_rowids) : nullptr;
     t.capacity = cap;
     CHGPU_HIP(hipMemsetAsync(m, 0, off_first, ctx->stream)); // ctrl + keys
@@ -493,6 +536,8 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
         ctx->counters[6] += 1;
         CHGPU_TRY(chgpu_read_back(ctx, total_dev, &j->inserted, sizeof(u64)));
     }
+    hipLaunchKernelGGL(k_join_finalize_values, dim3(chgpu_grid_for(ctx, cells, JT, 8)), dim3(JT), 0, ctx->stream, t, maps_all ? 1 : 0, take_last ? 1 : 0);
+    ctx->counters[6] += 1;
     CHGPU_HIP(hipGetLastError());
     JoinCtrl c;
     CHGPU_TRY(chgpu_read_back(ctx, t.ctrl, &c, sizeof(c)));
@@ -589,13 +634,14 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
     }
 
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t sl_b = al(n * 4), cnt_b = al(n * 4), tmp_b = chgpu_scan_tmp_bytes(n);
+    const size_t sl_b = al(n * 4), cnt_b = al(n * 4), val_b = al(n * 8), tmp_b = chgpu_scan_tmp_bytes(n);
     void * scratch = nullptr;
-    CHGPU_TRY(chgpu_scratch(ctx, sl_b + cnt_b + 256 + tmp_b, &scratch));
+    CHGPU_TRY(chgpu_scratch(ctx, sl_b + cnt_b + val_b + 256 + tmp_b, &scratch));
     u32 * slot_of_left = (u32 *)scratch;
     u32 * counts = (u32 *)((char *)scratch + sl_b);
-    u64 * total_dev = (u64 *)((char *)scratch + sl_b + cnt_b);
-    void * tmp = (char *)scratch + sl_b + cnt_b + 256;
+    u64 * val_of_left = (u64 *)((char *)scratch + sl_b + cnt_b);
+    u64 * total_dev = (u64 *)((char *)scratch + sl_b + cnt_b + val_b);
+    void * tmp = (char *)scratch + sl_b + cnt_b + val_b + 256;
 
     chgpu_col * filter = nullptr;
     chgpu_col * offsets = nullptr;
@@ -622,7 +668,7 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
         ctx->counters[6] += 1;
     }
     hipLaunchKernelGGL(k_join_probe_count, dim3(grid), dim3(JT), 0, ctx->stream, j->t, variant, kp, j->key_type, nm, n, seq_base,
-                       variant == PV_ANY_INNER ? 1 : 0, slot_of_left, counts, filter ? (u8 *)filter->data : nullptr);
+                       variant == PV_ANY_INNER ? 1 : 0, slot_of_left, val_of_left, counts, filter ? (u8 *)filter->data : nullptr);
     ctx->counters[6] += 1;
     if ((rc = chgpu_scan_inclusive_u32_u64(ctx, counts, (u64 *)offsets->data, n, total_dev, tmp, tmp_b)) != CHGPU_OK)
         return fail(rc);
@@ -635,8 +681,8 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
         return fail(rc);
     if (c.n_out)
     {
-        hipLaunchKernelGGL(k_join_emit, dim3(grid), dim3(JT), 0, ctx->stream, j->t, variant, (!need_repl && j->any_take_last_row) ? 1 : 0,
-                           (const u32 *)slot_of_left, (const u32 *)counts, (const u64 *)offsets->data, c.consumed, (u64 *)rowid->data);
+        hipLaunchKernelGGL(k_join_emit, dim3(grid), dim3(JT), 0, ctx->stream, j->t, variant, (const u64 *)val_of_left, (const u32 *)counts,
+                           (const u64 *)offsets->data, c.consumed, (u64 *)rowid->data);
         ctx->counters[6] += 1;
     }
     hipError_t e = hipGetLastError();
