@@ -437,16 +437,17 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_hist(const void * __restrict
         counts[(u64)p * gridDim.x + blockIdx.x] = cnt[p];
 }
 
-// dynamic LDS: stage_key u64[TILE] | stage_word u64[K][TILE] | cursor u64[P] | tile_cnt u32[P] | tile_off u32[P] | stage_part u16[TILE]
-template <u32 GBP_TILE>
+// dynamic LDS: stage_word u64[K][TILE] | cursor u64[P] | stage_key KT[TILE] | tile_cnt u32[P] | tile_off u32[P] | stage_part u16[TILE]
+// KT = u32 for key types of <= 4 bytes (the partition buffers then hold 4-byte keys: 12 instead of 16 B/row for C3), else u64
+template <u32 GBP_TILE, typename KT>
 __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restrict__ keys, int key_type, u64 row_begin, u64 n, u64 rows_per_wg,
-                                                            u32 P, const u64 * __restrict__ offsets, GbpCols cols, u64 * __restrict__ out_keys)
+                                                            u32 P, const u64 * __restrict__ offsets, GbpCols cols, KT * __restrict__ out_keys)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
-    u64 * stage_key = (u64 *)gb_lds;
-    u64 * stage_word = stage_key + GBP_TILE;
+    u64 * stage_word = (u64 *)gb_lds;
     u64 * cursor = stage_word + (size_t)cols.k * GBP_TILE;
-    u32 * tile_cnt = (u32 *)(cursor + P);
+    KT * stage_key = (KT *)(cursor + P);
+    u32 * tile_cnt = (u32 *)(stage_key + GBP_TILE);
     u32 * tile_off = tile_cnt + P;
     unsigned short * stage_part = (unsigned short *)(tile_off + P);
     __shared__ u32 wave_tot[GBP_THREADS / 64];
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
             if (part[j] == ~0u)
                 continue;
             const u32 pos = tile_off[part[j]] + rank[j];
-            stage_key[pos] = key[j];
+            stage_key[pos] = (KT)key[j];
             stage_part[pos] = (unsigned short)part[j];
             if (cols.k > 0)
                 stage_word[pos] = argw[j][0];
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
             for (u32 c = 0; c < cols.k; ++c)
                 cols.dst[c][dst] = stage_word[(size_t)c * GBP_TILE + pos];
 #else
-            if (dst == ~0ull) out_keys[0] = stage_key[pos] + stage_word[pos];
+            if (dst == ~0ull) out_keys[0] = stage_key[pos] + (KT)stage_word[pos];
 #endif
         }
         __syncthreads();
@@ -563,8 +564,9 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
 // One workgroup aggregates whole partitions in LDS.  Partition p occupies rows [offsets[p*G], offsets[(p+1)*G]) of the
 // partition buffers (n for the last).  Rows whose key cannot be placed in LDS go to the HBM table directly; rows that hit
 // the max-fill limit there are marked pending (atomicOr: 64-row groups straddle partition boundaries).
-__global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const u64 * __restrict__ keys, const u64 * __restrict__ offsets, u32 G,
-                                                       u32 P, u64 n, u64 * __restrict__ pending, u32 S, u32 K)
+template <typename KT>
+__global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const KT * __restrict__ keys, const u64 * __restrict__ words, const u64 * __restrict__ offsets,
+                                                       u32 G, u32 P, u64 n, u64 * __restrict__ pending, u32 S, u32 K)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u64 * lkeys = (u64 *)lds_raw;
@@ -594,10 +596,10 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
             {
                 const u64 i = (gb + q) * 64 + lane;
                 act[q] = i >= begin && i < end;
-                keyv[q] = act[q] ? keys[i] : 0;
-                // the K argument word columns follow the key column in the partition buffers, n rows apart
-                argv[q][0] = (act[q] && K > 0) ? keys[n + i] : 0;
-                argv[q][1] = (act[q] && K > 1) ? keys[2 * n + i] : 0;
+                keyv[q] = act[q] ? (u64)keys[i] : 0;
+                // the K argument word columns of the partition buffers, n rows apart
+                argv[q][0] = (act[q] && K > 0) ? words[i] : 0;
+                argv[q][1] = (act[q] && K > 1) ? words[n + i] : 0;
             }
 #pragma unroll
             for (int q = 0; q < PR; ++q)
@@ -949,8 +951,9 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     }
     const u32 G = (u32)ctx->num_cus * GBP_WG_PER_CU;
     u64 rows_per_wg = (n + G - 1) / G;
-    // the scatter's LDS image is tile*(8*(1+K)+2) + 16*P bytes and must stay under ~150 KiB
-    const bool big_tile = (size_t)GBP_TILE_MAX * (8 * (1 + K) + 2) + (size_t)P * 16 <= 150 * 1024;
+    const bool key32 = chgpu_type_size(a->key_type) <= 4; // 4-byte (or narrower) keys are stored as 4 bytes in the partition buffers
+    // the scatter's LDS image is tile*(8*K + key bytes + 2) + 16*P bytes and must stay under ~150 KiB
+    const bool big_tile = (size_t)GBP_TILE_MAX * (8 * K + (key32 ? 4 : 8) + 2) + (size_t)P * 16 <= 150 * 1024;
     const u32 tile = big_tile ? GBP_TILE_MAX : GBP_TILE_MAX / 2;
     rows_per_wg = (rows_per_wg + tile - 1) / tile * tile;
 
@@ -960,7 +963,8 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     const size_t cnt_b = al(m * 4), off_b = al(m * 8 + 8), tmp_b = chgpu_scan_tmp_bytes(m), pend_b = al(((n + 63) / 64) * 8 + 8);
     // The partition buffers live in the context's scratch arena, which is kept between calls: a fresh hipMalloc of
     // 16 GB costs ~0.4 s, fifteen times the kernels it would serve.
-    const size_t part_b = al((size_t)n * 8 * (1 + K));
+    const size_t keys_b = al((size_t)n * (key32 ? 4 : 8));
+    const size_t part_b = keys_b + al((size_t)n * 8 * K);
     void * scratch = nullptr;
     CHGPU_TRY(chgpu_scratch(ctx, cnt_b + off_b + 256 + tmp_b + pend_b + part_b, &scratch));
     u32 * counts = (u32 *)scratch;
@@ -968,7 +972,8 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     u64 * total_dev = (u64 *)((char *)scratch + cnt_b + off_b);
     void * tmp = (char *)scratch + cnt_b + off_b + 256;
     u64 * pending = (u64 *)((char *)scratch + cnt_b + off_b + 256 + tmp_b);
-    u64 * pkeys = (u64 *)((char *)scratch + cnt_b + off_b + 256 + tmp_b + pend_b); // keys | word0 | word1
+    void * pkeys = (char *)scratch + cnt_b + off_b + 256 + tmp_b + pend_b; // keys (4 or 8 B) | word0 | word1
+    u64 * pwords = (u64 *)((char *)pkeys + keys_b);
 
     GbpCols gc;
     gc.k = K;
@@ -981,7 +986,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
             continue;
         gc.src[kk] = arg_cols[j]->data;
         gc.type[kk] = a->arg_types[j];
-        gc.dst[kk] = pkeys + (u64)(1 + kk) * n;
+        gc.dst[kk] = pwords + (u64)kk * n;
         // the aggregate pass reads widened 8-byte words: integers were sign/zero-extended, Float64 kept its bits
         d.a[j].ptr = gc.dst[kk];
         d.a[j].arg_type = a->arg_types[j] == CHGPU_F64 ? CHGPU_F64 : CHGPU_U64;
@@ -993,30 +998,45 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     int rc = chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, m, total_dev, tmp, tmp_b);
     if (rc == CHGPU_OK)
     {
-        const size_t lds_sc = (size_t)tile * 8 * (1 + K) + (size_t)P * 16 + (size_t)tile * 2;
-        auto kern = big_tile ? k_gb_scatter<GBP_TILE_MAX> : k_gb_scatter<GBP_TILE_MAX / 2>;
-        rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
-        if (rc == CHGPU_OK)
-            hipLaunchKernelGGL(kern, dim3(G), dim3(GBP_THREADS), lds_sc, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P,
-                               (const u64 *)offsets, gc, pkeys);
+        const size_t lds_sc = (size_t)tile * (8 * K + (key32 ? 4 : 8) + 2) + (size_t)P * 16 + 64;
+#define GB_SCATTER(TILE_, KT_)                                                                                                                  \
+    do                                                                                                                                          \
+    {                                                                                                                                           \
+        auto kern = k_gb_scatter<TILE_, KT_>;                                                                                                   \
+        rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
+        if (rc == CHGPU_OK)                                                                                                                     \
+            hipLaunchKernelGGL(kern, dim3(G), dim3(GBP_THREADS), lds_sc, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P, \
+                               (const u64 *)offsets, gc, (KT_ *)pkeys);                                                                          \
+    } while (0)
+        if (big_tile) { if (key32) GB_SCATTER(GBP_TILE_MAX, u32); else GB_SCATTER(GBP_TILE_MAX, u64); }
+        else          { if (key32) GB_SCATTER(GBP_TILE_MAX / 2, u32); else GB_SCATTER(GBP_TILE_MAX / 2, u64); }
+#undef GB_SCATTER
     }
     if (rc == CHGPU_OK)
         rc = hipMemsetAsync(pending, 0, pend_b, ctx->stream) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
     if (rc == CHGPU_OK)
     {
         const size_t lds_ag = (size_t)(S + 1) * 8 * (1 + a->n_words);
-        rc = hipFuncSetAttribute((const void *)k_agg_part_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
         u32 grid = P < (u32)ctx->num_cus ? P : (u32)ctx->num_cus;
-        // flush slack: grid concurrent flushes of up to S+1 new cells each must stay below the capacity
-        if (rc == CHGPU_OK)
-            hipLaunchKernelGGL(k_agg_part_lds, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const u64 *)offsets, G, P, n, pending, S, K);
+        if (key32)
+        {
+            rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
+            if (rc == CHGPU_OK)
+                hipLaunchKernelGGL(k_agg_part_lds<u32>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)pkeys, (const u64 *)pwords, (const u64 *)offsets, G, P, n, pending, S, K);
+        }
+        else
+        {
+            rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
+            if (rc == CHGPU_OK)
+                hipLaunchKernelGGL(k_agg_part_lds<u64>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const u64 *)pwords, (const u64 *)offsets, G, P, n, pending, S, K);
+        }
     }
     ctx->counters[6] += 3;
     ctx->counters[5] += n;
     if (rc == CHGPU_OK && hipGetLastError() != hipSuccess)
         rc = CHGPU_ERR_DEVICE;
     if (rc == CHGPU_OK)
-        rc = agg_finish_rounds(a, d, pkeys, CHGPU_U64, 0, n, pending);
+        rc = agg_finish_rounds(a, d, pkeys, key32 ? CHGPU_U32 : CHGPU_U64, 0, n, pending);
     else
     {
         (void)hipGetLastError(); // do not leave a sticky launch error behind for the next call
