@@ -22,6 +22,7 @@
 // (HashTable.h:921-944) restructured for a device that cannot realloc inside a kernel.
 #include "chgpu_internal.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 static constexpr u32 AGG_MAX_AGGS = 8;
@@ -399,7 +400,10 @@ static constexpr u32 GBP_TILE_MAX = GBP_TILE_V; // rows per tile with <= 1 argum
 static constexpr u32 GBP_MAX_P = 1024;
 static constexpr u32 GBP_MAX_K = 2;
 
-__device__ __forceinline__ u32 gbp_part_of(u64 key, u32 pmask) { return (u32)(dev_intHash64(key) >> 52) & pmask; }
+// Fibonacci hashing: one 64-bit multiply; the top bits pick the partition, bits 20.. pick the LDS cell (the full murmur
+// finalizer cost ~20 VALU ops per row in three passes that turned out to be issue-bound, not HBM-bound)
+__device__ __forceinline__ u64 gbp_mix(u64 key) { return key * 0x9E3779B97F4A7C15ull; }
+__device__ __forceinline__ u32 gbp_part_of(u64 key, u32 pmask) { return (u32)(gbp_mix(key) >> 52) & pmask; }
 
 struct GbpCols
 {
@@ -437,9 +441,60 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_hist(const void * __restrict
         counts[(u64)p * gridDim.x + blockIdx.x] = cnt[p];
 }
 
+// Same histogram with 16-byte nontemporal key loads (4- and 8-byte keys whose first row is 16-byte aligned): four loads
+// per lane are issued before the first LDS atomic.
+template <typename KT>
+__global__ __launch_bounds__(GBP_THREADS) void k_gb_hist_wide(const KT * __restrict__ keys, u64 n, u64 rows_per_wg, u32 P, u32 * __restrict__ counts)
+{
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    constexpr u32 VEC = 16 / sizeof(KT);
+    constexpr int HU = 4;
+    __shared__ u32 cnt[GBP_MAX_P];
+    for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
+        cnt[p] = 0;
+    __syncthreads();
+    const u64 r0 = (u64)blockIdx.x * rows_per_wg;
+    const u64 r1 = r0 + rows_per_wg < n ? r0 + rows_per_wg : n;
+    const u32 pmask = P - 1;
+    u64 i = r0;
+    constexpr u64 STEP = (u64)HU * GBP_THREADS * VEC;
+    for (; i + STEP <= r1; i += STEP)
+    {
+        v4u v[HU];
+#pragma unroll
+        for (int q = 0; q < HU; ++q)
+            v[q] = __builtin_nontemporal_load((const v4u *)(keys + i + ((u64)q * GBP_THREADS + threadIdx.x) * VEC));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < HU; ++q)
+        {
+            if constexpr (sizeof(KT) == 4)
+            {
+                atomicAdd(&cnt[gbp_part_of(v[q].x, pmask)], 1u);
+                atomicAdd(&cnt[gbp_part_of(v[q].y, pmask)], 1u);
+                atomicAdd(&cnt[gbp_part_of(v[q].z, pmask)], 1u);
+                atomicAdd(&cnt[gbp_part_of(v[q].w, pmask)], 1u);
+            }
+            else
+            {
+                atomicAdd(&cnt[gbp_part_of((u64)v[q].x | ((u64)v[q].y << 32), pmask)], 1u);
+                atomicAdd(&cnt[gbp_part_of((u64)v[q].z | ((u64)v[q].w << 32), pmask)], 1u);
+            }
+        }
+    }
+    for (i += threadIdx.x; i < r1; i += GBP_THREADS)
+        atomicAdd(&cnt[gbp_part_of((u64)keys[i], pmask)], 1u);
+    __syncthreads();
+    for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
+        counts[(u64)p * gridDim.x + blockIdx.x] = cnt[p];
+}
+
 // dynamic LDS: stage_word u64[K][TILE] | cursor u64[P] | stage_key KT[TILE] | tile_cnt u32[P] | tile_off u32[P] | stage_part u16[TILE]
 // KT = u32 for key types of <= 4 bytes (the partition buffers then hold 4-byte keys: 12 instead of 16 B/row for C3), else u64
-template <u32 GBP_TILE, typename KT>
+// WIDE: the key column is KT-wide, every argument is 8 bytes wide and the first row is 16-byte aligned in all of them;
+// a thread then owns row PAIRS (tile row q*2*threads + 2*tid + {0,1}) and fetches each pair with one 8/16-byte
+// nontemporal load; otherwise rows are strided by the workgroup size and loaded one by one through the type switches.
+template <u32 GBP_TILE, typename KT, bool WIDE>
 __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restrict__ keys, int key_type, u64 row_begin, u64 n, u64 rows_per_wg,
                                                             u32 P, const u64 * __restrict__ offsets, GbpCols cols, KT * __restrict__ out_keys)
 {
@@ -464,27 +519,108 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
     u64 key[RPT], argw[RPT][GBP_MAX_K];
     // rows of a tile are held in registers; the NEXT tile's loads are issued right after the current tile has been
     // staged to LDS, so their latency hides behind the write-out phase (one workgroup per CU: nothing else would)
+    auto row_of = [&](u64 tb, u32 j) -> u64 {
+        if constexpr (WIDE)
+            return tb + (u64)(j >> 1) * (2 * GBP_THREADS) + 2 * threadIdx.x + (j & 1);
+        else
+            return tb + (u64)j * GBP_THREADS + threadIdx.x;
+    };
     auto load_tile = [&](u64 tb) {
-#pragma unroll
-        for (u32 j = 0; j < RPT; ++j)
+        if constexpr (WIDE)
         {
-            const u64 i = tb + (u64)j * GBP_THREADS + threadIdx.x;
-            const bool in = i < r1;
-            key[j] = in ? load_key_zext(keys, key_type, row_begin + i) : 0;
-            argw[j][0] = (in && cols.k > 0) ? load_arg_bits(cols.src[0], cols.type[0], row_begin + i) : 0;
-            argw[j][1] = (in && cols.k > 1) ? load_arg_bits(cols.src[1], cols.type[1], row_begin + i) : 0;
+            typedef u64 v2q __attribute__((ext_vector_type(2)));
+            typedef u32 v2d __attribute__((ext_vector_type(2)));
+            static_assert(RPT % 2 == 0, "row pairs");
+#pragma unroll
+            for (u32 j = 0; j < RPT; j += 2)
+            {
+                const u64 i = row_of(tb, j);
+                if (i + 1 < r1)
+                {
+                    if constexpr (sizeof(KT) == 4)
+                    {
+                        const v2d kk = __builtin_nontemporal_load((const v2d *)((const u32 *)keys + row_begin + i));
+                        key[j] = kk.x, key[j + 1] = kk.y;
+                    }
+                    else
+                    {
+                        const v2q kk = __builtin_nontemporal_load((const v2q *)((const u64 *)keys + row_begin + i));
+                        key[j] = kk.x, key[j + 1] = kk.y;
+                    }
+                    if (cols.k > 0)
+                    {
+                        const v2q a = __builtin_nontemporal_load((const v2q *)((const u64 *)cols.src[0] + row_begin + i));
+                        argw[j][0] = a.x, argw[j + 1][0] = a.y;
+                    }
+                    if (cols.k > 1)
+                    {
+                        const v2q a = __builtin_nontemporal_load((const v2q *)((const u64 *)cols.src[1] + row_begin + i));
+                        argw[j][1] = a.x, argw[j + 1][1] = a.y;
+                    }
+                }
+                else
+                {
+                    const bool in = i < r1; // at most the first row of the pair is left
+                    key[j] = in ? (u64)((const KT *)keys)[row_begin + i] : 0;
+                    argw[j][0] = (in && cols.k > 0) ? ((const u64 *)cols.src[0])[row_begin + i] : 0;
+                    argw[j][1] = (in && cols.k > 1) ? ((const u64 *)cols.src[1])[row_begin + i] : 0;
+                    key[j + 1] = 0, argw[j + 1][0] = 0, argw[j + 1][1] = 0;
+                }
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (u32 j = 0; j < RPT; ++j)
+            {
+                const u64 i = row_of(tb, j);
+                const bool in = i < r1;
+                key[j] = in ? load_key_zext(keys, key_type, row_begin + i) : 0;
+                argw[j][0] = (in && cols.k > 0) ? load_arg_bits(cols.src[0], cols.type[0], row_begin + i) : 0;
+                argw[j][1] = (in && cols.k > 1) ? load_arg_bits(cols.src[1], cols.type[1], row_begin + i) : 0;
+            }
         }
     };
     if (r0 < r1)
         load_tile(r0);
+#ifdef GBP_ABLATE
+    u64 ab_acc = 0;
+#endif
     for (u64 tbase = r0; tbase < r1; tbase += GBP_TILE)
     {
         u32 part[RPT], rank[RPT];
+#ifdef GBP_ABLATE
+#pragma unroll
+        for (u32 j = 0; j < RPT; ++j) ab_acc ^= key[j] ^ argw[j][0];
+#endif
+#if defined(GBP_ABLATE) && GBP_ABLATE == 4
+        if (tbase + GBP_TILE < r1)
+            load_tile(tbase + GBP_TILE);
+        continue;
+#endif
+#if defined(GBP_ABLATE) && GBP_ABLATE == 6
+        {
+            // pure copy in this kernel's geometry: rows go straight from registers to their own index
+            u64 kk[RPT], aa[RPT];
+#pragma unroll
+            for (u32 j = 0; j < RPT; ++j) kk[j] = key[j], aa[j] = argw[j][0];
+            const u64 tb0 = tbase;
+            if (tbase + GBP_TILE < r1)
+                load_tile(tbase + GBP_TILE);
+#pragma unroll
+            for (u32 j = 0; j < RPT; ++j)
+            {
+                const u64 i = row_of(tb0, j);
+                if (i < r1) { out_keys[i] = (KT)kk[j]; cols.dst[0][i] = aa[j]; }
+            }
+            continue;
+        }
+#endif
         // 1. take a rank inside the tile's partition bucket
 #pragma unroll
         for (u32 j = 0; j < RPT; ++j)
         {
-            const u64 i = tbase + (u64)j * GBP_THREADS + threadIdx.x;
+            const u64 i = row_of(tbase, j);
             part[j] = ~0u;
             if (i < r1)
             {
@@ -523,6 +659,10 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
 #pragma unroll
         for (u32 j = 0; j < RPT; ++j)
         {
+#if defined(GBP_ABLATE) && (GBP_ABLATE == 3 || GBP_ABLATE == 4)
+            ab_acc += tile_off[part[j] & (P - 1)] + rank[j];
+            continue;
+#endif
             if (part[j] == ~0u)
                 continue;
             const u32 pos = tile_off[part[j]] + rank[j];
@@ -538,11 +678,26 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
         __syncthreads();
         // 4. write the partition runs: consecutive lanes -> consecutive addresses inside a run
         const u32 tile_rows = (u32)(r1 - tbase < GBP_TILE ? r1 - tbase : GBP_TILE);
+#if defined(GBP_ABLATE) && (GBP_ABLATE >= 2 && GBP_ABLATE <= 4)
+        if (false)
+#endif
         for (u32 pos = threadIdx.x; pos < tile_rows; pos += GBP_THREADS)
         {
             const u32 p = stage_part[pos];
             const u64 dst = cursor[p] + (pos - tile_off[p]);
-#if !defined(GBP_ABLATE) || GBP_ABLATE != 1
+#if defined(GBP_ABLATE) && GBP_ABLATE == 5
+            {
+                // emulate ideal write combining: every tile writes P aligned runs of 16 rows
+                const u32 q = (pos / 16) & (P - 1);
+                const u64 d5 = (cursor[q] & ~15ull) + (pos & 15) + (u64)((tbase - r0) / GBP_TILE) * 16;
+                if (d5 < n && p != 0xFFFF && dst != ~0ull)
+                {
+                    out_keys[d5] = stage_key[pos];
+                    for (u32 c = 0; c < cols.k; ++c)
+                        cols.dst[c][d5] = stage_word[(size_t)c * GBP_TILE + pos];
+                }
+            }
+#elif !defined(GBP_ABLATE) || GBP_ABLATE != 1
             // plain stores: runs are 64-128 B, L2 write-combining completes the lines (nontemporal stores: 4.7 -> 8.1 ms)
             out_keys[dst] = stage_key[pos];
             for (u32 c = 0; c < cols.k; ++c)
@@ -554,11 +709,16 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
         __syncthreads();
         for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
         {
+#if !defined(GBP_ABLATE) || GBP_ABLATE != 5
             cursor[p] += tile_cnt[p];
+#endif
             tile_cnt[p] = 0;
         }
         __syncthreads();
     }
+#ifdef GBP_ABLATE
+    if (ab_acc == 0x1234567887654321ull) out_keys[0] = (KT)ab_acc;
+#endif
 }
 
 // One workgroup aggregates whole partitions in LDS.  Partition p occupies rows [offsets[p*G], offsets[(p+1)*G]) of the
@@ -587,20 +747,22 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
         const u64 g0 = begin / 64, g1 = (end + 63) / 64;
         constexpr int PR = 4;  // 64-row groups per wave iteration: all their loads are issued before LDS is touched
         constexpr u32 PPRE = 2; // argument words preloaded per row (GBP_MAX_K)
-        for (u64 gb = g0 + (u64)wave * PR; gb < g1; gb += (u64)n_waves * PR)
-        {
-            u64 keyv[PR], argv[PR][PPRE];
-            bool act[PR];
+        // Loads are unconditional (row indices clamped to the buffer) and double-buffered in registers: the loads of the
+        // wave's next PR groups are in flight while the current ones go through the LDS table.  No branch surrounds a
+        // load, so the compiler can keep exact vmcnt waits instead of draining the queue at a control-flow join.
+        auto load_set = [&](u64 gb, u64 (&kv)[PR], u64 (&av)[PR][PPRE]) {
 #pragma unroll
             for (int q = 0; q < PR; ++q)
             {
-                const u64 i = (gb + q) * 64 + lane;
-                act[q] = i >= begin && i < end;
-                keyv[q] = act[q] ? (u64)keys[i] : 0;
+                u64 i = (gb + q) * 64 + lane;
+                i = i < n ? i : n - 1;
+                kv[q] = (u64)__builtin_nontemporal_load(&keys[i]);
                 // the K argument word columns of the partition buffers, n rows apart
-                argv[q][0] = (act[q] && K > 0) ? words[i] : 0;
-                argv[q][1] = (act[q] && K > 1) ? words[n + i] : 0;
+                av[q][0] = K > 0 ? __builtin_nontemporal_load(&words[i]) : 0;
+                av[q][1] = K > 1 ? __builtin_nontemporal_load(&words[n + i]) : 0;
             }
+        };
+        auto process_set = [&](u64 gb, const u64 (&keyv)[PR], const u64 (&argv)[PR][PPRE]) {
 #pragma unroll
             for (int q = 0; q < PR; ++q)
             {
@@ -609,7 +771,7 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                     break;
                 const u64 i = g * 64 + lane;
                 bool failed = false;
-                if (act[q])
+                if (i >= begin && i < end)
                 {
                     const u64 key = keyv[q];
                     u32 ls = ~0u;
@@ -620,7 +782,7 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                     }
                     else
                     {
-                        u32 s = (u32)(dev_intHash64(key) >> 28) & (S - 1); // bits disjoint from the partition id (>> 52)
+                        u32 s = (u32)(gbp_mix(key) >> 20) & (S - 1); // bits disjoint from the partition id (>> 52)
 #pragma unroll 1
                         for (int probe = 0; probe < 64; ++probe)
                         {
@@ -670,6 +832,21 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                     atomicOr((unsigned long long *)&pending[g], (unsigned long long)b);
                     t.ctrl->overflow = 1;
                 }
+            }
+        };
+        {
+            const u64 step = (u64)n_waves * PR;
+            u64 kA[PR], aA[PR][PPRE], kB[PR], aB[PR][PPRE];
+            u64 gb = g0 + (u64)wave * PR;
+            load_set(gb, kA, aA);
+            for (; gb < g1; gb += 2 * step)
+            {
+                load_set(gb + step, kB, aB);
+                __builtin_amdgcn_sched_barrier(0);
+                process_set(gb, kA, aA);
+                load_set(gb + 2 * step, kA, aA);
+                __builtin_amdgcn_sched_barrier(0);
+                process_set(gb + step, kB, aB);
             }
         }
         __syncthreads();
@@ -932,8 +1109,10 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     chgpu_ctx * ctx = a->ctx;
     CHGPU_TRY(agg_ensure_table(a));
     // LDS table of the aggregate pass: as many cells as fit ~100 KiB, one 1024-thread workgroup per CU
-    u32 S = 4096;
-    while ((size_t)(S + 1) * 8 * (1 + a->n_words) > 100 * 1024 && S > 256)
+    static const u32 s_max = getenv("CHGPU_TUNE_GB_S") ? (u32)atoi(getenv("CHGPU_TUNE_GB_S")) : 4096;
+    static const u32 s_kib = getenv("CHGPU_TUNE_GB_KIB") ? (u32)atoi(getenv("CHGPU_TUNE_GB_KIB")) : 100;
+    u32 S = s_max;
+    while ((size_t)(S + 1) * 8 * (1 + a->n_words) > (size_t)s_kib * 1024 && S > 256)
         S >>= 1;
     // partitions so that a partition's expected groups fill at most half the LDS table
     u64 want_p = (a->size_hint + S / 2 - 1) / (S / 2);
@@ -956,6 +1135,9 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     const bool big_tile = (size_t)GBP_TILE_MAX * (8 * K + (key32 ? 4 : 8) + 2) + (size_t)P * 16 <= 150 * 1024;
     const u32 tile = big_tile ? GBP_TILE_MAX : GBP_TILE_MAX / 2;
     rows_per_wg = (rows_per_wg + tile - 1) / tile * tile;
+    static const bool debug = getenv("CHGPU_DEBUG") != nullptr;
+    if (debug)
+        fprintf(stderr, "chgpu: partitioned GROUP BY n=%llu hint=%llu S=%u P=%u G=%u tile=%u\n", (unsigned long long)n, (unsigned long long)a->size_hint, S, P, G, tile);
 
     // partition buffers (8-byte keys + K 8-byte words per row) and bookkeeping
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -994,15 +1176,28 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         ++kk;
     }
 
-    hipLaunchKernelGGL(k_gb_hist, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P, counts);
+    // wide loads need key/argument columns whose element width is the buffer width and a 16-byte aligned first row
+    const size_t key_w = chgpu_type_size(a->key_type);
+    bool wide = (key_w == 4 || key_w == 8) && ((uintptr_t)key_col->data + row_begin * key_w) % 16 == 0;
+    for (u32 c = 0; c < K; ++c)
+        wide = wide && chgpu_type_size(gc.type[c]) == 8 && ((uintptr_t)gc.src[c] + row_begin * 8) % 16 == 0;
+    static const bool no_wide = getenv("CHGPU_TUNE_GB_NOWIDE") != nullptr;
+    wide = wide && !no_wide;
+    if (wide && key_w == 4)
+        hipLaunchKernelGGL(k_gb_hist_wide<u32>, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const u32 *)key_col->data + row_begin, n, rows_per_wg, P, counts);
+    else if (wide)
+        hipLaunchKernelGGL(k_gb_hist_wide<u64>, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const u64 *)key_col->data + row_begin, n, rows_per_wg, P, counts);
+    else
+        hipLaunchKernelGGL(k_gb_hist, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P, counts);
     int rc = chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, m, total_dev, tmp, tmp_b);
     if (rc == CHGPU_OK)
     {
         const size_t lds_sc = (size_t)tile * (8 * K + (key32 ? 4 : 8) + 2) + (size_t)P * 16 + 64;
-#define GB_SCATTER(TILE_, KT_)                                                                                                                  \
+#define GB_SCATTER(TILE_, KT_) do { if (wide) GB_SCATTER_W(TILE_, KT_, true); else GB_SCATTER_W(TILE_, KT_, false); } while (0)
+#define GB_SCATTER_W(TILE_, KT_, W_)                                                                                                            \
     do                                                                                                                                          \
     {                                                                                                                                           \
-        auto kern = k_gb_scatter<TILE_, KT_>;                                                                                                   \
+        auto kern = k_gb_scatter<TILE_, KT_, W_>;                                                                                                 \
         rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
         if (rc == CHGPU_OK)                                                                                                                     \
             hipLaunchKernelGGL(kern, dim3(G), dim3(GBP_THREADS), lds_sc, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P, \
@@ -1011,6 +1206,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         if (big_tile) { if (key32) GB_SCATTER(GBP_TILE_MAX, u32); else GB_SCATTER(GBP_TILE_MAX, u64); }
         else          { if (key32) GB_SCATTER(GBP_TILE_MAX / 2, u32); else GB_SCATTER(GBP_TILE_MAX / 2, u64); }
 #undef GB_SCATTER
+#undef GB_SCATTER_W
     }
     if (rc == CHGPU_OK)
         rc = hipMemsetAsync(pending, 0, pend_b, ctx->stream) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
