@@ -24,6 +24,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 static constexpr u32 AGG_MAX_AGGS = 8;
 static constexpr u32 AGG_MAX_WORDS = 16;
@@ -389,14 +390,10 @@ __global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, co
 #ifndef GBP_THREADS_V
 #define GBP_THREADS_V 1024
 #endif
-#ifndef GBP_TILE_V
-#define GBP_TILE_V 8192
-#endif
 #ifndef GBP_WG_PER_CU
 #define GBP_WG_PER_CU 1
 #endif
 static constexpr u32 GBP_THREADS = GBP_THREADS_V;
-static constexpr u32 GBP_TILE_MAX = GBP_TILE_V; // rows per tile with <= 1 argument word; halved for 2 (LDS budget)
 static constexpr u32 GBP_MAX_P = 1024;
 static constexpr u32 GBP_MAX_K = 2;
 
@@ -489,7 +486,9 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_hist_wide(const KT * __restr
         counts[(u64)p * gridDim.x + blockIdx.x] = cnt[p];
 }
 
-// dynamic LDS: stage_word u64[K][TILE] | cursor u64[P] | stage_key KT[TILE] | tile_cnt u32[P] | tile_off u32[P] | stage_part u16[TILE]
+// dynamic LDS: stage_word u64[K][TILE] | cursor u64[P] | stage_key KT[TILE] | tile_cnt u32[P] | tile_off u32[P]
+// (the partition of a staged row is recomputed from its key in the write-out phase: one multiply instead of 2 B/row of LDS,
+//  which buys a 12288-row tile -> 1.5x longer partition runs for the 4-byte-key, one-word shape)
 // KT = u32 for key types of <= 4 bytes (the partition buffers then hold 4-byte keys: 12 instead of 16 B/row for C3), else u64
 // WIDE: the key column is KT-wide, every argument is 8 bytes wide and the first row is 16-byte aligned in all of them;
 // a thread then owns row PAIRS (tile row q*2*threads + 2*tid + {0,1}) and fetches each pair with one 8/16-byte
@@ -504,7 +503,6 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
     KT * stage_key = (KT *)(cursor + P);
     u32 * tile_cnt = (u32 *)(stage_key + GBP_TILE);
     u32 * tile_off = tile_cnt + P;
-    unsigned short * stage_part = (unsigned short *)(tile_off + P);
     __shared__ u32 wave_tot[GBP_THREADS / 64];
 
     for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
@@ -583,39 +581,9 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
     };
     if (r0 < r1)
         load_tile(r0);
-#ifdef GBP_ABLATE
-    u64 ab_acc = 0;
-#endif
     for (u64 tbase = r0; tbase < r1; tbase += GBP_TILE)
     {
         u32 part[RPT], rank[RPT];
-#ifdef GBP_ABLATE
-#pragma unroll
-        for (u32 j = 0; j < RPT; ++j) ab_acc ^= key[j] ^ argw[j][0];
-#endif
-#if defined(GBP_ABLATE) && GBP_ABLATE == 4
-        if (tbase + GBP_TILE < r1)
-            load_tile(tbase + GBP_TILE);
-        continue;
-#endif
-#if defined(GBP_ABLATE) && GBP_ABLATE == 6
-        {
-            // pure copy in this kernel's geometry: rows go straight from registers to their own index
-            u64 kk[RPT], aa[RPT];
-#pragma unroll
-            for (u32 j = 0; j < RPT; ++j) kk[j] = key[j], aa[j] = argw[j][0];
-            const u64 tb0 = tbase;
-            if (tbase + GBP_TILE < r1)
-                load_tile(tbase + GBP_TILE);
-#pragma unroll
-            for (u32 j = 0; j < RPT; ++j)
-            {
-                const u64 i = row_of(tb0, j);
-                if (i < r1) { out_keys[i] = (KT)kk[j]; cols.dst[0][i] = aa[j]; }
-            }
-            continue;
-        }
-#endif
         // 1. take a rank inside the tile's partition bucket
 #pragma unroll
         for (u32 j = 0; j < RPT; ++j)
@@ -659,15 +627,10 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
 #pragma unroll
         for (u32 j = 0; j < RPT; ++j)
         {
-#if defined(GBP_ABLATE) && (GBP_ABLATE == 3 || GBP_ABLATE == 4)
-            ab_acc += tile_off[part[j] & (P - 1)] + rank[j];
-            continue;
-#endif
             if (part[j] == ~0u)
                 continue;
             const u32 pos = tile_off[part[j]] + rank[j];
             stage_key[pos] = (KT)key[j];
-            stage_part[pos] = (unsigned short)part[j];
             if (cols.k > 0)
                 stage_word[pos] = argw[j][0];
             if (cols.k > 1)
@@ -678,67 +641,66 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
         __syncthreads();
         // 4. write the partition runs: consecutive lanes -> consecutive addresses inside a run
         const u32 tile_rows = (u32)(r1 - tbase < GBP_TILE ? r1 - tbase : GBP_TILE);
-#if defined(GBP_ABLATE) && (GBP_ABLATE >= 2 && GBP_ABLATE <= 4)
-        if (false)
-#endif
         for (u32 pos = threadIdx.x; pos < tile_rows; pos += GBP_THREADS)
         {
-            const u32 p = stage_part[pos];
+            const u32 p = gbp_part_of((u64)stage_key[pos], P - 1);
             const u64 dst = cursor[p] + (pos - tile_off[p]);
-#if defined(GBP_ABLATE) && GBP_ABLATE == 5
-            {
-                // emulate ideal write combining: every tile writes P aligned runs of 16 rows
-                const u32 q = (pos / 16) & (P - 1);
-                const u64 d5 = (cursor[q] & ~15ull) + (pos & 15) + (u64)((tbase - r0) / GBP_TILE) * 16;
-                if (d5 < n && p != 0xFFFF && dst != ~0ull)
-                {
-                    out_keys[d5] = stage_key[pos];
-                    for (u32 c = 0; c < cols.k; ++c)
-                        cols.dst[c][d5] = stage_word[(size_t)c * GBP_TILE + pos];
-                }
-            }
-#elif !defined(GBP_ABLATE) || GBP_ABLATE != 1
             // plain stores: runs are 64-128 B, L2 write-combining completes the lines (nontemporal stores: 4.7 -> 8.1 ms)
             out_keys[dst] = stage_key[pos];
             for (u32 c = 0; c < cols.k; ++c)
                 cols.dst[c][dst] = stage_word[(size_t)c * GBP_TILE + pos];
-#else
-            if (dst == ~0ull) out_keys[0] = stage_key[pos] + (KT)stage_word[pos];
-#endif
         }
         __syncthreads();
         for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
         {
-#if !defined(GBP_ABLATE) || GBP_ABLATE != 5
             cursor[p] += tile_cnt[p];
-#endif
             tile_cnt[p] = 0;
         }
         __syncthreads();
     }
-#ifdef GBP_ABLATE
-    if (ab_acc == 0x1234567887654321ull) out_keys[0] = (KT)ab_acc;
-#endif
 }
 
 // One workgroup aggregates whole partitions in LDS.  Partition p occupies rows [offsets[p*G], offsets[(p+1)*G]) of the
 // partition buffers (n for the last).  Rows whose key cannot be placed in LDS go to the HBM table directly; rows that hit
 // the max-fill limit there are marked pending (atomicOr: 64-row groups straddle partition boundaries).
+//
+// LDS cells are compact: the key array has the width of the partition buffer's keys (KT) and, when `cnt32` has bit w set,
+// state word w is a row COUNT kept as 32 bits (a call never sees 2^32 rows; the host checks).  For the C3 shape
+// (UInt32 key, sum, count) a cell is 4+8+4 = 16 B, so 8192 cells fit and 256 partitions suffice for 1 M groups --
+// half as many partitions means partition runs twice as long in the scatter, whose cost is dominated by short runs.
+// Layout: keys KT[S+1] (padded to 8 B) | every 8-byte word u64[S+1] in word order | every 4-byte word u32[S+1].
+struct PartLds
+{
+    u32 S1, cnt32, n8, keys_bytes;
+    __device__ __forceinline__ u32 off(u32 w) const
+    {
+        const u32 low = (1u << w) - 1;
+        if ((cnt32 >> w) & 1)
+            return keys_bytes + 8 * S1 * n8 + 4 * S1 * (u32)__popc(cnt32 & low);
+        return keys_bytes + 8 * S1 * (u32)__popc(~cnt32 & low);
+    }
+};
+
 template <typename KT>
 __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const KT * __restrict__ keys, const u64 * __restrict__ words, const u64 * __restrict__ offsets,
-                                                       u32 G, u32 P, u64 n, u64 * __restrict__ pending, u32 S, u32 K)
+                                                       u32 G, u32 P, u64 n, u64 * __restrict__ pending, u32 S, u32 K, u32 cnt32)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    u64 * lkeys = (u64 *)lds_raw;
-    u64 * lwords = lkeys + (S + 1);
+    typedef typename std::conditional<sizeof(KT) == 4, unsigned int, unsigned long long>::type CasT;
+    KT * lkeys = (KT *)lds_raw;
+    PartLds L;
+    L.S1 = S + 1;
+    L.cnt32 = cnt32;
+    L.n8 = d.n_words - (u32)__popc(cnt32);
+    L.keys_bytes = ((u32)sizeof(KT) * L.S1 + 7) & ~7u;
+    const u32 lds_bytes = L.keys_bytes + 8 * L.S1 * L.n8 + 4 * L.S1 * (u32)__popc(cnt32);
     __shared__ u32 lzero;
-    const u32 lstride = S + 1;
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const u64 gstride = t.capacity + 1;
     for (u32 p = blockIdx.x; p < P; p += gridDim.x)
     {
-        for (u32 s = threadIdx.x; s < (d.n_words + 1) * lstride; s += blockDim.x)
-            lkeys[s] = 0;
+        for (u32 s = threadIdx.x; s < lds_bytes / 8 + 1; s += blockDim.x)
+            ((u64 *)lds_raw)[s] = 0; // the host rounds the allocation up to 8 bytes past lds_bytes
         if (threadIdx.x == 0)
             lzero = 0;
         __syncthreads();
@@ -786,10 +748,10 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
 #pragma unroll 1
                         for (int probe = 0; probe < 64; ++probe)
                         {
-                            u64 k = lkeys[s];
+                            KT k = lkeys[s];
                             if (k == 0)
-                                k = atomicCAS((unsigned long long *)&lkeys[s], 0ull, (unsigned long long)key), k = (k == 0) ? key : k;
-                            if (k == key)
+                                k = (KT)atomicCAS((CasT *)&lkeys[s], (CasT)0, (CasT)key), k = (k == 0) ? (KT)key : k;
+                            if (k == (KT)key)
                             {
                                 ls = s;
                                 break;
@@ -802,18 +764,29 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                         for (u32 j = 0; j < d.n_aggs; ++j)
                         {
                             const AggArg & a = d.a[j];
-                            u64 * w = lwords + a.word * lstride + ls;
+                            unsigned char * w = lds_raw + L.off(a.word);
                             if (a.kind == CHGPU_AGG_COUNT)
-                                atomicAdd((unsigned long long *)w, 1ull);
+                            {
+                                if ((cnt32 >> a.word) & 1)
+                                    atomicAdd((unsigned int *)w + ls, 1u);
+                                else
+                                    atomicAdd((unsigned long long *)w + ls, 1ull);
+                            }
                             else
                             {
                                 const u64 bits = a.pre == 0 ? argv[q][0] : argv[q][1];
                                 if (a.arg_type == CHGPU_F64)
-                                    atomicAdd((double *)w, __longlong_as_double((long long)bits));
+                                    atomicAdd((double *)w + ls, __longlong_as_double((long long)bits));
                                 else
-                                    atomicAdd((unsigned long long *)w, (unsigned long long)bits);
+                                    atomicAdd((unsigned long long *)w + ls, (unsigned long long)bits);
                                 if (a.kind == CHGPU_AGG_AVG)
-                                    atomicAdd((unsigned long long *)(w + lstride), 1ull);
+                                {
+                                    unsigned char * wc = lds_raw + L.off(a.word + 1);
+                                    if ((cnt32 >> (a.word + 1)) & 1)
+                                        atomicAdd((unsigned int *)wc + ls, 1u);
+                                    else
+                                        atomicAdd((unsigned long long *)wc + ls, 1ull);
+                                }
                             }
                         }
                     }
@@ -852,7 +825,7 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
         __syncthreads();
         for (u32 s = threadIdx.x; s <= S; s += blockDim.x)
         {
-            const u64 key = lkeys[s];
+            const u64 key = (u64)lkeys[s];
             const bool occupied = (s == S) ? (lzero != 0) : (key != 0);
             if (!occupied)
                 continue;
@@ -864,7 +837,8 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
             }
             for (u32 w = 0; w < d.n_words; ++w)
             {
-                const u64 bits = lwords[w * lstride + s];
+                const unsigned char * wp = lds_raw + L.off(w);
+                const u64 bits = ((cnt32 >> w) & 1) ? (u64)((const u32 *)wp)[s] : ((const u64 *)wp)[s];
                 if (bits != 0)
                     global_add_word(t.words + (u64)w * gstride + slot, bits, (d.word_is_f64 >> w) & 1);
             }
@@ -1108,11 +1082,25 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
 {
     chgpu_ctx * ctx = a->ctx;
     CHGPU_TRY(agg_ensure_table(a));
-    // LDS table of the aggregate pass: as many cells as fit ~100 KiB, one 1024-thread workgroup per CU
-    static const u32 s_max = getenv("CHGPU_TUNE_GB_S") ? (u32)atoi(getenv("CHGPU_TUNE_GB_S")) : 4096;
-    static const u32 s_kib = getenv("CHGPU_TUNE_GB_KIB") ? (u32)atoi(getenv("CHGPU_TUNE_GB_KIB")) : 100;
+    // LDS table of the aggregate pass (one 1024-thread workgroup per CU): compact cells -- key as wide as the partition
+    // buffer's keys, COUNT words as 32 bits while the call has fewer than 2^32 rows -- and as many cells as fit ~150 KiB
+    const bool key32 = chgpu_type_size(a->key_type) <= 4; // 4-byte (or narrower) keys are stored as 4 bytes in the partition buffers
+    u32 cnt32 = 0;
+    static const bool no_cnt32 = getenv("CHGPU_TUNE_GB_NOCNT32") != nullptr;
+    if (n < (1ull << 32) && !no_cnt32)
+        for (u32 j = 0; j < a->n_aggs; ++j)
+        {
+            if (a->kinds[j] == CHGPU_AGG_COUNT)
+                cnt32 |= 1u << a->word_off[j];
+            else if (a->kinds[j] == CHGPU_AGG_AVG)
+                cnt32 |= 1u << (a->word_off[j] + 1);
+        }
+    const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
+    const size_t cell_b = (key32 ? 4 : 8) + 8 * n8 + 4 * n4;
+    static const u32 s_max = getenv("CHGPU_TUNE_GB_S") ? (u32)atoi(getenv("CHGPU_TUNE_GB_S")) : 8192;
+    static const u32 s_kib = getenv("CHGPU_TUNE_GB_KIB") ? (u32)atoi(getenv("CHGPU_TUNE_GB_KIB")) : 150;
     u32 S = s_max;
-    while ((size_t)(S + 1) * 8 * (1 + a->n_words) > (size_t)s_kib * 1024 && S > 256)
+    while ((size_t)(S + 1) * cell_b + 32 > (size_t)s_kib * 1024 && S > 256)
         S >>= 1;
     // partitions so that a partition's expected groups fill at most half the LDS table
     u64 want_p = (a->size_hint + S / 2 - 1) / (S / 2);
@@ -1130,10 +1118,13 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     }
     const u32 G = (u32)ctx->num_cus * GBP_WG_PER_CU;
     u64 rows_per_wg = (n + G - 1) / G;
-    const bool key32 = chgpu_type_size(a->key_type) <= 4; // 4-byte (or narrower) keys are stored as 4 bytes in the partition buffers
-    // the scatter's LDS image is tile*(8*K + key bytes + 2) + 16*P bytes and must stay under ~150 KiB
-    const bool big_tile = (size_t)GBP_TILE_MAX * (8 * K + (key32 ? 4 : 8) + 2) + (size_t)P * 16 <= 150 * 1024;
-    const u32 tile = big_tile ? GBP_TILE_MAX : GBP_TILE_MAX / 2;
+    // the scatter's LDS image is tile*(8*K + key bytes) + 16*P bytes and must stay under ~156 KiB
+    const size_t row_lds = 8 * K + (key32 ? 4 : 8);
+    static const u32 tile_cap = getenv("CHGPU_TUNE_GB_TILE") ? (u32)atoi(getenv("CHGPU_TUNE_GB_TILE")) : 12288;
+    u32 tile = 4096;
+    for (u32 cand : {8192u, 12288u})
+        if (cand <= tile_cap && cand * row_lds + (size_t)P * 16 + 64 <= 156 * 1024)
+            tile = cand;
     rows_per_wg = (rows_per_wg + tile - 1) / tile * tile;
     static const bool debug = getenv("CHGPU_DEBUG") != nullptr;
     if (debug)
@@ -1192,19 +1183,20 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     int rc = chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, m, total_dev, tmp, tmp_b);
     if (rc == CHGPU_OK)
     {
-        const size_t lds_sc = (size_t)tile * (8 * K + (key32 ? 4 : 8) + 2) + (size_t)P * 16 + 64;
+        const size_t lds_sc = (size_t)tile * row_lds + (size_t)P * 16 + 64;
 #define GB_SCATTER(TILE_, KT_) do { if (wide) GB_SCATTER_W(TILE_, KT_, true); else GB_SCATTER_W(TILE_, KT_, false); } while (0)
 #define GB_SCATTER_W(TILE_, KT_, W_)                                                                                                            \
     do                                                                                                                                          \
     {                                                                                                                                           \
-        auto kern = k_gb_scatter<TILE_, KT_, W_>;                                                                                                 \
+        auto kern = k_gb_scatter<TILE_, KT_, W_>;                                                                                               \
         rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
         if (rc == CHGPU_OK)                                                                                                                     \
             hipLaunchKernelGGL(kern, dim3(G), dim3(GBP_THREADS), lds_sc, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P, \
                                (const u64 *)offsets, gc, (KT_ *)pkeys);                                                                          \
     } while (0)
-        if (big_tile) { if (key32) GB_SCATTER(GBP_TILE_MAX, u32); else GB_SCATTER(GBP_TILE_MAX, u64); }
-        else          { if (key32) GB_SCATTER(GBP_TILE_MAX / 2, u32); else GB_SCATTER(GBP_TILE_MAX / 2, u64); }
+        if (tile == 12288)     { if (key32) GB_SCATTER(12288, u32); else GB_SCATTER(12288, u64); }
+        else if (tile == 8192) { if (key32) GB_SCATTER(8192, u32); else GB_SCATTER(8192, u64); }
+        else                   { if (key32) GB_SCATTER(4096, u32); else GB_SCATTER(4096, u64); }
 #undef GB_SCATTER
 #undef GB_SCATTER_W
     }
@@ -1212,19 +1204,20 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         rc = hipMemsetAsync(pending, 0, pend_b, ctx->stream) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
     if (rc == CHGPU_OK)
     {
-        const size_t lds_ag = (size_t)(S + 1) * 8 * (1 + a->n_words);
+        const size_t keys_lds = ((size_t)(key32 ? 4 : 8) * (S + 1) + 7) & ~(size_t)7;
+        const size_t lds_ag = keys_lds + (size_t)(S + 1) * (8 * n8 + 4 * n4) + 16; // the kernel zeroes whole 8-byte words
         u32 grid = P < (u32)ctx->num_cus ? P : (u32)ctx->num_cus;
         if (key32)
         {
             rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
             if (rc == CHGPU_OK)
-                hipLaunchKernelGGL(k_agg_part_lds<u32>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)pkeys, (const u64 *)pwords, (const u64 *)offsets, G, P, n, pending, S, K);
+                hipLaunchKernelGGL(k_agg_part_lds<u32>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)pkeys, (const u64 *)pwords, (const u64 *)offsets, G, P, n, pending, S, K, cnt32);
         }
         else
         {
             rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
             if (rc == CHGPU_OK)
-                hipLaunchKernelGGL(k_agg_part_lds<u64>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const u64 *)pwords, (const u64 *)offsets, G, P, n, pending, S, K);
+                hipLaunchKernelGGL(k_agg_part_lds<u64>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const u64 *)pwords, (const u64 *)offsets, G, P, n, pending, S, K, cnt32);
         }
     }
     ctx->counters[6] += 3;
