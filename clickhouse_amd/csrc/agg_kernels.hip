@@ -682,8 +682,9 @@ struct PartLds
 };
 
 template <typename KT>
-__global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const KT * __restrict__ keys, const u64 * __restrict__ words, const u64 * __restrict__ offsets,
-                                                       u32 G, u32 P, u64 n, u64 * __restrict__ pending, u32 S, u32 K, u32 cnt32)
+__global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const KT * __restrict__ keys, const u64 * __restrict__ words0, const u64 * __restrict__ words1,
+                                                       const u64 * __restrict__ offsets, u32 G, u32 P, u64 n, u64 * __restrict__ pending, u32 S, u32 K, u32 cnt32,
+                                                       u64 rows_per_chunk, u64 row_off)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     typedef typename std::conditional<sizeof(KT) == 4, unsigned int, unsigned long long>::type CasT;
@@ -704,8 +705,11 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
         if (threadIdx.x == 0)
             lzero = 0;
         __syncthreads();
-        const u64 begin = offsets[(u64)p * G];
-        const u64 end = p + 1 < P ? offsets[(u64)(p + 1) * G] : n;
+        // PARTITION mode: partition p of the partition buffers.  RANGE mode (offsets == nullptr): chunk p of the source
+        // columns themselves (keys/words0/words1 point at the block's first row; row_off is that row's index for the
+        // HBM fallback, whose descriptor addresses whole columns) -- the low-cardinality GROUP BY runs this way.
+        const u64 begin = offsets ? offsets[(u64)p * G] : (u64)p * rows_per_chunk;
+        const u64 end = offsets ? (p + 1 < P ? offsets[(u64)(p + 1) * G] : n) : (begin + rows_per_chunk < n ? begin + rows_per_chunk : n);
         const u64 g0 = begin / 64, g1 = (end + 63) / 64;
         constexpr int PR = 4;  // 64-row groups per wave iteration: all their loads are issued before LDS is touched
         constexpr u32 PPRE = 2; // argument words preloaded per row (GBP_MAX_K)
@@ -719,9 +723,8 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                 u64 i = (gb + q) * 64 + lane;
                 i = i < n ? i : n - 1;
                 kv[q] = (u64)__builtin_nontemporal_load(&keys[i]);
-                // the K argument word columns of the partition buffers, n rows apart
-                av[q][0] = K > 0 ? __builtin_nontemporal_load(&words[i]) : 0;
-                av[q][1] = K > 1 ? __builtin_nontemporal_load(&words[n + i]) : 0;
+                av[q][0] = K > 0 ? __builtin_nontemporal_load(&words0[i]) : 0;
+                av[q][1] = K > 1 ? __builtin_nontemporal_load(&words1[i]) : 0;
             }
         };
         auto process_set = [&](u64 gb, const u64 (&keyv)[PR], const u64 (&argv)[PR][PPRE]) {
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                         if (slot == ~0ull)
                             failed = true;
                         else
-                            add_row_global(t, d, slot, i);
+                            add_row_global(t, d, slot, row_off + i);
                     }
                 }
                 const u64 b = __ballot(failed);
@@ -1211,13 +1214,13 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         {
             rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
             if (rc == CHGPU_OK)
-                hipLaunchKernelGGL(k_agg_part_lds<u32>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)pkeys, (const u64 *)pwords, (const u64 *)offsets, G, P, n, pending, S, K, cnt32);
+                hipLaunchKernelGGL(k_agg_part_lds<u32>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)pkeys, (const u64 *)pwords, (const u64 *)pwords + n, (const u64 *)offsets, G, P, n, pending, S, K, cnt32, (u64)0, (u64)0);
         }
         else
         {
             rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
             if (rc == CHGPU_OK)
-                hipLaunchKernelGGL(k_agg_part_lds<u64>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const u64 *)pwords, (const u64 *)offsets, G, P, n, pending, S, K, cnt32);
+                hipLaunchKernelGGL(k_agg_part_lds<u64>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const u64 *)pwords, (const u64 *)pwords + n, (const u64 *)offsets, G, P, n, pending, S, K, cnt32, (u64)0, (u64)0);
         }
     }
     ctx->counters[6] += 3;
@@ -1312,7 +1315,71 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
     }
     // strategy: LDS-staged unless the caller promised a large cardinality (where nearly every key misses the LDS table)
     const bool use_lds = a->size_hint <= 65536;
-    if (use_lds)
+    // RANGE mode of the partition-aggregate kernel: 4/8-byte keys, at most GBP_MAX_K argument columns, all 8 bytes wide
+    bool ranged = use_lds && (chgpu_type_size(a->key_type) == 4 || chgpu_type_size(a->key_type) == 8) && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED");
+    u32 rk = 0;
+    const u64 * rwords[GBP_MAX_K] = {nullptr, nullptr};
+    for (u32 j = 0; j < a->n_aggs && ranged; ++j)
+    {
+        if (a->kinds[j] == CHGPU_AGG_COUNT)
+            continue;
+        if (rk == GBP_MAX_K || chgpu_type_size(a->arg_types[j]) != 8)
+            ranged = false;
+        else
+        {
+            rwords[rk] = (const u64 *)arg_cols[j]->data + row_begin;
+            d.a[j].pre = rk++;
+        }
+    }
+    if (ranged)
+    {
+        const bool key32 = chgpu_type_size(a->key_type) == 4;
+        u32 cnt32 = 0;
+        for (u32 j = 0; j < a->n_aggs; ++j)
+        {
+            if (a->kinds[j] == CHGPU_AGG_COUNT)
+                cnt32 |= 1u << a->word_off[j];
+            else if (a->kinds[j] == CHGPU_AGG_AVG)
+                cnt32 |= 1u << (a->word_off[j] + 1);
+        }
+        const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
+        const size_t cell_b = (key32 ? 4 : 8) + 8 * n8 + 4 * n4;
+        // cells: twice the promised groups (4096 when nothing was promised), bounded by ~150 KiB of LDS; tables of up to
+        // ~76 KiB let two 1024-thread workgroups share a CU
+        static const u32 s_dflt = getenv("CHGPU_TUNE_AGG_RANGED_S") ? (u32)atoi(getenv("CHGPU_TUNE_AGG_RANGED_S")) : 4096;
+        u32 S = s_dflt;
+        if (a->size_hint)
+            for (S = 1024; S < 2 * a->size_hint && S < 8192; S <<= 1)
+                ;
+        while ((size_t)(S + 1) * cell_b + 32 > 150 * 1024 && S > 256)
+            S >>= 1;
+        const size_t keys_lds = ((size_t)(key32 ? 4 : 8) * (S + 1) + 7) & ~(size_t)7;
+        const size_t lds_ag = keys_lds + (size_t)(S + 1) * (8 * n8 + 4 * n4) + 16;
+        const u32 wg_per_cu = lds_ag <= 76 * 1024 ? 2 : 1;
+        // flushes may claim up to grid * (S+1) cells above max fill: keep that inside the slack (capacity/2)
+        const u64 max_grid = (a->t.capacity / 2) / (S + 1);
+        u64 chunks = (u64)ctx->num_cus * wg_per_cu;
+        if (chunks > max_grid)
+            chunks = max_grid ? max_grid : 1;
+        if (chunks > (n + 4095) / 4096)
+            chunks = (n + 4095) / 4096;
+        const u64 rows_per_chunk = ((n + chunks - 1) / chunks + 63) / 64 * 64;
+        chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
+        CHGPU_HIP(hipMemsetAsync(pending, 0, n_words64 * sizeof(u64), ctx->stream));
+        if (key32)
+        {
+            CHGPU_HIP(hipFuncSetAttribute((const void *)k_agg_part_lds<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag));
+            hipLaunchKernelGGL(k_agg_part_lds<u32>, dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)key_col->data + row_begin, rwords[0], rwords[1],
+                               (const u64 *)nullptr, 1u, (u32)chunks, n, pending, S, rk, cnt32, rows_per_chunk, row_begin);
+        }
+        else
+        {
+            CHGPU_HIP(hipFuncSetAttribute((const void *)k_agg_part_lds<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag));
+            hipLaunchKernelGGL(k_agg_part_lds<u64>, dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)key_col->data + row_begin, rwords[0], rwords[1],
+                               (const u64 *)nullptr, 1u, (u32)chunks, n, pending, S, rk, cnt32, rows_per_chunk, row_begin);
+        }
+    }
+    else if (use_lds)
     {
         // LDS cells per workgroup: the largest power of two with (1 + n_words) * 8 * (S+1) <= AGG_LDS_BYTES
         u32 S = 4096;
