@@ -22,6 +22,7 @@
 // (HashTable.h:921-944) restructured for a device that cannot realloc inside a kernel.
 #include "chgpu_internal.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -1079,15 +1080,11 @@ static void agg_fill_desc(const chgpu_agg * a, const chgpu_col * const * arg_col
 
 static int agg_finish_rounds(chgpu_agg * a, const AggDesc & d, const void * keys, int key_type, u64 row_begin, u64 n, u64 * pending);
 
-// PARTITIONED executeOnBlock (see the kernel block comment).  Returns NOT_IMPLEMENTED when the shape does not fit
-// (the caller then uses the DIRECT kernel).
-static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols, u64 row_begin, u64 n, u32 K)
+// Compact LDS cell of the partition-aggregate kernel for this aggregator's shape (see PartLds): bytes per cell and which
+// state words are 32-bit counts.
+static size_t agg_part_cell_bytes(const chgpu_agg * a, u64 n, u32 * cnt32_out)
 {
-    chgpu_ctx * ctx = a->ctx;
-    CHGPU_TRY(agg_ensure_table(a));
-    // LDS table of the aggregate pass (one 1024-thread workgroup per CU): compact cells -- key as wide as the partition
-    // buffer's keys, COUNT words as 32 bits while the call has fewer than 2^32 rows -- and as many cells as fit ~150 KiB
-    const bool key32 = chgpu_type_size(a->key_type) <= 4; // 4-byte (or narrower) keys are stored as 4 bytes in the partition buffers
+    const bool key32 = chgpu_type_size(a->key_type) <= 4;
     u32 cnt32 = 0;
     static const bool no_cnt32 = getenv("CHGPU_TUNE_GB_NOCNT32") != nullptr;
     if (n < (1ull << 32) && !no_cnt32)
@@ -1099,15 +1096,61 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
                 cnt32 |= 1u << (a->word_off[j] + 1);
         }
     const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
-    const size_t cell_b = (key32 ? 4 : 8) + 8 * n8 + 4 * n4;
+    if (cnt32_out)
+        *cnt32_out = cnt32;
+    return (key32 ? 4 : 8) + 8 * n8 + 4 * n4;
+}
+
+// Largest power-of-two cell count whose table fits ~150 KiB of LDS (at most 8192).
+static u32 agg_part_max_cells(size_t cell_b)
+{
     static const u32 s_max = getenv("CHGPU_TUNE_GB_S") ? (u32)atoi(getenv("CHGPU_TUNE_GB_S")) : 8192;
     static const u32 s_kib = getenv("CHGPU_TUNE_GB_KIB") ? (u32)atoi(getenv("CHGPU_TUNE_GB_KIB")) : 150;
     u32 S = s_max;
     while ((size_t)(S + 1) * cell_b + 32 > (size_t)s_kib * 1024 && S > 256)
         S >>= 1;
+    return S;
+}
+
+// Number of distinct keys D that makes a uniform sample of m rows show d distinct ones: d = D (1 - exp(-m / D)).
+// (the reference adapts its strategy from observed statistics too: Aggregator.cpp:944-958, :83-89)
+static u64 agg_estimate_groups(u64 d, u64 m)
+{
+    if (d == 0)
+        return 0;
+    if ((double)d >= 0.97 * (double)m)
+        return ~0ull >> 8; // (nearly) every sampled row opened a group: no upper bound can be inferred
+    double lo = (double)d, hi = 1e15;
+    for (int it = 0; it < 200 && hi / lo > 1.0001; ++it)
+    {
+        const double mid = std::sqrt(lo * hi);
+        const double seen = mid * (1.0 - std::exp(-(double)m / mid));
+        if (seen < (double)d)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return (u64)hi;
+}
+
+// PARTITIONED executeOnBlock (see the kernel block comment).  Returns NOT_IMPLEMENTED when the shape does not fit
+// (the caller then uses the DIRECT kernel).
+static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols, u64 row_begin, u64 n, u32 K)
+{
+    chgpu_ctx * ctx = a->ctx;
+    CHGPU_TRY(agg_ensure_table(a));
+    // LDS table of the aggregate pass (one 1024-thread workgroup per CU): compact cells -- key as wide as the partition
+    // buffer's keys, COUNT words as 32 bits while the call has fewer than 2^32 rows -- and as many cells as fit ~150 KiB
+    const bool key32 = chgpu_type_size(a->key_type) <= 4; // 4-byte (or narrower) keys are stored as 4 bytes in the partition buffers
+    u32 cnt32 = 0;
+    const size_t cell_b = agg_part_cell_bytes(a, n, &cnt32);
+    const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
+    const u32 S = agg_part_max_cells(cell_b);
     // partitions so that a partition's expected groups fill at most half the LDS table
     u64 want_p = (a->size_hint + S / 2 - 1) / (S / 2);
     u32 P = 64;
+    while (P < (u32)ctx->num_cus && P < GBP_MAX_P) // the aggregate pass runs one workgroup per partition: give every CU one
+        P <<= 1;
     while (P < want_p && P < GBP_MAX_P)
         P <<= 1;
     if ((u64)P * (S / 2) < a->size_hint / 4) // hopelessly more groups than P * S: partitioning would not localise them
@@ -1277,19 +1320,28 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
     if (n == 0)
         return CHGPU_OK;
     CHGPU_TRY(agg_ensure_table(a));
-    // Adaptive strategy for callers that gave no size hint (the reference adapts too: consecutive-key cache hit rate,
-    // Aggregator.cpp:944-958; two-level conversion, :83-89): aggregate the first 4 Mi rows through the LDS-staged kernel,
-    // look at how many groups they produced, and let the remaining rows take the partitioned path when the cardinality is
-    // clearly beyond what per-workgroup LDS tables can absorb.
-    if (a->size_hint <= 65536 && a->n_groups > 65536)
-        a->size_hint = a->n_groups * 2;
+    // Strategy by promised/observed cardinality:
+    //   groups <= what one workgroup's LDS table holds (~70 % of its cells)   -> LDS-staged (RANGE mode / k_agg_rows_lds)
+    //   more, with enough rows to amortise two extra passes                   -> PARTITIONED
+    //   otherwise (or hopelessly many groups)                                 -> DIRECT
+    // Callers that gave no size hint (the reference adapts too: consecutive-key cache hit rate, Aggregator.cpp:944-958;
+    // two-level conversion, :83-89): the first 1 Mi rows go through the LDS-staged kernel and the number of groups they
+    // produced is extrapolated to the whole input.
+    const u32 lds_cells = agg_part_max_cells(agg_part_cell_bytes(a, n, nullptr));
+    const u64 lds_groups = (u64)lds_cells * 7 / 10;
+    if (a->size_hint <= lds_groups && a->n_groups > lds_groups)
+        a->size_hint = a->n_groups * 2; // the table already outgrew the LDS strategy
     if (a->size_hint == 0 && !a->hint_probed && n >= (8ull << 20))
     {
         a->hint_probed = true;
-        const u64 probe_rows = 4ull << 20;
+        const u64 probe_rows = 1ull << 20;
+        const u64 before = a->n_groups;
         CHGPU_TRY(chgpu_agg_add_block(a, key_col, arg_cols, row_begin, row_begin + probe_rows));
-        if (a->n_groups > 65536)
-            a->size_hint = a->n_groups >= probe_rows / 2 ? a->n_groups * 8 : a->n_groups * 2;
+        if (a->n_groups > lds_groups / 2)
+        {
+            const u64 est = agg_estimate_groups(a->n_groups - before, probe_rows);
+            a->size_hint = before + est + est / 4;
+        }
         return chgpu_agg_add_block(a, key_col, arg_cols, row_begin + probe_rows, row_end);
     }
     AggDesc d;
@@ -1306,7 +1358,7 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
         for (u32 j = 0; j < a->n_aggs; ++j)
             if (a->kinds[j] != CHGPU_AGG_COUNT)
                 ++n_argwords;
-        if (a->size_hint > 65536 && n >= (4u << 20) && n_argwords <= GBP_MAX_K && !getenv("CHGPU_AGG_NO_PARTITION"))
+        if (a->size_hint > lds_groups && n >= (4u << 20) && n_argwords <= GBP_MAX_K && !getenv("CHGPU_AGG_NO_PARTITION"))
         {
             int rc = agg_add_block_partitioned(a, key_col, arg_cols, row_begin, n, n_argwords);
             if (rc != CHGPU_ERR_NOT_IMPLEMENTED)
@@ -1314,7 +1366,7 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
         }
     }
     // strategy: LDS-staged unless the caller promised a large cardinality (where nearly every key misses the LDS table)
-    const bool use_lds = a->size_hint <= 65536;
+    const bool use_lds = a->size_hint <= 65536; // beyond that nearly every key misses a workgroup's LDS table
     // RANGE mode of the partition-aggregate kernel: 4/8-byte keys, at most GBP_MAX_K argument columns, all 8 bytes wide
     bool ranged = use_lds && (chgpu_type_size(a->key_type) == 4 || chgpu_type_size(a->key_type) == 8) && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED");
     u32 rk = 0;
@@ -1335,24 +1387,17 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
     {
         const bool key32 = chgpu_type_size(a->key_type) == 4;
         u32 cnt32 = 0;
-        for (u32 j = 0; j < a->n_aggs; ++j)
-        {
-            if (a->kinds[j] == CHGPU_AGG_COUNT)
-                cnt32 |= 1u << a->word_off[j];
-            else if (a->kinds[j] == CHGPU_AGG_AVG)
-                cnt32 |= 1u << (a->word_off[j] + 1);
-        }
+        (void)agg_part_cell_bytes(a, n, &cnt32);
         const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
-        const size_t cell_b = (key32 ? 4 : 8) + 8 * n8 + 4 * n4;
-        // cells: twice the promised groups (4096 when nothing was promised), bounded by ~150 KiB of LDS; tables of up to
-        // ~76 KiB let two 1024-thread workgroups share a CU
+        // cells: four times the promised groups (4096 when nothing was promised), bounded by ~150 KiB of LDS; tables of up
+        // to ~76 KiB let two 1024-thread workgroups share a CU
         static const u32 s_dflt = getenv("CHGPU_TUNE_AGG_RANGED_S") ? (u32)atoi(getenv("CHGPU_TUNE_AGG_RANGED_S")) : 4096;
         u32 S = s_dflt;
         if (a->size_hint)
-            for (S = 1024; S < 2 * a->size_hint && S < 8192; S <<= 1)
+            for (S = 1024; S < 4 * a->size_hint && S < lds_cells; S <<= 1)
                 ;
-        while ((size_t)(S + 1) * cell_b + 32 > 150 * 1024 && S > 256)
-            S >>= 1;
+        if (S > lds_cells)
+            S = lds_cells;
         const size_t keys_lds = ((size_t)(key32 ? 4 : 8) * (S + 1) + 7) & ~(size_t)7;
         const size_t lds_ag = keys_lds + (size_t)(S + 1) * (8 * n8 + 4 * n4) + 16;
         const u32 wg_per_cu = lds_ag <= 76 * 1024 ? 2 : 1;

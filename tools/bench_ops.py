@@ -50,6 +50,28 @@ if what in ("groupby", "all"):
         print(f"groupby rows={rows} groups={groups} hint={hint}: {dt*1e3:.2f} ms  {rows/dt:.3e} rows/s  {12*rows/dt/1e9:.1f} GB/s algorithmic (12 B/row)  groups_out={n}", flush=True)
         del k, v, kc, vc
 
+if what == "groupby_sweep":
+    # cardinality sweep (with and without a size hint) to place the strategy thresholds
+    for groups in (16, 1000, 4096, 16384, 65536, 262144, 1_000_000, 4_000_000, 16_000_000):
+        g = torch.Generator(device=dev).manual_seed(2)
+        k = torch.randint(0, groups, (rows,), dtype=torch.int32, device=dev, generator=g)
+        v = torch.randint(-2**31, 2**31, (rows,), dtype=torch.int64, device=dev, generator=g)
+        kc = ctx.wrap(k.data_ptr(), np.uint32, rows, keepalive=k)
+        vc = ctx.wrap(v.data_ptr(), np.int64, rows, keepalive=v)
+        res = []
+        for hint in (groups, 0):
+            def run():
+                a = ch.Aggregator(np.uint32, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], size_hint=hint, ctx=ctx)
+                a.execute_on_block(kc, [vc, None])
+                n = len(a)
+                a.close()
+                return n
+            dt, n = timed(run)
+            assert n == min(groups, n)
+            res.append(dt * 1e3)
+        print(f"groupby_sweep rows={rows} groups={groups}: hinted {res[0]:.2f} ms, no hint {res[1]:.2f} ms", flush=True)
+        del k, v, kc, vc
+
 if what in ("join", "all"):
     nb, npb = 10_000_000, min(rows, 100_000_000)
     g = torch.Generator(device=dev).manual_seed(5)
