@@ -33,14 +33,21 @@ static constexpr u64 AGG_MIN_CAPACITY = 1ull << 22; // 4 Mi cells: >= 2 Mi cells
 static constexpr u32 AGG_LDS_BYTES = 52 * 1024;    // LDS table budget per workgroup (3 workgroups per CU; 2048 cells x 24 B fits)
 static constexpr u32 AGG_THREADS = 256;
 
+// The group counter is striped: one same-address atomic per wave and claim serialises at ~10 ns each -- 16 M groups cost
+// 160 ms in the counter alone, and a rehash of 16 M cells 2.9 ms instead of 0.2.  A wave adds to (and checks the soft
+// limit against) the stripe picked by its workgroup/wave index, each stripe on its own 128-byte line.
+static constexpr u32 AGG_STRIPES = 64;
 struct AggCtrl
 {
-    unsigned long long n_groups; // occupied cells incl. the zero key
+    unsigned long long n_groups; // host side only: sum of the stripes, filled in by agg_read_ctrl
     u32 overflow;                // some row hit the max-fill limit and was left pending
     u32 has_zero;
     u32 fatal;                   // table completely full during a flush (cannot happen by construction)
     u32 pad;
+    unsigned long long pad2[13];
+    unsigned long long stripe[AGG_STRIPES][16]; // occupied cells incl. the zero key, [s][0] is the counter
 };
+static constexpr size_t AGG_HDR_BYTES = (sizeof(AggCtrl) + 255) / 256 * 256;
 
 struct AggArg
 {
@@ -79,7 +86,8 @@ struct chgpu_agg
     u32 word_is_f64 = 0;
     u64 size_hint = 0;
     AggTable t{nullptr, nullptr, 0, 0, nullptr};
-    void * table_mem = nullptr;
+    void * table_mem = nullptr; // from the context's column pool (stream-ordered reuse: no hipMalloc/hipFree per query)
+    size_t table_class = 0;
     u64 n_groups = 0; // host copy, refreshed after every call
     bool hint_probed = false; // the cardinality of a hint-less aggregation was sampled on its first large block
     u64 host_words[AGG_MAX_WORDS]; // without_key states live on the host (8 B each)
@@ -123,14 +131,15 @@ __device__ __forceinline__ void global_add_word(u64 * p, u64 bits, bool is_f64)
 // Find-or-claim the cell of `key` (emplace).  Returns the slot, or ~0 when the row must wait for a bigger table.
 // soft_limit: refuse to claim new cells once n_groups >= max_fill (rows); flushes/rehash pass false and may use
 // the slack above max fill.  Every loop is bounded by the capacity, so the wave always exits.
+__device__ __forceinline__ u32 agg_stripe() { return (blockIdx.x * 5 + (threadIdx.x >> 6)) & (AGG_STRIPES - 1); }
+
 __device__ __forceinline__ void count_claim(const AggTable & t, bool claimed)
 {
-    // one atomic per wave on the shared group counter (a per-lane atomicAdd on one address serialises the kernel)
+    // one atomic per wave, on the wave's stripe of the group counter
     const u64 cb = __ballot(claimed);
     if (claimed && mbcnt(cb) == 0)
-        atomicAdd(&t.ctrl->n_groups, (unsigned long long)__popcll(cb));
+        atomicAdd(&t.ctrl->stripe[agg_stripe()][0], (unsigned long long)__popcll(cb));
 }
-
 __device__ __forceinline__ u64 table_emplace_impl(const AggTable & t, u64 key, bool soft_limit, bool & claimed)
 {
     claimed = false;
@@ -151,7 +160,7 @@ __device__ __forceinline__ u64 table_emplace_impl(const AggTable & t, u64 key, b
             return slot;
         if (k == 0)
         {
-            if (soft_limit && __hip_atomic_load(&t.ctrl->n_groups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= t.max_fill)
+            if (soft_limit && __hip_atomic_load(&t.ctrl->stripe[agg_stripe()][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= t.max_fill / AGG_STRIPES)
                 return ~0ull;
             const u64 prev = atomicCAS((unsigned long long *)&t.keys[slot], 0ull, (unsigned long long)key);
             if (prev == 0)
@@ -190,6 +199,26 @@ __device__ __forceinline__ void add_row_global(const AggTable & t, const AggDesc
             global_add_word(w, load_arg_bits(a.ptr, a.arg_type, i), a.arg_type == CHGPU_F64);
             if (a.kind == CHGPU_AGG_AVG)
                 global_add_word(w + stride, 1, false); // denominator
+        }
+    }
+}
+
+// The same update from values already in registers: `bits0/bits1` are the 8-byte argument words selected by AggArg::pre,
+// `cnt` the number of rows they stand for.
+__device__ __forceinline__ void add_vals_global(const AggTable & t, const AggDesc & d, u64 slot, u64 bits0, u64 bits1, u64 cnt)
+{
+    const u64 stride = t.capacity + 1;
+    for (u32 j = 0; j < d.n_aggs; ++j)
+    {
+        const AggArg & a = d.a[j];
+        u64 * w = t.words + (u64)a.word * stride + slot;
+        if (a.kind == CHGPU_AGG_COUNT)
+            global_add_word(w, cnt, false);
+        else
+        {
+            global_add_word(w, a.pre == 0 ? bits0 : bits1, a.arg_type == CHGPU_F64);
+            if (a.kind == CHGPU_AGG_AVG)
+                global_add_word(w + stride, cnt, false); // denominator
         }
     }
 }
@@ -661,6 +690,37 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
     }
 }
 
+// Work units of the aggregate pass: partition p is cut into ceil(rows_p / chunk_rows) chunks so that a partition swollen
+// by a hot key (Zipf) is shared by many workgroups instead of serialising the pass on one.  unit_start[p] = first unit of
+// partition p, unit_start[P] = number of units; ctr is the dynamic work counter the workgroups draw units from.
+__global__ __launch_bounds__(1024) void k_gb_units(const u64 * __restrict__ offsets, u32 G, u32 P, u64 n, u64 chunk_rows, u32 * __restrict__ unit_start, u32 * __restrict__ ctr)
+{
+    __shared__ u32 sc[1024];
+    const u32 p = threadIdx.x;
+    u32 c = 0;
+    if (p < P)
+    {
+        const u64 begin = offsets[(u64)p * G];
+        const u64 end = p + 1 < P ? offsets[(u64)(p + 1) * G] : n;
+        c = (u32)((end - begin + chunk_rows - 1) / chunk_rows);
+    }
+    sc[p] = c;
+    __syncthreads();
+    for (u32 dlt = 1; dlt < 1024; dlt <<= 1)
+    {
+        const u32 o = p >= dlt ? sc[p - dlt] : 0;
+        __syncthreads();
+        sc[p] += o;
+        __syncthreads();
+    }
+    if (p < P)
+        unit_start[p] = sc[p] - c;
+    if (p == P - 1)
+        unit_start[P] = sc[p];
+    if (p == 0)
+        *ctr = 0;
+}
+
 // One workgroup aggregates whole partitions in LDS.  Partition p occupies rows [offsets[p*G], offsets[(p+1)*G]) of the
 // partition buffers (n for the last).  Rows whose key cannot be placed in LDS go to the HBM table directly; rows that hit
 // the max-fill limit there are marked pending (atomicOr: 64-row groups straddle partition boundaries).
@@ -685,7 +745,7 @@ struct PartLds
 template <typename KT>
 __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const KT * __restrict__ keys, const u64 * __restrict__ words0, const u64 * __restrict__ words1,
                                                        const u64 * __restrict__ offsets, u32 G, u32 P, u64 n, u64 * __restrict__ pending, u32 S, u32 K, u32 cnt32,
-                                                       u64 rows_per_chunk, u64 row_off)
+                                                       u64 rows_per_chunk, const u32 * __restrict__ unit_start, u32 * __restrict__ unit_ctr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     typedef typename std::conditional<sizeof(KT) == 4, unsigned int, unsigned long long>::type CasT;
@@ -696,21 +756,55 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
     L.n8 = d.n_words - (u32)__popc(cnt32);
     L.keys_bytes = ((u32)sizeof(KT) * L.S1 + 7) & ~7u;
     const u32 lds_bytes = L.keys_bytes + 8 * L.S1 * L.n8 + 4 * L.S1 * (u32)__popc(cnt32);
-    __shared__ u32 lzero;
+    __shared__ u32 lzero, sh_unit;
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const u64 gstride = t.capacity + 1;
-    for (u32 p = blockIdx.x; p < P; p += gridDim.x)
+    // PARTITION mode: work units (partition, chunk) are drawn from a device-wide counter until it passes the unit count
+    // (every workgroup reaches that exit).  RANGE mode (offsets == nullptr): chunk blockIdx.x, +gridDim.x, ... of the
+    // source columns themselves (keys/words0/words1 point at the block's first row) -- the low-cardinality GROUP BY runs this way.
+    const u32 n_units = offsets ? unit_start[P] : P;
+    for (u32 iter = 0;; ++iter)
     {
+        u32 unit;
+        if (offsets)
+        {
+            if (threadIdx.x == 0)
+                sh_unit = atomicAdd(unit_ctr, 1u);
+            __syncthreads();
+            unit = sh_unit;
+        }
+        else
+            unit = blockIdx.x + iter * gridDim.x;
+        if (unit >= n_units)
+            break;
+        u64 begin, end;
+        if (offsets)
+        {
+            u32 lo = 0, hi = P - 1; // largest p with unit_start[p] <= unit
+            while (lo < hi)
+            {
+                const u32 mid = (lo + hi + 1) >> 1;
+                if (unit_start[mid] <= unit)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            const u32 p = lo;
+            const u64 pbegin = offsets[(u64)p * G];
+            const u64 pend = p + 1 < P ? offsets[(u64)(p + 1) * G] : n;
+            begin = pbegin + (u64)(unit - unit_start[p]) * rows_per_chunk;
+            end = begin + rows_per_chunk < pend ? begin + rows_per_chunk : pend;
+        }
+        else
+        {
+            begin = (u64)unit * rows_per_chunk;
+            end = begin + rows_per_chunk < n ? begin + rows_per_chunk : n;
+        }
         for (u32 s = threadIdx.x; s < lds_bytes / 8 + 1; s += blockDim.x)
             ((u64 *)lds_raw)[s] = 0; // the host rounds the allocation up to 8 bytes past lds_bytes
         if (threadIdx.x == 0)
             lzero = 0;
         __syncthreads();
-        // PARTITION mode: partition p of the partition buffers.  RANGE mode (offsets == nullptr): chunk p of the source
-        // columns themselves (keys/words0/words1 point at the block's first row; row_off is that row's index for the
-        // HBM fallback, whose descriptor addresses whole columns) -- the low-cardinality GROUP BY runs this way.
-        const u64 begin = offsets ? offsets[(u64)p * G] : (u64)p * rows_per_chunk;
-        const u64 end = offsets ? (p + 1 < P ? offsets[(u64)(p + 1) * G] : n) : (begin + rows_per_chunk < n ? begin + rows_per_chunk : n);
         const u64 g0 = begin / 64, g1 = (end + 63) / 64;
         constexpr int PR = 4;  // 64-row groups per wave iteration: all their loads are issued before LDS is touched
         constexpr u32 PPRE = 2; // argument words preloaded per row (GBP_MAX_K)
@@ -728,6 +822,8 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                 av[q][1] = K > 1 ? __builtin_nontemporal_load(&words1[i]) : 0;
             }
         };
+        // (Combining the rows of a hot key in registers before the LDS atomic was tried for Zipf inputs: once partitions are
+        //  cut into work units it gains nothing -- 15.2 ms without vs 14.9-15.7 ms with -- and costs the uniform case 3-10 %.)
         auto process_set = [&](u64 gb, const u64 (&keyv)[PR], const u64 (&argv)[PR][PPRE]) {
 #pragma unroll
             for (int q = 0; q < PR; ++q)
@@ -800,7 +896,7 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                         if (slot == ~0ull)
                             failed = true;
                         else
-                            add_row_global(t, d, slot, row_off + i);
+                            add_vals_global(t, d, slot, argv[q][0], argv[q][1], 1);
                     }
                 }
                 const u64 b = __ballot(failed);
@@ -864,6 +960,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_tuples(AggTable t, u32 n_wo
     const u64 n_waves = ((u64)gridDim.x * AGG_THREADS) >> 6;
     const u64 n_groups64 = (n + 63) / 64;
     const u64 gstride = t.capacity + 1;
+    u32 my_claims = 0; // without a soft limit nobody reads the counter mid-kernel: count in registers, add once per wave
     for (u64 g = wave0; g < n_groups64; g += n_waves)
     {
         const u64 i = g * 64 + lane;
@@ -884,7 +981,12 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_tuples(AggTable t, u32 n_wo
                 key = 0;
             if (!(skip_zero_keys && key == 0 && !is_zero_cell))
             {
-                const u64 slot = table_emplace(t, key, soft_limit != 0);
+                bool claimed;
+                const u64 slot = table_emplace_impl(t, key, soft_limit != 0, claimed);
+                if (soft_limit)
+                    count_claim(t, claimed); // the only divergent caller: count_claim's ballot sees the lanes in this branch
+                else
+                    my_claims += claimed;
                 if (slot == ~0ull)
                     failed = true;
                 else
@@ -897,6 +999,15 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_tuples(AggTable t, u32 n_wo
             pending[g] = b;
         if (b != 0 && lane == 0)
             t.ctrl->overflow = 1;
+    }
+    if (!soft_limit)
+    {
+        u32 tot = my_claims;
+#pragma unroll
+        for (int dlt = 32; dlt >= 1; dlt >>= 1)
+            tot += __shfl_xor(tot, dlt, WAVE);
+        if (lane == 0 && tot)
+            atomicAdd(&t.ctrl->stripe[agg_stripe()][0], (unsigned long long)tot);
     }
 }
 
@@ -947,20 +1058,20 @@ static u64 pow2_ceil(u64 x)
     return p;
 }
 
-static int agg_alloc_table(chgpu_agg * a, u64 capacity, AggTable * t, void ** mem)
+static int agg_alloc_table(chgpu_agg * a, u64 capacity, AggTable * t, void ** mem, size_t * mem_class)
 {
     const size_t cells = capacity + 1;
-    const size_t bytes = cells * 8 * (1 + a->n_words) + 256;
+    const size_t bytes = cells * 8 * (1 + a->n_words) + AGG_HDR_BYTES;
     void * m = nullptr;
-    CHGPU_HIP(hipMalloc(&m, bytes));
+    CHGPU_TRY(chgpu_pool_alloc(a->ctx, bytes, &m, mem_class));
     hipError_t e = hipMemsetAsync(m, 0, bytes, a->ctx->stream); // HashTableAllocator zero-fills (HashTableAllocator.h:11)
     if (e != hipSuccess)
     {
-        (void)hipFree(m);
+        chgpu_pool_free(a->ctx, m, *mem_class);
         return chgpu_set_error(CHGPU_ERR_DEVICE, "memset: %s", hipGetErrorString(e));
     }
     t->ctrl = (AggCtrl *)m;
-    t->keys = (u64 *)((char *)m + 256);
+    t->keys = (u64 *)((char *)m + AGG_HDR_BYTES);
     t->words = t->keys + cells;
     t->capacity = capacity;
     t->max_fill = capacity / 2;
@@ -971,6 +1082,9 @@ static int agg_alloc_table(chgpu_agg * a, u64 capacity, AggTable * t, void ** me
 static int agg_read_ctrl(chgpu_agg * a, AggCtrl * out)
 {
     CHGPU_TRY(chgpu_read_back(a->ctx, a->t.ctrl, out, sizeof(AggCtrl)));
+    out->n_groups = 0;
+    for (u32 s = 0; s < AGG_STRIPES; ++s)
+        out->n_groups += out->stripe[s][0];
     a->n_groups = out->n_groups;
     CHGPU_REQUIRE(!out->fatal, CHGPU_ERR_LOGICAL, "aggregation table filled completely during a flush");
     return CHGPU_OK;
@@ -987,7 +1101,8 @@ static int agg_grow(chgpu_agg * a, u64 min_groups, bool has_zero)
     } while (cap / 2 <= min_groups);
     AggTable nt;
     void * nmem = nullptr;
-    CHGPU_TRY(agg_alloc_table(a, cap, &nt, &nmem));
+    size_t nclass = 0;
+    CHGPU_TRY(agg_alloc_table(a, cap, &nt, &nmem, &nclass));
     // old cells [0, capacity) plus the out-of-line zero cell when it is set; no soft limit: the new table fits them all
     const u64 n = a->t.capacity + (has_zero ? 1 : 0);
     const u32 grid = chgpu_grid_for(a->ctx, n, AGG_THREADS, 8);
@@ -996,9 +1111,9 @@ static int agg_grow(chgpu_agg * a, u64 min_groups, bool has_zero)
     a->ctx->counters[6] += 1;
     a->ctx->counters[7] += 1;
     CHGPU_HIP(hipGetLastError());
-    CHGPU_HIP(hipStreamSynchronize(a->ctx->stream));
-    CHGPU_HIP(hipFree(a->table_mem));
+    chgpu_pool_free(a->ctx, a->table_mem, a->table_class); // stream-ordered: later users queue behind the rehash
     a->table_mem = nmem;
+    a->table_class = nclass;
     a->t = nt;
     return CHGPU_OK;
 }
@@ -1010,7 +1125,7 @@ static int agg_ensure_table(chgpu_agg * a)
     u64 cap = pow2_ceil(a->size_hint * 2);
     if (cap < AGG_MIN_CAPACITY)
         cap = AGG_MIN_CAPACITY;
-    return agg_alloc_table(a, cap, &a->t, &a->table_mem);
+    return agg_alloc_table(a, cap, &a->t, &a->table_mem, &a->table_class);
 }
 
 extern "C" int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, const int * agg_kinds, const int * arg_types,
@@ -1058,7 +1173,7 @@ extern "C" int chgpu_agg_free(chgpu_agg * a)
     if (!a)
         return CHGPU_OK;
     if (a->table_mem)
-        (void)hipFree(a->table_mem);
+        chgpu_pool_free(a->ctx, a->table_mem, a->table_class);
     delete a;
     return CHGPU_OK;
 }
@@ -1155,8 +1270,15 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         P <<= 1;
     if ((u64)P * (S / 2) < a->size_hint / 4) // hopelessly more groups than P * S: partitioning would not localise them
         return CHGPU_ERR_NOT_IMPLEMENTED;
-    // every partition flush may claim up to S+1 cells without the max-fill check: keep all of them inside the slack
-    for (int guard = 0; guard < 16 && a->t.capacity / 2 < (u64)P * (S + 1) + a->n_groups; ++guard)
+    // work units of the aggregate pass: half an average partition each, so a uniform input gives every workgroup two
+    // units and a partition swollen by a hot key is spread over many workgroups; each unit flushes its LDS table once
+    static const u32 unit_div = getenv("CHGPU_TUNE_GB_UNITDIV") ? (u32)atoi(getenv("CHGPU_TUNE_GB_UNITDIV")) : 2;
+    u64 chunk_rows = (n / ((u64)P * unit_div) + 63) / 64 * 64;
+    if (chunk_rows < 65536)
+        chunk_rows = 65536;
+    const u64 max_units = n / chunk_rows + P; // sum over partitions of ceil(rows_p / chunk_rows)
+    // every unit's flush may claim up to S+1 cells without the max-fill check: keep all of them inside the slack
+    for (int guard = 0; guard < 16 && a->t.capacity / 2 < max_units * (S + 1) + a->n_groups; ++guard)
     {
         AggCtrl c0;
         CHGPU_TRY(agg_read_ctrl(a, &c0));
@@ -1179,7 +1301,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     // partition buffers (8-byte keys + K 8-byte words per row) and bookkeeping
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     const u64 m = (u64)P * G;
-    const size_t cnt_b = al(m * 4), off_b = al(m * 8 + 8), tmp_b = chgpu_scan_tmp_bytes(m), pend_b = al(((n + 63) / 64) * 8 + 8);
+    const size_t cnt_b = al(m * 4), off_b = al(m * 8 + 8), tmp_b = chgpu_scan_tmp_bytes(m), pend_b = al(((n + 63) / 64) * 8 + 8) + al((GBP_MAX_P + 2) * 4);
     // The partition buffers live in the context's scratch arena, which is kept between calls: a fresh hipMalloc of
     // 16 GB costs ~0.4 s, fifteen times the kernels it would serve.
     const size_t keys_b = al((size_t)n * (key32 ? 4 : 8));
@@ -1191,6 +1313,8 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     u64 * total_dev = (u64 *)((char *)scratch + cnt_b + off_b);
     void * tmp = (char *)scratch + cnt_b + off_b + 256;
     u64 * pending = (u64 *)((char *)scratch + cnt_b + off_b + 256 + tmp_b);
+    u32 * unit_start = (u32 *)((char *)pending + al(((n + 63) / 64) * 8 + 8)); // [P + 1] then the work counter
+    u32 * unit_ctr = unit_start + GBP_MAX_P + 1;
     void * pkeys = (char *)scratch + cnt_b + off_b + 256 + tmp_b + pend_b; // keys (4 or 8 B) | word0 | word1
     u64 * pwords = (u64 *)((char *)pkeys + keys_b);
 
@@ -1252,18 +1376,20 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     {
         const size_t keys_lds = ((size_t)(key32 ? 4 : 8) * (S + 1) + 7) & ~(size_t)7;
         const size_t lds_ag = keys_lds + (size_t)(S + 1) * (8 * n8 + 4 * n4) + 16; // the kernel zeroes whole 8-byte words
-        u32 grid = P < (u32)ctx->num_cus ? P : (u32)ctx->num_cus;
+        hipLaunchKernelGGL(k_gb_units, dim3(1), dim3(1024), 0, ctx->stream, (const u64 *)offsets, G, P, n, chunk_rows, unit_start, unit_ctr);
+        const u64 rows_per_chunk = chunk_rows;
+        u32 grid = (u32)ctx->num_cus;
         if (key32)
         {
             rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
             if (rc == CHGPU_OK)
-                hipLaunchKernelGGL(k_agg_part_lds<u32>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)pkeys, (const u64 *)pwords, (const u64 *)pwords + n, (const u64 *)offsets, G, P, n, pending, S, K, cnt32, (u64)0, (u64)0);
+                hipLaunchKernelGGL(k_agg_part_lds<u32>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)pkeys, (const u64 *)pwords, (const u64 *)pwords + n, (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr);
         }
         else
         {
             rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
             if (rc == CHGPU_OK)
-                hipLaunchKernelGGL(k_agg_part_lds<u64>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const u64 *)pwords, (const u64 *)pwords + n, (const u64 *)offsets, G, P, n, pending, S, K, cnt32, (u64)0, (u64)0);
+                hipLaunchKernelGGL(k_agg_part_lds<u64>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const u64 *)pwords, (const u64 *)pwords + n, (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr);
         }
     }
     ctx->counters[6] += 3;
@@ -1415,13 +1541,13 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
         {
             CHGPU_HIP(hipFuncSetAttribute((const void *)k_agg_part_lds<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag));
             hipLaunchKernelGGL(k_agg_part_lds<u32>, dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)key_col->data + row_begin, rwords[0], rwords[1],
-                               (const u64 *)nullptr, 1u, (u32)chunks, n, pending, S, rk, cnt32, rows_per_chunk, row_begin);
+                               (const u64 *)nullptr, 1u, (u32)chunks, n, pending, S, rk, cnt32, rows_per_chunk, (const u32 *)nullptr, (u32 *)nullptr);
         }
         else
         {
             CHGPU_HIP(hipFuncSetAttribute((const void *)k_agg_part_lds<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag));
             hipLaunchKernelGGL(k_agg_part_lds<u64>, dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)key_col->data + row_begin, rwords[0], rwords[1],
-                               (const u64 *)nullptr, 1u, (u32)chunks, n, pending, S, rk, cnt32, rows_per_chunk, row_begin);
+                               (const u64 *)nullptr, 1u, (u32)chunks, n, pending, S, rk, cnt32, rows_per_chunk, (const u32 *)nullptr, (u32 *)nullptr);
         }
     }
     else if (use_lds)

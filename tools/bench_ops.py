@@ -72,6 +72,28 @@ if what == "groupby_sweep":
         print(f"groupby_sweep rows={rows} groups={groups}: hinted {res[0]:.2f} ms, no hint {res[1]:.2f} ms", flush=True)
         del k, v, kc, vc
 
+if what == "groupby_zipf":
+    # SURVEY C3's skew variant: keys ~ Zipf(1.1) folded into [0, 1e6) (continuous inverse-CDF approximation on device)
+    groups, sz = 1_000_000, 1.1
+    g = torch.Generator(device=dev).manual_seed(2)
+    u = torch.rand(rows, device=dev, generator=g, dtype=torch.float64)
+    z = torch.floor(torch.pow(u * (float(groups) ** (1 - sz) - 1) + 1, 1 / (1 - sz))).to(torch.int64)
+    k = (z % groups).to(torch.int32)
+    del u, z
+    v = torch.randint(-2**31, 2**31, (rows,), dtype=torch.int64, device=dev, generator=g)
+    top = torch.bincount(k[: 10_000_000].to(torch.int64), minlength=groups).max().item() / 10_000_000
+    kc = ctx.wrap(k.data_ptr(), np.uint32, rows, keepalive=k)
+    vc = ctx.wrap(v.data_ptr(), np.int64, rows, keepalive=v)
+    for hint in (groups, 0):
+        def run():
+            a = ch.Aggregator(np.uint32, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], size_hint=hint, ctx=ctx)
+            a.execute_on_block(kc, [vc, None])
+            n = len(a)
+            a.close()
+            return n
+        dt, n = timed(run)
+        print(f"groupby_zipf rows={rows} hint={hint}: {dt*1e3:.2f} ms  {rows/dt:.3e} rows/s  groups_out={n}  hottest key share={top:.3f}", flush=True)
+
 if what in ("join", "all"):
     nb, npb = 10_000_000, min(rows, 100_000_000)
     g = torch.Generator(device=dev).manual_seed(5)
