@@ -38,21 +38,23 @@ struct JoinCtrl
 
 struct JoinTable
 {
-    u64 * keys;      // [cap+1], 0 = empty, cell cap = the zero key
+    u64 * kv;        // [cap+1][2] interleaved {key (0 = empty; cell cap = the zero key), value}: a probe's random access
+                     // fetches the key and the answer from ONE 16-byte cell (separate arrays cost two HBM transactions)
     u64 * first_row; // [cap+1] global row id of the first (ANY: min or max) inserted row
     u32 * cnt;       // [cap+1] rows per key (ALL)
     u64 * start;     // [cap+1] CSR start (ALL)
     u64 * used_by;   // [cap+1] left-row sequence that consumed this cell (INNER ANY)
     u64 * rowids;    // [inserted] CSR payload (ALL)
-    u64 * value;     // [cap+1] what a probe needs in ONE read: the row id itself (unique key / ANY), or MULTI | count | CSR start
+                     // value = the row id itself (unique key / ANY), or MULTI | count | CSR start
     u64 capacity;
     JoinCtrl * ctrl;
 };
 
 struct BuildBlock
 {
-    u64 * keys = nullptr; // zero-extended keys on device
+    u64 * keys = nullptr; // zero-extended keys on device (context pool)
     u8 * valid = nullptr; // NULL = all rows valid
+    size_t keys_class = 0, valid_class = 0;
     u64 rows = 0;
     u64 base = 0;         // running position of this block's first row in slot_of_row
 };
@@ -67,6 +69,7 @@ struct chgpu_join
     bool finished = false;
     JoinTable t{};
     void * table_mem = nullptr;
+    size_t table_class = 0;
     u64 n_keys = 0;
     u64 inserted = 0;
     u64 left_seq = 0; // running left-row sequence across joinBlock calls (INNER ANY)
@@ -104,8 +107,8 @@ __global__ __launch_bounds__(JT) void k_join_stage_keys(const void * __restrict_
     }
 }
 
-// `claimed` tells the caller a new cell was taken; callers add the per-wave total to ctrl->n_keys with ONE atomic (a
-// per-lane atomicAdd on that single address serialised the whole build: 6.3 ms for 1e7 rows).
+// `claimed` tells the caller a new cell was taken; callers count claims in registers and add them to ctrl->n_keys once
+// per wave when the kernel ends (a per-lane atomicAdd on that single address serialised the whole build: 6.3 ms for 1e7 rows).
 __device__ __forceinline__ u32 jt_emplace(const JoinTable & t, u64 key, bool & claimed)
 {
     claimed = false;
@@ -119,10 +122,10 @@ __device__ __forceinline__ u32 jt_emplace(const JoinTable & t, u64 key, bool & c
     u64 slot = dev_intHash64(key) & mask;
     for (u64 step = 0; step < t.capacity; ++step)
     {
-        u64 k = t.keys[slot];
+        u64 k = t.kv[2 * slot];
         if (k == 0)
         {
-            k = atomicCAS((unsigned long long *)&t.keys[slot], 0ull, (unsigned long long)key);
+            k = atomicCAS((unsigned long long *)&t.kv[2 * slot], 0ull, (unsigned long long)key);
             if (k == 0)
             {
                 claimed = true;
@@ -144,7 +147,7 @@ __device__ __forceinline__ u32 jt_find(const JoinTable & t, u64 key)
     u64 slot = dev_intHash64(key) & mask;
     for (u64 step = 0; step < t.capacity; ++step)
     {
-        const u64 k = t.keys[slot];
+        const u64 k = t.kv[2 * slot];
         if (k == key)
             return (u32)slot;
         if (k == 0)
@@ -158,6 +161,7 @@ __device__ __forceinline__ u32 jt_find(const JoinTable & t, u64 key)
 __global__ __launch_bounds__(JT) void k_join_insert(JoinTable t, const u64 * __restrict__ keys, const u8 * __restrict__ valid, u64 n,
                                                     u64 block_index, int maps_all, int take_last, u32 * __restrict__ slot_of_row)
 {
+    u32 my_claims = 0; // nobody reads n_keys before the kernel ends: count in registers, one atomic per wave at the end
     for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
     {
         u32 slot = NO_SLOT;
@@ -180,10 +184,15 @@ __global__ __launch_bounds__(JT) void k_join_insert(JoinTable t, const u64 * __r
             }
         }
         slot_of_row[i] = slot;
-        const u64 cb = __ballot(claimed);
-        if (claimed && mbcnt(cb) == 0)
-            atomicAdd(&t.ctrl->n_keys, (unsigned long long)__popcll(cb));
+        my_claims += claimed;
     }
+    // (a same-address atomic per wave and iteration costs ~10 ns each: 1.5 ms of a 1e7-row build)
+    u32 tot = my_claims;
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1)
+        tot += __shfl_xor(tot, dlt, 64);
+    if ((threadIdx.x & 63) == 0 && tot)
+        atomicAdd(&t.ctrl->n_keys, (unsigned long long)tot);
 }
 
 // build pass 3: CSR fill
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(JT) void k_join_finalize_values(JoinTable t, int ma
 {
     for (u64 s = (u64)blockIdx.x * JT + threadIdx.x; s <= t.capacity; s += (u64)gridDim.x * JT)
     {
-        const bool occupied = s == t.capacity ? (t.ctrl->has_zero != 0) : (t.keys[s] != 0);
+        const bool occupied = s == t.capacity ? (t.ctrl->has_zero != 0) : (t.kv[2 * s] != 0);
         u64 v = NO_ROW;
         if (occupied)
         {
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(JT) void k_join_finalize_values(JoinTable t, int ma
                     v = JV_MULTI | ((u64)(c < JV_CNT_SAT ? c : JV_CNT_SAT) << 40) | (t.start[s] & JV_START_MASK);
             }
         }
-        t.value[s] = v;
+        t.kv[2 * s + 1] = v;
     }
 }
 
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(JT) void k_join_probe_count(JoinTable t, int varian
                 slot = jt_find(t, jload_key(keys, key_type, i));
         }
         const bool found = slot != NO_SLOT;
-        const u64 v = found ? t.value[slot] : NO_ROW;
+        const u64 v = found ? t.kv[2 * (u64)slot + 1] : NO_ROW;
         u32 rows_here = 0; // RowRefList::rows of the matched cell
         if (found)
         {
@@ -410,11 +419,11 @@ extern "C" int chgpu_join_free(chgpu_join * j)
         return CHGPU_OK;
     for (auto & b : j->blocks)
     {
-        if (b.keys) (void)hipFree(b.keys);
-        if (b.valid) (void)hipFree(b.valid);
+        chgpu_pool_free(j->ctx, b.keys, b.keys_class);
+        chgpu_pool_free(j->ctx, b.valid, b.valid_class);
     }
     if (j->table_mem)
-        (void)hipFree(j->table_mem);
+        chgpu_pool_free(j->ctx, j->table_mem, j->table_class);
     delete j;
     return CHGPU_OK;
 }
@@ -438,14 +447,14 @@ extern "C" int chgpu_join_add_block(chgpu_join * j, const chgpu_col * key_col, c
     if (b.rows)
     {
         // the right block stays alive for the join's lifetime (data->blocks, HashJoin.cpp:656-658): keep its keys in HBM
-        CHGPU_HIP(hipMalloc((void **)&b.keys, b.rows * sizeof(u64)));
+        CHGPU_TRY(chgpu_pool_alloc(ctx, b.rows * sizeof(u64), (void **)&b.keys, &b.keys_class));
         if (null_map || join_mask)
         {
-            hipError_t e = hipMalloc((void **)&b.valid, b.rows);
-            if (e != hipSuccess)
+            const int rc = chgpu_pool_alloc(ctx, b.rows, (void **)&b.valid, &b.valid_class);
+            if (rc != CHGPU_OK)
             {
-                (void)hipFree(b.keys);
-                return chgpu_set_error(CHGPU_ERR_OOM, "hipMalloc: %s", hipGetErrorString(e));
+                chgpu_pool_free(ctx, b.keys, b.keys_class);
+                return rc;
             }
         }
         hipLaunchKernelGGL(k_join_stage_keys, dim3(chgpu_grid_for(ctx, b.rows, JT, 8)), dim3(JT), 0, ctx->stream, (const void *)key_col->data, key_col->type,
@@ -474,26 +483,24 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
     CHGPU_REQUIRE(cap + 1 < 0xFFFFFFFFull, CHGPU_ERR_NOT_IMPLEMENTED, "build side of %llu rows exceeds the 32-bit cell index", (unsigned long long)j->total_rows);
     const u64 cells = cap + 1;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
-    size_t off_keys = 256, off_first = off_keys + al(cells * 8), off_cnt = off_first + al(cells * 8);
+    size_t off_keys = 256, off_first = off_keys + al(cells * 16), off_cnt = off_first + al(cells * 8);
     size_t off_start = off_cnt + (maps_all ? al(cells * 4) : 0);
     size_t off_used = off_start + (maps_all ? al(cells * 8) : 0);
-    size_t off_value = off_used + (flagged ? al(cells * 8) : 0);
-    size_t off_rowids = off_value + al(cells * 8);
+    size_t off_rowids = off_used + (flagged ? al(cells * 8) : 0);
     size_t total_b = off_rowids + (maps_all ? al(j->total_rows * 8) : 0) + 256;
     void * m = nullptr;
-    CHGPU_HIP(hipMalloc(&m, total_b));
+    CHGPU_TRY(chgpu_pool_alloc(ctx, total_b, &m, &j->table_class)); // pooled: no hipMalloc/hipFree per join
     j->table_mem = m;
     JoinTable & t = j->t;
     t.ctrl = (JoinCtrl *)m;
-    t.keys = (u64 *)((char *)m + off_keys);
+    t.kv = (u64 *)((char *)m + off_keys);
     t.first_row = (u64 *)((char *)m + off_first);
     t.cnt = maps_all ? (u32 *)((char *)m + off_cnt) : nullptr;
     t.start = maps_all ? (u64 *)((char *)m + off_start) : nullptr;
     t.used_by = flagged ? (u64 *)((char *)m + off_used) : nullptr;
-    t.value = (u64 *)((char *)m + off_value);
     t.rowids = maps_all ? (u64 *)((char *)m + off_rowids) : nullptr;
     t.capacity = cap;
-    CHGPU_HIP(hipMemsetAsync(m, 0, off_first, ctx->stream)); // ctrl + keys
+    CHGPU_HIP(hipMemsetAsync(m, 0, off_first, ctx->stream)); // ctrl + {key, value} cells
     const bool take_last = !maps_all && j->any_take_last_row;
     // first_row: ~0 for atomicMin, 0 for atomicMax(+1)
     CHGPU_HIP(hipMemsetAsync(t.first_row, take_last ? 0x00 : 0xFF, cells * 8, ctx->stream));
