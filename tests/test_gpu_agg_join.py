@@ -343,8 +343,76 @@ def test_group_by_partitioned_path_large_cardinality(ch, engine, oracle_mod, agg
             assert np.array_equal(a, b)
 
 
+def _check_against_numpy(g, k, v, f=None):
+    gk, res = g.convert_to_block()
+    uk, inv = np.unique(k, return_inverse=True)
+    ws = np.zeros(uk.shape[0], dtype=np.int64)
+    np.add.at(ws, inv, v)
+    gi = np.argsort(gk)
+    assert np.array_equal(gk[gi], uk)
+    assert np.array_equal(res[0][gi], ws)
+    cnt = np.bincount(inv)
+    if f is not None:
+        wf = np.zeros(uk.shape[0])
+        np.add.at(wf, inv, f)
+        assert np.allclose(res[1][gi], wf / cnt, rtol=1e-6, atol=0)      # avg(Float64): north_star tolerance
+        assert np.array_equal(res[2][gi], cnt.astype(np.uint64))
+    else:
+        assert np.array_equal(res[1][gi], cnt.astype(np.uint64))
+
+
+@pytest.mark.parametrize("key_dtype,groups,size_hint,row_begin", [
+    (np.uint32, 1, 0, 0), (np.uint64, 100, 0, 3), (np.int64, 5000, 5000, 0), (np.uint32, 4096, 0, 64), (np.int32, 3000, 3000, 1),
+])
+def test_group_by_lds_range_mode(ch, engine, key_dtype, groups, size_hint, row_begin):
+    # 4/8-byte keys with <= 2 eight-byte arguments and few groups: the partition-aggregate kernel in RANGE mode
+    rng = np.random.Generator(np.random.PCG64(groups + row_begin))
+    n = 2_500_000
+    k = rng.integers(0, groups, size=n).astype(key_dtype)
+    if np.dtype(key_dtype).kind == "i":
+        k -= groups // 2                                  # negative keys keep their raw bits
+    k[row_begin:row_begin + 5] = 0                        # the zero key lives out of line
+    v = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
+    f = rng.random(n)
+    g = engine.Aggregator(key_dtype, [(ch.AGG_SUM, np.int64), (ch.AGG_AVG, np.float64), (ch.AGG_COUNT, None)], size_hint=size_hint)
+    mid = row_begin + 1_000_001
+    g.execute_on_block(k, [v, f, None], row_begin, mid)
+    g.execute_on_block(k, [v, f, None], mid, n)
+    _check_against_numpy(g, k[row_begin:], v[row_begin:], f[row_begin:])
+
+
+@pytest.mark.parametrize("key_dtype", [np.uint32, np.uint64])
+def test_group_by_partitioned_wide_path_with_hot_partition(ch, engine, key_dtype):
+    # aligned first row (wide loads), a key holding 30 % of the rows: its partition is cut into many work units
+    rng = np.random.Generator(np.random.PCG64(31))
+    n, groups = 6_000_000, 200_000
+    k = rng.integers(1, groups, size=n).astype(key_dtype)
+    hot = rng.random(n) < 0.3
+    k[hot] = 77_777
+    k[:2] = 0
+    v = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
+    f = rng.random(n)
+    g = engine.Aggregator(key_dtype, [(ch.AGG_SUM, np.int64), (ch.AGG_AVG, np.float64), (ch.AGG_COUNT, None)], size_hint=groups)
+    before = g.ctx.counters()["KernelLaunches"]
+    g.execute_on_block(k, [v, f, None])
+    assert g.ctx.counters()["KernelLaunches"] - before >= 6
+    _check_against_numpy(g, k, v, f)
+
+
+def test_group_by_cardinality_beyond_partitioned_capacity(ch, engine):
+    # more groups than partitions x LDS cells: LDS tables overflow into the HBM table, pending rows, growth
+    rng = np.random.Generator(np.random.PCG64(8))
+    n = 9_000_000
+    k = rng.integers(0, 6_000_000, size=n).astype(np.uint32)
+    v = rng.integers(-2**40, 2**40, size=n, dtype=np.int64)
+    for hint in (300_000, 0):                             # a hint that is 20x too small, and none at all
+        g = engine.Aggregator(np.uint32, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], size_hint=hint)
+        g.execute_on_block(k, [v, None])
+        _check_against_numpy(g, k, v)
+
+
 def test_group_by_without_hint_adapts_to_high_cardinality(ch, engine):
-    # no size hint, >= 8 Mi rows: the first 4 Mi rows are probed through the LDS-staged kernel, the rest is partitioned
+    # no size hint, >= 8 Mi rows: the first 1 Mi rows are probed through the LDS-staged kernel, the rest is partitioned
     rng = np.random.Generator(np.random.PCG64(123))
     n = 9_000_000
     k = rng.integers(0, 700_000, size=n).astype(np.uint32)
