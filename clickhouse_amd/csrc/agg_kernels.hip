@@ -25,7 +25,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
+#include <vector>
 
 static constexpr u32 AGG_MAX_AGGS = 8;
 static constexpr u32 AGG_MAX_WORDS = 16;
@@ -429,8 +431,10 @@ static constexpr u32 GBP_MAX_K = 2;
 
 // Fibonacci hashing: one 64-bit multiply; the top bits pick the partition, bits 20.. pick the LDS cell (the full murmur
 // finalizer cost ~20 VALU ops per row in three passes that turned out to be issue-bound, not HBM-bound)
-__device__ __forceinline__ u64 gbp_mix(u64 key) { return key * 0x9E3779B97F4A7C15ull; }
-__device__ __forceinline__ u32 gbp_part_of(u64 key, u32 pmask) { return (u32)(gbp_mix(key) >> 52) & pmask; }
+static constexpr u64 GBP_MULT = 0x9E3779B97F4A7C15ull;  // partitions of the (second-level) pass that feeds the LDS aggregate
+static constexpr u64 GBP_MULT1 = 0xC2B2AE3D27D4EB4Full; // first level of a two-level partitioning: an independent multiplier
+__device__ __forceinline__ u64 gbp_mix(u64 key) { return key * GBP_MULT; }
+__device__ __forceinline__ u32 gbp_part_of(u64 key, u32 pmask, u64 mult) { return (u32)((key * mult) >> 52) & pmask; }
 
 struct GbpCols
 {
@@ -441,7 +445,7 @@ struct GbpCols
 };
 
 __global__ __launch_bounds__(GBP_THREADS) void k_gb_hist(const void * __restrict__ keys, int key_type, u64 row_begin, u64 n, u64 rows_per_wg,
-                                                         u32 P, u32 * __restrict__ counts)
+                                                         u32 P, u32 * __restrict__ counts, u64 mult)
 {
     __shared__ u32 cnt[GBP_MAX_P];
     for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
@@ -459,10 +463,10 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_hist(const void * __restrict
             k[q] = load_key_zext(keys, key_type, row_begin + i + (u64)q * GBP_THREADS);
 #pragma unroll
         for (int q = 0; q < HU; ++q)
-            atomicAdd(&cnt[gbp_part_of(k[q], P - 1)], 1u);
+            atomicAdd(&cnt[gbp_part_of(k[q], P - 1, mult)], 1u);
     }
     for (; i < r1; i += GBP_THREADS)
-        atomicAdd(&cnt[gbp_part_of(load_key_zext(keys, key_type, row_begin + i), P - 1)], 1u);
+        atomicAdd(&cnt[gbp_part_of(load_key_zext(keys, key_type, row_begin + i), P - 1, mult)], 1u);
     __syncthreads();
     for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
         counts[(u64)p * gridDim.x + blockIdx.x] = cnt[p];
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_hist(const void * __restrict
 // Same histogram with 16-byte nontemporal key loads (4- and 8-byte keys whose first row is 16-byte aligned): four loads
 // per lane are issued before the first LDS atomic.
 template <typename KT>
-__global__ __launch_bounds__(GBP_THREADS) void k_gb_hist_wide(const KT * __restrict__ keys, u64 n, u64 rows_per_wg, u32 P, u32 * __restrict__ counts)
+__global__ __launch_bounds__(GBP_THREADS) void k_gb_hist_wide(const KT * __restrict__ keys, u64 n, u64 rows_per_wg, u32 P, u32 * __restrict__ counts, u64 mult)
 {
     typedef u32 v4u __attribute__((ext_vector_type(4)));
     constexpr u32 VEC = 16 / sizeof(KT);
@@ -497,20 +501,20 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_hist_wide(const KT * __restr
         {
             if constexpr (sizeof(KT) == 4)
             {
-                atomicAdd(&cnt[gbp_part_of(v[q].x, pmask)], 1u);
-                atomicAdd(&cnt[gbp_part_of(v[q].y, pmask)], 1u);
-                atomicAdd(&cnt[gbp_part_of(v[q].z, pmask)], 1u);
-                atomicAdd(&cnt[gbp_part_of(v[q].w, pmask)], 1u);
+                atomicAdd(&cnt[gbp_part_of(v[q].x, pmask, mult)], 1u);
+                atomicAdd(&cnt[gbp_part_of(v[q].y, pmask, mult)], 1u);
+                atomicAdd(&cnt[gbp_part_of(v[q].z, pmask, mult)], 1u);
+                atomicAdd(&cnt[gbp_part_of(v[q].w, pmask, mult)], 1u);
             }
             else
             {
-                atomicAdd(&cnt[gbp_part_of((u64)v[q].x | ((u64)v[q].y << 32), pmask)], 1u);
-                atomicAdd(&cnt[gbp_part_of((u64)v[q].z | ((u64)v[q].w << 32), pmask)], 1u);
+                atomicAdd(&cnt[gbp_part_of((u64)v[q].x | ((u64)v[q].y << 32), pmask, mult)], 1u);
+                atomicAdd(&cnt[gbp_part_of((u64)v[q].z | ((u64)v[q].w << 32), pmask, mult)], 1u);
             }
         }
     }
     for (i += threadIdx.x; i < r1; i += GBP_THREADS)
-        atomicAdd(&cnt[gbp_part_of((u64)keys[i], pmask)], 1u);
+        atomicAdd(&cnt[gbp_part_of((u64)keys[i], pmask, mult)], 1u);
     __syncthreads();
     for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
         counts[(u64)p * gridDim.x + blockIdx.x] = cnt[p];
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_hist_wide(const KT * __restr
 // nontemporal load; otherwise rows are strided by the workgroup size and loaded one by one through the type switches.
 template <u32 GBP_TILE, typename KT, bool WIDE>
 __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restrict__ keys, int key_type, u64 row_begin, u64 n, u64 rows_per_wg,
-                                                            u32 P, const u64 * __restrict__ offsets, GbpCols cols, KT * __restrict__ out_keys)
+                                                            u32 P, const u64 * __restrict__ offsets, GbpCols cols, KT * __restrict__ out_keys, u64 mult)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
     u64 * stage_word = (u64 *)gb_lds;
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
             part[j] = ~0u;
             if (i < r1)
             {
-                part[j] = gbp_part_of(key[j], P - 1);
+                part[j] = gbp_part_of(key[j], P - 1, mult);
                 rank[j] = atomicAdd(&tile_cnt[part[j]], 1u);
             }
         }
@@ -673,7 +677,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
         const u32 tile_rows = (u32)(r1 - tbase < GBP_TILE ? r1 - tbase : GBP_TILE);
         for (u32 pos = threadIdx.x; pos < tile_rows; pos += GBP_THREADS)
         {
-            const u32 p = gbp_part_of((u64)stage_key[pos], P - 1);
+            const u32 p = gbp_part_of((u64)stage_key[pos], P - 1, mult);
             const u64 dst = cursor[p] + (pos - tile_off[p]);
             // plain stores: runs are 64-128 B, L2 write-combining completes the lines (nontemporal stores: 4.7 -> 8.1 ms)
             out_keys[dst] = stage_key[pos];
@@ -1250,7 +1254,10 @@ static u64 agg_estimate_groups(u64 d, u64 m)
 
 // PARTITIONED executeOnBlock (see the kernel block comment).  Returns NOT_IMPLEMENTED when the shape does not fit
 // (the caller then uses the DIRECT kernel).
-static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols, u64 row_begin, u64 n, u32 K)
+// level 0: called by add_block; may turn itself into level 1 (the first of two partitioning levels: partitions the rows
+// into P1 big partitions and runs a level-2 call over each partition buffer slice); level 2 never recurses.
+static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols, u64 row_begin, u64 n, u32 K,
+                                     int level = 0, size_t scratch_off = 0)
 {
     chgpu_ctx * ctx = a->ctx;
     CHGPU_TRY(agg_ensure_table(a));
@@ -1268,7 +1275,24 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         P <<= 1;
     while (P < want_p && P < GBP_MAX_P)
         P <<= 1;
-    if ((u64)P * (S / 2) < a->size_hint / 4) // hopelessly more groups than P * S: partitioning would not localise them
+    // More groups than P_max partitions x half an LDS table: TWO LEVELS.  Level 1 cuts the rows into P1 big partitions with an
+    // independent hash (long runs: close to a copy), then every big partition -- already in the 4/8-byte key + 8-byte word
+    // layout -- goes through this function again (level 2) with its share of the promised groups.
+    u64 mult = GBP_MULT;
+    u32 P1 = 0;
+    // (up to 1.5x over the single-level budget -- LDS tables 75 % full -- one level is still the faster plan: 16 vs 24 ms at 5 M)
+    if (want_p > GBP_MAX_P + GBP_MAX_P / 2 && level == 0 && !getenv("CHGPU_TUNE_GB_NO_TWO_LEVEL"))
+    {
+        const u64 sub_groups = (u64)(GBP_MAX_P / 2) * (S / 2); // leaves the second level at half its partition budget
+        for (P1 = 2; (u64)P1 * sub_groups < a->size_hint && P1 < 256; P1 <<= 1)
+            ;
+        if ((u64)P1 * sub_groups * 2 < a->size_hint || n / P1 < (1u << 20))
+            return CHGPU_ERR_NOT_IMPLEMENTED; // beyond two levels, or partitions too small to be worth three passes each
+        P = P1;
+        mult = GBP_MULT1;
+        level = 1;
+    }
+    else if (level == 0 && (u64)P * (S / 2) < a->size_hint / 4) // hopelessly more groups than P * S: partitioning would not localise them
         return CHGPU_ERR_NOT_IMPLEMENTED;
     // work units of the aggregate pass: half an average partition each, so a uniform input gives every workgroup two
     // units and a partition swollen by a hot key is spread over many workgroups; each unit flushes its LDS table once
@@ -1278,7 +1302,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         chunk_rows = 65536;
     const u64 max_units = n / chunk_rows + P; // sum over partitions of ceil(rows_p / chunk_rows)
     // every unit's flush may claim up to S+1 cells without the max-fill check: keep all of them inside the slack
-    for (int guard = 0; guard < 16 && a->t.capacity / 2 < max_units * (S + 1) + a->n_groups; ++guard)
+    for (int guard = 0; level != 1 && guard < 16 && a->t.capacity / 2 < max_units * (S + 1) + a->n_groups; ++guard)
     {
         AggCtrl c0;
         CHGPU_TRY(agg_read_ctrl(a, &c0));
@@ -1296,7 +1320,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     rows_per_wg = (rows_per_wg + tile - 1) / tile * tile;
     static const bool debug = getenv("CHGPU_DEBUG") != nullptr;
     if (debug)
-        fprintf(stderr, "chgpu: partitioned GROUP BY n=%llu hint=%llu S=%u P=%u G=%u tile=%u\n", (unsigned long long)n, (unsigned long long)a->size_hint, S, P, G, tile);
+        fprintf(stderr, "chgpu: partitioned GROUP BY level=%d n=%llu hint=%llu S=%u P=%u G=%u tile=%u\n", level, (unsigned long long)n, (unsigned long long)a->size_hint, S, P, G, tile);
 
     // partition buffers (8-byte keys + K 8-byte words per row) and bookkeeping
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -1306,8 +1330,14 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     // 16 GB costs ~0.4 s, fifteen times the kernels it would serve.
     const size_t keys_b = al((size_t)n * (key32 ? 4 : 8));
     const size_t part_b = keys_b + al((size_t)n * 8 * K);
-    void * scratch = nullptr;
-    CHGPU_TRY(chgpu_scratch(ctx, cnt_b + off_b + 256 + tmp_b + pend_b + part_b, &scratch));
+    const size_t own_b = al(cnt_b + off_b + 256 + tmp_b + pend_b + part_b);
+    // a level-1 call reserves the region of its level-2 calls up front (growing the arena later would move it): the same
+    // row count at most, bookkeeping for the largest partition count
+    const u64 m2 = (u64)GBP_MAX_P * G;
+    const size_t sub_b = level == 1 ? al(al(m2 * 4) + al(m2 * 8 + 8) + 256 + chgpu_scan_tmp_bytes(m2) + pend_b + part_b) + 4096 : 0;
+    void * scratch_base = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, scratch_off + own_b + sub_b, &scratch_base));
+    void * scratch = (char *)scratch_base + scratch_off;
     u32 * counts = (u32 *)scratch;
     u64 * offsets = (u64 *)((char *)scratch + cnt_b);
     u64 * total_dev = (u64 *)((char *)scratch + cnt_b + off_b);
@@ -1345,11 +1375,11 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     static const bool no_wide = getenv("CHGPU_TUNE_GB_NOWIDE") != nullptr;
     wide = wide && !no_wide;
     if (wide && key_w == 4)
-        hipLaunchKernelGGL(k_gb_hist_wide<u32>, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const u32 *)key_col->data + row_begin, n, rows_per_wg, P, counts);
+        hipLaunchKernelGGL(k_gb_hist_wide<u32>, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const u32 *)key_col->data + row_begin, n, rows_per_wg, P, counts, mult);
     else if (wide)
-        hipLaunchKernelGGL(k_gb_hist_wide<u64>, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const u64 *)key_col->data + row_begin, n, rows_per_wg, P, counts);
+        hipLaunchKernelGGL(k_gb_hist_wide<u64>, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const u64 *)key_col->data + row_begin, n, rows_per_wg, P, counts, mult);
     else
-        hipLaunchKernelGGL(k_gb_hist, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P, counts);
+        hipLaunchKernelGGL(k_gb_hist, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P, counts, mult);
     int rc = chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, m, total_dev, tmp, tmp_b);
     if (rc == CHGPU_OK)
     {
@@ -1362,13 +1392,69 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
         if (rc == CHGPU_OK)                                                                                                                     \
             hipLaunchKernelGGL(kern, dim3(G), dim3(GBP_THREADS), lds_sc, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P, \
-                               (const u64 *)offsets, gc, (KT_ *)pkeys);                                                                          \
+                               (const u64 *)offsets, gc, (KT_ *)pkeys, mult);                                                                        \
     } while (0)
         if (tile == 12288)     { if (key32) GB_SCATTER(12288, u32); else GB_SCATTER(12288, u64); }
         else if (tile == 8192) { if (key32) GB_SCATTER(8192, u32); else GB_SCATTER(8192, u64); }
         else                   { if (key32) GB_SCATTER(4096, u32); else GB_SCATTER(4096, u64); }
 #undef GB_SCATTER
 #undef GB_SCATTER_W
+    }
+    if (level == 1)
+    {
+        ctx->counters[6] += 2;
+        if (rc == CHGPU_OK && hipGetLastError() != hipSuccess)
+            rc = CHGPU_ERR_DEVICE;
+        if (rc != CHGPU_OK)
+        {
+            (void)hipGetLastError();
+            return chgpu_set_error(rc, "partitioned aggregation launch failed");
+        }
+        // partition boundaries: offsets[p * G] for p = 0..P1-1 (the read-back also orders the host behind the scatter)
+        std::vector<u64> starts(P1 + 1);
+        {
+            void * stage = nullptr;
+            CHGPU_TRY(chgpu_pinned(ctx, (size_t)P1 * 8, &stage));
+            CHGPU_HIP(hipMemcpy2DAsync(stage, 8, offsets, (size_t)G * 8, 8, P1, hipMemcpyDeviceToHost, ctx->stream));
+            CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+            memcpy(starts.data(), stage, (size_t)P1 * 8);
+            starts[P1] = n;
+        }
+        // the partition buffers as columns: keys of the buffer width, arguments widened to 8 bytes (Float64 kept its bits)
+        chgpu_col kc{};
+        kc.ctx = ctx;
+        kc.type = key32 ? CHGPU_U32 : CHGPU_U64;
+        kc.rows = n;
+        kc.data = pkeys;
+        chgpu_col ac[GBP_MAX_K]{};
+        const chgpu_col * sub_args[AGG_MAX_AGGS] = {};
+        const int saved_key_type = a->key_type;
+        int saved_arg_types[AGG_MAX_AGGS];
+        const u64 saved_hint = a->size_hint;
+        u32 c = 0;
+        for (u32 j = 0; j < a->n_aggs; ++j)
+        {
+            saved_arg_types[j] = a->arg_types[j];
+            if (a->kinds[j] == CHGPU_AGG_COUNT)
+                continue;
+            ac[c].ctx = ctx;
+            ac[c].type = a->arg_types[j] == CHGPU_F64 ? CHGPU_F64 : CHGPU_U64; // two's complement sums: width is what matters
+            ac[c].rows = n;
+            ac[c].data = pwords + (u64)c * n;
+            a->arg_types[j] = ac[c].type;
+            sub_args[j] = &ac[c];
+            ++c;
+        }
+        a->key_type = kc.type;
+        a->size_hint = saved_hint / P1 + saved_hint / P1 / 4 + 1024;
+        for (u32 q = 0; q < P1 && rc == CHGPU_OK; ++q)
+            if (starts[q + 1] > starts[q])
+                rc = agg_add_block_partitioned(a, &kc, sub_args, starts[q], starts[q + 1] - starts[q], K, 2, scratch_off + own_b);
+        a->key_type = saved_key_type;
+        a->size_hint = saved_hint;
+        for (u32 j = 0; j < a->n_aggs; ++j)
+            a->arg_types[j] = saved_arg_types[j];
+        return rc;
     }
     if (rc == CHGPU_OK)
         rc = hipMemsetAsync(pending, 0, pend_b, ctx->stream) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
