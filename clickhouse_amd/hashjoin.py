@@ -72,18 +72,19 @@ class HashJoin:
         K.check(K.lib().chgpu_join_total_rows(self._h, C.byref(r), C.byref(k)))
         return int(k.value)
 
-    def probe_columns(self, keys, null_map=None, max_joined_block_rows: int = 0):
-        """joinBlock's joinRightColumns -> dict(consumed, n_out, filter, offsets, right_rowid) of device Columns."""
+    def probe_columns(self, keys, null_map=None, max_joined_block_rows: int = 0, need_right_rows: bool = True):
+        """joinBlock's joinRightColumns -> dict(consumed, n_out, filter, offsets, right_rowid) of device Columns.
+        need_right_rows=False (LEFT SEMI / LEFT ANTI only): the right side contributes no columns, only the filter is built."""
         k = self._col(keys, self.key_dtype)
         nm = self._col(null_map, np.uint8) if null_map is not None else None
         fh, oh, rh = C.c_void_p(), C.c_void_p(), C.c_void_p()
         n_out, consumed = C.c_uint64(0), C.c_uint64(0)
-        K.check(K.lib().chgpu_join_probe(self._h, k._h, nm._h if nm else None, max_joined_block_rows, C.byref(fh), C.byref(oh), C.byref(rh),
-                                         C.byref(n_out), C.byref(consumed)))
+        K.check(K.lib().chgpu_join_probe(self._h, k._h, nm._h if nm else None, max_joined_block_rows, C.byref(fh), C.byref(oh),
+                                         C.byref(rh) if need_right_rows else None, C.byref(n_out), C.byref(consumed)))
         return dict(consumed=int(consumed.value), n_out=int(n_out.value),
                     filter=Column(self.ctx, fh) if fh.value else None,
                     offsets=Column(self.ctx, oh) if oh.value else None,
-                    right_rowid=Column(self.ctx, rh))
+                    right_rowid=Column(self.ctx, rh) if need_right_rows else None)
 
     def flatten_rowids(self, right_rowid: Column) -> Column:
         """(block << 32 | row) -> ordinal over all right blocks (index into concatenated payload columns)"""

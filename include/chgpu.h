@@ -247,7 +247,9 @@ int chgpu_join_total_rows(chgpu_join * j, uint64_t * rows, uint64_t * keys);
 /* joinRightColumns over the left key column.  Outputs (all device columns, caller frees; unused ones are NULL):
      filter_u8        [n_left_consumed]  need_filter variants (INNER ANY, LEFT SEMI, LEFT ANTI)
      offsets_u64      [n_left_consumed]  need_replication variants (ALL): cumulative offsets_to_replicate
-     right_rowid_u64  [n_out]            one entry per appended right row: (block<<32|row), all-ones = default row
+     right_rowid_u64  [n_out]            one entry per appended right row: (block<<32|row), all-ones = default row;
+                                         may be NULL for LEFT SEMI / LEFT ANTI when the right side contributes no columns
+                                         (an empty AddedColumns, AddedColumns.h): only the filter and n_out are produced
    max_joined_block_rows: 0 = unlimited; else processing stops BEFORE the first left row at which the running
    output count is already >= max (HashJoinMethodsImpl.h:436-444) and n_left_consumed < rows tells the caller to
    resubmit the tail (JoiningTransform.cpp:220-260). */

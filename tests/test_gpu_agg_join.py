@@ -427,6 +427,30 @@ def test_group_by_without_hint_adapts_to_high_cardinality(ch, engine):
     assert np.array_equal(gk[gi], uk) and np.array_equal(gs[gi], ws) and np.array_equal(gc[gi], np.bincount(inv).astype(np.uint64))
 
 
+@pytest.mark.parametrize("strict_name", ["SEMI", "ANTI"])
+def test_join_filter_only_probe_matches_full_probe(ch, ctx, strict_name):
+    # right_rowid == NULL (the right side contributes no columns): same filter and n_out as the full probe, NULL keys included
+    strict = getattr(ch, "STRICT_" + strict_name)
+    rng = np.random.Generator(np.random.PCG64(17))
+    build = rng.integers(0, 50_000, size=30_000).astype(np.uint32)
+    build[:3] = 0
+    left = rng.integers(0, 100_000, size=1_000_003).astype(np.uint32)
+    nulls = (rng.random(left.shape[0]) < 0.01).astype(np.uint8)
+    j = ch.HashJoin(ch.JOIN_LEFT, strict, key_dtype=np.uint32, ctx=ctx)
+    j.add_block(build)
+    j.finish_build()
+    full = j.probe_columns(left, null_map=nulls)
+    fast = j.probe_columns(left, null_map=nulls, need_right_rows=False)
+    assert fast["right_rowid"] is None and fast["consumed"] == full["consumed"] == left.shape[0]
+    assert fast["n_out"] == full["n_out"]
+    f_full, f_fast = full["filter"].numpy(), fast["filter"].numpy()
+    assert np.array_equal(f_full, f_fast)
+    found = np.isin(left, build) & (nulls == 0)
+    assert np.array_equal(f_fast.astype(bool), found if strict_name == "SEMI" else ~found)
+    with pytest.raises(ch.ChgpuError):
+        ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, key_dtype=np.uint32, ctx=ctx).probe_columns(left, need_right_rows=False)
+
+
 def test_join_payload_across_many_right_blocks(ch, ctx, engine):
     # the build side arrives Block by Block (FillingRightJoinSideTransform); payload = concatenated columns + flattened row ids
     rng = np.random.Generator(np.random.PCG64(17))

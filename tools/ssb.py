@@ -72,10 +72,10 @@ def q41_gpu(ch, ctx, dims, lo):
     for j in (j_c, j_s, j_p, j_d):
         j.finish_build()
     # ---- the fact table through the joins (JoiningTransform x4), most selective first ----
-    r = j_s.probe_columns(lo["lo_suppkey"])
+    r = j_s.probe_columns(lo["lo_suppkey"], need_right_rows=False)   # semi joins: the dimension contributes no column
     f = r["filter"]
     cust, part, date, rev, cost = (lo[k].filter(f) for k in ("lo_custkey", "lo_partkey", "lo_orderdate", "lo_revenue", "lo_supplycost"))
-    r = j_p.probe_columns(part)
+    r = j_p.probe_columns(part, need_right_rows=False)
     f = r["filter"]
     cust, date, rev, cost = (c.filter(f) for c in (cust, date, rev, cost))
     r = j_c.probe_columns(cust)
