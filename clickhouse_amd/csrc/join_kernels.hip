@@ -419,7 +419,11 @@ __global__ __launch_bounds__(JT) void k_join_probe_filter(JoinTable t, int anti,
         {
             if (!in[q])
                 continue;
-            const bool found = ok[q] && jt_find<PF>(t, pf, key[q]) != NO_SLOT;
+            bool found;
+            if (PF && pf.dense && key[q] != 0)
+                found = ok[q] && jt_pf_maybe(pf, key[q]); // a dense prefilter is exact: membership needs no table access
+            else
+                found = ok[q] && jt_find<PF>(t, pf, key[q]) != NO_SLOT;
             const u8 f = anti ? !found : found;             // :515-519, :535-536
             filter[i0 + (u64)q * stride] = f;
             kept += f;

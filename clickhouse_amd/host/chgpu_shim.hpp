@@ -442,11 +442,14 @@ public:
             onBuildPhaseFinish();
         chgpu_col *filter = nullptr, *offsets = nullptr, *rowid = nullptr;
         uint64_t n_out = 0, consumed = 0;
-        check(chgpu_join_probe(h, block.columns.at(key_position)->handle(), nullptr, max_joined_block_rows, &filter, &offsets, &rowid, &n_out, &consumed));
+        // LEFT SEMI / LEFT ANTI with no right column requested (an empty AddedColumns): the filter-only probe
+        const bool filter_only = right_payload.empty() && (strictness == CHGPU_STRICT_SEMI || strictness == CHGPU_STRICT_ANTI);
+        check(chgpu_join_probe(h, block.columns.at(key_position)->handle(), nullptr, max_joined_block_rows, &filter, &offsets,
+                               filter_only ? nullptr : &rowid, &n_out, &consumed));
         auto filter_c = filter ? std::make_shared<ColumnVector>(ctx, filter) : nullptr;
         auto offsets_c = offsets ? std::make_shared<ColumnVector>(ctx, offsets) : nullptr;
-        auto rowid_c = std::make_shared<ColumnVector>(ctx, rowid);
-        if (right_blocks.size() > 1)
+        auto rowid_c = rowid ? std::make_shared<ColumnVector>(ctx, rowid) : nullptr;
+        if (rowid && right_blocks.size() > 1)
         {
             chgpu_col * flat = nullptr; // (block, row) -> ordinal in the concatenated payload
             check(chgpu_join_flatten_rowids(h, rowid, &flat));

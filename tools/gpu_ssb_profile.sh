@@ -13,7 +13,7 @@ import csv, glob
 f = glob.glob('/tmp/p_ssb/**/*kernel_trace.csv', recursive=True)
 if f:
     rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r['Start_Timestamp']))
-    rows = [r for r in rows if 'k_join_probe_count' in r['Kernel_Name'] or 'k_join_insert' in r['Kernel_Name']]
-    for r in [r for r in rows if int(r['End_Timestamp']) - int(r['Start_Timestamp']) > 300000][-8:]:
+    rows = [r for r in rows if 'k_join_probe' in r['Kernel_Name'] or 'k_join_insert' in r['Kernel_Name'] or 'k_filter_scatter' in r['Kernel_Name']]
+    for r in [r for r in rows if int(r['End_Timestamp']) - int(r['Start_Timestamp']) > 300000][-14:]:
         print(r['Kernel_Name'][:24], 'grid', r.get('Grid_Size_X', '?'), round((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6, 3), 'ms')
 PY
