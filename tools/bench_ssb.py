@@ -37,6 +37,17 @@ for _ in range(3):
     ctx.synchronize()
     dt = time.perf_counter() - t0
     best = dt if best is None else min(best, dt)
+dims_dev = ssb.upload_dims(ctx, dims)
+ctx.synchronize()
+best_resident = None
+for _ in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res_resident = ssb.q41_gpu(ch, ctx, dims_dev, lo)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    best_resident = dt if best_resident is None else min(best_resident, dt)
+assert res_resident == res
 
 m = min(sample, rows)
 lo_s = {k: v[:m].cpu().numpy().view(np.uint32) for k, v in lo_t.items()}
@@ -47,7 +58,9 @@ got = ssb.q41_gpu(ch, ctx, dims, {k: c.cut(0, m) for k, c in lo.items()})
 assert got == want, "GPU plan differs from the CPU restatement on the sample"
 print(json.dumps({"config": "C5 SSB Q4.1-style, one GPU share", "lineorder_rows": rows, "groups": len(res), "gpu_ms": best * 1e3,
                   "gpu_rows_per_s": rows / best, "algorithmic_GBps_24B_per_row": 24 * rows / best / 1e9, "roofline_frac": 24 * rows / best / 8e12,
+                  "gpu_ms_dims_resident": best_resident * 1e3, "gpu_rows_per_s_dims_resident": rows / best_resident,
+                  "roofline_frac_dims_resident": 24 * rows / best_resident / 8e12,
                   "cpu_sample_rows": m, "cpu_1thread_rows_per_s": m / t_cpu,
-                  "note": "GPU time includes uploading and filtering the dimension tables and building the 4 hash tables; "
+                  "note": "gpu_ms includes uploading (PCIe) and filtering the dimension tables and building the 4 hash tables; *_dims_resident has the dimension columns already in HBM (filtering and builds still inside); "
                           "CPU = oracle plan driven per 65409-row Block from Python, 1 thread",
                   "parity": "all 35 (year, nation) groups: profit and row count bit-exact on the sample"}))
