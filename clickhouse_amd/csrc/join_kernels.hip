@@ -399,7 +399,10 @@ __global__ __launch_bounds__(JT) void k_join_probe_filter(JoinTable t, int anti,
     PfView pf{};
     if constexpr (PF)
         pf = jt_pf_view(t);
-    constexpr int R = 4;
+#ifndef JPF_R
+#define JPF_R 4
+#endif
+    constexpr int R = JPF_R;
     u32 kept = 0;
     const u64 stride = (u64)gridDim.x * JT;
     for (u64 i0 = (u64)blockIdx.x * JT + threadIdx.x; i0 < n; i0 += stride * R)
@@ -772,7 +775,7 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
         if (e == hipSuccess)
         {
             auto kern = j->t.pf ? k_join_probe_filter<true> : k_join_probe_filter<false>;
-            hipLaunchKernelGGL(kern, dim3(chgpu_grid_for(ctx, (n + 3) / 4, JT, 8)), dim3(JT), 0, ctx->stream, j->t, variant == PV_ANTI_LEFT ? 1 : 0,
+            hipLaunchKernelGGL(kern, dim3(chgpu_grid_for(ctx, (n + JPF_R - 1) / JPF_R, JT, 8)), dim3(JT), 0, ctx->stream, j->t, variant == PV_ANTI_LEFT ? 1 : 0,
                                (const void *)key_col->data, j->key_type, null_map ? (const u8 *)null_map->data : nullptr, n, (u8 *)fcol->data, j->t.ctrl);
             ctx->counters[6] += 1;
             e = hipGetLastError();
