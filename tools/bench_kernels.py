@@ -22,6 +22,8 @@ k32 = torch.randint(0, 1_000_000, (rows,), dtype=torch.int32, device=dev, genera
 ac = ctx.wrap(a.data_ptr(), np.int64, rows, keepalive=a)
 bc = ctx.wrap(b.data_ptr(), np.int64, rows, keepalive=b)
 kc = ctx.wrap(k32.data_ptr(), np.uint32, rows, keepalive=k32)
+k64 = (k32 % 1000).to(torch.int64)
+k64c = ctx.wrap(k64.data_ptr(), np.int64, rows, keepalive=k64)
 THR = 214748365
 for rep in range(2):
     ch.filter_sum(ac, ch.LT, THR)                       # k_filter_sum 1 column
@@ -40,8 +42,13 @@ for rep in range(2):
     A = ch.Aggregator(np.uint32, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], size_hint=1_000_000, ctx=ctx)
     A.execute_on_block(kc, [ac, None])                  # k_gb_hist, k_gb_scatter, k_agg_part_lds
     A.convert_to_block()                                # k_occupied_mask + filter kernels
-    B = ch.Aggregator(np.uint32, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], ctx=ctx)
-    B.execute_on_block(kc, [ac, None], 0, rows // 4)    # k_agg_rows_lds (1M groups: mostly LDS misses)
+    B = ch.Aggregator(np.int64, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], ctx=ctx)
+    B.execute_on_block(k64c, [ac, None])                # k_agg_part_lds<u64> in RANGE mode (1000 groups, LDS-staged)
+    dim = ctx.upload(np.arange(1, 400_001, dtype=np.uint32) * 5)
+    sj = ch.HashJoin(ch.JOIN_LEFT, ch.STRICT_SEMI, key_dtype=np.uint32, ctx=ctx)
+    sj.add_block(dim)
+    sj.finish_build()
+    sj.probe_columns(kc, need_right_rows=False)         # k_join_probe_filter<true> (dense prefilter bitmap)
     D = ch.Aggregator(np.uint32, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], size_hint=100_000, ctx=ctx)
     D.execute_on_block(kc, [ac, None], 0, 2_000_000)    # k_agg_rows_direct
     nb = 10_000_000

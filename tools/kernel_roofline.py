@@ -18,14 +18,15 @@ ALG = [
     ("k_part_hist", 4 * R, "partition histogram (4 B selector)"),
     ("k_part_scatter", 36 * R, "stable 8-way partition of 2 Int64 columns (4 + 2*(8+8) B/row)"),
     ("k_index<unsigned long, unsigned long>", (8 + 8 + 8) * (R // 4), "random gather of R/4 rows (8 idx + 8 data + 8 out)"),
-    ("k_gb_hist", 4 * R, "GROUP BY partition histogram (4 B key)"),
-    ("k_gb_scatter", (12 + 16) * R, "GROUP BY partition scatter (12 B in, 16 B out)"),
-    ("k_agg_part_lds", 16 * R, "GROUP BY LDS aggregation of partitions (16 B/row)"),
-    ("k_agg_rows_lds", 12 * (R // 4), "GROUP BY LDS-staged rows, 1 M groups = LDS misses -> HBM atomics"),
+    ("k_gb_hist_wide<unsigned int>", 4 * R, "GROUP BY partition histogram (4 B key)"),
+    ("k_gb_scatter<12288u, unsigned int, true>", (12 + 12) * R, "GROUP BY partition scatter (12 B in, 12 B out)"),
+    ("k_agg_part_lds<unsigned int>", 12 * R, "GROUP BY LDS aggregation of partitions (12 B/row), 1 M groups"),
+    ("k_agg_part_lds<unsigned long>", 16 * R, "GROUP BY LDS-staged over the source columns (RANGE mode, 16 B/row), 1000 groups"),
+    ("k_join_probe_filter<true>", 5 * R, "filter-only LEFT SEMI probe, dense prefilter (4 B key in, 1 B out)"),
     ("k_join_insert", 8 * 10_000_000, "join build: insert 1e7 keys (8 B/row)"),
     ("k_join_fill", 12 * 10_000_000, "join build: CSR fill"),
     ("k_join_probe_count", 8 * (R // 4), "join probe: lookup (8 B/row in)"),
-    ("k_join_emit", 16 * (R // 4), "join probe: emit (slot, count, offset in)"),
+    ("k_join_emit", 4 * (R // 4), "join probe: emit at a 0.5 % match rate (4 B count per left row; value/offset only for matches)"),
 ]
 stats = {}
 for r in csv.DictReader(open(path)):
