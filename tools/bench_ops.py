@@ -72,6 +72,25 @@ if what == "groupby_sweep":
         print(f"groupby_sweep rows={rows} groups={groups}: hinted {res[0]:.2f} ms, no hint {res[1]:.2f} ms", flush=True)
         del k, v, kc, vc
 
+if what == "groupby_finalize":
+    # convertToBlockImplFinal on the device: table -> (keys, sum, count) columns, left in HBM
+    for groups in (1000, 1_000_000, 4_000_000):
+        g = torch.Generator(device=dev).manual_seed(2)
+        k = torch.randint(0, groups, (rows,), dtype=torch.int32, device=dev, generator=g)
+        v = torch.randint(-2**31, 2**31, (rows,), dtype=torch.int64, device=dev, generator=g)
+        kc = ctx.wrap(k.data_ptr(), np.uint32, rows, keepalive=k)
+        vc = ctx.wrap(v.data_ptr(), np.int64, rows, keepalive=v)
+        a = ch.Aggregator(np.uint32, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], size_hint=groups, ctx=ctx)
+        a.execute_on_block(kc, [vc, None])
+
+        def fin():
+            keys_c, cols = a.finalize_columns()
+            return keys_c.size()
+        dt, n = timed(fin)
+        print(f"groupby_finalize groups={groups}: {dt*1e3:.3f} ms for {n} result rows", flush=True)
+        a.close()
+        del k, v, kc, vc
+
 if what == "groupby_zipf":
     # SURVEY C3's skew variant: keys ~ Zipf(1.1) folded into [0, 1e6) (continuous inverse-CDF approximation on device)
     groups, sz = 1_000_000, 1.1
