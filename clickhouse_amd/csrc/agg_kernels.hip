@@ -520,7 +520,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_hist_wide(const KT * __restr
         counts[(u64)p * gridDim.x + blockIdx.x] = cnt[p];
 }
 
-// dynamic LDS: stage_word u64[K][TILE] | cursor u64[P] | stage_key KT[TILE] | tile_cnt u32[P] | tile_off u32[P]
+// dynamic LDS: stage_word u64[K][TILE] | cursor u64[P] | delta u64[P] | stage_key KT[TILE] | tile_cnt u32[P] | tile_off u32[P]
 // (the partition of a staged row is recomputed from its key in the write-out phase: one multiply instead of 2 B/row of LDS,
 //  which buys a 12288-row tile -> 1.5x longer partition runs for the 4-byte-key, one-word shape)
 // KT = u32 for key types of <= 4 bytes (the partition buffers then hold 4-byte keys: 12 instead of 16 B/row for C3), else u64
@@ -534,7 +534,8 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
     extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
     u64 * stage_word = (u64 *)gb_lds;
     u64 * cursor = stage_word + (size_t)cols.k * GBP_TILE;
-    KT * stage_key = (KT *)(cursor + P);
+    u64 * delta = cursor + P; // cursor[p] - tile_off[p] of the current tile: destination row = delta[p] + position in the sorted tile
+    KT * stage_key = (KT *)(delta + P);
     u32 * tile_cnt = (u32 *)(stage_key + GBP_TILE);
     u32 * tile_off = tile_cnt + P;
     __shared__ u32 wave_tot[GBP_THREADS / 64];
@@ -651,10 +652,24 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
             u32 base = inc - v;
             for (u32 w = 0; w < wave; ++w)
                 base += wave_tot[w];
+            // the same thread that scanned partition p also advances its cursor and clears its counter for the next tile:
+            // step 1 of the next tile only starts after the barrier below, and nobody reads cursor[] again in this tile
             if (e0 < P)
+            {
                 tile_off[e0] = base;
+                const u64 c = cursor[e0];
+                delta[e0] = c - base;
+                cursor[e0] = c + c0;
+                tile_cnt[e0] = 0;
+            }
             if (e1 < P)
+            {
                 tile_off[e1] = base + c0;
+                const u64 c = cursor[e1];
+                delta[e1] = c - (base + c0);
+                cursor[e1] = c + c1;
+                tile_cnt[e1] = 0;
+            }
         }
         __syncthreads();
         // 3. counting sort into the LDS staging arrays
@@ -678,19 +693,15 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
         for (u32 pos = threadIdx.x; pos < tile_rows; pos += GBP_THREADS)
         {
             const u32 p = gbp_part_of((u64)stage_key[pos], P - 1, mult);
-            const u64 dst = cursor[p] + (pos - tile_off[p]);
+            const u64 dst = delta[p] + pos;
             // plain stores: runs are 64-128 B, L2 write-combining completes the lines (nontemporal stores: 4.7 -> 8.1 ms)
             out_keys[dst] = stage_key[pos];
             for (u32 c = 0; c < cols.k; ++c)
                 cols.dst[c][dst] = stage_word[(size_t)c * GBP_TILE + pos];
         }
-        __syncthreads();
-        for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
-        {
-            cursor[p] += tile_cnt[p];
-            tile_cnt[p] = 0;
-        }
-        __syncthreads();
+        // no barrier here: the next tile's step 1 touches only tile_cnt[] (cleared in step 2 above), and its step 2 -- the
+        // first writer of tile_off[]/delta[] -- sits behind the barrier that ends step 1, which every wave reaches only
+        // after it has finished writing this tile out
     }
 }
 
@@ -1310,12 +1321,12 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     }
     const u32 G = (u32)ctx->num_cus * GBP_WG_PER_CU;
     u64 rows_per_wg = (n + G - 1) / G;
-    // the scatter's LDS image is tile*(8*K + key bytes) + 16*P bytes and must stay under ~156 KiB
+    // the scatter's LDS image is tile*(8*K + key bytes) + 24*P bytes and must stay under ~159 KiB (160 KiB per workgroup, 64 B static)
     const size_t row_lds = 8 * K + (key32 ? 4 : 8);
     static const u32 tile_cap = getenv("CHGPU_TUNE_GB_TILE") ? (u32)atoi(getenv("CHGPU_TUNE_GB_TILE")) : 12288;
     u32 tile = 4096;
     for (u32 cand : {8192u, 12288u})
-        if (cand <= tile_cap && cand * row_lds + (size_t)P * 16 + 64 <= 156 * 1024)
+        if (cand <= tile_cap && cand * row_lds + (size_t)P * 24 + 64 <= 159 * 1024)
             tile = cand;
     rows_per_wg = (rows_per_wg + tile - 1) / tile * tile;
     static const bool debug = getenv("CHGPU_DEBUG") != nullptr;
@@ -1383,7 +1394,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     int rc = chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, m, total_dev, tmp, tmp_b);
     if (rc == CHGPU_OK)
     {
-        const size_t lds_sc = (size_t)tile * row_lds + (size_t)P * 16 + 64;
+        const size_t lds_sc = (size_t)tile * row_lds + (size_t)P * 24 + 64;
 #define GB_SCATTER(TILE_, KT_) do { if (wide) GB_SCATTER_W(TILE_, KT_, true); else GB_SCATTER_W(TILE_, KT_, false); } while (0)
 #define GB_SCATTER_W(TILE_, KT_, W_)                                                                                                            \
     do                                                                                                                                          \
