@@ -774,6 +774,36 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
     __shared__ u32 lzero, sh_unit;
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const u64 gstride = t.capacity + 1;
+    // The aggregate descriptors are decoded ONCE into wave-uniform registers (all loops over them are fully unrolled, so the
+    // indices are constants): fetching d.a[j] inside the row loop meant an s_load per function and row group, and its
+    // s_waitcnt lgkmcnt(0) also drains every LDS operation the wave has in flight -- the pass was issue-bound at ~170
+    // clocks per 64 rows while the LDS itself can take this mix at 8.5 lanes/clock (tools/lds_bench.hip).
+    //   op: 0 none, 1 add u64 (integer sum), 2 add f64, 3 count as u32, 4 count as u64
+    u32 a_off[AGG_MAX_AGGS], a_off2[AGG_MAX_AGGS];
+    int a_op[AGG_MAX_AGGS], a_op2[AGG_MAX_AGGS], a_src[AGG_MAX_AGGS];
+#pragma unroll
+    for (u32 j = 0; j < AGG_MAX_AGGS; ++j)
+    {
+        a_off[j] = a_off2[j] = 0;
+        a_op[j] = a_op2[j] = a_src[j] = 0;
+        if (j < d.n_aggs)
+        {
+            const u32 w = d.a[j].word;
+            a_off[j] = L.off(w);
+            if (d.a[j].kind == CHGPU_AGG_COUNT)
+                a_op[j] = ((cnt32 >> w) & 1) ? 3 : 4;
+            else
+            {
+                a_op[j] = d.a[j].arg_type == CHGPU_F64 ? 2 : 1;
+                a_src[j] = (int)d.a[j].pre;
+                if (d.a[j].kind == CHGPU_AGG_AVG)
+                {
+                    a_off2[j] = L.off(w + 1);
+                    a_op2[j] = ((cnt32 >> (w + 1)) & 1) ? 3 : 4;
+                }
+            }
+        }
+    }
     // PARTITION mode: work units (partition, chunk) are drawn from a device-wide counter until it passes the unit count
     // (every workgroup reaches that exit).  RANGE mode (offsets == nullptr): chunk blockIdx.x, +gridDim.x, ... of the
     // source columns themselves (keys/words0/words1 point at the block's first row) -- the low-cardinality GROUP BY runs this way.
@@ -876,33 +906,25 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                     }
                     if (ls != ~0u)
                     {
-                        for (u32 j = 0; j < d.n_aggs; ++j)
+#pragma unroll
+                        for (u32 j = 0; j < AGG_MAX_AGGS; ++j)
                         {
-                            const AggArg & a = d.a[j];
-                            unsigned char * w = lds_raw + L.off(a.word);
-                            if (a.kind == CHGPU_AGG_COUNT)
-                            {
-                                if ((cnt32 >> a.word) & 1)
-                                    atomicAdd((unsigned int *)w + ls, 1u);
-                                else
-                                    atomicAdd((unsigned long long *)w + ls, 1ull);
-                            }
+                            if (a_op[j] == 0)
+                                break;
+                            unsigned char * w = lds_raw + a_off[j];
+                            const u64 bits = a_src[j] == 0 ? argv[q][0] : argv[q][1];
+                            if (a_op[j] == 1)
+                                atomicAdd((unsigned long long *)w + ls, (unsigned long long)bits);
+                            else if (a_op[j] == 2)
+                                atomicAdd((double *)w + ls, __longlong_as_double((long long)bits));
+                            else if (a_op[j] == 3)
+                                atomicAdd((unsigned int *)w + ls, 1u);
                             else
-                            {
-                                const u64 bits = a.pre == 0 ? argv[q][0] : argv[q][1];
-                                if (a.arg_type == CHGPU_F64)
-                                    atomicAdd((double *)w + ls, __longlong_as_double((long long)bits));
-                                else
-                                    atomicAdd((unsigned long long *)w + ls, (unsigned long long)bits);
-                                if (a.kind == CHGPU_AGG_AVG)
-                                {
-                                    unsigned char * wc = lds_raw + L.off(a.word + 1);
-                                    if ((cnt32 >> (a.word + 1)) & 1)
-                                        atomicAdd((unsigned int *)wc + ls, 1u);
-                                    else
-                                        atomicAdd((unsigned long long *)wc + ls, 1ull);
-                                }
-                            }
+                                atomicAdd((unsigned long long *)w + ls, 1ull);
+                            if (a_op2[j] == 3)
+                                atomicAdd((unsigned int *)(lds_raw + a_off2[j]) + ls, 1u); // avg's denominator
+                            else if (a_op2[j] == 4)
+                                atomicAdd((unsigned long long *)(lds_raw + a_off2[j]) + ls, 1ull);
                         }
                     }
                     else
