@@ -82,16 +82,12 @@ class LocalEngine:
         return self.ctx.wrap(t.data_ptr(), dtype, t.shape[0], keepalive=t)
 
     def tensor(self, col, dtype) -> torch.Tensor:
+        """Device column -> torch tensor that owns its memory (one device-to-device copy on the shared stream)."""
         n = col.size()
         out = torch.empty(n, dtype=_NP2T[np.dtype(dtype)], device=self.device)
         if n:
-            view = self.ctx.wrap(out.data_ptr(), np.uint8, n * np.dtype(dtype).itemsize, keepalive=out)
-            src = self.ctx.wrap(col.device_ptr, np.uint8, n * np.dtype(dtype).itemsize, keepalive=col)
-            # device-to-device copy expressed with the library's own gather-free primitive: filter with an all-ones mask
-            # would cost a pass; a plain torch copy from a borrowed pointer is simpler:
-            borrowed = _borrow(src.device_ptr, n * np.dtype(dtype).itemsize, self.device, keepalive=col)
-            out.view(torch.uint8).copy_(borrowed)
-            del view
+            nbytes = n * np.dtype(dtype).itemsize
+            out.view(torch.uint8).copy_(_borrow(col.device_ptr, nbytes, self.device, keepalive=col))
         return out
 
     def partition_by_hash(self, keys: torch.Tensor, key_dtype, cols, dtypes, n_shards: int):
