@@ -11,6 +11,7 @@
 //   k_index/k_replicate ColumnVector<T>::indexImpl / replicate    src/Columns/ColumnVector.cpp:1121-1143, 879-907
 #include "chgpu_internal.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -78,16 +79,7 @@ static int make_cmp_spec(int col_type, int op, int scalar_type, const void * sca
 {
     CHGPU_REQUIRE(op >= CHGPU_EQ && op <= CHGPU_GE, CHGPU_ERR_BAD_ARGUMENTS, "unknown comparison op %d", op);
     CHGPU_REQUIRE(scalar, CHGPU_ERR_BAD_ARGUMENTS, "scalar is NULL");
-    if (col_type == CHGPU_F64)
-    {
-        CHGPU_REQUIRE(scalar_type == CHGPU_F64, CHGPU_ERR_NOT_IMPLEMENTED, "Float64 column vs non-Float64 constant: CPU path");
-        spec->is_f64 = true;
-        spec->op = op;
-        spec->fs = *(const double *)scalar;
-        return CHGPU_OK;
-    }
-    CHGPU_REQUIRE(chgpu_type_is_int(col_type), CHGPU_ERR_BAD_ARGUMENTS, "unknown column type %d", col_type);
-    CHGPU_REQUIRE(chgpu_type_is_int(scalar_type), CHGPU_ERR_NOT_IMPLEMENTED, "integer column vs Float64 constant: CPU path");
+    CHGPU_REQUIRE(col_type == CHGPU_F64 || chgpu_type_is_int(col_type), CHGPU_ERR_BAD_ARGUMENTS, "unknown column type %d", col_type);
     __int128 s = 0;
     switch (scalar_type)
     {
@@ -96,7 +88,66 @@ static int make_cmp_spec(int col_type, int op, int scalar_type, const void * sca
         case CHGPU_U32: s = *(const u32 *)scalar; break;
         case CHGPU_I32: s = *(const i32 *)scalar; break;
         case CHGPU_U8: s = *(const u8 *)scalar; break;
+        case CHGPU_F64: break;
         default: return chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "unknown scalar type %d", scalar_type);
+    }
+    if (col_type == CHGPU_F64)
+    {
+        spec->is_f64 = true;
+        spec->op = op;
+        if (scalar_type == CHGPU_F64)
+        {
+            spec->fs = *(const double *)scalar;
+            return CHGPU_OK;
+        }
+        // Float64 column vs integer constant s, compared mathematically (accurate::lessOp/equalsOp, AccurateComparison.h:20-130):
+        // d_down / d_up = the doubles next to s (equal when s is representable); every double is < s iff it is < d_up, etc.
+        double d = (double)s, d_down = d, d_up = d;
+        const __int128 back = (__int128)d; // |s| < 2^64: exact
+        if (back < s)
+            d_up = std::nextafter(d, INFINITY);
+        else if (back > s)
+            d_down = std::nextafter(d, -INFINITY);
+        switch (op)
+        {
+            case CHGPU_LT: spec->fs = d_up; break;
+            case CHGPU_GE: spec->fs = d_up; break;
+            case CHGPU_LE: spec->fs = d_down; break;
+            case CHGPU_GT: spec->fs = d_down; break;
+            case CHGPU_EQ:
+                if (back == s)
+                    spec->fs = d;
+                else
+                {
+                    spec->op = CHGPU_LT; // no double equals s: `a < -inf` is false for every a, NaN included
+                    spec->fs = -INFINITY;
+                }
+                break;
+            case CHGPU_NE:
+                spec->fs = back == s ? d : (double)NAN; // `a != NaN` holds for every a
+                break;
+        }
+        return CHGPU_OK;
+    }
+    if (scalar_type == CHGPU_F64)
+    {
+        // integer column vs Float64 constant c, compared mathematically: fold c into the integer threshold of an equivalent
+        // integer comparison (a < c <=> a < ceil(c); a <= c <=> a <= floor(c); a == c needs an integral c); NaN compares
+        // false except under != (notEqualsOp = !equalsOp)
+        const double c = *(const double *)scalar;
+        const __int128 big = (__int128)1 << 65; // beyond both 64-bit domains
+        auto to_i128 = [&](double x) -> __int128 { return x >= 0x1p65 ? big : x <= -0x1p65 ? -big : (__int128)x; };
+        if (std::isnan(c) || ((op == CHGPU_EQ || op == CHGPU_NE) && (std::isinf(c) || std::floor(c) != c)))
+        {
+            s = big; // equals nothing
+            op = op == CHGPU_NE ? CHGPU_NE : CHGPU_EQ;
+        }
+        else if (op == CHGPU_LT || op == CHGPU_GE)
+            s = to_i128(std::ceil(c));
+        else if (op == CHGPU_LE || op == CHGPU_GT)
+            s = to_i128(std::floor(c));
+        else
+            s = to_i128(c);
     }
     const bool sgn = chgpu_type_is_signed(col_type);
     // the 64-bit extension domain of the column's signedness class

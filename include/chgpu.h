@@ -111,7 +111,9 @@ int chgpu_col_free(chgpu_col * col);
  * a3 comparison  —  IFunction::executeImpl for less/greater/equals... with a constant right argument:
  * NumComparisonImpl<A,B,Op>::vectorConstant (src/Functions/FunctionsComparison.h:204-245), semantics
  * accurate::lessOp/equalsOp (src/Core/AccurateComparison.h:20-130).  mask[i] = Op(col[i], scalar) ? 1 : 0.
- * Supported: integer column x integer scalar of any signedness (compared mathematically), F64 x F64.
+ * Supported: integer column x integer scalar of any signedness, F64 x F64, integer column x F64 scalar and F64 column x
+ * integer scalar -- all compared mathematically (a constant no value of the column type can equal compares accordingly;
+ * NaN is unequal to everything and unordered).
  * ============================================================================================== */
 int chgpu_cmp_const(chgpu_ctx * ctx, const chgpu_col * col, int op, int scalar_type, const void * scalar,
                     chgpu_col ** mask_u8);

@@ -87,9 +87,28 @@ def test_cmp_const_all_ops_and_mixed_signedness(ch, ctx, oracle_mod):
     for s in (0.0, 0.5, np.nan, np.inf):
         for op in ops:
             assert np.array_equal(ch.cmp_const(fc, op, s).numpy(), O.cmp_const(f, op, s)), (s, op)
-    with pytest.raises(ch.ChgpuError) as e:  # int column vs float constant: explicit CPU fallback signal
-        ch.cmp_const(ctx.upload(a64), ch.LT, 1.5, ch.F64)
-    assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED
+    # integer column vs Float64 constant and Float64 column vs integer constant: the mathematical comparison of
+    # accurate::lessOp / equalsOp (AccurateComparison.h:20-130), incl. constants no integer / no double can equal
+    fconsts = [0.0, -0.0, 1.5, -0.5, -7.0, 49.0, 49.000001, 2.0**31, 2.0**53, 2.0**53 + 2, 2.0**63, -2.0**63, 2.0**64, 1e19, -1e19,
+               1.8446744073709552e19, 3e38, -3e38, np.inf, -np.inf, np.nan]
+    big = np.array([2**53, 2**53 + 1, 2**53 + 2, 2**63 - 1, -2**63, -2**53 - 1], dtype=np.int64)
+    ubig = np.array([2**53 + 1, 2**63, 2**64 - 1, 2**64 - 1025], dtype=np.uint64)
+    for arr in (a64, np.concatenate([a64, big]), np.concatenate([u64, ubig]), u32, i32):
+        col = ctx.upload(arr)
+        for c in fconsts:
+            for op in ops:
+                got = ch.cmp_const(col, op, c, ch.F64).numpy()
+                want = O.cmp_const(arr, op, c, O.F64)
+                assert np.array_equal(got, want), (arr.dtype, c, op)
+    fx = np.concatenate([f, np.array([2.0**53, 2.0**53 + 2, 2.0**63, -2.0**63, 2.0**64, 1.8446744073709552e19, 9007199254740993.0, 1e300, -1e300])])
+    fxc = ctx.upload(fx)
+    for stag, scalars in ((O.I64, [0, -1, 7, 2**53, 2**53 + 1, 2**63 - 1, -2**63, -2**53 - 1]), (O.U64, [0, 5, 2**53 + 1, 2**63, 2**64 - 1]),
+                          (O.U32, [0, 2**32 - 1]), (O.I32, [-2**31, 3])):
+        for sc in scalars:
+            for op in ops:
+                got = ch.cmp_const(fxc, op, sc, stag).numpy()
+                want = O.cmp_const(fx, op, sc, stag)
+                assert np.array_equal(got, want), (stag, sc, op)
 
 
 @pytest.mark.parametrize("dtype", [np.int64, np.uint64, np.uint32, np.int32, np.uint8])
