@@ -502,17 +502,31 @@ static int launch_filter_sum(chgpu_ctx * ctx, int type, const void * pred, const
     return launch_filter_sum_int<IntRangePred>(ctx, type, pred, val, cond, n, spec->ip, result_dev);
 }
 
+// Predicate and value columns of different types: the one-pass kernel is instantiated per type, so the predicate is first
+// materialised as a UInt8 mask (k_cmp_mask) and the value column summed under it (addManyConditional,
+// AggregateFunctionSum.h:138-236) -- what the reference does, minus its filtered copy.  9 + w B/row instead of 8 + w.
+extern "C" int chgpu_cmp_const(chgpu_ctx * ctx, const chgpu_col * col, int op, int scalar_type, const void * scalar, chgpu_col ** mask_out);
+static int filter_sum_mixed(chgpu_ctx * ctx, const chgpu_col * pred, int op, int scalar_type, const void * scalar, const chgpu_col * val, u64 * result_dev)
+{
+    chgpu_col * mask = nullptr;
+    CHGPU_TRY(chgpu_cmp_const(ctx, pred, op, scalar_type, scalar, &mask));
+    const int rc = launch_filter_sum(ctx, val->type, val->data, val->data, (const u8 *)mask->data, val->rows, nullptr, result_dev);
+    chgpu_col_free(mask); // back to the pool: reuse is ordered behind the kernel on the context's stream
+    return rc;
+}
+
 extern "C" int chgpu_filter_sum_async(chgpu_ctx * ctx, const chgpu_col * pred, int op, int scalar_type, const void * scalar,
                                       const chgpu_col * val, chgpu_col * result)
 {
     CHGPU_REQUIRE(ctx && pred && val && result, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(pred->rows == val->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of predicate column (%llu) doesn't match size of value column (%llu)",
                   (unsigned long long)pred->rows, (unsigned long long)val->rows);
-    CHGPU_REQUIRE(pred->type == val->type, CHGPU_ERR_NOT_IMPLEMENTED, "fused filter+sum needs predicate and value columns of one type");
     CHGPU_REQUIRE(result->type == CHGPU_U64 && result->rows >= 2, CHGPU_ERR_BAD_ARGUMENTS, "result must be a UInt64 column of 2 rows");
+    ctx->counters[5] += pred->rows;
+    if (pred->type != val->type)
+        return filter_sum_mixed(ctx, pred, op, scalar_type, scalar, val, (u64 *)result->data);
     CmpSpec spec;
     CHGPU_TRY(make_cmp_spec(pred->type, op, scalar_type, scalar, &spec));
-    ctx->counters[5] += pred->rows;
     return launch_filter_sum(ctx, pred->type, pred->data, val->data, nullptr, pred->rows, &spec, (u64 *)result->data);
 }
 
@@ -522,15 +536,19 @@ extern "C" int chgpu_filter_sum(chgpu_ctx * ctx, const chgpu_col * pred, int op,
     CHGPU_REQUIRE(ctx && pred && val && sum_out && count_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(pred->rows == val->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of predicate column (%llu) doesn't match size of value column (%llu)",
                   (unsigned long long)pred->rows, (unsigned long long)val->rows);
-    CHGPU_REQUIRE(pred->type == val->type, CHGPU_ERR_NOT_IMPLEMENTED, "fused filter+sum needs predicate and value columns of one type");
-    CmpSpec spec;
-    CHGPU_TRY(make_cmp_spec(pred->type, op, scalar_type, scalar, &spec));
     void * scratch = nullptr;
     // result slot lives behind the partials: ask for the partials' worth first so the pointer stays valid
     const u32 grid_cap = (u32)ctx->num_cus * 8;
     CHGPU_TRY(chgpu_scratch(ctx, (size_t)grid_cap * 2 * sizeof(u64) + 64, &scratch));
     u64 * result_dev = (u64 *)((char *)scratch + (size_t)grid_cap * 2 * sizeof(u64));
-    CHGPU_TRY(launch_filter_sum(ctx, pred->type, pred->data, val->data, nullptr, pred->rows, &spec, result_dev));
+    if (pred->type != val->type)
+        CHGPU_TRY(filter_sum_mixed(ctx, pred, op, scalar_type, scalar, val, result_dev));
+    else
+    {
+        CmpSpec spec;
+        CHGPU_TRY(make_cmp_spec(pred->type, op, scalar_type, scalar, &spec));
+        CHGPU_TRY(launch_filter_sum(ctx, pred->type, pred->data, val->data, nullptr, pred->rows, &spec, result_dev));
+    }
     u64 res[2];
     CHGPU_TRY(chgpu_read_back(ctx, result_dev, res, sizeof(res)));
     memcpy(sum_out, &res[0], 8);

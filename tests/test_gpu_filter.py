@@ -178,6 +178,39 @@ def test_fused_filter_sum_two_columns_types_and_views(ch, ctx, oracle_mod):
     assert e.value.code == ch._capi.ERR_SIZES_MISMATCH
 
 
+def test_fused_filter_sum_predicate_and_value_of_different_types(ch, ctx, oracle_mod):
+    # WHERE over one type, sum over another: mask + conditional sum on the device (addManyConditional semantics);
+    # also a Float64 threshold against an integer predicate column
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(21))
+    n = 700_003
+    preds = {np.int32: rng.integers(-1000, 1000, size=n).astype(np.int32), np.uint8: rng.integers(0, 256, size=n).astype(np.uint8),
+             np.float64: rng.standard_normal(n), np.uint64: rng.integers(0, 2**63, size=n, dtype=np.uint64)}
+    vals = {np.int64: rng.integers(-2**62, 2**62, size=n, dtype=np.int64), np.uint32: rng.integers(0, 2**32, size=n, dtype=np.uint32),
+            np.float64: rng.random(n)}
+    for pdt, p in preds.items():
+        for vdt, v in vals.items():
+            if pdt == vdt:
+                continue
+            for op, thr, tag in ((ch.LT, np.quantile(p.astype(np.float64), 0.3), None), (ch.GE, 0.5, ch.F64)):
+                scalar = float(thr) if (tag == ch.F64 or pdt == np.float64) else int(thr)
+                s, c = ch.filter_sum(ctx.upload(p), op, scalar, ctx.upload(v), scalar_tag=tag)
+                mask = O.cmp_const(p, op, scalar, tag).astype(bool)
+                assert c == int(mask.sum()), (pdt, vdt, op)
+                if vdt == np.float64:
+                    want = float(v[mask].sum())
+                    assert abs(float(s) - want) <= 1e-6 * abs(want) + 1e-12
+                else:
+                    want = int(v[mask].astype(np.uint64).sum(dtype=np.uint64)) if vdt == np.uint32 else int(v[mask].view(np.uint64).sum(dtype=np.uint64))
+                    assert int(np.array(s).astype(np.uint64)) == want % 2**64, (pdt, vdt, op)   # modulo 2^64
+    r = ctx.upload(np.zeros(2, dtype=np.uint64))
+    ch.filter_sum_async(ctx.upload(preds[np.int32]), ch.LT, 0, ctx.upload(vals[np.int64]), r)
+    ctx.synchronize()
+    got = r.numpy()
+    m = preds[np.int32] < 0
+    assert int(got[1]) == int(m.sum()) and int(got[0]) == int(vals[np.int64][m].view(np.uint64).sum(dtype=np.uint64))
+
+
 def test_filter_description_nullable(ch, ctx, oracle_mod):
     rng = np.random.Generator(np.random.PCG64(3))
     d = rng.integers(0, 3, size=10007).astype(np.uint8)
