@@ -1085,7 +1085,16 @@ extern "C" int chgpu_and(chgpu_ctx * ctx, const chgpu_col * a, const chgpu_col *
     return CHGPU_OK;
 }
 
+// Type of sum(a OP b): the operation's result type (NumberTraits.h:73-87) summed (Int64 for signed, UInt64 for unsigned).
+static int arith_sum_type(int value_op, int a_type, int b_type);
+// Result type of a OP b as a column; two 1-byte operands promote to a 2-byte type this library does not carry: -1.
 static int arith_result_type(int value_op, int a_type, int b_type)
+{
+    if (chgpu_type_size(a_type) == 1 && chgpu_type_size(b_type) == 1)
+        return -1;
+    return arith_sum_type(value_op, a_type, b_type);
+}
+static int arith_sum_type(int value_op, int a_type, int b_type)
 {
     if (!chgpu_type_is_int(a_type) || !chgpu_type_is_int(b_type))
         return -1;
@@ -1161,6 +1170,7 @@ struct ExprPred
 struct ExprSpec
 {
     u32 n_cols, n_preds;
+    int col_type[EX_MAX_COLS]; // used by the mixed-width kernel
     const void * col[EX_MAX_COLS];
     ExprPred pred[EX_MAX_PREDS];
     int value_op;
@@ -1198,6 +1208,20 @@ __global__ __launch_bounds__(FS_THREADS) void k_expr_filter_sum(ExprSpec sp, u64
     constexpr int E = VEC * UNROLL; // elements per lane per iteration
     const u64 nvec = n / VEC;
     u64 s = 0, c = 0;
+    // predicate constants in wave-uniform registers for the whole kernel (see k_expr_filter_sum_narrow), in the key width
+    typedef typename std::conditional<sizeof(T) <= 4, u32, u64>::type KT;
+    KT p_lo[EX_MAX_PREDS], p_span[EX_MAX_PREDS], p_flip[EX_MAX_PREDS];
+    u32 p_inv[EX_MAX_PREDS], p_col[EX_MAX_PREDS];
+#pragma unroll
+    for (u32 q = 0; q < EX_MAX_PREDS; ++q)
+    {
+        const bool on = q < sp.n_preds;
+        p_lo[q] = on ? (KT)sp.pred[q].lo : 0;
+        p_span[q] = on ? (KT)sp.pred[q].span : 0;
+        p_flip[q] = on ? (KT)sp.pred[q].flip : 0;
+        p_inv[q] = on ? sp.pred[q].invert : 0;
+        p_col[q] = on ? sp.pred[q].col : 0xFFu;
+    }
 
     auto reduce_rows = [&](const T (&x0)[E], const T (&x1)[E], const T (&x2)[E], const T (&x3)[E], int n_elem) {
         bool pass[E];
@@ -1210,13 +1234,13 @@ __global__ __launch_bounds__(FS_THREADS) void k_expr_filter_sum(ExprSpec sp, u64
             vb[e] = 0;
         }
         auto column = [&](u32 k, const T (&x)[E]) {
-            for (u32 q = 0; q < sp.n_preds; ++q)
-                if (sp.pred[q].col == k)
+#pragma unroll
+            for (u32 q = 0; q < EX_MAX_PREDS; ++q)
+                if (p_col[q] == k)
                 {
-                    const ExprPred pr = sp.pred[q];
 #pragma unroll
                     for (int e = 0; e < E; ++e)
-                        pass[e] = pass[e] && expr_pass<T>(pr, x[e]);
+                        pass[e] = pass[e] && ((((KT)x[e] ^ p_flip[q]) - p_lo[q]) <= p_span[q]) != (p_inv[q] != 0);
                 }
             if (sp.val_a == k)
             {
@@ -1316,6 +1340,314 @@ __global__ __launch_bounds__(FS_THREADS) void k_expr_filter_sum(ExprSpec sp, u64
     }
 }
 
+// Columns of DIFFERENT integer widths (the real SSB lineorder: UInt32 dates and prices next to UInt8 discount and quantity).
+// A lane owns units of 4 consecutive rows, EXM_UNROLL units per iteration at a stride of the workgroup: a 4-byte column is
+// one 16-byte load per unit, a 1-byte column one 4-byte load, an 8-byte column two 16-byte loads -- every instruction
+// coalesced across the wave.  Per column (static) a wave-uniform switch selects the width-native path; predicates are
+// applied in the column's own width exactly as in the same-type kernel.
+#ifndef EXM_UNROLL
+#define EXM_UNROLL 4
+#endif
+template <typename T>
+__device__ __forceinline__ void exm_load_unit(const void * col, u64 unit, T (&x)[4])
+{
+    if constexpr (sizeof(T) == 1)
+    {
+        const u32 w = __builtin_nontemporal_load((const u32 *)col + unit);
+        x[0] = (T)(w & 0xFF), x[1] = (T)((w >> 8) & 0xFF), x[2] = (T)((w >> 16) & 0xFF), x[3] = (T)(w >> 24);
+    }
+    else if constexpr (sizeof(T) == 4)
+    {
+        const Vec<T, 4> v = load_stream((const Vec<T, 4> *)col + unit);
+        x[0] = v.v[0], x[1] = v.v[1], x[2] = v.v[2], x[3] = v.v[3];
+    }
+    else
+    {
+        const Vec<T, 2> a = load_stream((const Vec<T, 2> *)col + 2 * unit), b = load_stream((const Vec<T, 2> *)col + 2 * unit + 1);
+        x[0] = a.v[0], x[1] = a.v[1], x[2] = b.v[0], x[3] = b.v[1];
+    }
+}
+
+__global__ __launch_bounds__(FS_THREADS) void k_expr_filter_sum_mixed(ExprSpec sp, u64 n, u64 * __restrict__ part_sum, u64 * __restrict__ part_cnt)
+{
+    constexpr int U = EXM_UNROLL, E = 4 * U;
+    u64 s = 0, c = 0;
+    const u64 n_units = n / 4;
+    constexpr u64 CHUNK = (u64)U * FS_THREADS; // units per workgroup iteration
+    const u64 n_chunks = n_units / CHUNK;
+
+    // one column over the E rows of this lane: load (if whole units) or take the single tail row, test, extract values
+    auto column_t = [&](auto tag, u32 k, u64 unit0, u64 tail_row, bool tail, bool (&pass)[E], u64 (&va)[E], u64 (&vb)[E]) {
+        using T = decltype(tag);
+        T x[E];
+        if (!tail)
+        {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                T q[4];
+                exm_load_unit<T>(sp.col[k], unit0 + (u64)u * FS_THREADS, q);
+                x[4 * u] = q[0], x[4 * u + 1] = q[1], x[4 * u + 2] = q[2], x[4 * u + 3] = q[3];
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                x[e] = 0;
+            x[0] = ((const T *)sp.col[k])[tail_row];
+        }
+        for (u32 q = 0; q < sp.n_preds; ++q)
+            if (sp.pred[q].col == k)
+            {
+                const ExprPred pr = sp.pred[q];
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    pass[e] = pass[e] && expr_pass<T>(pr, x[e]);
+            }
+        if (sp.val_a == k)
+        {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                va[e] = ext64(x[e]);
+        }
+        if (sp.value_op != CHGPU_VAL_COL && sp.val_b == k)
+        {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                vb[e] = ext64(x[e]);
+        }
+    };
+    auto column = [&](u32 k, u64 unit0, u64 tail_row, bool tail, bool (&pass)[E], u64 (&va)[E], u64 (&vb)[E]) {
+        switch (sp.col_type[k]) // wave-uniform
+        {
+            case CHGPU_U8: column_t((u8)0, k, unit0, tail_row, tail, pass, va, vb); break;
+            case CHGPU_U32: column_t((u32)0, k, unit0, tail_row, tail, pass, va, vb); break;
+            case CHGPU_I32: column_t((i32)0, k, unit0, tail_row, tail, pass, va, vb); break;
+            case CHGPU_U64: column_t((u64)0, k, unit0, tail_row, tail, pass, va, vb); break;
+            default: column_t((i64)0, k, unit0, tail_row, tail, pass, va, vb); break;
+        }
+    };
+    auto rows = [&](u64 unit0, u64 tail_row, bool tail) {
+        bool pass[E];
+        u64 va[E], vb[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+        {
+            pass[e] = !tail || e == 0;
+            va[e] = 0;
+            vb[e] = 0;
+        }
+        column(0, unit0, tail_row, tail, pass, va, vb);
+        if (sp.n_cols > 1) column(1, unit0, tail_row, tail, pass, va, vb);
+        if (sp.n_cols > 2) column(2, unit0, tail_row, tail, pass, va, vb);
+        if (sp.n_cols > 3) column(3, unit0, tail_row, tail, pass, va, vb);
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+        {
+            const u64 v = sp.value_op == CHGPU_VAL_COL ? va[e] : apply_val(sp.value_op, va[e], vb[e]);
+            s += pass[e] ? v : 0;
+            c += pass[e] ? 1 : 0;
+        }
+    };
+    for (u64 ch = blockIdx.x; ch < n_chunks; ch += gridDim.x)
+        rows(ch * CHUNK + threadIdx.x, 0, false);
+    const u64 tid = (u64)blockIdx.x * FS_THREADS + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * FS_THREADS;
+    for (u64 r = n_chunks * CHUNK * 4 + tid; r < n; r += stride)
+        rows(0, r, true);
+
+    __shared__ u64 lds_s[FS_THREADS / WAVE];
+    __shared__ u64 lds_c[FS_THREADS / WAVE];
+    s = wave_reduce_add_u64(s);
+    c = wave_reduce_add_u64(c);
+    if ((threadIdx.x & 63) == 0)
+    {
+        lds_s[threadIdx.x >> 6] = s;
+        lds_c[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        u64 ss = 0, cc = 0;
+        for (int w = 0; w < FS_THREADS / WAVE; ++w)
+        {
+            ss += lds_s[w];
+            cc += lds_c[w];
+        }
+        part_sum[blockIdx.x] = ss;
+        part_cnt[blockIdx.x] = cc;
+    }
+}
+
+// The common mixed case -- every column 1 or 4 bytes wide (SSB lineorder) -- with ALL loads of an iteration issued before the
+// first use, like the same-type kernel: 4 registers per (4-byte column, unit), 1 per (1-byte column, unit).  The generic
+// mixed kernel above loads column after column (187 VGPRs, 2 waves/SIMD: 6.7 ms for the 1e9-row Q1.1 shape).
+// WMASK: bit k set = column k is 4 bytes wide (else 1 byte).  The widths are compile-time so that the loads of all four
+// columns are straight-line code: with a run-time width test around them hipcc drained the load queue (vmcnt(0)) at every
+// join and the kernel ran at the speed of four dependent loads per iteration (6.7 ms for 1e9 rows).  Absent columns alias
+// column 0 (their loads hit L1) so that no column-count branch surrounds a load either.
+template <u32 WMASK>
+__global__ __launch_bounds__(FS_THREADS) void k_expr_filter_sum_narrow(ExprSpec sp, u64 n, u64 * __restrict__ part_sum, u64 * __restrict__ part_cnt)
+{
+#ifndef EXN_UNROLL
+#define EXN_UNROLL 2 // 4 units per lane needed 256 VGPRs (1 wave/SIMD)
+#endif
+    constexpr int U = EXN_UNROLL, E = 4 * U;
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    u64 s = 0, c = 0;
+    const u64 n_units = n / 4;
+    constexpr u64 CHUNK = (u64)U * FS_THREADS;
+    const u64 n_chunks = n_units / CHUNK;
+
+    // predicate constants live in wave-uniform registers for the whole kernel (constant indices after unrolling): fetching
+    // sp.pred[q] inside the row loop cost an s_load + wait per (column, predicate) and iteration -- 6.0 ms instead of 2.x
+    u32 p_lo[EX_MAX_PREDS], p_span[EX_MAX_PREDS], p_flip[EX_MAX_PREDS], p_inv[EX_MAX_PREDS], p_col[EX_MAX_PREDS];
+#pragma unroll
+    for (u32 q = 0; q < EX_MAX_PREDS; ++q)
+    {
+        const bool on = q < sp.n_preds;
+        p_lo[q] = on ? (u32)sp.pred[q].lo : 0;
+        p_span[q] = on ? (u32)sp.pred[q].span : 0;
+        p_flip[q] = on ? (u32)sp.pred[q].flip : 0;
+        p_inv[q] = on ? sp.pred[q].invert : 0;
+        p_col[q] = on ? sp.pred[q].col : 0xFFu;
+    }
+    auto load_col = [&](auto kc, u64 unit0, v4u (&raw)[U]) {
+        constexpr u32 k = decltype(kc)::value;
+        if constexpr (((WMASK >> k) & 1) == 0)
+        {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                raw[u].x = __builtin_nontemporal_load((const u32 *)sp.col[k] + unit0 + (u64)u * FS_THREADS);
+        }
+        else
+        {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                raw[u] = __builtin_nontemporal_load((const v4u *)sp.col[k] + unit0 + (u64)u * FS_THREADS);
+        }
+    };
+    // decode + test + extract for one column; x holds the zero/sign-extended 32-bit pattern of each element
+    auto column_t = [&](auto tag, u32 k, const u32 (&x)[E], bool (&pass)[E], u32 (&va)[E], u32 (&vb)[E]) {
+        (void)tag; // the element's signedness only matters for the value (finish()); the key test is width-native u32
+#pragma unroll
+        for (u32 q = 0; q < EX_MAX_PREDS; ++q)
+            if (p_col[q] == k)
+            {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    pass[e] = pass[e] && ((((x[e] ^ p_flip[q]) - p_lo[q]) <= p_span[q]) != (p_inv[q] != 0));
+            }
+        if (sp.val_a == k)
+        {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                va[e] = x[e]; // widened in finish() by the column's signedness
+        }
+        if (sp.value_op != CHGPU_VAL_COL && sp.val_b == k)
+        {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                vb[e] = x[e];
+        }
+    };
+    auto column = [&](u32 k, const v4u (&raw)[U], bool (&pass)[E], u32 (&va)[E], u32 (&vb)[E]) {
+        u32 x[E];
+        if (sp.col_type[k] == CHGPU_U8)
+        {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                const u32 w = raw[u].x;
+                x[4 * u] = w & 0xFF, x[4 * u + 1] = (w >> 8) & 0xFF, x[4 * u + 2] = (w >> 16) & 0xFF, x[4 * u + 3] = w >> 24;
+            }
+            column_t((u8)0, k, x, pass, va, vb);
+        }
+        else
+        {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                x[4 * u] = raw[u].x, x[4 * u + 1] = raw[u].y, x[4 * u + 2] = raw[u].z, x[4 * u + 3] = raw[u].w;
+            if (sp.col_type[k] == CHGPU_I32)
+                column_t((i32)0, k, x, pass, va, vb);
+            else
+                column_t((u32)0, k, x, pass, va, vb);
+        }
+    };
+    const bool a_signed = sp.col_type[sp.val_a] == CHGPU_I32, b_signed = sp.col_type[sp.val_b < EX_MAX_COLS ? sp.val_b : 0] == CHGPU_I32;
+    auto finish = [&](const bool (&pass)[E], const u32 (&va)[E], const u32 (&vb)[E]) {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+        {
+            const u64 xa = a_signed ? (u64)(i64)(i32)va[e] : (u64)va[e], xb = b_signed ? (u64)(i64)(i32)vb[e] : (u64)vb[e];
+            const u64 v = sp.value_op == CHGPU_VAL_COL ? xa : apply_val(sp.value_op, xa, xb);
+            s += pass[e] ? v : 0;
+            c += pass[e] ? 1 : 0;
+        }
+    };
+    for (u64 ch = blockIdx.x; ch < n_chunks; ch += gridDim.x)
+    {
+        const u64 unit0 = ch * CHUNK + threadIdx.x;
+        v4u r0[U] = {}, r1[U] = {}, r2[U] = {}, r3[U] = {};
+        load_col(std::integral_constant<u32, 0>{}, unit0, r0);
+        load_col(std::integral_constant<u32, 1>{}, unit0, r1);
+        load_col(std::integral_constant<u32, 2>{}, unit0, r2);
+        load_col(std::integral_constant<u32, 3>{}, unit0, r3);
+        __builtin_amdgcn_sched_barrier(0);
+        bool pass[E];
+        u32 va[E], vb[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            pass[e] = true, va[e] = 0, vb[e] = 0;
+        column(0, r0, pass, va, vb);
+        if (sp.n_cols > 1) column(1, r1, pass, va, vb);
+        if (sp.n_cols > 2) column(2, r2, pass, va, vb);
+        if (sp.n_cols > 3) column(3, r3, pass, va, vb);
+        finish(pass, va, vb);
+    }
+    // tail rows one by one
+    const u64 tid = (u64)blockIdx.x * FS_THREADS + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * FS_THREADS;
+    for (u64 r = n_chunks * CHUNK * 4 + tid; r < n; r += stride)
+    {
+        bool pass[E];
+        u32 va[E], vb[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            pass[e] = e == 0, va[e] = 0, vb[e] = 0;
+        for (u32 k = 0; k < sp.n_cols; ++k)
+        {
+            v4u raw[U] = {};
+            raw[0].x = sp.col_type[k] == CHGPU_U8 ? (u32)((const u8 *)sp.col[k])[r] : ((const u32 *)sp.col[k])[r];
+            column(k, raw, pass, va, vb);
+        }
+        finish(pass, va, vb);
+    }
+
+    __shared__ u64 lds_s[FS_THREADS / WAVE];
+    __shared__ u64 lds_c[FS_THREADS / WAVE];
+    s = wave_reduce_add_u64(s);
+    c = wave_reduce_add_u64(c);
+    if ((threadIdx.x & 63) == 0)
+    {
+        lds_s[threadIdx.x >> 6] = s;
+        lds_c[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        u64 ss = 0, cc = 0;
+        for (int w = 0; w < FS_THREADS / WAVE; ++w)
+        {
+            ss += lds_s[w];
+            cc += lds_c[w];
+        }
+        part_sum[blockIdx.x] = ss;
+        part_cnt[blockIdx.x] = cc;
+    }
+}
+
 extern "C" int chgpu_expr_filter_sum(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, uint32_t n_preds,
                                      const uint32_t * pred_col, const int * pred_op, const int * pred_scalar_type,
                                      const uint64_t * pred_scalar_bits, int value_op, uint32_t val_a, uint32_t val_b,
@@ -1331,23 +1663,25 @@ extern "C" int chgpu_expr_filter_sum(chgpu_ctx * ctx, uint32_t n_cols, const chg
     memset(&sp, 0, sizeof(sp));
     sp.n_cols = n_cols;
     sp.n_preds = n_preds;
-    const int type = cols[0] ? cols[0]->type : -1;
+    const int type0 = cols[0] ? cols[0]->type : -1;
     u64 n = cols[0] ? cols[0]->rows : 0;
-    bool aligned = true;
+    bool aligned = true, one_type = true;
     for (u32 k = 0; k < EX_MAX_COLS; ++k)
     {
         const chgpu_col * cc = cols[k < n_cols ? k : 0];
         CHGPU_REQUIRE(cc, CHGPU_ERR_BAD_ARGUMENTS, "column %u is NULL", k);
-        CHGPU_REQUIRE(cc->type == type, CHGPU_ERR_NOT_IMPLEMENTED, "fused expression needs columns of one type");
+        CHGPU_REQUIRE(chgpu_type_is_int(cc->type), CHGPU_ERR_NOT_IMPLEMENTED, "fused expression over Float64: CPU path");
         CHGPU_REQUIRE(cc->rows == n, CHGPU_ERR_SIZES_MISMATCH, "Sizes of columns doesn't match");
+        one_type = one_type && cc->type == type0;
         sp.col[k] = cc->data;
+        sp.col_type[k] = cc->type;
         aligned = aligned && (((uintptr_t)cc->data) & 15) == 0;
     }
-    CHGPU_REQUIRE(chgpu_type_is_int(type), CHGPU_ERR_NOT_IMPLEMENTED, "fused expression over Float64: CPU path");
     CHGPU_REQUIRE(aligned, CHGPU_ERR_NOT_IMPLEMENTED, "fused expression needs 16-byte aligned columns");
     for (u32 k = 0; k < n_preds; ++k)
     {
         CHGPU_REQUIRE(pred_col[k] < n_cols, CHGPU_ERR_BAD_ARGUMENTS, "predicate %u refers to column %u of %u", k, pred_col[k], n_cols);
+        const int type = cols[pred_col[k]]->type; // predicates are folded in the width of the column they test
         CmpSpec cs;
         CHGPU_TRY(make_cmp_spec(type, pred_op[k], pred_scalar_type[k], &pred_scalar_bits[k], &cs));
         // make_cmp_spec folds the comparison over the 64-bit extension of the column's signedness class; a 4-byte (or
@@ -1392,20 +1726,44 @@ extern "C" int chgpu_expr_filter_sum(chgpu_ctx * ctx, uint32_t n_cols, const chg
     sp.value_op = value_op;
     sp.val_a = val_a;
     sp.val_b = val_b;
-    const int rt = value_op == CHGPU_VAL_COL ? chgpu_sum_result_type(type) : arith_result_type(value_op, type, type);
+    const int type_a = cols[val_a]->type, type_b = value_op == CHGPU_VAL_COL ? type_a : cols[val_b]->type;
+    // the kernels compute in 64 bits (operands sign/zero-extended): exact for every result type up to 8 bytes, and a 2-byte
+    // result (UInt8 op UInt8) cannot overflow, so the 64-bit sum is the reference's sum in every supported case
+    const int rt = value_op == CHGPU_VAL_COL ? chgpu_sum_result_type(type_a) : arith_sum_type(value_op, type_a, type_b);
     CHGPU_REQUIRE(rt >= 0, CHGPU_ERR_NOT_IMPLEMENTED, "value expression: CPU path");
     if (result_type_out)
         *result_type_out = rt;
 
-    const u32 vecw = 16 / (u32)chgpu_type_size(type);
-    static const u32 ex_wg = tune_env("CHGPU_TUNE_EXPR_WG", 3);
-    const u32 grid = chgpu_grid_for(ctx, (n + vecw - 1) / vecw, FS_THREADS, ex_wg);
+    const int type = type0;
+    const u32 vecw = one_type ? 16 / (u32)chgpu_type_size(type) : 4;
+    bool narrow = true; // every column 1 or 4 bytes wide
+    for (u32 k = 0; k < n_cols; ++k)
+        narrow = narrow && chgpu_type_size(cols[k]->type) <= 4;
+    // workgroups per CU (measured on the 4-column Q1.1 shape): same-type kernel 3; narrow mixed kernel 6 (86 VGPRs, 2 units
+    // per lane: 2.36 ms vs 3.02 ms with 3; 3-4 units per lane 2.7 ms)
+    static const u32 ex_wg = tune_env("CHGPU_TUNE_EXPR_WG", 3), exn_wg = tune_env("CHGPU_TUNE_EXPRN_WG", 6);
+    const u32 grid = chgpu_grid_for(ctx, (n + vecw - 1) / vecw, FS_THREADS, (!one_type && narrow) ? exn_wg : ex_wg);
     void * scratch = nullptr;
     const u32 grid_cap = (u32)ctx->num_cus * 8;
     CHGPU_TRY(chgpu_scratch(ctx, (size_t)grid_cap * 2 * sizeof(u64) + 64, &scratch));
     u64 * part_sum = (u64 *)scratch;
     u64 * part_cnt = part_sum + grid;
     u64 * result_dev = (u64 *)((char *)scratch + (size_t)grid_cap * 2 * sizeof(u64));
+    if (!one_type && narrow)
+    {
+        u32 wmask = 0;
+        for (u32 k = 0; k < EX_MAX_COLS; ++k)
+            wmask |= (chgpu_type_size(cols[k < n_cols ? k : 0]->type) == 4 ? 1u : 0u) << k;
+#define EXN(M) case M: hipLaunchKernelGGL(k_expr_filter_sum_narrow<M>, dim3(grid), dim3(FS_THREADS), 0, ctx->stream, sp, n, part_sum, part_cnt); break;
+        switch (wmask)
+        {
+            EXN(0) EXN(1) EXN(2) EXN(3) EXN(4) EXN(5) EXN(6) EXN(7) EXN(8) EXN(9) EXN(10) EXN(11) EXN(12) EXN(13) EXN(14) EXN(15)
+        }
+#undef EXN
+    }
+    else if (!one_type)
+        hipLaunchKernelGGL(k_expr_filter_sum_mixed, dim3(grid), dim3(FS_THREADS), 0, ctx->stream, sp, n, part_sum, part_cnt);
+    else
     switch (type)
     {
         case CHGPU_I64: hipLaunchKernelGGL(k_expr_filter_sum<i64>, dim3(grid), dim3(FS_THREADS), 0, ctx->stream, sp, n, part_sum, part_cnt); break;

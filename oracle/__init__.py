@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
             "cho_filter_sum_pipeline": (i32, [i32, vp, vp, sz, i32, vp, sz, i32, vp, vp, vp, vp]),
             "cho_and_u8": (None, [vp, vp, sz, vp]),
             "cho_arith_result_type": (i32, [i32, i32, i32]),
+            "cho_arith_sum_type": (i32, [i32, i32, i32]),
             "cho_arith": (i32, [i32, i32, vp, i32, vp, sz, vp]),
             "cho_expr_filter_sum_pipeline": (i32, [sz, vp, vp, sz, sz, vp, vp, vp, vp, i32, C.c_uint32, C.c_uint32, sz, i32, vp, vp]),
             "cho_hashmap_create": (vp, []),
@@ -315,7 +316,7 @@ def expr_filter_sum_pipeline(cols, preds, value_op, val_a, val_b=0, block_rows=D
     ps = np.array([(p[3] if len(p) > 3 and p[3] is not None else tag_of(cols[p[0]])) for p in preds], dtype=np.int32)
     pb = np.array([scalar_bits(int(t), p[2]) for p, t in zip(preds, ps)], dtype=np.uint64)
     ta = tag_of(cols[val_a])
-    rt = sum_result_dtype(ta) if value_op == VAL_COL else NP_OF[lib().cho_arith_result_type(value_op, ta, tag_of(cols[val_b]))]
+    rt = sum_result_dtype(ta) if value_op == VAL_COL else NP_OF[lib().cho_arith_sum_type(value_op, ta, tag_of(cols[val_b]))]
     out = np.zeros(1, dtype=rt)
     cnt = np.zeros(1, dtype=np.uint64)
     rc = lib().cho_expr_filter_sum_pipeline(len(cols), _p(types), ptrs, n, len(preds), _p(pc), _p(po), _p(ps), _p(pb), value_op, val_a, val_b,

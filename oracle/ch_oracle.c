@@ -693,17 +693,27 @@ void cho_and_u8(const uint8_t * a, const uint8_t * b, size_t n, uint8_t * out)
         out[i] = a[i] & b[i];
 }
 
-int cho_arith_result_type(int value_op, int a_type, int b_type)
+/* Type of sum(a OP b) over integer columns: the operation's result type (NumberTraits.h:73-87: the next size above the wider
+   operand, signed if either is or for minus) summed (AggregateFunctionSum: Int64 for signed, UInt64 for unsigned). */
+int cho_arith_sum_type(int value_op, int a_type, int b_type)
 {
     if (a_type == CHO_F64 || b_type == CHO_F64 || !type_size(a_type) || !type_size(b_type))
         return -1;
     const int sgn_a = a_type == CHO_I64 || a_type == CHO_I32, sgn_b = b_type == CHO_I64 || b_type == CHO_I32;
-    /* NumberTraits.h:73-87: every size this path handles (1, 4, 8 bytes) promotes to at most 8 bytes */
     if (value_op == CHO_VAL_MINUS)
         return CHO_I64;
     if (value_op == CHO_VAL_MUL || value_op == CHO_VAL_PLUS)
         return (sgn_a || sgn_b) ? CHO_I64 : CHO_U64;
     return -1;
+}
+
+/* Result type of a OP b as a column.  Operands of 4 or 8 bytes promote to 8 bytes; two 1-byte operands promote to a 2-byte
+   type (UInt16 / Int16), which this path does not carry: -1. */
+int cho_arith_result_type(int value_op, int a_type, int b_type)
+{
+    if (type_size(a_type) == 1 && type_size(b_type) == 1)
+        return -1;
+    return cho_arith_sum_type(value_op, a_type, b_type);
 }
 
 static inline uint64_t load_int_as_u64(int type, const void * p, size_t i)
@@ -719,18 +729,25 @@ static inline uint64_t load_int_as_u64(int type, const void * p, size_t i)
     }
 }
 
+/* values of a OP b in 64-bit two's complement: exact for every result type up to 8 bytes (a 2-byte result cannot overflow) */
+static void arith_u64(int value_op, int a_type, const void * a, int b_type, const void * b, size_t n, uint64_t * o);
+
 int cho_arith(int value_op, int a_type, const void * a, int b_type, const void * b, size_t n, void * out)
 {
     if (cho_arith_result_type(value_op, a_type, b_type) < 0)
         return -1;
-    uint64_t * o = (uint64_t *)out;
+    arith_u64(value_op, a_type, a, b_type, b, n, (uint64_t *)out);
+    return 0;
+}
+
+static void arith_u64(int value_op, int a_type, const void * a, int b_type, const void * b, size_t n, uint64_t * o)
+{
     for (size_t i = 0; i < n; ++i)
     {
         /* static_cast<Result>(a) OP b in the 64-bit result type; two's complement wrap (NO_SANITIZE_UNDEFINED) */
         const uint64_t x = load_int_as_u64(a_type, a, i), y = load_int_as_u64(b_type, b, i);
         o[i] = value_op == CHO_VAL_MUL ? x * y : value_op == CHO_VAL_PLUS ? x + y : x - y;
     }
-    return 0;
 }
 
 typedef struct
@@ -800,8 +817,8 @@ static void * expr_stream(void * arg)
                 cho_filter((int)type_size(tb), cb, rows, mask, rows, fb);
                 pb = fb;
             }
-            cho_arith(s->value_op, ta, pa, tb, pb, kept, val);
-            cho_sum_add_many(cho_arith_result_type(s->value_op, ta, tb), &s->sum_state, val, 0, kept);
+            arith_u64(s->value_op, ta, pa, tb, pb, kept, (uint64_t *)val);
+            cho_sum_add_many(cho_arith_sum_type(s->value_op, ta, tb), &s->sum_state, val, 0, kept);
         }
         s->count += kept;
     }

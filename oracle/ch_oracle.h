@@ -100,6 +100,7 @@ enum { CHO_VAL_COL = 0, CHO_VAL_MUL = 1, CHO_VAL_PLUS = 2, CHO_VAL_MINUS = 3 };
 void cho_and_u8(const uint8_t * a, const uint8_t * b, size_t n, uint8_t * out);
 /* out type = cho_arith_result_type(op, a_type, b_type) (CHO_I64 or CHO_U64 here); integer inputs only */
 int cho_arith_result_type(int value_op, int a_type, int b_type);
+int cho_arith_sum_type(int value_op, int a_type, int b_type);
 int cho_arith(int value_op, int a_type, const void * a, int b_type, const void * b, size_t n, void * out);
 /* `SELECT sum(<value>), count() WHERE p1 AND p2 ...` through the per-Block pipeline: every predicate is a comparison of a
    column with a constant (a3), the masks are and-ed, FilterTransform filters the columns the projection needs, the value

@@ -60,6 +60,39 @@ def test_gpu_and_arith_columns(oracle_mod):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 3, 4099, 2_000_003])
+def test_gpu_fused_expression_over_columns_of_different_widths(oracle_mod, n):
+    # the real SSB lineorder shape: UInt32 orderdate / extendedprice next to UInt8 discount / quantity (10 B/row), plus
+    # signed and 8-byte columns; every predicate is folded in the width of the column it tests
+    import clickhouse_amd as ch
+    O = oracle_mod
+    ctx = ch.Context(0)
+    rng = np.random.Generator(np.random.PCG64(n + 11))
+    orderdate = rng.integers(19920101, 19981231, size=n).astype(np.uint32)
+    discount = rng.integers(0, 11, size=n).astype(np.uint8)
+    quantity = rng.integers(1, 51, size=n).astype(np.uint8)
+    price = rng.integers(90_000, 10_500_000, size=n).astype(np.uint32)
+    cols_np = [orderdate, discount, quantity, price]
+    cols = [ctx.upload(c) for c in cols_np]
+    preds = lambda M: [(0, M.GE, 19930101), (0, M.LE, 19931231), (1, M.GE, 1), (1, M.LE, 3), (2, M.LT, 25)]
+    for vop, va, vb in ((ch.VAL_MUL, 3, 1), (ch.VAL_COL, 3, 0), (ch.VAL_PLUS, 1, 2), (ch.VAL_MINUS, 1, 2), (ch.VAL_MUL, 1, 2)):
+        s, c = ch.expr_filter_sum(cols, preds(ch), vop, va, vb)
+        so, co = O.expr_filter_sum_pipeline(cols_np, preds(O), vop, va, vb)
+        assert s.dtype == so.dtype and (int(s), c) == (int(so), co), (vop, va, vb)
+    # signed / 8-byte mix, constants outside a column's range, a Float64 constant against an integer column
+    a = rng.integers(-2**31, 2**31, size=n).astype(np.int32)
+    b = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
+    u = rng.integers(0, 2**64, size=n, dtype=np.uint64)
+    mixed_np = [a, b, u, discount]
+    mixed = [ctx.upload(c) for c in mixed_np]
+    p2 = lambda M: [(0, M.GT, -2**40, M.I64), (1, M.LT, 2**61), (2, M.GE, 2**63, M.U64), (3, M.LT, 7.5, M.F64), (0, M.NE, 5)]
+    for vop, va, vb in ((ch.VAL_MUL, 0, 3), (ch.VAL_MINUS, 0, 1), (ch.VAL_PLUS, 2, 3), (ch.VAL_COL, 1, 0)):
+        s, c = ch.expr_filter_sum(mixed, p2(ch), vop, va, vb)
+        so, co = O.expr_filter_sum_pipeline(mixed_np, p2(O), vop, va, vb)
+        assert s.dtype == so.dtype and (int(s), c) == (int(so), co), (vop, va, vb)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [0, 1, 1023, 65409, 3_000_001])
 def test_gpu_fused_q11_matches_oracle_pipeline_and_unfused_path(oracle_mod, n):
     import clickhouse_amd as ch

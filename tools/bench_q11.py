@@ -43,7 +43,21 @@ t0 = time.perf_counter(); r1 = O.expr_filter_sum_pipeline(host, preds, O.VAL_MUL
 t0 = time.perf_counter(); rN = O.expr_filter_sum_pipeline(host, preds, O.VAL_MUL, 3, 1, threads=cores); tN = time.perf_counter() - t0
 sg, cg = ch.expr_filter_sum([c_.cut(0, m) for c_ in cols], preds, ch.VAL_MUL, 3, 1)
 assert (int(sg), cg) == (int(r1[0]), r1[1]) == (int(rN[0]), rN[1])
-print(json.dumps({"query": "SSB Q1.1-style fused filter(5 predicates, 3 columns) + multiply + sum", "rows": rows, "gpu_ms_incl_readback": best * 1e3,
+# the same query over the schema's real widths: UInt32 orderdate / extendedprice, UInt8 discount / quantity (10 B/row)
+ts8 = [od, disc.to(torch.uint8), qty.to(torch.uint8), price]
+cols8 = [ctx.wrap(t.data_ptr(), np.uint32 if t.dtype == torch.int32 else np.uint8, rows, keepalive=t) for t in ts8]
+best8 = None
+for _ in range(10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s8, c8 = ch.expr_filter_sum(cols8, preds, ch.VAL_MUL, 3, 1)
+    dt = time.perf_counter() - t0
+    best8 = dt if best8 is None else min(best8, dt)
+assert (int(s8), c8) == (int(s), c)
+print(json.dumps({"query": "SSB Q1.1-style fused filter(5 predicates, 3 columns) + multiply + sum", "rows": rows,
+                  "mixed_width_schema_u32_u8_u8_u32": {"gpu_ms_incl_readback": best8 * 1e3, "gpu_rows_per_s": rows / best8,
+                                                       "algorithmic_GBps_10B_per_row": 10 * rows / best8 / 1e9, "roofline_frac": 10 * rows / best8 / 8e12,
+                                                       "parity": "sum and count equal to the all-UInt32 run"}, "gpu_ms_incl_readback": best * 1e3,
                   "gpu_rows_per_s": rows / best, "algorithmic_GBps_16B_per_row": 16 * rows / best / 1e9, "roofline_frac": 16 * rows / best / 8e12,
                   "cpu_sample_rows": m, "cpu_1thread_rows_per_s": m / t1, f"cpu_{cores}threads_rows_per_s": m / tN, "selected_rows": c,
                   "parity": "sum and count bit-exact on the sample"}))
