@@ -757,8 +757,10 @@ struct PartLds
     }
 };
 
-template <typename KT>
-__global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const KT * __restrict__ keys, const u64 * __restrict__ words0, const u64 * __restrict__ words1,
+// AW: bytes per element of the argument columns (8 in PARTITION mode -- the buffers hold widened words; 8, 4 or 1 in RANGE mode,
+// where the source columns are read as they are and 4-byte signed arguments are sign-extended after the load)
+template <typename KT, int AW>
+__global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const KT * __restrict__ keys, const void * __restrict__ words0, const void * __restrict__ words1,
                                                        const u64 * __restrict__ offsets, u32 G, u32 P, u64 n, u64 * __restrict__ pending, u32 S, u32 K, u32 cnt32,
                                                        u64 rows_per_chunk, const u32 * __restrict__ unit_start, u32 * __restrict__ unit_ctr)
 {
@@ -781,6 +783,7 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
     //   op: 0 none, 1 add u64 (integer sum), 2 add f64, 3 count as u32, 4 count as u64
     u32 a_off[AGG_MAX_AGGS], a_off2[AGG_MAX_AGGS];
     int a_op[AGG_MAX_AGGS], a_op2[AGG_MAX_AGGS], a_src[AGG_MAX_AGGS];
+    bool sx0 = false, sx1 = false; // argument word 0 / 1 is an Int32 column: sign-extend the zero-extended load
 #pragma unroll
     for (u32 j = 0; j < AGG_MAX_AGGS; ++j)
     {
@@ -796,6 +799,8 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
             {
                 a_op[j] = d.a[j].arg_type == CHGPU_F64 ? 2 : 1;
                 a_src[j] = (int)d.a[j].pre;
+                if (AW == 4 && d.a[j].arg_type == CHGPU_I32)
+                    (d.a[j].pre == 0 ? sx0 : sx1) = true;
                 if (d.a[j].kind == CHGPU_AGG_AVG)
                 {
                     a_off2[j] = L.off(w + 1);
@@ -863,8 +868,9 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                 u64 i = (gb + q) * 64 + lane;
                 i = i < n ? i : n - 1;
                 kv[q] = (u64)__builtin_nontemporal_load(&keys[i]);
-                av[q][0] = K > 0 ? __builtin_nontemporal_load(&words0[i]) : 0;
-                av[q][1] = K > 1 ? __builtin_nontemporal_load(&words1[i]) : 0;
+                typedef typename std::conditional<AW == 8, u64, typename std::conditional<AW == 4, u32, u8>::type>::type AT;
+                av[q][0] = K > 0 ? (u64)__builtin_nontemporal_load((const AT *)words0 + i) : 0;
+                av[q][1] = K > 1 ? (u64)__builtin_nontemporal_load((const AT *)words1 + i) : 0;
             }
         };
         // (Combining the rows of a hot key in registers before the LDS atomic was tried for Zipf inputs: once partitions are
@@ -881,6 +887,8 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                 if (i >= begin && i < end)
                 {
                     const u64 key = keyv[q];
+                    const u64 b0 = sx0 ? (u64)(i64)(i32)(u32)argv[q][0] : argv[q][0];
+                    const u64 b1 = sx1 ? (u64)(i64)(i32)(u32)argv[q][1] : argv[q][1];
                     u32 ls = ~0u;
                     if (key == 0)
                     {
@@ -912,7 +920,7 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                             if (a_op[j] == 0)
                                 break;
                             unsigned char * w = lds_raw + a_off[j];
-                            const u64 bits = a_src[j] == 0 ? argv[q][0] : argv[q][1];
+                            const u64 bits = a_src[j] == 0 ? b0 : b1;
                             if (a_op[j] == 1)
                                 atomicAdd((unsigned long long *)w + ls, (unsigned long long)bits);
                             else if (a_op[j] == 2)
@@ -933,7 +941,7 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                         if (slot == ~0ull)
                             failed = true;
                         else
-                            add_vals_global(t, d, slot, argv[q][0], argv[q][1], 1);
+                            add_vals_global(t, d, slot, b0, b1, 1);
                     }
                 }
                 const u64 b = __ballot(failed);
@@ -1500,15 +1508,15 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         u32 grid = (u32)ctx->num_cus;
         if (key32)
         {
-            rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
+            rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
             if (rc == CHGPU_OK)
-                hipLaunchKernelGGL(k_agg_part_lds<u32>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)pkeys, (const u64 *)pwords, (const u64 *)pwords + n, (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr);
+                hipLaunchKernelGGL((k_agg_part_lds<u32, 8>), dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)pkeys, (const void *)pwords, (const void *)(pwords + n), (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr);
         }
         else
         {
-            rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
+            rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
             if (rc == CHGPU_OK)
-                hipLaunchKernelGGL(k_agg_part_lds<u64>, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const u64 *)pwords, (const u64 *)pwords + n, (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr);
+                hipLaunchKernelGGL((k_agg_part_lds<u64, 8>), dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const void *)pwords, (const void *)(pwords + n), (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr);
         }
     }
     ctx->counters[6] += 3;
@@ -1612,22 +1620,27 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
     }
     // strategy: LDS-staged unless the caller promised a large cardinality (where nearly every key misses the LDS table)
     const bool use_lds = a->size_hint <= 65536; // beyond that nearly every key misses a workgroup's LDS table
-    // RANGE mode of the partition-aggregate kernel: 4/8-byte keys, at most GBP_MAX_K argument columns, all 8 bytes wide
+    // RANGE mode of the partition-aggregate kernel: 4/8-byte keys, at most GBP_MAX_K argument columns of one width (8, 4 or 1 B)
     bool ranged = use_lds && (chgpu_type_size(a->key_type) == 4 || chgpu_type_size(a->key_type) == 8) && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED");
     u32 rk = 0;
-    const u64 * rwords[GBP_MAX_K] = {nullptr, nullptr};
+    size_t aw = 0; // common element width of the argument columns (8, 4 or 1 bytes)
+    const void * rwords[GBP_MAX_K] = {nullptr, nullptr};
     for (u32 j = 0; j < a->n_aggs && ranged; ++j)
     {
         if (a->kinds[j] == CHGPU_AGG_COUNT)
             continue;
-        if (rk == GBP_MAX_K || chgpu_type_size(a->arg_types[j]) != 8)
+        const size_t w = chgpu_type_size(a->arg_types[j]);
+        if (rk == GBP_MAX_K || (aw != 0 && w != aw))
             ranged = false;
         else
         {
-            rwords[rk] = (const u64 *)arg_cols[j]->data + row_begin;
+            aw = w;
+            rwords[rk] = (const char *)arg_cols[j]->data + row_begin * w;
             d.a[j].pre = rk++;
         }
     }
+    if (aw == 0)
+        aw = 8;
     if (ranged)
     {
         const bool key32 = chgpu_type_size(a->key_type) == 4;
@@ -1656,18 +1669,23 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
         const u64 rows_per_chunk = ((n + chunks - 1) / chunks + 63) / 64 * 64;
         chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
         CHGPU_HIP(hipMemsetAsync(pending, 0, n_words64 * sizeof(u64), ctx->stream));
+#define RANGE_LAUNCH(KT_, AW_)                                                                                                                         \
+    do                                                                                                                                                \
+    {                                                                                                                                                 \
+        CHGPU_HIP(hipFuncSetAttribute((const void *)k_agg_part_lds<KT_, AW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag));              \
+        hipLaunchKernelGGL((k_agg_part_lds<KT_, AW_>), dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, d, (const KT_ *)key_col->data + row_begin, \
+                           rwords[0], rwords[1], (const u64 *)nullptr, 1u, (u32)chunks, n, pending, S, rk, cnt32, rows_per_chunk, (const u32 *)nullptr,  \
+                           (u32 *)nullptr);                                                                                                           \
+    } while (0)
         if (key32)
         {
-            CHGPU_HIP(hipFuncSetAttribute((const void *)k_agg_part_lds<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag));
-            hipLaunchKernelGGL(k_agg_part_lds<u32>, dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)key_col->data + row_begin, rwords[0], rwords[1],
-                               (const u64 *)nullptr, 1u, (u32)chunks, n, pending, S, rk, cnt32, rows_per_chunk, (const u32 *)nullptr, (u32 *)nullptr);
+            if (aw == 8) RANGE_LAUNCH(u32, 8); else if (aw == 4) RANGE_LAUNCH(u32, 4); else RANGE_LAUNCH(u32, 1);
         }
         else
         {
-            CHGPU_HIP(hipFuncSetAttribute((const void *)k_agg_part_lds<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag));
-            hipLaunchKernelGGL(k_agg_part_lds<u64>, dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)key_col->data + row_begin, rwords[0], rwords[1],
-                               (const u64 *)nullptr, 1u, (u32)chunks, n, pending, S, rk, cnt32, rows_per_chunk, (const u32 *)nullptr, (u32 *)nullptr);
+            if (aw == 8) RANGE_LAUNCH(u64, 8); else if (aw == 4) RANGE_LAUNCH(u64, 4); else RANGE_LAUNCH(u64, 1);
         }
+#undef RANGE_LAUNCH
     }
     else if (use_lds)
     {

@@ -91,6 +91,25 @@ if what == "groupby_finalize":
         a.close()
         del k, v, kc, vc
 
+if what == "groupby_narrow_args":
+    # low-cardinality GROUP BY over 4-byte argument columns (SSB: sum(lo_revenue), sum(lo_supplycost) GROUP BY year, nation)
+    g = torch.Generator(device=dev).manual_seed(2)
+    k = torch.randint(0, 1000, (rows,), dtype=torch.int32, device=dev, generator=g)
+    r = torch.randint(0, 2**31 - 1, (rows,), dtype=torch.int32, device=dev, generator=g)
+    c2 = torch.randint(-2**31, 2**31 - 1, (rows,), dtype=torch.int32, device=dev, generator=g)
+    kc = ctx.wrap(k.data_ptr(), np.uint32, rows, keepalive=k)
+    rc = ctx.wrap(r.data_ptr(), np.uint32, rows, keepalive=r)
+    cc = ctx.wrap(c2.data_ptr(), np.int32, rows, keepalive=c2)
+
+    def run():
+        a = ch.Aggregator(np.uint32, [(ch.AGG_SUM, np.uint32), (ch.AGG_SUM, np.int32), (ch.AGG_COUNT, None)], ctx=ctx)
+        a.execute_on_block(kc, [rc, cc, None])
+        n = len(a)
+        a.close()
+        return n
+    dt, n = timed(run)
+    print(f"groupby_narrow_args rows={rows} groups={n}: {dt*1e3:.2f} ms  {rows/dt:.3e} rows/s  {12*rows/dt/1e9:.0f} GB/s algorithmic (4+4+4 B/row)", flush=True)
+
 if what == "groupby_zipf":
     # SURVEY C3's skew variant: keys ~ Zipf(1.1) folded into [0, 1e6) (continuous inverse-CDF approximation on device)
     groups, sz = 1_000_000, 1.1
