@@ -281,6 +281,20 @@ __global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, co
     __syncthreads();
 
     const u32 lane = threadIdx.x & 63;
+    // aggregate descriptors decoded once into wave-uniform registers (loops over them are fully unrolled): an s_load of d.a[j]
+    // per function and row group also drains the wave's LDS queue through lgkmcnt(0) -- see k_agg_part_lds
+    const void * a_ptr[AGG_MAX_AGGS];
+    int a_kind[AGG_MAX_AGGS], a_type[AGG_MAX_AGGS];
+    u32 a_word[AGG_MAX_AGGS];
+#pragma unroll
+    for (u32 j = 0; j < AGG_MAX_AGGS; ++j)
+    {
+        const bool on = j < d.n_aggs;
+        a_ptr[j] = on ? d.a[j].ptr : nullptr;
+        a_kind[j] = on ? d.a[j].kind : -1;
+        a_type[j] = on ? d.a[j].arg_type : 0;
+        a_word[j] = on ? d.a[j].word : 0;
+    }
     const u64 wave0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u64 n_waves = ((u64)gridDim.x * blockDim.x) >> 6;
     const u64 n_groups64 = (n + 63) / 64;
@@ -303,7 +317,7 @@ __global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, co
             keyv[q] = act[q] ? load_key_zext(keys, key_type, i) : 0;
 #pragma unroll
             for (u32 j = 0; j < PRE; ++j)
-                argv[q][j] = (act[q] && j < d.n_aggs && d.a[j].kind != CHGPU_AGG_COUNT) ? load_arg_bits(d.a[j].ptr, d.a[j].arg_type, i) : 0;
+                argv[q][j] = (act[q] && a_kind[j] >= 0 && a_kind[j] != CHGPU_AGG_COUNT) ? load_arg_bits(a_ptr[j], a_type[j], i) : 0;
         }
 #pragma unroll
         for (int q = 0; q < LDS_R; ++q)
@@ -342,24 +356,24 @@ __global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, co
                 }
                 if (ls != ~0u)
                 {
-                    for (u32 j = 0; j < d.n_aggs; ++j)
+#pragma unroll
+                    for (u32 j = 0; j < AGG_MAX_AGGS; ++j)
                     {
-                        const AggArg & a = d.a[j];
-                        u64 * w = lwords + a.word * lstride + ls;
-                        if (a.kind == CHGPU_AGG_COUNT)
+                        if (a_kind[j] < 0)
+                            break;
+                        u64 * w = lwords + a_word[j] * lstride + ls;
+                        if (a_kind[j] == CHGPU_AGG_COUNT)
                             atomicAdd((unsigned long long *)w, 1ull);
                         else
                         {
                             u64 bits;
-                            if (j == 0) bits = argv[q][0];
-                            else if (j == 1) bits = argv[q][1];
-                            else if (j == 2) bits = argv[q][2];
-                            else bits = load_arg_bits(a.ptr, a.arg_type, i);
-                            if (a.arg_type == CHGPU_F64)
+                            if (j < PRE) bits = argv[q][j < PRE ? j : 0];
+                            else bits = load_arg_bits(a_ptr[j], a_type[j], i);
+                            if (a_type[j] == CHGPU_F64)
                                 atomicAdd((double *)w, __longlong_as_double((long long)bits));
                             else
                                 atomicAdd((unsigned long long *)w, (unsigned long long)bits);
-                            if (a.kind == CHGPU_AGG_AVG)
+                            if (a_kind[j] == CHGPU_AGG_AVG)
                                 atomicAdd((unsigned long long *)(w + lstride), 1ull);
                         }
                     }
