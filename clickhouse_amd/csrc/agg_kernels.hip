@@ -1634,29 +1634,40 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
     }
     // strategy: LDS-staged unless the caller promised a large cardinality (where nearly every key misses the LDS table)
     const bool use_lds = a->size_hint <= 65536; // beyond that nearly every key misses a workgroup's LDS table
-    // RANGE mode of the partition-aggregate kernel: 4/8-byte keys, at most GBP_MAX_K argument columns of one width (8, 4 or 1 B)
-    bool ranged = use_lds && (chgpu_type_size(a->key_type) == 4 || chgpu_type_size(a->key_type) == 8) && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED");
-    u32 rk = 0;
-    size_t aw = 0; // common element width of the argument columns (8, 4 or 1 bytes)
-    const void * rwords[GBP_MAX_K] = {nullptr, nullptr};
-    for (u32 j = 0; j < a->n_aggs && ranged; ++j)
-    {
-        if (a->kinds[j] == CHGPU_AGG_COUNT)
-            continue;
-        const size_t w = chgpu_type_size(a->arg_types[j]);
-        if (rk == GBP_MAX_K || (aw != 0 && w != aw))
-            ranged = false;
-        else
-        {
-            aw = w;
-            rwords[rk] = (const char *)arg_cols[j]->data + row_begin * w;
-            d.a[j].pre = rk++;
-        }
-    }
-    if (aw == 0)
-        aw = 8;
+    // RANGE mode of the partition-aggregate kernel: 4/8-byte keys; a launch takes at most GBP_MAX_K argument columns of one
+    // width (8, 4 or 1 B), so the aggregate functions are split into PASSES over the same rows -- each pass re-reads the key
+    // column and updates its own state words of the same groups (TPC-H Q1's seven sums and averages: 4 passes x ~20 B/row
+    // instead of one trip through the generic kernel, which is 6x slower per row).
+    const bool ranged = use_lds && (chgpu_type_size(a->key_type) == 4 || chgpu_type_size(a->key_type) == 8) && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED");
     if (ranged)
     {
+        struct Pass
+        {
+            u32 n = 0;           // argument columns in this pass
+            u32 agg[GBP_MAX_K];  // their aggregate indices
+            size_t aw = 8;
+        };
+        Pass passes[AGG_MAX_AGGS];
+        u32 n_passes = 0;
+        for (u32 j = 0; j < a->n_aggs; ++j)
+        {
+            if (a->kinds[j] == CHGPU_AGG_COUNT)
+                continue;
+            const size_t w = chgpu_type_size(a->arg_types[j]);
+            u32 p = 0;
+            for (; p < n_passes; ++p) // first pass of this width with a free slot
+                if (passes[p].aw == w && passes[p].n < GBP_MAX_K)
+                    break;
+            if (p == n_passes)
+            {
+                passes[n_passes].aw = w;
+                ++n_passes;
+            }
+            passes[p].agg[passes[p].n++] = j;
+        }
+        if (n_passes == 0)
+            n_passes = 1; // only count(): one pass without argument columns
+
         const bool key32 = chgpu_type_size(a->key_type) == 4;
         u32 cnt32 = 0;
         (void)agg_part_cell_bytes(a, n, &cnt32);
@@ -1682,26 +1693,54 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
             chunks = (n + 4095) / 4096;
         const u64 rows_per_chunk = ((n + chunks - 1) / chunks + 63) / 64 * 64;
         chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
-        CHGPU_HIP(hipMemsetAsync(pending, 0, n_words64 * sizeof(u64), ctx->stream));
+        for (u32 p = 0; p < n_passes; ++p)
+        {
+            // this pass's descriptor: its argument functions, plus every count() in the first pass; state word indices are
+            // the aggregator's own, so all passes meet in the same cells
+            AggDesc dp = d;
+            dp.n_aggs = 0;
+            const void * rwords[GBP_MAX_K] = {nullptr, nullptr};
+            for (u32 c = 0; c < passes[p].n; ++c)
+            {
+                const u32 j = passes[p].agg[c];
+                dp.a[dp.n_aggs] = d.a[j];
+                dp.a[dp.n_aggs].pre = c;
+                ++dp.n_aggs;
+                rwords[c] = (const char *)arg_cols[j]->data + row_begin * passes[p].aw;
+            }
+            if (p == 0)
+                for (u32 j = 0; j < a->n_aggs; ++j)
+                    if (a->kinds[j] == CHGPU_AGG_COUNT)
+                        dp.a[dp.n_aggs++] = d.a[j];
+            const u32 rk = passes[p].n;
+            const size_t aw = passes[p].aw;
+            CHGPU_HIP(hipMemsetAsync(pending, 0, n_words64 * sizeof(u64), ctx->stream));
 #define RANGE_LAUNCH(KT_, AW_)                                                                                                                         \
     do                                                                                                                                                \
     {                                                                                                                                                 \
         CHGPU_HIP(hipFuncSetAttribute((const void *)k_agg_part_lds<KT_, AW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag));              \
-        hipLaunchKernelGGL((k_agg_part_lds<KT_, AW_>), dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, d, (const KT_ *)key_col->data + row_begin, \
+        hipLaunchKernelGGL((k_agg_part_lds<KT_, AW_>), dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, dp, (const KT_ *)key_col->data + row_begin, \
                            rwords[0], rwords[1], (const u64 *)nullptr, 1u, (u32)chunks, n, pending, S, rk, cnt32, rows_per_chunk, (const u32 *)nullptr,  \
                            (u32 *)nullptr);                                                                                                           \
     } while (0)
-        if (key32)
-        {
-            if (aw == 8) RANGE_LAUNCH(u32, 8); else if (aw == 4) RANGE_LAUNCH(u32, 4); else RANGE_LAUNCH(u32, 1);
-        }
-        else
-        {
-            if (aw == 8) RANGE_LAUNCH(u64, 8); else if (aw == 4) RANGE_LAUNCH(u64, 4); else RANGE_LAUNCH(u64, 1);
-        }
+            if (key32)
+            {
+                if (aw == 8) RANGE_LAUNCH(u32, 8); else if (aw == 4) RANGE_LAUNCH(u32, 4); else RANGE_LAUNCH(u32, 1);
+            }
+            else
+            {
+                if (aw == 8) RANGE_LAUNCH(u64, 8); else if (aw == 4) RANGE_LAUNCH(u64, 4); else RANGE_LAUNCH(u64, 1);
+            }
 #undef RANGE_LAUNCH
+            ctx->counters[6] += 1;
+            CHGPU_HIP(hipGetLastError());
+            // rows this pass could not place (table at max fill) are retried with THIS pass's functions only
+            CHGPU_TRY(agg_finish_rounds(a, dp, key_col->data, a->key_type, row_begin, n, pending));
+        }
+        ctx->counters[5] += n;
+        return CHGPU_OK;
     }
-    else if (use_lds)
+    if (use_lds)
     {
         // LDS cells per workgroup: the largest power of two with (1 + n_words) * 8 * (S+1) <= AGG_LDS_BYTES
         u32 S = 4096;

@@ -381,6 +381,38 @@ def test_group_by_lds_range_mode(ch, engine, key_dtype, groups, size_hint, row_b
     _check_against_numpy(g, k[row_begin:], v[row_begin:], f[row_begin:])
 
 
+def test_group_by_many_functions_take_several_range_passes(ch, engine, oracle_mod):
+    # TPC-H Q1 shape: seven argument functions of three widths + count -> several passes of the RANGE kernel over the same rows
+    rng = np.random.Generator(np.random.PCG64(41))
+    n = 900_001
+    k = rng.integers(0, 6, size=n).astype(np.uint32)
+    i64 = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
+    u32 = rng.integers(0, 2**32, size=n, dtype=np.uint32)
+    i32 = rng.integers(-2**31, 2**31, size=n).astype(np.int32)
+    f64 = rng.random(n)
+    u8 = rng.integers(0, 256, size=n).astype(np.uint8)
+    aggs = [(ch.AGG_SUM, np.int64), (ch.AGG_AVG, np.uint32), (ch.AGG_SUM, np.float64), (ch.AGG_COUNT, None), (ch.AGG_AVG, np.int32),
+            (ch.AGG_SUM, np.uint8), (ch.AGG_AVG, np.float64), (ch.AGG_SUM, np.int32)]
+    args = [i64, u32, f64, None, i32, u8, f64, i32]
+    g = engine.Aggregator(np.uint32, aggs)
+    o = oracle_mod.Aggregator(np.uint32, aggs)
+    before = g.ctx.counters()["KernelLaunches"]
+    g.execute_on_block(k, args, 5, n)
+    assert g.ctx.counters()["KernelLaunches"] - before >= 4     # 8-byte x2 (two passes of <= 2), 4-byte x2, 1-byte
+    o.execute_on_block(k, args, 5, n)
+    gk, gr = g.convert_to_block()
+    ok, orr = o.convert_to_block()
+    gi, oi = np.argsort(gk), np.argsort(ok)
+    assert np.array_equal(gk[gi], ok[oi])
+    for j in range(len(aggs)):
+        x, y = gr[j][gi], orr[j][oi]
+        assert x.dtype == y.dtype
+        if x.dtype == np.float64:
+            assert np.allclose(x, y, rtol=1e-6, atol=0), j
+        else:
+            assert np.array_equal(x, y), j
+
+
 @pytest.mark.parametrize("key_dtype", [np.uint32, np.uint64])
 def test_group_by_partitioned_wide_path_with_hot_partition(ch, engine, key_dtype):
     # aligned first row (wide loads), a key holding 30 % of the rows: its partition is cut into many work units

@@ -110,6 +110,29 @@ if what == "groupby_narrow_args":
     dt, n = timed(run)
     print(f"groupby_narrow_args rows={rows} groups={n}: {dt*1e3:.2f} ms  {rows/dt:.3e} rows/s  {12*rows/dt/1e9:.0f} GB/s algorithmic (4+4+4 B/row)", flush=True)
 
+if what == "groupby_q1":
+    # TPC-H Q1 shape: 4 groups, sum x4, avg x3, count over 1e9 rows (7 argument functions -> 4 RANGE passes)
+    g = torch.Generator(device=dev).manual_seed(2)
+    k = torch.randint(0, 4, (rows,), dtype=torch.int32, device=dev, generator=g)
+    qty = torch.randint(1, 51, (rows,), dtype=torch.int64, device=dev, generator=g)
+    price = torch.randint(90_000, 10_000_000, (rows,), dtype=torch.int64, device=dev, generator=g)
+    disc = torch.rand(rows, dtype=torch.float64, device=dev, generator=g)
+    kc = ctx.wrap(k.data_ptr(), np.uint32, rows, keepalive=k)
+    qc = ctx.wrap(qty.data_ptr(), np.int64, rows, keepalive=qty)
+    pc = ctx.wrap(price.data_ptr(), np.int64, rows, keepalive=price)
+    dc = ctx.wrap(disc.data_ptr(), np.float64, rows, keepalive=disc)
+    aggs = [(ch.AGG_SUM, np.int64), (ch.AGG_SUM, np.int64), (ch.AGG_SUM, np.float64), (ch.AGG_SUM, np.int64),
+            (ch.AGG_AVG, np.int64), (ch.AGG_AVG, np.int64), (ch.AGG_AVG, np.float64), (ch.AGG_COUNT, None)]
+
+    def run():
+        a = ch.Aggregator(np.uint32, aggs, ctx=ctx)
+        a.execute_on_block(kc, [qc, pc, dc, pc, qc, pc, dc, None])
+        n = len(a)
+        a.close()
+        return n
+    dt, n = timed(run)
+    print(f"groupby_q1 rows={rows} groups={n}: {dt*1e3:.2f} ms  {rows/dt:.3e} rows/s  {60*rows/dt/1e9:.0f} GB/s algorithmic (4 + 7x8 B/row)", flush=True)
+
 if what == "groupby_zipf":
     # SURVEY C3's skew variant: keys ~ Zipf(1.1) folded into [0, 1e6) (continuous inverse-CDF approximation on device)
     groups, sz = 1_000_000, 1.1
