@@ -1311,8 +1311,10 @@ static u64 agg_estimate_groups(u64 d, u64 m)
 // (the caller then uses the DIRECT kernel).
 // level 0: called by add_block; may turn itself into level 1 (the first of two partitioning levels: partitions the rows
 // into P1 big partitions and runs a level-2 call over each partition buffer slice); level 2 never recurses.
+// agg_mask: the aggregate functions this call applies (bit j = function j); the caller splits more than GBP_MAX_K argument
+// columns into several calls over the same rows, each partitioning the key column with its own two argument columns.
 static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols, u64 row_begin, u64 n, u32 K,
-                                     int level = 0, size_t scratch_off = 0)
+                                     int level = 0, size_t scratch_off = 0, u32 agg_mask = ~0u)
 {
     chgpu_ctx * ctx = a->ctx;
     CHGPU_TRY(agg_ensure_table(a));
@@ -1410,7 +1412,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     u32 kk = 0;
     for (u32 j = 0; j < a->n_aggs; ++j)
     {
-        if (a->kinds[j] == CHGPU_AGG_COUNT)
+        if (a->kinds[j] == CHGPU_AGG_COUNT || !((agg_mask >> j) & 1))
             continue;
         gc.src[kk] = arg_cols[j]->data;
         gc.type[kk] = a->arg_types[j];
@@ -1420,6 +1422,15 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         d.a[j].arg_type = a->arg_types[j] == CHGPU_F64 ? CHGPU_F64 : CHGPU_U64;
         d.a[j].pre = kk;
         ++kk;
+    }
+    if (agg_mask != ~0u)
+    {
+        // keep only this call's functions in the descriptor (their state word indices stay the aggregator's own)
+        u32 m = 0;
+        for (u32 j = 0; j < a->n_aggs; ++j)
+            if ((agg_mask >> j) & 1)
+                d.a[m++] = d.a[j];
+        d.n_aggs = m;
     }
 
     // wide loads need key/argument columns whose element width is the buffer width and a 16-byte aligned first row
@@ -1490,7 +1501,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         for (u32 j = 0; j < a->n_aggs; ++j)
         {
             saved_arg_types[j] = a->arg_types[j];
-            if (a->kinds[j] == CHGPU_AGG_COUNT)
+            if (a->kinds[j] == CHGPU_AGG_COUNT || !((agg_mask >> j) & 1))
                 continue;
             ac[c].ctx = ctx;
             ac[c].type = a->arg_types[j] == CHGPU_F64 ? CHGPU_F64 : CHGPU_U64; // two's complement sums: width is what matters
@@ -1504,7 +1515,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         a->size_hint = saved_hint / P1 + saved_hint / P1 / 4 + 1024;
         for (u32 q = 0; q < P1 && rc == CHGPU_OK; ++q)
             if (starts[q + 1] > starts[q])
-                rc = agg_add_block_partitioned(a, &kc, sub_args, starts[q], starts[q + 1] - starts[q], K, 2, scratch_off + own_b);
+                rc = agg_add_block_partitioned(a, &kc, sub_args, starts[q], starts[q + 1] - starts[q], K, 2, scratch_off + own_b, agg_mask);
         a->key_type = saved_key_type;
         a->size_hint = saved_hint;
         for (u32 j = 0; j < a->n_aggs; ++j)
@@ -1630,6 +1641,42 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
             int rc = agg_add_block_partitioned(a, key_col, arg_cols, row_begin, n, n_argwords);
             if (rc != CHGPU_ERR_NOT_IMPLEMENTED)
                 return rc;
+        }
+        else if (a->size_hint > lds_groups && n >= (4u << 20) && !getenv("CHGPU_AGG_NO_PARTITION"))
+        {
+            // more argument columns than a partition buffer row carries: several partitioned calls over the same rows, each with
+            // two of them (plus every count() in the first) -- ~12 ms per 1e9 rows and call, against one HBM atomic per row
+            // and state word on the DIRECT path
+            u32 masks[AGG_MAX_AGGS], ks[AGG_MAX_AGGS], n_calls = 0;
+            u32 cur = 0, cur_k = 0;
+            for (u32 j = 0; j < a->n_aggs; ++j)
+            {
+                if (a->kinds[j] == CHGPU_AGG_COUNT)
+                    continue;
+                cur |= 1u << j;
+                if (++cur_k == GBP_MAX_K)
+                {
+                    masks[n_calls] = cur, ks[n_calls] = cur_k, ++n_calls;
+                    cur = 0, cur_k = 0;
+                }
+            }
+            if (cur_k)
+                masks[n_calls] = cur, ks[n_calls] = cur_k, ++n_calls;
+            for (u32 j = 0; j < a->n_aggs; ++j)
+                if (a->kinds[j] == CHGPU_AGG_COUNT)
+                    masks[0] |= 1u << j;
+            int rc = CHGPU_OK;
+            for (u32 c = 0; c < n_calls && rc == CHGPU_OK; ++c)
+            {
+                rc = agg_add_block_partitioned(a, key_col, arg_cols, row_begin, n, ks[c], 0, 0, masks[c]);
+                if (rc == CHGPU_ERR_NOT_IMPLEMENTED && c == 0)
+                    break; // nothing applied yet: fall through to the other strategies
+            }
+            if (rc != CHGPU_ERR_NOT_IMPLEMENTED)
+            {
+                ctx->counters[5] -= (u64)(n_calls - 1) * n; // rows were counted once per call
+                return rc;
+            }
         }
     }
     // strategy: LDS-staged unless the caller promised a large cardinality (where nearly every key misses the LDS table)

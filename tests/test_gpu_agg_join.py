@@ -310,7 +310,7 @@ def test_selector_weak_hash_scatter_partition(ch, ctx, oracle_mod):
         assert np.array_equal(parts[s].numpy(), pay[sel3 == s])
 
 
-@pytest.mark.parametrize("aggs_name", ["sum_count", "avg_f64", "two_args"])
+@pytest.mark.parametrize("aggs_name", ["sum_count", "avg_f64", "two_args", "five_args"])
 def test_group_by_partitioned_path_large_cardinality(ch, engine, oracle_mod, aggs_name):
     # >= 4 Mi rows with a large size hint take the partition -> LDS-aggregate path
     rng = np.random.Generator(np.random.PCG64(99))
@@ -323,8 +323,12 @@ def test_group_by_partitioned_path_large_cardinality(ch, engine, oracle_mod, agg
         aggs, args = [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], [v, None]
     elif aggs_name == "avg_f64":
         aggs, args = [(ch.AGG_AVG, np.float64)], [f]
-    else:
+    elif aggs_name == "two_args":
         aggs, args = [(ch.AGG_SUM, np.int64), (ch.AGG_SUM, np.float64), (ch.AGG_COUNT, None)], [v, f, None]
+    else:   # more argument columns than a partition buffer row carries: three partitioned calls over the same rows
+        u = rng.integers(0, 2**32, size=n, dtype=np.uint32)
+        aggs = [(ch.AGG_AVG, np.int64), (ch.AGG_SUM, np.uint32), (ch.AGG_COUNT, None), (ch.AGG_SUM, np.float64), (ch.AGG_AVG, np.uint32), (ch.AGG_SUM, np.int64)]
+        args = [v, u, None, f, u, v]
     g = engine.Aggregator(np.uint32, aggs, size_hint=groups)
     before = g.ctx.counters()["KernelLaunches"]
     g.execute_on_block(k, args, 1, n)          # odd row_begin on purpose
