@@ -773,8 +773,9 @@ struct PartLds
 
 // AW: bytes per element of the argument columns (8 in PARTITION mode -- the buffers hold widened words; 8, 4 or 1 in RANGE mode,
 // where the source columns are read as they are and 4-byte signed arguments are sign-extended after the load)
-template <typename KT, int AW>
-__global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const KT * __restrict__ keys, const void * __restrict__ words0, const void * __restrict__ words1,
+// KS: element type of the key column as stored (UInt8 keys are read as they are and held as KT = UInt32 in LDS)
+template <typename KT, int AW, typename KS = KT>
+__global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const KS * __restrict__ keys, const void * __restrict__ words0, const void * __restrict__ words1,
                                                        const u64 * __restrict__ offsets, u32 G, u32 P, u64 n, u64 * __restrict__ pending, u32 S, u32 K, u32 cnt32,
                                                        u64 rows_per_chunk, const u32 * __restrict__ unit_start, u32 * __restrict__ unit_ctr)
 {
@@ -1685,7 +1686,7 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
     // width (8, 4 or 1 B), so the aggregate functions are split into PASSES over the same rows -- each pass re-reads the key
     // column and updates its own state words of the same groups (TPC-H Q1's seven sums and averages: 4 passes x ~20 B/row
     // instead of one trip through the generic kernel, which is 6x slower per row).
-    const bool ranged = use_lds && (chgpu_type_size(a->key_type) == 4 || chgpu_type_size(a->key_type) == 8) && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED");
+    const bool ranged = use_lds && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED"); // keys of 1, 4 or 8 bytes: all supported key types
     if (ranged)
     {
         struct Pass
@@ -1715,7 +1716,7 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
         if (n_passes == 0)
             n_passes = 1; // only count(): one pass without argument columns
 
-        const bool key32 = chgpu_type_size(a->key_type) == 4;
+        const bool key32 = chgpu_type_size(a->key_type) <= 4, key8 = chgpu_type_size(a->key_type) == 1;
         u32 cnt32 = 0;
         (void)agg_part_cell_bytes(a, n, &cnt32);
         const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
@@ -1762,15 +1763,20 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
             const u32 rk = passes[p].n;
             const size_t aw = passes[p].aw;
             CHGPU_HIP(hipMemsetAsync(pending, 0, n_words64 * sizeof(u64), ctx->stream));
-#define RANGE_LAUNCH(KT_, AW_)                                                                                                                         \
+#define RANGE_LAUNCH_KS(KT_, AW_, KS_)                                                                                                                 \
     do                                                                                                                                                \
     {                                                                                                                                                 \
-        CHGPU_HIP(hipFuncSetAttribute((const void *)k_agg_part_lds<KT_, AW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag));              \
-        hipLaunchKernelGGL((k_agg_part_lds<KT_, AW_>), dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, dp, (const KT_ *)key_col->data + row_begin, \
+        CHGPU_HIP(hipFuncSetAttribute((const void *)k_agg_part_lds<KT_, AW_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag));         \
+        hipLaunchKernelGGL((k_agg_part_lds<KT_, AW_, KS_>), dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, dp, (const KS_ *)key_col->data + row_begin, \
                            rwords[0], rwords[1], (const u64 *)nullptr, 1u, (u32)chunks, n, pending, S, rk, cnt32, rows_per_chunk, (const u32 *)nullptr,  \
                            (u32 *)nullptr);                                                                                                           \
     } while (0)
-            if (key32)
+#define RANGE_LAUNCH(KT_, AW_) RANGE_LAUNCH_KS(KT_, AW_, KT_)
+            if (key8)
+            {
+                if (aw == 8) RANGE_LAUNCH_KS(u32, 8, u8); else if (aw == 4) RANGE_LAUNCH_KS(u32, 4, u8); else RANGE_LAUNCH_KS(u32, 1, u8);
+            }
+            else if (key32)
             {
                 if (aw == 8) RANGE_LAUNCH(u32, 8); else if (aw == 4) RANGE_LAUNCH(u32, 4); else RANGE_LAUNCH(u32, 1);
             }
@@ -1779,6 +1785,7 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
                 if (aw == 8) RANGE_LAUNCH(u64, 8); else if (aw == 4) RANGE_LAUNCH(u64, 4); else RANGE_LAUNCH(u64, 1);
             }
 #undef RANGE_LAUNCH
+#undef RANGE_LAUNCH_KS
             ctx->counters[6] += 1;
             CHGPU_HIP(hipGetLastError());
             // rows this pass could not place (table at max fill) are retried with THIS pass's functions only
