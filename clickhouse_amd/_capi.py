@@ -50,6 +50,7 @@ SIGNATURES = {
     "chgpu_cmp_const": (_i, [_vp, _vp, _i, _i, _vp, _pp]),
     "chgpu_count_bytes_in_filter": (_i, [_vp, _vp, _pu64]),
     "chgpu_filter": (_i, [_vp, _vp, _vp, _i64, _pp, _pu64]),
+    "chgpu_filter_columns": (_i, [_vp, _u32, _vp, _vp, _i64, _vp, _pu64]),
     "chgpu_filter_description_nullable": (_i, [_vp, _vp, _vp, _pp]),
     "chgpu_sum_add_many": (_i, [_vp, _vp, _u64, _u64, _vp]),
     "chgpu_sum_add_many_conditional": (_i, [_vp, _vp, _vp, _u64, _u64, _vp]),

@@ -235,6 +235,17 @@ def filter_sum_async(pred: Column, op: int, scalar, val: Column | None, result: 
     K.check(K.lib().chgpu_filter_sum_async(pred.ctx._h, pred._h, op, st, s.ctypes.data_as(C.c_void_p), val._h, result._h))
 
 
+def filter_columns(cols, filt: Column, result_size_hint: int = 0):
+    """Every column of a Block filtered by one mask (FilterTransform's loop over the chunk's columns): the mask is counted and
+    scanned once, one host synchronisation for all columns."""
+    n = len(cols)
+    cp = (C.c_void_p * max(1, n))(*[c._h for c in cols])
+    outs = (C.c_void_p * max(1, n))()
+    rows = C.c_uint64(0)
+    K.check(K.lib().chgpu_filter_columns(filt.ctx._h, n, cp, filt._h, result_size_hint, outs, C.byref(rows)))
+    return [Column(filt.ctx, C.c_void_p(outs[k])) for k in range(n)]
+
+
 def hash_to_selector(keys: Column, num_shards: int) -> Column:
     h = C.c_void_p()
     K.check(K.lib().chgpu_hash_to_selector(keys.ctx._h, keys._h, num_shards, C.byref(h)))

@@ -906,22 +906,17 @@ extern "C" int chgpu_count_bytes_in_filter(chgpu_ctx * ctx, const chgpu_col * ma
     return CHGPU_OK;
 }
 
-extern "C" int chgpu_filter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * mask, int64_t result_size_hint,
-                            chgpu_col ** out, uint64_t * out_rows)
+// Shared by chgpu_filter and chgpu_filter_columns: per-chunk popcounts of the mask, exclusive scan, total (one read-back).
+struct FilterPlan
 {
-    (void)result_size_hint; // the device path sizes the result exactly from the scan; the hint only matters for CPU reserve()
-    CHGPU_REQUIRE(ctx && col && mask && out && out_rows, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
-    CHGPU_REQUIRE(mask->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "filter must be a UInt8 column");
-    CHGPU_REQUIRE(col->rows == mask->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of filter (%llu) doesn't match size of column (%llu)",
-                  (unsigned long long)mask->rows, (unsigned long long)col->rows);
-    const u64 n = col->rows;
+    u64 n = 0, n_chunks = 0, total = 0;
+    u64 * offsets = nullptr;
+    u32 grid = 0;
+};
+static int filter_plan(chgpu_ctx * ctx, const chgpu_col * mask, FilterPlan * fp)
+{
+    const u64 n = mask->rows;
     const u64 n_chunks = (n + CHUNK_ROWS - 1) / CHUNK_ROWS;
-    if (n == 0)
-    {
-        CHGPU_TRY(chgpu_col_new(ctx, col->type, 0, out));
-        *out_rows = 0;
-        return CHGPU_OK;
-    }
     // scratch layout: counts u32[n_chunks] | offsets u64[n_chunks] | total u64 | scan tmp
     const size_t counts_b = ((n_chunks * sizeof(u32) + 255) / 256) * 256;
     const size_t offs_b = ((n_chunks * sizeof(u64) + 255) / 256) * 256;
@@ -932,30 +927,34 @@ extern "C" int chgpu_filter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_
     u64 * offsets = (u64 *)((char *)scratch + counts_b);
     u64 * total_dev = (u64 *)((char *)scratch + counts_b + offs_b);
     void * tmp = (char *)scratch + counts_b + offs_b + 256;
-
     static const u32 wg_cnt = tune_env("CHGPU_TUNE_FCOUNT_WG", 8), wg_sc = tune_env("CHGPU_TUNE_FSCATTER_WG", 8);
     const u32 grid_cnt = chgpu_grid_for(ctx, n_chunks * 64, 256, wg_cnt);
-    const u32 grid = chgpu_grid_for(ctx, n_chunks * 64, 256, wg_sc);
     hipLaunchKernelGGL(k_mask_chunk_counts, dim3(grid_cnt), dim3(256), 0, ctx->stream, (const u8 *)mask->data, n, counts, n_chunks);
     ctx->counters[6] += 1;
     CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, n_chunks, total_dev, tmp, tmp_b));
-    u64 total = 0;
-    CHGPU_TRY(chgpu_read_back(ctx, total_dev, &total, sizeof(total)));
-
+    CHGPU_TRY(chgpu_read_back(ctx, total_dev, &fp->total, sizeof(fp->total)));
+    fp->n = n;
+    fp->n_chunks = n_chunks;
+    fp->offsets = offsets;
+    fp->grid = chgpu_grid_for(ctx, n_chunks * 64, 256, wg_sc);
+    return CHGPU_OK;
+}
+static int filter_apply(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * mask, const FilterPlan & fp, chgpu_col ** out)
+{
     chgpu_col * res = nullptr;
-    CHGPU_TRY(chgpu_col_new(ctx, col->type, total, &res));
-    if (total)
+    CHGPU_TRY(chgpu_col_new(ctx, col->type, fp.total, &res));
+    if (fp.total)
     {
         switch (chgpu_type_size(col->type))
         {
             case 8:
-                hipLaunchKernelGGL(k_filter_scatter<u64>, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)col->data, (const u8 *)mask->data, n, offsets, n_chunks, (u64 *)res->data);
+                hipLaunchKernelGGL(k_filter_scatter<u64>, dim3(fp.grid), dim3(256), 0, ctx->stream, (const u64 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u64 *)res->data);
                 break;
             case 4:
-                hipLaunchKernelGGL(k_filter_scatter<u32>, dim3(grid), dim3(256), 0, ctx->stream, (const u32 *)col->data, (const u8 *)mask->data, n, offsets, n_chunks, (u32 *)res->data);
+                hipLaunchKernelGGL(k_filter_scatter<u32>, dim3(fp.grid), dim3(256), 0, ctx->stream, (const u32 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u32 *)res->data);
                 break;
             default:
-                hipLaunchKernelGGL(k_filter_scatter<u8>, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)col->data, (const u8 *)mask->data, n, offsets, n_chunks, (u8 *)res->data);
+                hipLaunchKernelGGL(k_filter_scatter<u8>, dim3(fp.grid), dim3(256), 0, ctx->stream, (const u8 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u8 *)res->data);
                 break;
         }
         ctx->counters[6] += 1;
@@ -966,10 +965,63 @@ extern "C" int chgpu_filter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_
         chgpu_col_free(res);
         return chgpu_set_error(CHGPU_ERR_DEVICE, "filter launch: %s", hipGetErrorString(e));
     }
-    ctx->counters[0] += total;
-    ctx->counters[1] += total * chgpu_type_size(col->type);
+    ctx->counters[0] += fp.total;
+    ctx->counters[1] += fp.total * chgpu_type_size(col->type);
     *out = res;
-    *out_rows = total;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_filter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * mask, int64_t result_size_hint,
+                            chgpu_col ** out, uint64_t * out_rows)
+{
+    (void)result_size_hint; // the device path sizes the result exactly from the scan; the hint only matters for CPU reserve()
+    CHGPU_REQUIRE(ctx && col && mask && out && out_rows, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(mask->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "filter must be a UInt8 column");
+    CHGPU_REQUIRE(col->rows == mask->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of filter (%llu) doesn't match size of column (%llu)",
+                  (unsigned long long)mask->rows, (unsigned long long)col->rows);
+    if (col->rows == 0)
+    {
+        CHGPU_TRY(chgpu_col_new(ctx, col->type, 0, out));
+        *out_rows = 0;
+        return CHGPU_OK;
+    }
+    FilterPlan fp;
+    CHGPU_TRY(filter_plan(ctx, mask, &fp));
+    CHGPU_TRY(filter_apply(ctx, col, mask, fp, out));
+    *out_rows = fp.total;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_filter_columns(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, const chgpu_col * mask,
+                                    int64_t result_size_hint, chgpu_col ** outs, uint64_t * out_rows)
+{
+    (void)result_size_hint;
+    CHGPU_REQUIRE(ctx && mask && out_rows && (n_cols == 0 || (cols && outs)), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(mask->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "filter must be a UInt8 column");
+    for (u32 k = 0; k < n_cols; ++k)
+    {
+        CHGPU_REQUIRE(cols[k], CHGPU_ERR_BAD_ARGUMENTS, "column %u is NULL", k);
+        CHGPU_REQUIRE(cols[k]->rows == mask->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of filter (%llu) doesn't match size of column (%llu)",
+                      (unsigned long long)mask->rows, (unsigned long long)cols[k]->rows);
+        outs[k] = nullptr;
+    }
+    FilterPlan fp;
+    if (mask->rows)
+        CHGPU_TRY(filter_plan(ctx, mask, &fp)); // the mask is counted and scanned ONCE for the whole Block
+    for (u32 k = 0; k < n_cols; ++k)
+    {
+        const int rc = mask->rows ? filter_apply(ctx, cols[k], mask, fp, &outs[k]) : chgpu_col_new(ctx, cols[k]->type, 0, &outs[k]);
+        if (rc != CHGPU_OK)
+        {
+            for (u32 q = 0; q < k; ++q)
+            {
+                chgpu_col_free(outs[q]);
+                outs[q] = nullptr;
+            }
+            return rc;
+        }
+    }
+    *out_rows = fp.total;
     return CHGPU_OK;
 }
 

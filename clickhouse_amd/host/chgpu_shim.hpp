@@ -253,6 +253,23 @@ protected:
 };
 
 /// FilterTransform::doTransform (FilterTransform.cpp:136-256): expression -> filter column -> filter every column.
+/// Every column of a chunk filtered by one mask: the loop `for (auto & col : columns) col = col->filter(filter, hint)` of
+/// FilterTransform::doTransform (FilterTransform.cpp:238-252) and of joinBlock (HashJoinMethodsImpl.h:122-123) as ONE call --
+/// the mask is counted and scanned once on the device, one host synchronisation for the whole chunk.
+inline void filterColumns(Columns & columns, const ColumnVector & filter, ssize_t result_size_hint)
+{
+    if (columns.empty())
+        return;
+    std::vector<const chgpu_col *> in;
+    for (auto & c : columns)
+        in.push_back(c->handle());
+    std::vector<chgpu_col *> out(columns.size(), nullptr);
+    uint64_t rows = 0;
+    check(chgpu_filter_columns(filter.context()->get(), static_cast<uint32_t>(in.size()), in.data(), filter.handle(), result_size_hint, out.data(), &rows));
+    for (size_t k = 0; k < columns.size(); ++k)
+        columns[k] = std::make_shared<ColumnVector>(filter.context(), out[k]);
+}
+
 class GpuFilterTransform : public ISimpleTransform
 {
 public:
@@ -278,8 +295,7 @@ protected:
             passed_rows += num_filtered_rows;
             return;
         }
-        for (auto & col : chunk.columns) // :238-252
-            col = col->filter(*mask, static_cast<ssize_t>(num_filtered_rows));
+        filterColumns(chunk.columns, *mask, static_cast<ssize_t>(num_filtered_rows)); // :238-252
         chunk.num_rows = num_filtered_rows;
         passed_rows += num_filtered_rows;
     }

@@ -126,6 +126,12 @@ int chgpu_cmp_const(chgpu_ctx * ctx, const chgpu_col * col, int op, int scalar_t
 int chgpu_count_bytes_in_filter(chgpu_ctx * ctx, const chgpu_col * mask_u8, uint64_t * count); /* ColumnsCommon.cpp:31-58 */
 int chgpu_filter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * mask_u8, int64_t result_size_hint,
                  chgpu_col ** out, uint64_t * out_rows);
+/* The same for every column of a Block at once -- FilterTransform::doTransform's loop over the chunk's columns
+   (src/Processors/Transforms/FilterTransform.cpp:238-252) and joinBlock's filtering of the left columns
+   (src/Interpreters/HashJoin/HashJoinMethodsImpl.h:122-123): the mask is counted and scanned once, one host synchronisation
+   for the whole Block.  outs[k] receives column k filtered; all have out_rows rows. */
+int chgpu_filter_columns(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, const chgpu_col * filter_u8,
+                         int64_t result_size_hint, chgpu_col ** outs, uint64_t * out_rows);
 /* a6 FilterDescription for Nullable(UInt8): res = data && !null (src/Columns/FilterDescription.cpp:86-92) */
 int chgpu_filter_description_nullable(chgpu_ctx * ctx, const chgpu_col * data_u8, const chgpu_col * null_u8, chgpu_col ** out);
 

@@ -53,6 +53,23 @@ def test_filter_ragged_sizes_and_unaligned_views(ch, ctx, oracle_mod, rows):
         assert np.array_equal(got, oracle_mod.filter_column(data[start:start + n], filt[start:start + n]))
 
 
+def test_filter_columns_of_a_block_with_one_mask(ch, ctx, oracle_mod):
+    rng = np.random.Generator(np.random.PCG64(19))
+    for n in (0, 1, 1025, 300_007):
+        cols_np = [rng.integers(-2**62, 2**62, size=n, dtype=np.int64), rng.integers(0, 2**32, size=n, dtype=np.uint32),
+                   rng.integers(0, 256, size=n).astype(np.uint8), rng.random(n)]
+        filt = (rng.integers(0, 4, size=n) == 0).astype(np.uint8)
+        outs = ch.filter_columns([ctx.upload(c) for c in cols_np], ctx.upload(filt))
+        assert len(outs) == 4
+        for got, c in zip(outs, cols_np):
+            want = oracle_mod.filter_column(c, filt)
+            assert got.numpy().dtype == want.dtype and np.array_equal(got.numpy(), want)
+    assert ch.filter_columns([], ctx.upload(np.ones(5, dtype=np.uint8))) == []
+    with pytest.raises(ch.ChgpuError) as e:
+        ch.filter_columns([ctx.upload(np.arange(4, dtype=np.int64)), ctx.upload(np.arange(5, dtype=np.int64))], ctx.upload(np.ones(4, dtype=np.uint8)))
+    assert e.value.code == ch._capi.ERR_SIZES_MISMATCH
+
+
 def test_filter_size_mismatch_is_an_error(ch, ctx):
     col = ctx.upload(np.arange(10, dtype=np.int64))
     m = ctx.upload(np.ones(9, dtype=np.uint8))

@@ -80,10 +80,10 @@ def q41_gpu(ch, ctx, dims, lo):
     # ---- the fact table through the joins (JoiningTransform x4), most selective first ----
     r = j_s.probe_columns(lo["lo_suppkey"], need_right_rows=False)   # semi joins: the dimension contributes no column
     f = r["filter"]
-    cust, part, date, rev, cost = (lo[k].filter(f) for k in ("lo_custkey", "lo_partkey", "lo_orderdate", "lo_revenue", "lo_supplycost"))
+    cust, part, date, rev, cost = ch.filter_columns([lo[k] for k in ("lo_custkey", "lo_partkey", "lo_orderdate", "lo_revenue", "lo_supplycost")], f)
     r = j_p.probe_columns(part, need_right_rows=False)
     f = r["filter"]
-    cust, date, rev, cost = (c.filter(f) for c in (cust, date, rev, cost))
+    cust, date, rev, cost = ch.filter_columns([cust, date, rev, cost], f)
     r = j_c.probe_columns(cust)
     off = r["offsets"]
     date, rev, cost = (c.replicate(off) for c in (date, rev, cost))
