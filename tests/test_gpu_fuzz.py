@@ -2,10 +2,15 @@
 aggregate sets (<= 2 and > 2 argument columns take different kernels), size hints (none, too small, exact, too large),
 cardinalities from 1 group to all-distinct, skew, row ranges, NULL maps and join variants.  Integer results bit-exact,
 Float64 within BASELINE's 1e-6 relative tolerance."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+# CHGPU_FUZZ_SEED=<n> shifts every seed: the committed run is deterministic, extra seeds are for soak runs
+SEED = int(os.environ.get("CHGPU_FUZZ_SEED", "0"))
 
 
 @pytest.fixture(scope="module")
@@ -111,7 +116,7 @@ def _agg_case(ch, ctx, oracle_mod, rng, n, groups, use_oracle):
 
 
 def test_fuzz_group_by_small_against_oracle(ch, ctx, oracle_mod):
-    rng = np.random.Generator(np.random.PCG64(20261003))
+    rng = np.random.Generator(np.random.PCG64(20261003 + SEED))
     for case in range(60):
         n = int(rng.integers(1, 200_000))
         groups = int([1, 7, 300, 5000, 60_000, n][rng.integers(0, 6)]) or 1
@@ -120,7 +125,7 @@ def test_fuzz_group_by_small_against_oracle(ch, ctx, oracle_mod):
 
 def test_fuzz_group_by_large_paths_against_numpy(ch, ctx, oracle_mod):
     # >= 4 Mi rows so that hints and observed cardinalities choose between RANGE, PARTITIONED and DIRECT
-    rng = np.random.Generator(np.random.PCG64(777))
+    rng = np.random.Generator(np.random.PCG64(777 + SEED))
     for case in range(10):
         n = int(rng.integers(4_300_000, 5_500_000))
         groups = int([3, 2000, 5000, 40_000, 900_000, n][rng.integers(0, 6)])
@@ -129,7 +134,7 @@ def test_fuzz_group_by_large_paths_against_numpy(ch, ctx, oracle_mod):
 
 def test_fuzz_join_against_oracle(ch, ctx, oracle_mod):
     O = oracle_mod
-    rng = np.random.Generator(np.random.PCG64(4242))
+    rng = np.random.Generator(np.random.PCG64(4242 + SEED))
     variants = [(ch.JOIN_INNER, ch.STRICT_ALL, {}), (ch.JOIN_LEFT, ch.STRICT_ALL, {}), (ch.JOIN_LEFT, ch.STRICT_ANY, {}),
                 (ch.JOIN_LEFT, ch.STRICT_ANY, {"any_take_last_row": True}), (ch.JOIN_INNER, ch.STRICT_ANY, {}),
                 (ch.JOIN_LEFT, ch.STRICT_SEMI, {}), (ch.JOIN_LEFT, ch.STRICT_ANTI, {})]
