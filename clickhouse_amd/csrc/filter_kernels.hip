@@ -1207,6 +1207,8 @@ extern "C" int chgpu_arith(chgpu_ctx * ctx, int value_op, const chgpu_col * a, c
     return CHGPU_OK;
 }
 
+__device__ __forceinline__ u32 chgpu_type_size_dev(int type) { return type == CHGPU_U8 ? 1u : (type == CHGPU_U32 || type == CHGPU_I32) ? 4u : 8u; }
+
 static constexpr u32 EX_MAX_COLS = 4;
 static constexpr u32 EX_MAX_PREDS = 8;
 
@@ -1392,122 +1394,96 @@ __global__ __launch_bounds__(FS_THREADS) void k_expr_filter_sum(ExprSpec sp, u64
     }
 }
 
-// Columns of DIFFERENT integer widths (the real SSB lineorder: UInt32 dates and prices next to UInt8 discount and quantity).
-// A lane owns units of 4 consecutive rows, EXM_UNROLL units per iteration at a stride of the workgroup: a 4-byte column is
-// one 16-byte load per unit, a 1-byte column one 4-byte load, an 8-byte column two 16-byte loads -- every instruction
-// coalesced across the wave.  Per column (static) a wave-uniform switch selects the width-native path; predicates are
-// applied in the column's own width exactly as in the same-type kernel.
+// Columns of DIFFERENT integer widths, general case (any mix of 1-, 4- and 8-byte columns): one row per lane and step, four
+// steps in flight; every column is fetched through a wave-uniform type switch and widened to 64 bits, predicates are the
+// 64-bit range tests.  Simple on purpose: the mix with 8-byte columns is rare, the 1/4-byte mix has its own kernel below (a
+// unit-vectorised generic version spilled to scratch and ran 3-7x slower than this one).
 #ifndef EXM_UNROLL
 #define EXM_UNROLL 4
 #endif
-template <typename T>
-__device__ __forceinline__ void exm_load_unit(const void * col, u64 unit, T (&x)[4])
+__device__ __forceinline__ u64 exm_load_ext(const void * col, int type, u64 i)
 {
-    if constexpr (sizeof(T) == 1)
+    switch (type) // wave-uniform
     {
-        const u32 w = __builtin_nontemporal_load((const u32 *)col + unit);
-        x[0] = (T)(w & 0xFF), x[1] = (T)((w >> 8) & 0xFF), x[2] = (T)((w >> 16) & 0xFF), x[3] = (T)(w >> 24);
-    }
-    else if constexpr (sizeof(T) == 4)
-    {
-        const Vec<T, 4> v = load_stream((const Vec<T, 4> *)col + unit);
-        x[0] = v.v[0], x[1] = v.v[1], x[2] = v.v[2], x[3] = v.v[3];
-    }
-    else
-    {
-        const Vec<T, 2> a = load_stream((const Vec<T, 2> *)col + 2 * unit), b = load_stream((const Vec<T, 2> *)col + 2 * unit + 1);
-        x[0] = a.v[0], x[1] = a.v[1], x[2] = b.v[0], x[3] = b.v[1];
+        case CHGPU_U8: return ((const u8 *)col)[i];
+        case CHGPU_U32: return ((const u32 *)col)[i];
+        case CHGPU_I32: return (u64)(i64)((const i32 *)col)[i];
+        default: return ((const u64 *)col)[i];
     }
 }
 
 __global__ __launch_bounds__(FS_THREADS) void k_expr_filter_sum_mixed(ExprSpec sp, u64 n, u64 * __restrict__ part_sum, u64 * __restrict__ part_cnt)
 {
-    constexpr int U = EXM_UNROLL, E = 4 * U;
+    constexpr int U = EXM_UNROLL;
     u64 s = 0, c = 0;
-    const u64 n_units = n / 4;
-    constexpr u64 CHUNK = (u64)U * FS_THREADS; // units per workgroup iteration
-    const u64 n_chunks = n_units / CHUNK;
-
-    // one column over the E rows of this lane: load (if whole units) or take the single tail row, test, extract values
-    auto column_t = [&](auto tag, u32 k, u64 unit0, u64 tail_row, bool tail, bool (&pass)[E], u64 (&va)[E], u64 (&vb)[E]) {
-        using T = decltype(tag);
-        T x[E];
-        if (!tail)
-        {
+    const u64 stride = (u64)gridDim.x * FS_THREADS;
+    // bit k: column k is 1 or 4 bytes wide (constant indices only: a run-time index into the by-value spec lands it in scratch)
+    const u32 narrow_mask = (chgpu_type_size_dev(sp.col_type[0]) <= 4 ? 1u : 0u) | (chgpu_type_size_dev(sp.col_type[1]) <= 4 ? 2u : 0u) |
+                            (chgpu_type_size_dev(sp.col_type[2]) <= 4 ? 4u : 0u) | (chgpu_type_size_dev(sp.col_type[3]) <= 4 ? 8u : 0u);
+    // 64-bit key domain of each column: signed types are compared after flipping bit 63 of the sign-extended value; the host
+    // folded 4- and 1-byte columns' predicates into their own 32-bit key space (ExprPred), so widen those constants back
+    for (u64 i0 = (u64)blockIdx.x * FS_THREADS + threadIdx.x; i0 < n; i0 += stride * U)
+    {
+        u64 x0[U], x1[U], x2[U], x3[U]; // one array per column: constant indices only, so they stay in registers
+        bool pass[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-            {
-                T q[4];
-                exm_load_unit<T>(sp.col[k], unit0 + (u64)u * FS_THREADS, q);
-                x[4 * u] = q[0], x[4 * u + 1] = q[1], x[4 * u + 2] = q[2], x[4 * u + 3] = q[3];
-            }
-        }
-        else
+        for (int u = 0; u < U; ++u)
         {
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-                x[e] = 0;
-            x[0] = ((const T *)sp.col[k])[tail_row];
+            const u64 i = i0 + (u64)u * stride;
+            pass[u] = i < n;
+            const u64 ic = pass[u] ? i : n - 1;
+            x0[u] = exm_load_ext(sp.col[0], sp.col_type[0], ic);
+            x1[u] = sp.n_cols > 1 ? exm_load_ext(sp.col[1], sp.col_type[1], ic) : 0;
+            x2[u] = sp.n_cols > 2 ? exm_load_ext(sp.col[2], sp.col_type[2], ic) : 0;
+            x3[u] = sp.n_cols > 3 ? exm_load_ext(sp.col[3], sp.col_type[3], ic) : 0;
         }
-        for (u32 q = 0; q < sp.n_preds; ++q)
-            if (sp.pred[q].col == k)
+        // column-major, with wave-uniform branches on the column index (a select chain over x0..x3 is turned into a scratch
+        // lookup table by the compiler: 27 ms instead of 4)
+        u64 va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            va[u] = 0, vb[u] = 0;
+        auto column = [&](u32 k, const u64 (&x)[U]) {
+            const bool narrow = (narrow_mask >> k) & 1;
+#pragma unroll
+            for (u32 q = 0; q < EX_MAX_PREDS; ++q)
             {
+                if (q >= sp.n_preds || sp.pred[q].col != k)
+                    continue;
                 const ExprPred pr = sp.pred[q];
 #pragma unroll
-                for (int e = 0; e < E; ++e)
-                    pass[e] = pass[e] && expr_pass<T>(pr, x[e]);
+                for (int u = 0; u < U; ++u)
+                {
+                    // narrow columns: the 32-bit key test on the low word (exactly expr_pass<u32/i32/u8>); wide: the 64-bit one
+                    const bool ok = narrow ? ((((u32)x[u] ^ (u32)pr.flip) - (u32)pr.lo) <= (u32)pr.span) : (((x[u] ^ pr.flip) - pr.lo) <= pr.span);
+                    pass[u] = pass[u] && (ok != (pr.invert != 0));
+                }
             }
-        if (sp.val_a == k)
-        {
+            if (sp.val_a == k)
+            {
 #pragma unroll
-            for (int e = 0; e < E; ++e)
-                va[e] = ext64(x[e]);
-        }
-        if (sp.value_op != CHGPU_VAL_COL && sp.val_b == k)
-        {
+                for (int u = 0; u < U; ++u)
+                    va[u] = x[u];
+            }
+            if (sp.value_op != CHGPU_VAL_COL && sp.val_b == k)
+            {
 #pragma unroll
-            for (int e = 0; e < E; ++e)
-                vb[e] = ext64(x[e]);
-        }
-    };
-    auto column = [&](u32 k, u64 unit0, u64 tail_row, bool tail, bool (&pass)[E], u64 (&va)[E], u64 (&vb)[E]) {
-        switch (sp.col_type[k]) // wave-uniform
-        {
-            case CHGPU_U8: column_t((u8)0, k, unit0, tail_row, tail, pass, va, vb); break;
-            case CHGPU_U32: column_t((u32)0, k, unit0, tail_row, tail, pass, va, vb); break;
-            case CHGPU_I32: column_t((i32)0, k, unit0, tail_row, tail, pass, va, vb); break;
-            case CHGPU_U64: column_t((u64)0, k, unit0, tail_row, tail, pass, va, vb); break;
-            default: column_t((i64)0, k, unit0, tail_row, tail, pass, va, vb); break;
-        }
-    };
-    auto rows = [&](u64 unit0, u64 tail_row, bool tail) {
-        bool pass[E];
-        u64 va[E], vb[E];
+                for (int u = 0; u < U; ++u)
+                    vb[u] = x[u];
+            }
+        };
+        column(0, x0);
+        if (sp.n_cols > 1) column(1, x1);
+        if (sp.n_cols > 2) column(2, x2);
+        if (sp.n_cols > 3) column(3, x3);
 #pragma unroll
-        for (int e = 0; e < E; ++e)
+        for (int u = 0; u < U; ++u)
         {
-            pass[e] = !tail || e == 0;
-            va[e] = 0;
-            vb[e] = 0;
+            const u64 v = sp.value_op == CHGPU_VAL_COL ? va[u] : apply_val(sp.value_op, va[u], vb[u]);
+            s += pass[u] ? v : 0;
+            c += pass[u] ? 1 : 0;
         }
-        column(0, unit0, tail_row, tail, pass, va, vb);
-        if (sp.n_cols > 1) column(1, unit0, tail_row, tail, pass, va, vb);
-        if (sp.n_cols > 2) column(2, unit0, tail_row, tail, pass, va, vb);
-        if (sp.n_cols > 3) column(3, unit0, tail_row, tail, pass, va, vb);
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-        {
-            const u64 v = sp.value_op == CHGPU_VAL_COL ? va[e] : apply_val(sp.value_op, va[e], vb[e]);
-            s += pass[e] ? v : 0;
-            c += pass[e] ? 1 : 0;
-        }
-    };
-    for (u64 ch = blockIdx.x; ch < n_chunks; ch += gridDim.x)
-        rows(ch * CHUNK + threadIdx.x, 0, false);
-    const u64 tid = (u64)blockIdx.x * FS_THREADS + threadIdx.x;
-    const u64 stride = (u64)gridDim.x * FS_THREADS;
-    for (u64 r = n_chunks * CHUNK * 4 + tid; r < n; r += stride)
-        rows(0, r, true);
+    }
 
     __shared__ u64 lds_s[FS_THREADS / WAVE];
     __shared__ u64 lds_c[FS_THREADS / WAVE];

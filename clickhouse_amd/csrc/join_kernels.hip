@@ -594,7 +594,8 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
     chgpu_ctx * ctx = j->ctx;
     const bool maps_all = j->strictness == CHGPU_STRICT_ALL;
     const bool flagged = j->kind == CHGPU_JOIN_INNER && j->strictness == CHGPU_STRICT_ANY;
-    const u64 cap = jpow2_ceil(j->total_rows + j->total_rows * 3 / 7 + 1);
+    static const u32 cap_shift = getenv("CHGPU_TUNE_JOIN_CAP_SHIFT") ? (u32)atoi(getenv("CHGPU_TUNE_JOIN_CAP_SHIFT")) : 0;
+    const u64 cap = jpow2_ceil(j->total_rows + j->total_rows * 3 / 7 + 1) << cap_shift;
     CHGPU_REQUIRE(cap + 1 < 0xFFFFFFFFull, CHGPU_ERR_NOT_IMPLEMENTED, "build side of %llu rows exceeds the 32-bit cell index", (unsigned long long)j->total_rows);
     const u64 cells = cap + 1;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };

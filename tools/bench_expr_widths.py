@@ -21,6 +21,8 @@ cases = {"u32 u32 u32 u32 (same-type kernel)": ([W(od, np.uint32), W(disc, np.ui
          "u32 i32 i32 u32 (narrow kernel, all 4-byte)": ([W(od, np.uint32), W(disc, np.int32), W(qty, np.int32), W(price, np.uint32)], 16),
          "u32 u8 u8 u32 (narrow kernel)": ([W(od, np.uint32), W(d8, np.uint8), W(q8, np.uint8), W(price, np.uint32)], 10),
          "u32 u8 i32 u32 (narrow kernel)": ([W(od, np.uint32), W(d8, np.uint8), W(qty, np.int32), W(price, np.uint32)], 13)}
+p64 = price.to(torch.int64)
+cases["u32 u8 u8 i64 (generic mixed kernel)"] = ([W(od, np.uint32), W(d8, np.uint8), W(q8, np.uint8), W(p64, np.int64)], 14)
 ref = None
 for name, (cols, bpr) in cases.items():
     best = None
