@@ -563,7 +563,11 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
     const u64 r0 = (u64)blockIdx.x * rows_per_wg;
     const u64 r1 = r0 + rows_per_wg < n ? r0 + rows_per_wg : n;
     constexpr u32 RPT = GBP_TILE / GBP_THREADS; // rows per thread per tile
-    u64 key[RPT], argw[RPT][GBP_MAX_K];
+    // Register budget at 1024 threads is 128 VGPRs: keys are held in the buffer's key width, and the 12288-row tile -- which
+    // only fits LDS with one argument word -- does not carry registers for a second one (it used to spill 9 dwords per lane)
+    constexpr u32 KW = GBP_TILE >= 12288 ? 1 : GBP_MAX_K;
+    KT key[RPT];
+    u64 argw[RPT][KW];
     // rows of a tile are held in registers; the NEXT tile's loads are issued right after the current tile has been
     // staged to LDS, so their latency hides behind the write-out phase (one workgroup per CU: nothing else would)
     auto row_of = [&](u64 tb, u32 j) -> u64 {
@@ -599,19 +603,24 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
                         const v2q a = __builtin_nontemporal_load((const v2q *)((const u64 *)cols.src[0] + row_begin + i));
                         argw[j][0] = a.x, argw[j + 1][0] = a.y;
                     }
-                    if (cols.k > 1)
-                    {
-                        const v2q a = __builtin_nontemporal_load((const v2q *)((const u64 *)cols.src[1] + row_begin + i));
-                        argw[j][1] = a.x, argw[j + 1][1] = a.y;
-                    }
+                    if constexpr (KW > 1)
+                        if (cols.k > 1)
+                        {
+                            const v2q a = __builtin_nontemporal_load((const v2q *)((const u64 *)cols.src[1] + row_begin + i));
+                            argw[j][KW - 1] = a.x, argw[j + 1][KW - 1] = a.y;
+                        }
                 }
                 else
                 {
                     const bool in = i < r1; // at most the first row of the pair is left
-                    key[j] = in ? (u64)((const KT *)keys)[row_begin + i] : 0;
+                    key[j] = in ? ((const KT *)keys)[row_begin + i] : (KT)0;
                     argw[j][0] = (in && cols.k > 0) ? ((const u64 *)cols.src[0])[row_begin + i] : 0;
-                    argw[j][1] = (in && cols.k > 1) ? ((const u64 *)cols.src[1])[row_begin + i] : 0;
-                    key[j + 1] = 0, argw[j + 1][0] = 0, argw[j + 1][1] = 0;
+                    key[j + 1] = 0, argw[j + 1][0] = 0;
+                    if constexpr (KW > 1)
+                    {
+                        argw[j][KW - 1] = (in && cols.k > 1) ? ((const u64 *)cols.src[1])[row_begin + i] : 0;
+                        argw[j + 1][KW - 1] = 0;
+                    }
                 }
             }
         }
@@ -622,9 +631,10 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
             {
                 const u64 i = row_of(tb, j);
                 const bool in = i < r1;
-                key[j] = in ? load_key_zext(keys, key_type, row_begin + i) : 0;
+                key[j] = in ? (KT)load_key_zext(keys, key_type, row_begin + i) : (KT)0;
                 argw[j][0] = (in && cols.k > 0) ? load_arg_bits(cols.src[0], cols.type[0], row_begin + i) : 0;
-                argw[j][1] = (in && cols.k > 1) ? load_arg_bits(cols.src[1], cols.type[1], row_begin + i) : 0;
+                if constexpr (KW > 1)
+                    argw[j][KW - 1] = (in && cols.k > 1) ? load_arg_bits(cols.src[1], cols.type[1], row_begin + i) : 0;
             }
         }
     };
@@ -641,7 +651,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
             part[j] = ~0u;
             if (i < r1)
             {
-                part[j] = gbp_part_of(key[j], P - 1, mult);
+                part[j] = gbp_part_of((u64)key[j], P - 1, mult);
                 rank[j] = atomicAdd(&tile_cnt[part[j]], 1u);
             }
         }
@@ -696,8 +706,9 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
             stage_key[pos] = (KT)key[j];
             if (cols.k > 0)
                 stage_word[pos] = argw[j][0];
-            if (cols.k > 1)
-                stage_word[(size_t)GBP_TILE + pos] = argw[j][1];
+            if constexpr (KW > 1)
+                if (cols.k > 1)
+                    stage_word[(size_t)GBP_TILE + pos] = argw[j][KW - 1];
         }
         if (tbase + GBP_TILE < r1)
             load_tile(tbase + GBP_TILE); // prefetch: lands while this tile is written out

@@ -1693,7 +1693,8 @@ extern "C" int chgpu_expr_filter_sum(chgpu_ctx * ctx, uint32_t n_cols, const chg
     sp.n_preds = n_preds;
     const int type0 = cols[0] ? cols[0]->type : -1;
     u64 n = cols[0] ? cols[0]->rows : 0;
-    bool aligned = true, one_type = true;
+    bool aligned = true, one_type = cols[0] && cols[0]->type != CHGPU_U8; // all-UInt8: the same-type kernel would hold 64 elements per lane
+                                                                           // (256 VGPRs + scratch); the narrow kernel takes it
     for (u32 k = 0; k < EX_MAX_COLS; ++k)
     {
         const chgpu_col * cc = cols[k < n_cols ? k : 0];
