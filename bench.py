@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU (default: the 1 B rows of configs[1])")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL code path on one GPU)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (rehearsal of the N>1 code path on one GPU)")
     args = ap.parse_args()
 
@@ -52,9 +53,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    _saved_stdout_fd = None
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # stdout carries exactly one JSON line: RCCL prints its version banner to stdout when the communicator is created
+        # (NCCL_DEBUG=VERSION is exported on the GPU boxes), so fd 1 points at stderr until the result is printed
+        sys.stdout.flush()
+        _saved_stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -193,8 +200,13 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, args.cpu_sample_rows, ctx, ch)
 
+    if _saved_stdout_fd is not None:
+        sys.stdout.flush()
+        os.dup2(_saved_stdout_fd, 1)  # the real stdout is back for the one JSON line
+        os.close(_saved_stdout_fd)
     print(json.dumps(out), flush=True)
     if dist is not None:
+        os.dup2(2, 1)  # anything RCCL says while shutting down goes to stderr again
         dist.destroy_process_group()
 
 
