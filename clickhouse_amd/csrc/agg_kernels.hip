@@ -15,11 +15,15 @@
 // 8-byte keys and state updates are single 64-bit atomics.  Placement hash = intHash64 (Hash.h:27-36); CRC32-C is
 // only needed where the hash is externally visible (partition_kernels.hip).
 //
-// Two row kernels: DIRECT (global atomics per row; large cardinalities) and LDS-STAGED (a per-workgroup open-addressing
-// table in LDS absorbs repeated keys — the device analogue of the consecutive-key cache, ColumnsHashingImpl.h:313-366 —
-// and is flushed once per workgroup).  Rows that would push the table over max fill are marked in a pending bitmap;
-// the host grows the table (rehash) and re-runs only those rows, which is the reference's resize-on-overflow
-// (HashTable.h:921-944) restructured for a device that cannot realloc inside a kernel.
+// Strategies (chgpu_agg_add_block picks by promised / observed cardinality):
+//   LDS-STAGED  a per-workgroup open-addressing table in LDS absorbs repeated keys -- the device analogue of the
+//               consecutive-key cache, ColumnsHashingImpl.h:313-366 -- and is flushed once per workgroup; k_agg_part_lds in
+//               RANGE mode straight over the source columns (k_agg_rows_lds is the older generic form of it);
+//   PARTITIONED k_gb_hist -> scan -> k_gb_scatter -> k_gb_units -> k_agg_part_lds, one or two partitioning levels;
+//   DIRECT      k_agg_rows_direct, one HBM atomic per row and state word.
+// Rows that would push the table over max fill are marked in a pending bitmap; the host grows the table (rehash) and
+// re-runs only those rows, which is the reference's resize-on-overflow (HashTable.h:921-944) restructured for a device
+// that cannot realloc inside a kernel.
 #include "chgpu_internal.h"
 
 #include <cmath>
@@ -426,12 +430,15 @@ __global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, co
 // the DIRECT kernel at ~1e10 rows/s whatever the bandwidth.  Instead the rows are first split by key hash into P
 // partitions small enough that a partition's groups fit one workgroup's LDS table, then every partition is aggregated
 // entirely in LDS by one workgroup and flushed once:
-//   k_gb_hist     per-workgroup histogram of partition ids over its contiguous row range        (key bytes read)
-//   scan          exclusive scan of counts[P][G] -> exact, atomics-free write offsets
-//   k_gb_scatter  per 8192-row tile: LDS counting sort by partition, then coalesced run writes     (rows read + 8(1+K) B/row written)
-//                 (measured at 1e9 rows, P=512: 512 thr/4096-row tiles 19.5 ms, 1024 thr/8192-row tiles 12.2 ms)
-//   k_agg_part_lds  one workgroup per partition: LDS open-addressing table, flush to the HBM table (8(1+K) B/row read)
-// Keys and argument values are widened to 8-byte words in the partition buffers.
+//   k_gb_hist[_wide]  per-workgroup histogram of partition ids over its contiguous row range      (key bytes read)
+//   scan              exclusive scan of counts[P][G] -> exact, atomics-free write offsets
+//   k_gb_scatter      per 12288-row tile (8192 / 4096 when LDS is short): LDS counting sort by partition, then coalesced run
+//                     writes                                                                     (rows read, key + 8K B/row written)
+//   k_gb_units        cuts partitions into work units (a hot key's partition is shared by many workgroups)
+//   k_agg_part_lds    a workgroup aggregates a unit in an LDS open-addressing table and flushes it to the HBM table
+// Partition buffers hold keys in 4 bytes (key types of <= 4 bytes) or 8, argument values widened to 8-byte words.
+// More groups than 1024 partitions x half an LDS table: a first level with an independent hash cuts the rows into big
+// partitions, each of which goes through the same passes again.
 // ---------------------------------------------------------------------------------------------
 #ifndef GBP_THREADS_V
 #define GBP_THREADS_V 1024
