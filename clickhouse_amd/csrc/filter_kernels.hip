@@ -1262,20 +1262,6 @@ __global__ __launch_bounds__(FS_THREADS) void k_expr_filter_sum(ExprSpec sp, u64
     constexpr int E = VEC * UNROLL; // elements per lane per iteration
     const u64 nvec = n / VEC;
     u64 s = 0, c = 0;
-    // predicate constants in wave-uniform registers for the whole kernel (see k_expr_filter_sum_narrow), in the key width
-    typedef typename std::conditional<sizeof(T) <= 4, u32, u64>::type KT;
-    KT p_lo[EX_MAX_PREDS], p_span[EX_MAX_PREDS], p_flip[EX_MAX_PREDS];
-    u32 p_inv[EX_MAX_PREDS], p_col[EX_MAX_PREDS];
-#pragma unroll
-    for (u32 q = 0; q < EX_MAX_PREDS; ++q)
-    {
-        const bool on = q < sp.n_preds;
-        p_lo[q] = on ? (KT)sp.pred[q].lo : 0;
-        p_span[q] = on ? (KT)sp.pred[q].span : 0;
-        p_flip[q] = on ? (KT)sp.pred[q].flip : 0;
-        p_inv[q] = on ? sp.pred[q].invert : 0;
-        p_col[q] = on ? sp.pred[q].col : 0xFFu;
-    }
 
     auto reduce_rows = [&](const T (&x0)[E], const T (&x1)[E], const T (&x2)[E], const T (&x3)[E], int n_elem) {
         bool pass[E];
@@ -1288,13 +1274,15 @@ __global__ __launch_bounds__(FS_THREADS) void k_expr_filter_sum(ExprSpec sp, u64
             vb[e] = 0;
         }
         auto column = [&](u32 k, const T (&x)[E]) {
-#pragma unroll
-            for (u32 q = 0; q < EX_MAX_PREDS; ++q)
-                if (p_col[q] == k)
+            // (keeping the predicate constants in registers for the whole kernel, as the narrow mixed-width kernel does, was
+            //  measured SLOWER here: 1.04 -> 1.24 ms at 4e8 rows; this kernel holds 16 elements per lane and is HBM-bound)
+            for (u32 q = 0; q < sp.n_preds; ++q)
+                if (sp.pred[q].col == k)
                 {
+                    const ExprPred pr = sp.pred[q];
 #pragma unroll
                     for (int e = 0; e < E; ++e)
-                        pass[e] = pass[e] && ((((KT)x[e] ^ p_flip[q]) - p_lo[q]) <= p_span[q]) != (p_inv[q] != 0);
+                        pass[e] = pass[e] && expr_pass<T>(pr, x[e]);
                 }
             if (sp.val_a == k)
             {

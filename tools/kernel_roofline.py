@@ -20,8 +20,8 @@ ALG = [
     ("k_index<unsigned long, unsigned long>", (8 + 8 + 8) * (R // 4), "random gather of R/4 rows (8 idx + 8 data + 8 out)"),
     ("k_gb_hist_wide<unsigned int>", 4 * R, "GROUP BY partition histogram (4 B key)"),
     ("k_gb_scatter<12288u, unsigned int, true>", (12 + 12) * R, "GROUP BY partition scatter (12 B in, 12 B out)"),
-    ("k_agg_part_lds<unsigned int>", 12 * R, "GROUP BY LDS aggregation of partitions (12 B/row), 1 M groups"),
-    ("k_agg_part_lds<unsigned long>", 16 * R, "GROUP BY LDS-staged over the source columns (RANGE mode, 16 B/row), 1000 groups"),
+    ("k_agg_part_lds<unsigned int, 8", 12 * R, "GROUP BY LDS aggregation of partitions (12 B/row), 1 M groups"),
+    ("k_agg_part_lds<unsigned long, 8", 16 * R, "GROUP BY LDS-staged over the source columns (RANGE mode, 16 B/row), 1000 groups"),
     ("k_join_probe_filter<true>", 5 * R, "filter-only LEFT SEMI probe, dense prefilter (4 B key in, 1 B out)"),
     ("k_join_insert", 8 * 10_000_000, "join build: insert 1e7 keys (8 B/row)"),
     ("k_join_fill", 12 * 10_000_000, "join build: CSR fill"),
