@@ -12,7 +12,7 @@ ALG = [
     ("k_filter_sum<long, 2, false, false, IntRangePred>", 16 * R, "filter+sum, predicate and value columns (16 B/row)"),
     ("k_expr_filter_sum<unsigned int>", 16 * R, "fused 2-column expression over 2R UInt32 rows"),
     ("k_cmp_mask<long", 9 * R, "compare -> UInt8 mask (8+1 B/row)"),
-    ("k_filter_sum<unsigned char, 16, true, false, IntRangePred>", 1 * R, "countBytesInFilter (1 B/row)"),
+    ("k_count_nonzero", 1 * R, "countBytesInFilter (1 B/row; a 0.4 GB input at R = 4e8: ramp-up dominated)"),
     ("k_selector", 12 * R, "CRC32-C shard selector (8 B key in, 4 B out)"),
     ("k_weak_hash32", 16 * R, "getWeakHash32 (8 B key + 4 B hash in, 4 B out)"),
     ("k_part_hist", 4 * R, "partition histogram (4 B selector)"),
