@@ -69,6 +69,7 @@ SIGNATURES = {
     "chgpu_unpack_fixed_key": (_i, [_vp, _vp, _u32, _i, _pp]),
     "chgpu_agg_create": (_i, [_vp, _i, _u32, C.POINTER(_i), C.POINTER(_i), _u64, _pp]),
     "chgpu_agg_add_block": (_i, [_vp, _vp, _pp, _u64, _u64]),
+    "chgpu_agg_add_block_filtered": (_i, [_vp, _vp, _pp, _u64, _u64, _vp]),
     "chgpu_agg_merge": (_i, [_vp, _vp]),
     "chgpu_agg_merge_states": (_i, [_vp, _vp, _pp, _u64]),
     "chgpu_agg_size": (_i, [_vp, _pu64]),

@@ -35,14 +35,19 @@ class Aggregator:
         except Exception:
             pass
 
-    def execute_on_block(self, keys, args, row_begin: int = 0, row_end: int | None = None):
-        """Aggregator::executeOnBlock(columns, row_begin, row_end, result, key_columns, aggregate_columns, ...)"""
+    def execute_on_block(self, keys, args, row_begin: int = 0, row_end: int | None = None, filter=None):
+        """Aggregator::executeOnBlock(columns, row_begin, row_end, result, key_columns, aggregate_columns, ...).
+        filter: a UInt8 WHERE mask over the same rows (a FilterTransform fused in front of the aggregation)."""
         kcol = self.ctx.column(keys) if keys is not None else None
         acols = [self.ctx.column(a) if a is not None else None for a in args]
-        n = kcol.size() if kcol is not None else next(a.size() for a in acols if a is not None)
+        fcol = self.ctx.column(filter) if filter is not None else None
+        n = kcol.size() if kcol is not None else (fcol.size() if fcol is not None else next(a.size() for a in acols if a is not None))
         row_end = n if row_end is None else row_end
         ptrs = (C.c_void_p * max(1, len(acols)))(*[(a._h if a is not None else None) for a in acols])
-        K.check(K.lib().chgpu_agg_add_block(self._h, kcol._h if kcol is not None else None, ptrs, row_begin, row_end))
+        if fcol is None:
+            K.check(K.lib().chgpu_agg_add_block(self._h, kcol._h if kcol is not None else None, ptrs, row_begin, row_end))
+        else:
+            K.check(K.lib().chgpu_agg_add_block_filtered(self._h, kcol._h if kcol is not None else None, ptrs, row_begin, row_end, fcol._h))
 
     def merge(self, other: "Aggregator"):
         K.check(K.lib().chgpu_agg_merge(self._h, other._h))

@@ -795,7 +795,8 @@ struct PartLds
 template <typename KT, int AW, typename KS = KT>
 __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const KS * __restrict__ keys, const void * __restrict__ words0, const void * __restrict__ words1,
                                                        const u64 * __restrict__ offsets, u32 G, u32 P, u64 n, u64 * __restrict__ pending, u32 S, u32 K, u32 cnt32,
-                                                       u64 rows_per_chunk, const u32 * __restrict__ unit_start, u32 * __restrict__ unit_ctr)
+                                                       u64 rows_per_chunk, const u32 * __restrict__ unit_start, u32 * __restrict__ unit_ctr,
+                                                       const u8 * __restrict__ cond)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     typedef typename std::conditional<sizeof(KT) == 4, unsigned int, unsigned long long>::type CasT;
@@ -894,12 +895,15 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
         // Loads are unconditional (row indices clamped to the buffer) and double-buffered in registers: the loads of the
         // wave's next PR groups are in flight while the current ones go through the LDS table.  No branch surrounds a
         // load, so the compiler can keep exact vmcnt waits instead of draining the queue at a control-flow join.
-        auto load_set = [&](u64 gb, u64 (&kv)[PR], u64 (&av)[PR][PPRE]) {
+        // cond (RANGE mode only): the WHERE mask of a fused filter + GROUP BY; rows whose byte is 0 are skipped entirely, as if a
+        // FilterTransform had removed them before the AggregatingTransform.
+        auto load_set = [&](u64 gb, u64 (&kv)[PR], u64 (&av)[PR][PPRE], u32 (&cv)[PR]) {
 #pragma unroll
             for (int q = 0; q < PR; ++q)
             {
                 u64 i = (gb + q) * 64 + lane;
                 i = i < n ? i : n - 1;
+                cv[q] = cond ? (u32)__builtin_nontemporal_load(&cond[i]) : 1u;
                 kv[q] = (u64)__builtin_nontemporal_load(&keys[i]);
                 typedef typename std::conditional<AW == 8, u64, typename std::conditional<AW == 4, u32, u8>::type>::type AT;
                 av[q][0] = K > 0 ? (u64)__builtin_nontemporal_load((const AT *)words0 + i) : 0;
@@ -908,7 +912,7 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
         };
         // (Combining the rows of a hot key in registers before the LDS atomic was tried for Zipf inputs: once partitions are
         //  cut into work units it gains nothing -- 15.2 ms without vs 14.9-15.7 ms with -- and costs the uniform case 3-10 %.)
-        auto process_set = [&](u64 gb, const u64 (&keyv)[PR], const u64 (&argv)[PR][PPRE]) {
+        auto process_set = [&](u64 gb, const u64 (&keyv)[PR], const u64 (&argv)[PR][PPRE], const u32 (&cv)[PR]) {
 #pragma unroll
             for (int q = 0; q < PR; ++q)
             {
@@ -917,7 +921,7 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                     break;
                 const u64 i = g * 64 + lane;
                 bool failed = false;
-                if (i >= begin && i < end)
+                if (i >= begin && i < end && cv[q] != 0)
                 {
                     const u64 key = keyv[q];
                     const u64 b0 = sx0 ? (u64)(i64)(i32)(u32)argv[q][0] : argv[q][0];
@@ -988,16 +992,17 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
         {
             const u64 step = (u64)n_waves * PR;
             u64 kA[PR], aA[PR][PPRE], kB[PR], aB[PR][PPRE];
+            u32 cA[PR], cB[PR];
             u64 gb = g0 + (u64)wave * PR;
-            load_set(gb, kA, aA);
+            load_set(gb, kA, aA, cA);
             for (; gb < g1; gb += 2 * step)
             {
-                load_set(gb + step, kB, aB);
+                load_set(gb + step, kB, aB, cB);
                 __builtin_amdgcn_sched_barrier(0);
-                process_set(gb, kA, aA);
-                load_set(gb + 2 * step, kA, aA);
+                process_set(gb, kA, aA, cA);
+                load_set(gb + 2 * step, kA, aA, cA);
                 __builtin_amdgcn_sched_barrier(0);
-                process_set(gb + step, kB, aB);
+                process_set(gb + step, kB, aB, cB);
             }
         }
         __syncthreads();
@@ -1554,13 +1559,13 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         {
             rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
             if (rc == CHGPU_OK)
-                hipLaunchKernelGGL((k_agg_part_lds<u32, 8>), dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)pkeys, (const void *)pwords, (const void *)(pwords + n), (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr);
+                hipLaunchKernelGGL((k_agg_part_lds<u32, 8>), dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)pkeys, (const void *)pwords, (const void *)(pwords + n), (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr, (const u8 *)nullptr);
         }
         else
         {
             rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
             if (rc == CHGPU_OK)
-                hipLaunchKernelGGL((k_agg_part_lds<u64, 8>), dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const void *)pwords, (const void *)(pwords + n), (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr);
+                hipLaunchKernelGGL((k_agg_part_lds<u64, 8>), dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const void *)pwords, (const void *)(pwords + n), (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr, (const u8 *)nullptr);
         }
     }
     ctx->counters[6] += 3;
@@ -1577,13 +1582,84 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     return rc;
 }
 
+static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols, u64 row_begin, u64 row_end,
+                              const chgpu_col * filter);
+
 extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols,
                                    uint64_t row_begin, uint64_t row_end)
+{
+    return agg_add_block_impl(a, key_col, arg_cols, row_begin, row_end, nullptr);
+}
+
+extern "C" int chgpu_agg_add_block_filtered(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols,
+                                            uint64_t row_begin, uint64_t row_end, const chgpu_col * filter_u8)
+{
+    return agg_add_block_impl(a, key_col, arg_cols, row_begin, row_end, filter_u8);
+}
+
+// The strategies that have no fused form: FilterTransform's work is done first (every column of the block filtered by the
+// mask, chgpu_filter_columns) and the filtered block aggregated.
+static int agg_add_block_materialised(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols, u64 row_begin, u64 row_end,
+                                      const chgpu_col * filter)
+{
+    chgpu_ctx * ctx = a->ctx;
+    const u64 n = row_end - row_begin;
+    const chgpu_col * src[1 + AGG_MAX_AGGS];
+    chgpu_col * views[2 + AGG_MAX_AGGS] = {};
+    u32 m = 0;
+    int rc = CHGPU_OK;
+    auto view = [&](const chgpu_col * c) {
+        if (rc == CHGPU_OK)
+            rc = chgpu_col_slice(ctx, c, row_begin, n, &views[m]);
+        if (rc == CHGPU_OK)
+            ++m;
+    };
+    view(filter);
+    view(key_col);
+    u32 arg_slot[AGG_MAX_AGGS];
+    for (u32 j = 0; j < a->n_aggs; ++j)
+        if (a->kinds[j] != CHGPU_AGG_COUNT)
+        {
+            arg_slot[j] = m - 1; // index among the data columns (key = 0)
+            view(arg_cols[j]);
+        }
+    chgpu_col * outs[1 + AGG_MAX_AGGS] = {};
+    u64 kept = 0;
+    const u32 n_data = m ? m - 1 : 0;
+    if (rc == CHGPU_OK)
+    {
+        for (u32 k = 0; k < n_data; ++k)
+            src[k] = views[1 + k];
+        rc = chgpu_filter_columns(ctx, n_data, src, views[0], -1, outs, &kept);
+    }
+    if (rc == CHGPU_OK && kept)
+    {
+        const chgpu_col * fargs[AGG_MAX_AGGS] = {};
+        for (u32 j = 0; j < a->n_aggs; ++j)
+            if (a->kinds[j] != CHGPU_AGG_COUNT)
+                fargs[j] = outs[arg_slot[j]];
+        rc = agg_add_block_impl(a, outs[0], fargs, 0, kept, nullptr);
+    }
+    for (u32 k = 0; k < n_data; ++k)
+        chgpu_col_free(outs[k]);
+    for (u32 k = 0; k < m; ++k)
+        chgpu_col_free(views[k]);
+    return rc;
+}
+
+static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols, u64 row_begin, u64 row_end,
+                              const chgpu_col * filter)
 {
     CHGPU_REQUIRE(a, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(row_begin <= row_end, CHGPU_ERR_BAD_ARGUMENTS, "row_begin > row_end");
     chgpu_ctx * ctx = a->ctx;
     const u64 n = row_end - row_begin;
+    if (filter)
+    {
+        CHGPU_REQUIRE(filter->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "filter must be a UInt8 column");
+        CHGPU_REQUIRE(row_end <= filter->rows, CHGPU_ERR_SIZES_MISMATCH, "filter has %llu rows, block ends at %llu",
+                      (unsigned long long)filter->rows, (unsigned long long)row_end);
+    }
     for (u32 j = 0; j < a->n_aggs; ++j)
     {
         if (a->kinds[j] == CHGPU_AGG_COUNT)
@@ -1596,16 +1672,29 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
     if (a->key_type < 0)
     {
         // executeWithoutKeyImpl (Aggregator.cpp:1276-1321): addBatchSinglePlace per function
+        u64 kept = n;
+        if (filter)
+        {
+            // addBatchSinglePlace under a condition (addManyConditional, AggregateFunctionSum.h:138-236); count = countBytesInFilter
+            chgpu_col * fv = nullptr;
+            CHGPU_TRY(chgpu_col_slice(ctx, filter, row_begin, n, &fv));
+            const int rc = chgpu_count_bytes_in_filter(ctx, fv, &kept);
+            chgpu_col_free(fv);
+            CHGPU_TRY(rc);
+        }
         for (u32 j = 0; j < a->n_aggs; ++j)
         {
             u64 * st = &a->host_words[a->word_off[j]];
             if (a->kinds[j] == CHGPU_AGG_COUNT)
-                st[0] += n;
+                st[0] += kept;
             else
             {
-                CHGPU_TRY(chgpu_sum_add_many(ctx, arg_cols[j], row_begin, row_end, st));
+                if (filter)
+                    CHGPU_TRY(chgpu_sum_add_many_conditional(ctx, arg_cols[j], filter, row_begin, row_end, st));
+                else
+                    CHGPU_TRY(chgpu_sum_add_many(ctx, arg_cols[j], row_begin, row_end, st));
                 if (a->kinds[j] == CHGPU_AGG_AVG)
-                    st[1] += n;
+                    st[1] += kept;
             }
         }
         return CHGPU_OK;
@@ -1633,13 +1722,37 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
         a->hint_probed = true;
         const u64 probe_rows = 1ull << 20;
         const u64 before = a->n_groups;
-        CHGPU_TRY(chgpu_agg_add_block(a, key_col, arg_cols, row_begin, row_begin + probe_rows));
+        CHGPU_TRY(agg_add_block_impl(a, key_col, arg_cols, row_begin, row_begin + probe_rows, filter));
         if (a->n_groups > lds_groups / 2)
         {
             const u64 est = agg_estimate_groups(a->n_groups - before, probe_rows);
             a->size_hint = before + est + est / 4;
         }
-        return chgpu_agg_add_block(a, key_col, arg_cols, row_begin + probe_rows, row_end);
+        return agg_add_block_impl(a, key_col, arg_cols, row_begin + probe_rows, row_end, filter);
+    }
+    // a WHERE mask is fused only into the RANGE-mode kernel; every other strategy gets the filtered block materialised first
+    if (filter)
+    {
+        const bool partitioned = a->size_hint > lds_groups && n >= (4u << 20) && !getenv("CHGPU_AGG_NO_PARTITION");
+        const bool will_range = !partitioned && a->size_hint <= 65536 && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED");
+        if (!will_range)
+            return agg_add_block_materialised(a, key_col, arg_cols, row_begin, row_end, filter);
+        // The aggregation kernel is issue-bound: it spends nearly the same time on a masked-out row as on a kept one, while
+        // chgpu_filter_columns runs at HBM speed.  Measured break-even at ~30 % of the rows kept (1e9 rows, 1000 groups,
+        // 10 % kept: 5.7 ms fused vs 5.3 ms materialised), so big blocks count the mask first (0.35 ms per 1e9 rows).
+        if (n >= (16u << 20))
+        {
+            chgpu_col * fv = nullptr;
+            CHGPU_TRY(chgpu_col_slice(ctx, filter, row_begin, n, &fv));
+            u64 kept = 0;
+            const int rc = chgpu_count_bytes_in_filter(ctx, fv, &kept);
+            chgpu_col_free(fv);
+            CHGPU_TRY(rc);
+            if (kept == 0)
+                return CHGPU_OK;
+            if (kept * 10 < n * 3)
+                return agg_add_block_materialised(a, key_col, arg_cols, row_begin, row_end, filter);
+        }
     }
     AggDesc d;
     agg_fill_desc(a, arg_cols, &d);
@@ -1759,6 +1872,7 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
             chunks = (n + 4095) / 4096;
         const u64 rows_per_chunk = ((n + chunks - 1) / chunks + 63) / 64 * 64;
         chunks = (n + rows_per_chunk - 1) / rows_per_chunk;
+        const u8 * cond_ptr = filter ? (const u8 *)filter->data + row_begin : nullptr;
         for (u32 p = 0; p < n_passes; ++p)
         {
             // this pass's descriptor: its argument functions, plus every count() in the first pass; state word indices are
@@ -1787,7 +1901,7 @@ extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, con
         CHGPU_HIP(hipFuncSetAttribute((const void *)k_agg_part_lds<KT_, AW_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag));         \
         hipLaunchKernelGGL((k_agg_part_lds<KT_, AW_, KS_>), dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, dp, (const KS_ *)key_col->data + row_begin, \
                            rwords[0], rwords[1], (const u64 *)nullptr, 1u, (u32)chunks, n, pending, S, rk, cnt32, rows_per_chunk, (const u32 *)nullptr,  \
-                           (u32 *)nullptr);                                                                                                           \
+                           (u32 *)nullptr, cond_ptr);                                                                                                           \
     } while (0)
 #define RANGE_LAUNCH(KT_, AW_) RANGE_LAUNCH_KS(KT_, AW_, KT_)
             if (key8)

@@ -224,6 +224,12 @@ int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, const int *
    for count()) */
 int chgpu_agg_add_block(chgpu_agg * agg, const chgpu_col * key_col, const chgpu_col * const * arg_cols,
                         uint64_t row_begin, uint64_t row_end);
+/* The same over the rows of [row_begin,row_end) whose filter byte is non-zero -- a FilterTransform (FilterTransform.cpp:136-256)
+   directly in front of the AggregatingTransform, fused: rows that fail the WHERE clause neither create groups nor update
+   states.  Low-cardinality aggregations read the mask inside the aggregation kernel (no filtered copy of the columns is made);
+   the other strategies filter the block's columns first (chgpu_filter_columns).  filter_u8 == NULL: plain add_block. */
+int chgpu_agg_add_block_filtered(chgpu_agg * agg, const chgpu_col * key_col, const chgpu_col * const * arg_cols,
+                                 uint64_t row_begin, uint64_t row_end, const chgpu_col * filter_u8);
 /* mergeDataImpl: fold src's states into dst (src stays valid but should be freed) */
 int chgpu_agg_merge(chgpu_agg * dst, const chgpu_agg * src);
 /* merge partial states that arrive as columns (the ColumnAggregateFunction blocks of a distributed GROUP BY,

@@ -385,6 +385,33 @@ def test_group_by_lds_range_mode(ch, engine, key_dtype, groups, size_hint, row_b
     _check_against_numpy(g, k[row_begin:], v[row_begin:], f[row_begin:])
 
 
+@pytest.mark.parametrize("groups,size_hint,n", [(7, 0, 1_000_003), (3000, 3000, 2_500_000), (400_000, 400_000, 5_000_000), (None, 0, 700_001)])
+def test_group_by_with_fused_where_mask(ch, ctx, engine, groups, size_hint, n):
+    # FilterTransform fused in front of the aggregation: low cardinalities read the mask inside the kernel, the partitioned /
+    # keyless strategies filter the block first; rows that fail create no groups
+    rng = np.random.Generator(np.random.PCG64(n))
+    v = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
+    f = rng.random(n)
+    mask = ((rng.random(n) < 0.1) * rng.integers(1, 255, size=n)).astype(np.uint8)
+    sel = mask != 0
+    aggs = [(ch.AGG_SUM, np.int64), (ch.AGG_AVG, np.float64), (ch.AGG_COUNT, None)]
+    if groups is None:                                   # without a key: addManyConditional + countBytesInFilter
+        g = engine.Aggregator(None, aggs)
+        g.execute_on_block(None, [v, f, None], 3, n, filter=mask)
+        _, (s, avg, c) = g.convert_to_block()
+        m = sel[3:]
+        assert int(c[0]) == int(m.sum()) and int(s[0]) == int(v[3:][m].view(np.uint64).sum(dtype=np.uint64).astype(np.int64))
+        assert abs(float(avg[0]) - f[3:][m].mean()) <= 1e-6 * abs(f[3:][m].mean())
+        return
+    k = rng.integers(0, groups, size=n).astype(np.uint32)
+    k[~sel] += np.uint32(groups)                          # keys that only occur on filtered-out rows must not become groups
+    g = engine.Aggregator(np.uint32, aggs, size_hint=size_hint)
+    mid = n // 3
+    g.execute_on_block(k, [v, f, None], 0, mid, filter=mask)
+    g.execute_on_block(k, [v, f, None], mid, n, filter=mask)
+    _check_against_numpy(g, k[sel], v[sel], f[sel])
+
+
 def test_group_by_many_functions_take_several_range_passes(ch, engine, oracle_mod):
     # TPC-H Q1 shape: seven argument functions of three widths + count -> several passes of the RANGE kernel over the same rows
     rng = np.random.Generator(np.random.PCG64(41))

@@ -133,6 +133,40 @@ if what == "groupby_q1":
     dt, n = timed(run)
     print(f"groupby_q1 rows={rows} groups={n}: {dt*1e3:.2f} ms  {rows/dt:.3e} rows/s  {60*rows/dt/1e9:.0f} GB/s algorithmic (4 + 7x8 B/row)", flush=True)
 
+if what == "filter_groupby":
+    # SELECT k, sum(v), count() FROM t WHERE a < C GROUP BY k -- BASELINE's "filter + GROUP BY" with a key: 10 % of 1e9 rows pass
+    g = torch.Generator(device=dev).manual_seed(2)
+    a = torch.randint(0, 2**31, (rows,), dtype=torch.int64, device=dev, generator=g)
+    v = torch.randint(-2**31, 2**31, (rows,), dtype=torch.int64, device=dev, generator=g)
+    ac = ctx.wrap(a.data_ptr(), np.int64, rows, keepalive=a)
+    vc = ctx.wrap(v.data_ptr(), np.int64, rows, keepalive=v)
+    for groups, thr in ((1000, 214748365), (1000, 1503238554), (1_000_000, 214748365)):   # 10 % and 70 % of the rows pass
+        k = torch.randint(0, groups, (rows,), dtype=torch.int32, device=dev, generator=g)
+        kc = ctx.wrap(k.data_ptr(), np.uint32, rows, keepalive=k)
+
+        def fused():
+            m = ch.cmp_const(ac, ch.LT, thr)
+            agg = ch.Aggregator(np.uint32, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], size_hint=groups, ctx=ctx)
+            agg.execute_on_block(kc, [vc, None], filter=m)
+            n = len(agg)
+            agg.close()
+            return n
+
+        def unfused():
+            m = ch.cmp_const(ac, ch.LT, thr)
+            fk, fv = ch.filter_columns([kc, vc], m)
+            agg = ch.Aggregator(np.uint32, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], size_hint=groups, ctx=ctx)
+            agg.execute_on_block(fk, [fv, None])
+            n = len(agg)
+            agg.close()
+            return n
+        t1, n1 = timed(fused)
+        t2, n2 = timed(unfused)
+        assert n1 == n2
+        print(f"filter_groupby rows={rows} groups={n1} pass={thr/2**31:.0%}: add_block_filtered {t1*1e3:.2f} ms ({rows/t1:.3e} rows/s, {21*rows/t1/1e9:.0f} GB/s of 8+1+4+8 B/row)   "
+              f"cmp + filter_columns + add_block {t2*1e3:.2f} ms", flush=True)
+        del k, kc
+
 if what == "groupby_zipf":
     # SURVEY C3's skew variant: keys ~ Zipf(1.1) folded into [0, 1e6) (continuous inverse-CDF approximation on device)
     groups, sz = 1_000_000, 1.1
