@@ -1349,8 +1349,10 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     const size_t cell_b = agg_part_cell_bytes(a, n, &cnt32);
     const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
     const u32 S = agg_part_max_cells(cell_b);
-    // partitions so that a partition's expected groups fill at most half the LDS table
-    u64 want_p = (a->size_hint + S / 2 - 1) / (S / 2);
+    // partitions so that a partition's expected groups fill at most 70 % of the LDS table (fewer partitions = longer runs in
+    // the scatter: an estimate of 1.25 M groups still gets 256 partitions)
+    const u64 part_cap = (u64)S * 7 / 10;
+    u64 want_p = (a->size_hint + part_cap - 1) / part_cap;
     u32 P = 64;
     while (P < (u32)ctx->num_cus && P < GBP_MAX_P) // the aggregate pass runs one workgroup per partition: give every CU one
         P <<= 1;
@@ -1361,8 +1363,8 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     // layout -- goes through this function again (level 2) with its share of the promised groups.
     u64 mult = GBP_MULT;
     u32 P1 = 0;
-    // (up to 1.5x over the single-level budget -- LDS tables 75 % full -- one level is still the faster plan: 16 vs 24 ms at 5 M)
-    if (want_p > GBP_MAX_P + GBP_MAX_P / 2 && level == 0 && !getenv("CHGPU_TUNE_GB_NO_TWO_LEVEL"))
+    // (want_p already allows LDS tables 70 % full: up to ~5.9 M groups one level is the faster plan, 16 vs 24 ms at 5 M)
+    if (want_p > GBP_MAX_P && level == 0 && !getenv("CHGPU_TUNE_GB_NO_TWO_LEVEL"))
     {
         const u64 sub_groups = (u64)(GBP_MAX_P / 2) * (S / 2); // leaves the second level at half its partition budget
         for (P1 = 2; (u64)P1 * sub_groups < a->size_hint && P1 < 256; P1 <<= 1)
