@@ -1201,13 +1201,17 @@ static int agg_grow(chgpu_agg * a, u64 min_groups, bool has_zero)
     return CHGPU_OK;
 }
 
-static int agg_ensure_table(chgpu_agg * a)
+// min_cells: what the first strategy to touch the table wants it to hold (the partitioned path's flush slack): a table that
+// does not exist yet is created that large at once instead of being created small and rehashed empty a moment later
+static int agg_ensure_table(chgpu_agg * a, u64 min_cells = 0)
 {
     if (a->table_mem)
         return CHGPU_OK;
     u64 cap = pow2_ceil(a->size_hint * 2);
     if (cap < AGG_MIN_CAPACITY)
         cap = AGG_MIN_CAPACITY;
+    if (cap < min_cells)
+        cap = pow2_ceil(min_cells);
     return agg_alloc_table(a, cap, &a->t, &a->table_mem, &a->table_class);
 }
 
@@ -1341,7 +1345,6 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
                                      int level = 0, size_t scratch_off = 0, u32 agg_mask = ~0u)
 {
     chgpu_ctx * ctx = a->ctx;
-    CHGPU_TRY(agg_ensure_table(a));
     // LDS table of the aggregate pass (one 1024-thread workgroup per CU): compact cells -- key as wide as the partition
     // buffer's keys, COUNT words as 32 bits while the call has fewer than 2^32 rows -- and as many cells as fit ~150 KiB
     const bool key32 = chgpu_type_size(a->key_type) <= 4; // 4-byte (or narrower) keys are stored as 4 bytes in the partition buffers
@@ -1385,6 +1388,8 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         chunk_rows = 65536;
     const u64 max_units = n / chunk_rows + P; // sum over partitions of ceil(rows_p / chunk_rows)
     // every unit's flush may claim up to S+1 cells without the max-fill check: keep all of them inside the slack
+    if (level != 1) // a first partitioning level touches no table: its level-2 calls size it
+        CHGPU_TRY(agg_ensure_table(a, 2 * (max_units * (S + 1) + a->n_groups) + 2));
     for (int guard = 0; level != 1 && guard < 16 && a->t.capacity / 2 < max_units * (S + 1) + a->n_groups; ++guard)
     {
         AggCtrl c0;
@@ -1707,7 +1712,6 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
                   (unsigned long long)key_col->rows, (unsigned long long)row_end);
     if (n == 0)
         return CHGPU_OK;
-    CHGPU_TRY(agg_ensure_table(a));
     // Strategy by promised/observed cardinality:
     //   groups <= what one workgroup's LDS table holds (~70 % of its cells)   -> LDS-staged (RANGE mode / k_agg_rows_lds)
     //   more, with enough rows to amortise two extra passes                   -> PARTITIONED
@@ -1813,6 +1817,7 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
             }
         }
     }
+    CHGPU_TRY(agg_ensure_table(a));
     // strategy: LDS-staged unless the caller promised a large cardinality (where nearly every key misses the LDS table)
     const bool use_lds = a->size_hint <= 65536; // beyond that nearly every key misses a workgroup's LDS table
     // RANGE mode of the partition-aggregate kernel: 4/8-byte keys; a launch takes at most GBP_MAX_K argument columns of one
