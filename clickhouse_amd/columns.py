@@ -12,15 +12,16 @@ import numpy as np
 
 from . import _capi as K
 
-NP_OF = {K.I64: np.int64, K.U32: np.uint32, K.U64: np.uint64, K.F64: np.float64, K.U8: np.uint8, K.I32: np.int32}
+NP_OF = {K.I64: np.int64, K.U32: np.uint32, K.U64: np.uint64, K.F64: np.float64, K.U8: np.uint8, K.I32: np.int32,
+         K.U16: np.uint16, K.I16: np.int16, K.I8: np.int8}
 TAG_OF = {np.dtype(v): k for k, v in NP_OF.items()}
 
 
 def sum_result_dtype(tag: int):
     """SumSimple (src/AggregateFunctions/AggregateFunctionSum.cpp:19-28)."""
-    if tag in (K.I64, K.I32):
+    if tag in (K.I64, K.I32, K.I16, K.I8):
         return np.int64
-    if tag in (K.U64, K.U32, K.U8):
+    if tag in (K.U64, K.U32, K.U16, K.U8):
         return np.uint64
     return np.float64
 

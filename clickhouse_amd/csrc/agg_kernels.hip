@@ -109,7 +109,8 @@ __device__ __forceinline__ u64 load_key_zext(const void * keys, int type, u64 i)
     switch (type)
     {
         case CHGPU_U32: case CHGPU_I32: return ((const u32 *)keys)[i];
-        case CHGPU_U8: return ((const u8 *)keys)[i];
+        case CHGPU_U16: case CHGPU_I16: return ((const u16 *)keys)[i];
+        case CHGPU_U8: case CHGPU_I8: return ((const u8 *)keys)[i];
         default: return ((const u64 *)keys)[i];
     }
 }
@@ -122,6 +123,9 @@ __device__ __forceinline__ u64 load_arg_bits(const void * p, int type, u64 i)
         case CHGPU_U32: return ((const u32 *)p)[i];
         case CHGPU_I32: return (u64)(i64)((const i32 *)p)[i]; // sign-extend: wrap-around two's complement sum
         case CHGPU_U8: return ((const u8 *)p)[i];
+        case CHGPU_U16: return ((const u16 *)p)[i];
+        case CHGPU_I16: return (u64)(i64)((const i16 *)p)[i];
+        case CHGPU_I8: return (u64)(i64)((const i8 *)p)[i];
         default: return 0;
     }
 }
@@ -1220,7 +1224,7 @@ extern "C" int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, 
 {
     CHGPU_REQUIRE(ctx && out && (agg_kinds || n_aggs == 0), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(n_aggs <= AGG_MAX_AGGS, CHGPU_ERR_NOT_IMPLEMENTED, "more than %u aggregate functions: CPU path", AGG_MAX_AGGS);
-    CHGPU_REQUIRE(key_type < 0 || key_type == CHGPU_U32 || key_type == CHGPU_U64 || key_type == CHGPU_I64 || key_type == CHGPU_I32 || key_type == CHGPU_U8,
+    CHGPU_REQUIRE(key_type < 0 || (chgpu_type_is_int(key_type)),
                   CHGPU_ERR_NOT_IMPLEMENTED, "GROUP BY key type %d: CPU path", key_type);
     chgpu_agg * a = new chgpu_agg();
     a->ctx = ctx;
@@ -1824,7 +1828,10 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
     // width (8, 4 or 1 B), so the aggregate functions are split into PASSES over the same rows -- each pass re-reads the key
     // column and updates its own state words of the same groups (TPC-H Q1's seven sums and averages: 4 passes x ~20 B/row
     // instead of one trip through the generic kernel, which is 6x slower per row).
-    const bool ranged = use_lds && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED"); // keys of 1, 4 or 8 bytes: all supported key types
+    bool ranged = use_lds && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED") && chgpu_type_size(a->key_type) != 2; // keys of 1, 4 or 8 bytes
+    for (u32 j = 0; j < a->n_aggs; ++j) // 2-byte and Int8 arguments (no instantiation / sign extension for them): the generic LDS kernel
+        if (a->kinds[j] != CHGPU_AGG_COUNT && (chgpu_type_size(a->arg_types[j]) == 2 || a->arg_types[j] == CHGPU_I8))
+            ranged = false;
     if (ranged)
     {
         struct Pass
@@ -2216,6 +2223,8 @@ static int agg_export(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** word_co
                 const u32 g2 = chgpu_grid_for(ctx, n_out, 256, 8);
                 if (chgpu_type_size(a->key_type) == 4)
                     hipLaunchKernelGGL(k_narrow_keys<u32>, dim3(g2), dim3(256), 0, ctx->stream, (const u64 *)k64->data, n_out, (u32 *)kn->data);
+                else if (chgpu_type_size(a->key_type) == 2)
+                    hipLaunchKernelGGL(k_narrow_keys<u16>, dim3(g2), dim3(256), 0, ctx->stream, (const u64 *)k64->data, n_out, (u16 *)kn->data);
                 else
                     hipLaunchKernelGGL(k_narrow_keys<u8>, dim3(g2), dim3(256), 0, ctx->stream, (const u64 *)k64->data, n_out, (u8 *)kn->data);
                 ctx->counters[6] += 1;

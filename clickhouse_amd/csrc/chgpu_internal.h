@@ -18,6 +18,9 @@ typedef int64_t i64;
 typedef uint32_t u32;
 typedef int32_t i32;
 typedef uint8_t u8;
+typedef uint16_t u16;
+typedef int16_t i16;
+typedef int8_t i8;
 
 // ---------------------------------------------------------------------------------------------
 // error handling: thread-local last error, no exceptions across the C ABI
@@ -94,13 +97,14 @@ static inline size_t chgpu_type_size(int type)
     {
         case CHGPU_I64: case CHGPU_U64: case CHGPU_F64: return 8;
         case CHGPU_U32: case CHGPU_I32: return 4;
-        case CHGPU_U8: return 1;
+        case CHGPU_U16: case CHGPU_I16: return 2;
+        case CHGPU_U8: case CHGPU_I8: return 1;
         default: return 0;
     }
 }
 
 static inline bool chgpu_type_is_int(int type) { return type != CHGPU_F64 && chgpu_type_size(type) != 0; }
-static inline bool chgpu_type_is_signed(int type) { return type == CHGPU_I64 || type == CHGPU_I32; }
+static inline bool chgpu_type_is_signed(int type) { return type == CHGPU_I64 || type == CHGPU_I32 || type == CHGPU_I16 || type == CHGPU_I8; }
 // SumSimple result type (src/AggregateFunctions/AggregateFunctionSum.cpp:19-28)
 static inline int chgpu_sum_result_type(int t)
 {

@@ -88,6 +88,9 @@ static int make_cmp_spec(int col_type, int op, int scalar_type, const void * sca
         case CHGPU_U32: s = *(const u32 *)scalar; break;
         case CHGPU_I32: s = *(const i32 *)scalar; break;
         case CHGPU_U8: s = *(const u8 *)scalar; break;
+        case CHGPU_U16: s = *(const u16 *)scalar; break;
+        case CHGPU_I16: s = *(const i16 *)scalar; break;
+        case CHGPU_I8: s = *(const i8 *)scalar; break;
         case CHGPU_F64: break;
         default: return chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "unknown scalar type %d", scalar_type);
     }
@@ -476,6 +479,9 @@ static int launch_filter_sum_int(chgpu_ctx * ctx, int type, const void * pred, c
         case CHGPU_U32: return launch_filter_sum_t<u32, Pred>(ctx, pred, val, cond, n, p, result_dev);
         case CHGPU_I32: return launch_filter_sum_t<i32, Pred>(ctx, pred, val, cond, n, p, result_dev);
         case CHGPU_U8: return launch_filter_sum_t<u8, Pred>(ctx, pred, val, cond, n, p, result_dev);
+        case CHGPU_U16: return launch_filter_sum_t<u16, Pred>(ctx, pred, val, cond, n, p, result_dev);
+        case CHGPU_I16: return launch_filter_sum_t<i16, Pred>(ctx, pred, val, cond, n, p, result_dev);
+        case CHGPU_I8: return launch_filter_sum_t<i8, Pred>(ctx, pred, val, cond, n, p, result_dev);
         default: return chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "unsupported column type %d", type);
     }
 }
@@ -735,6 +741,9 @@ extern "C" int chgpu_cmp_const(chgpu_ctx * ctx, const chgpu_col * col, int op, i
                 case CHGPU_U32: rc = launch_cmp_t<u32, IntRangePred>(ctx, col->data, n, spec.ip, c); break;
                 case CHGPU_I32: rc = launch_cmp_t<i32, IntRangePred>(ctx, col->data, n, spec.ip, c); break;
                 case CHGPU_U8: rc = launch_cmp_t<u8, IntRangePred>(ctx, col->data, n, spec.ip, c); break;
+                case CHGPU_U16: rc = launch_cmp_t<u16, IntRangePred>(ctx, col->data, n, spec.ip, c); break;
+                case CHGPU_I16: rc = launch_cmp_t<i16, IntRangePred>(ctx, col->data, n, spec.ip, c); break;
+                case CHGPU_I8: rc = launch_cmp_t<i8, IntRangePred>(ctx, col->data, n, spec.ip, c); break;
                 default: rc = chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "unsupported column type");
             }
         }
@@ -1008,6 +1017,9 @@ static int filter_apply(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col 
             case 4:
                 hipLaunchKernelGGL(k_filter_scatter<u32>, dim3(fp.grid), dim3(256), 0, ctx->stream, (const u32 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u32 *)res->data);
                 break;
+            case 2:
+                hipLaunchKernelGGL(k_filter_scatter<u16>, dim3(fp.grid), dim3(256), 0, ctx->stream, (const u16 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u16 *)res->data);
+                break;
             default:
                 hipLaunchKernelGGL(k_filter_scatter<u8>, dim3(fp.grid), dim3(256), 0, ctx->stream, (const u8 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u8 *)res->data);
                 break;
@@ -1116,11 +1128,11 @@ extern "C" int chgpu_index(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_c
 #define IDX_LAUNCH(T, I) hipLaunchKernelGGL((k_index<T, I>), dim3(grid), dim3(256), 0, ctx->stream, (const T *)col->data, (const I *)indexes->data, limit, col->rows, default_for_missing, (T *)res->data)
         if (indexes->type == CHGPU_U64)
         {
-            if (es == 8) IDX_LAUNCH(u64, u64); else if (es == 4) IDX_LAUNCH(u32, u64); else IDX_LAUNCH(u8, u64);
+            if (es == 8) IDX_LAUNCH(u64, u64); else if (es == 4) IDX_LAUNCH(u32, u64); else if (es == 2) IDX_LAUNCH(u16, u64); else IDX_LAUNCH(u8, u64);
         }
         else
         {
-            if (es == 8) IDX_LAUNCH(u64, u32); else if (es == 4) IDX_LAUNCH(u32, u32); else IDX_LAUNCH(u8, u32);
+            if (es == 8) IDX_LAUNCH(u64, u32); else if (es == 4) IDX_LAUNCH(u32, u32); else if (es == 2) IDX_LAUNCH(u16, u32); else IDX_LAUNCH(u8, u32);
         }
 #undef IDX_LAUNCH
         ctx->counters[6] += 1;
@@ -1159,6 +1171,7 @@ extern "C" int chgpu_replicate(chgpu_ctx * ctx, const chgpu_col * col, const chg
         {
             case 8: hipLaunchKernelGGL(k_replicate<u64>, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)col->data, (const u64 *)offsets->data, col->rows, (u64 *)res->data); break;
             case 4: hipLaunchKernelGGL(k_replicate<u32>, dim3(grid), dim3(256), 0, ctx->stream, (const u32 *)col->data, (const u64 *)offsets->data, col->rows, (u32 *)res->data); break;
+            case 2: hipLaunchKernelGGL(k_replicate<u16>, dim3(grid), dim3(256), 0, ctx->stream, (const u16 *)col->data, (const u64 *)offsets->data, col->rows, (u16 *)res->data); break;
             default: hipLaunchKernelGGL(k_replicate<u8>, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)col->data, (const u64 *)offsets->data, col->rows, (u8 *)res->data); break;
         }
         ctx->counters[6] += 1;
@@ -1205,6 +1218,8 @@ static int arith_sum_type(int value_op, int a_type, int b_type)
 {
     if (!chgpu_type_is_int(a_type) || !chgpu_type_is_int(b_type))
         return -1;
+    if (a_type > CHGPU_I32 || b_type > CHGPU_I32)
+        return -1; // UInt16 / Int16 / Int8 operands: arithmetic stays on the CPU path
     if (value_op == CHGPU_VAL_MINUS)
         return CHGPU_I64; // ResultOfSubtraction: always signed (NumberTraits.h:81-87)
     if (value_op == CHGPU_VAL_MUL || value_op == CHGPU_VAL_PLUS)
@@ -1742,7 +1757,7 @@ extern "C" int chgpu_expr_filter_sum(chgpu_ctx * ctx, uint32_t n_cols, const chg
     {
         const chgpu_col * cc = cols[k < n_cols ? k : 0];
         CHGPU_REQUIRE(cc, CHGPU_ERR_BAD_ARGUMENTS, "column %u is NULL", k);
-        CHGPU_REQUIRE(chgpu_type_is_int(cc->type), CHGPU_ERR_NOT_IMPLEMENTED, "fused expression over Float64: CPU path");
+        CHGPU_REQUIRE(chgpu_type_is_int(cc->type) && cc->type <= CHGPU_I32, CHGPU_ERR_NOT_IMPLEMENTED, "fused expression over Float64 / 2-byte / Int8 columns: CPU path");
         CHGPU_REQUIRE(cc->rows == n, CHGPU_ERR_SIZES_MISMATCH, "Sizes of columns doesn't match");
         one_type = one_type && cc->type == type0;
         sp.col[k] = cc->data;

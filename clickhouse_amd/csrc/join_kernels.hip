@@ -126,7 +126,8 @@ __device__ __forceinline__ u64 jload_key(const void * keys, int type, u64 i)
     switch (type)
     {
         case CHGPU_U32: case CHGPU_I32: return ((const u32 *)keys)[i];
-        case CHGPU_U8: return ((const u8 *)keys)[i];
+        case CHGPU_U16: case CHGPU_I16: return ((const u16 *)keys)[i];
+        case CHGPU_U8: case CHGPU_I8: return ((const u8 *)keys)[i];
         default: return ((const u64 *)keys)[i];
     }
 }
@@ -512,7 +513,7 @@ extern "C" int chgpu_join_create(chgpu_ctx * ctx, int key_type, int kind, int st
 {
     (void)size_hint;
     CHGPU_REQUIRE(ctx && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
-    CHGPU_REQUIRE(key_type == CHGPU_U64 || key_type == CHGPU_I64 || key_type == CHGPU_U32 || key_type == CHGPU_I32 || key_type == CHGPU_U8,
+    CHGPU_REQUIRE(chgpu_type_is_int(key_type),
                   CHGPU_ERR_NOT_IMPLEMENTED, "join key type %d: CPU path", key_type);
     CHGPU_REQUIRE(kind == CHGPU_JOIN_INNER || kind == CHGPU_JOIN_LEFT, CHGPU_ERR_NOT_IMPLEMENTED, "join kind %d (RIGHT/FULL need non-joined rows): CPU path", kind);
     CHGPU_REQUIRE(strictness >= CHGPU_STRICT_ANY && strictness <= CHGPU_STRICT_ANTI, CHGPU_ERR_NOT_IMPLEMENTED, "join strictness %d: CPU path", strictness);

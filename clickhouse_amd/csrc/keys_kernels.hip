@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void k_pack_fixed(PackCols c, u64 rows, u64 * 
             switch (c.size[j])
             {
                 case 1: v = ((const u8 *)c.src[j])[i]; break;
+                case 2: v = ((const u16 *)c.src[j])[i]; break;
                 case 4: v = ((const u32 *)c.src[j])[i]; break;
                 default: v = ((const u64 *)c.src[j])[i]; break;
             }
@@ -94,6 +95,8 @@ extern "C" int chgpu_unpack_fixed_key(chgpu_ctx * ctx, const chgpu_col * packed_
             hipLaunchKernelGGL(k_unpack_fixed<u64>, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)packed_u64->data, rows, byte_offset, (u64 *)out->data);
         else if (es == 4)
             hipLaunchKernelGGL(k_unpack_fixed<u32>, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)packed_u64->data, rows, byte_offset, (u32 *)out->data);
+        else if (es == 2)
+            hipLaunchKernelGGL(k_unpack_fixed<u16>, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)packed_u64->data, rows, byte_offset, (u16 *)out->data);
         else
             hipLaunchKernelGGL(k_unpack_fixed<u8>, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)packed_u64->data, rows, byte_offset, (u8 *)out->data);
         ctx->counters[6] += 1;

@@ -22,7 +22,8 @@ __device__ __forceinline__ u64 pload_key(const void * keys, int type, u64 i)
     switch (type)
     {
         case CHGPU_U32: case CHGPU_I32: return ((const u32 *)keys)[i];
-        case CHGPU_U8: return ((const u8 *)keys)[i];
+        case CHGPU_U16: case CHGPU_I16: return ((const u16 *)keys)[i];
+        case CHGPU_U8: case CHGPU_I8: return ((const u8 *)keys)[i];
         default: return ((const u64 *)keys)[i];
     }
 }
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(PT) void k_part_scatter(const u32 * __restrict__ se
                     {
                         case 8: ((u64 *)cols.dst[c])[pos] = ((const u64 *)cols.src[c])[i]; break;
                         case 4: ((u32 *)cols.dst[c])[pos] = ((const u32 *)cols.src[c])[i]; break;
+                        case 2: ((u16 *)cols.dst[c])[pos] = ((const u16 *)cols.src[c])[i]; break;
                         default: ((u8 *)cols.dst[c])[pos] = ((const u8 *)cols.src[c])[i]; break;
                     }
                 }

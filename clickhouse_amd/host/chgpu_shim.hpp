@@ -61,6 +61,9 @@ template <> struct TypeTag<uint64_t> { static constexpr int value = CHGPU_U64; }
 template <> struct TypeTag<uint32_t> { static constexpr int value = CHGPU_U32; };
 template <> struct TypeTag<int32_t> { static constexpr int value = CHGPU_I32; };
 template <> struct TypeTag<uint8_t> { static constexpr int value = CHGPU_U8; };
+template <> struct TypeTag<uint16_t> { static constexpr int value = CHGPU_U16; }; // also Date
+template <> struct TypeTag<int16_t> { static constexpr int value = CHGPU_I16; };
+template <> struct TypeTag<int8_t> { static constexpr int value = CHGPU_I8; };
 template <> struct TypeTag<double> { static constexpr int value = CHGPU_F64; };
 
 /// One device + one HIP stream: create one per pipeline thread (IProcessor::work() of different processors runs

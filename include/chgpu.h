@@ -41,7 +41,9 @@ enum
     CHGPU_ERR_TOO_MANY_ROWS = -7    /* TOO_MANY_ROWS (HashJoin.cpp:563-564: block >= 2^32 rows) */
 };
 
-/* ---- column element types (the TypeIndex subset of the hot path, src/Core/TypeId.h) ---- */
+/* ---- column element types (the TypeIndex subset of the hot path, src/Core/TypeId.h) ----
+   Every entry point takes every type unless it says otherwise; arithmetic (chgpu_arith) and the fused expression kernel
+   (chgpu_expr_filter_sum) are limited to the first six and answer CHGPU_ERR_NOT_IMPLEMENTED for UInt16 / Int16 / Int8. */
 enum
 {
     CHGPU_I64 = 0,
@@ -49,7 +51,10 @@ enum
     CHGPU_U64 = 2,
     CHGPU_F64 = 3,
     CHGPU_U8 = 4,
-    CHGPU_I32 = 5
+    CHGPU_I32 = 5,
+    CHGPU_U16 = 6, /* also Date (days since epoch) */
+    CHGPU_I16 = 7,
+    CHGPU_I8 = 8
 };
 
 /* ---- comparison functions (src/Functions/FunctionsComparison.h: equals..greaterOrEquals) ---- */

@@ -85,7 +85,8 @@ static size_t type_size(int type)
     {
         case CHO_I64: case CHO_U64: case CHO_F64: return 8;
         case CHO_U32: case CHO_I32: return 4;
-        case CHO_U8: return 1;
+        case CHO_U16: case CHO_I16: return 2;
+        case CHO_U8: case CHO_I8: return 1;
         default: return 0;
     }
 }
@@ -152,6 +153,9 @@ static inline num_t load_num(int type, const void * p, size_t idx)
         case CHO_U32: r.i = ((const uint32_t *)p)[idx]; break;
         case CHO_I32: r.i = ((const int32_t *)p)[idx]; break;
         case CHO_U8: r.i = ((const uint8_t *)p)[idx]; break;
+        case CHO_U16: r.i = ((const uint16_t *)p)[idx]; break;
+        case CHO_I16: r.i = ((const int16_t *)p)[idx]; break;
+        case CHO_I8: r.i = ((const int8_t *)p)[idx]; break;
         case CHO_F64: r.is_float = 1; r.f = ((const double *)p)[idx]; break;
         default: break;
     }
@@ -452,6 +456,9 @@ void cho_sum_add_many(int type, void * state, const void * ptr, size_t start, si
         case CHO_U32: SUM_INT_LOOP(uint32_t) break;
         case CHO_I32: SUM_INT_LOOP(int32_t) break;
         case CHO_U8: SUM_INT_LOOP(uint8_t) break;
+        case CHO_U16: SUM_INT_LOOP(uint16_t) break;
+        case CHO_I16: SUM_INT_LOOP(int16_t) break;
+        case CHO_I8: SUM_INT_LOOP(int8_t) break;
         case CHO_F64: sum_add_many_f64((double *)state, (const double *)ptr, start, end); break;
         default: break;
     }
@@ -483,6 +490,9 @@ void cho_sum_add_many_conditional(int type, void * state, const void * ptr, cons
         case CHO_U32: SUM_INT_COND_LOOP(uint32_t) break;
         case CHO_I32: SUM_INT_COND_LOOP(int32_t) break;
         case CHO_U8: SUM_INT_COND_LOOP(uint8_t) break;
+        case CHO_U16: SUM_INT_COND_LOOP(uint16_t) break;
+        case CHO_I16: SUM_INT_COND_LOOP(int16_t) break;
+        case CHO_I8: SUM_INT_COND_LOOP(int8_t) break;
         case CHO_F64:
         {
             /* AggregateFunctionSum.h:196-235: mask trick over 16 lanes, then branchy tail */
@@ -532,8 +542,8 @@ double cho_avg_divide(int numerator_type, const void * numerator, uint64_t denom
     /* AvgFraction::divide (AggregateFunctionAvg.h:61-67): static_cast<Float64>(numerator) / denominator */
     switch (numerator_type)
     {
-        case CHO_I64: case CHO_I32: return (double)(*(const int64_t *)numerator) / (double)denominator;
-        case CHO_U64: case CHO_U32: case CHO_U8: return (double)(*(const uint64_t *)numerator) / (double)denominator;
+        case CHO_I64: case CHO_I32: case CHO_I16: case CHO_I8: return (double)(*(const int64_t *)numerator) / (double)denominator;
+        case CHO_U64: case CHO_U32: case CHO_U16: case CHO_U8: return (double)(*(const uint64_t *)numerator) / (double)denominator;
         case CHO_F64: return *(const double *)numerator / (double)denominator;
         default: return NAN;
     }
@@ -544,8 +554,8 @@ static int sum_result_type(int arg_type)
 {
     switch (arg_type)
     {
-        case CHO_I64: case CHO_I32: return CHO_I64;
-        case CHO_U64: case CHO_U32: case CHO_U8: return CHO_U64;
+        case CHO_I64: case CHO_I32: case CHO_I16: case CHO_I8: return CHO_I64;
+        case CHO_U64: case CHO_U32: case CHO_U16: case CHO_U8: return CHO_U64;
         default: return CHO_F64;
     }
 }
@@ -699,6 +709,8 @@ int cho_arith_sum_type(int value_op, int a_type, int b_type)
 {
     if (a_type == CHO_F64 || b_type == CHO_F64 || !type_size(a_type) || !type_size(b_type))
         return -1;
+    if (a_type > CHO_I32 || b_type > CHO_I32)
+        return -1; /* UInt16 / Int16 / Int8 operands: arithmetic is not restated for them */
     const int sgn_a = a_type == CHO_I64 || a_type == CHO_I32, sgn_b = b_type == CHO_I64 || b_type == CHO_I32;
     if (value_op == CHO_VAL_MINUS)
         return CHO_I64;
@@ -1094,6 +1106,9 @@ static inline void agg_add_row(const cho_agg * a, int j, char * place, const voi
                 case CHO_U32: *(uint64_t *)st += ((const uint32_t *)arg)[i]; break;
                 case CHO_I32: *(uint64_t *)st += (uint64_t)(int64_t)((const int32_t *)arg)[i]; break;
                 case CHO_U8: *(uint64_t *)st += ((const uint8_t *)arg)[i]; break;
+                case CHO_U16: *(uint64_t *)st += ((const uint16_t *)arg)[i]; break;
+                case CHO_I16: *(uint64_t *)st += (uint64_t)(int64_t)((const int16_t *)arg)[i]; break;
+                case CHO_I8: *(uint64_t *)st += (uint64_t)(int64_t)((const int8_t *)arg)[i]; break;
                 case CHO_F64: *(double *)st += ((const double *)arg)[i]; break;
                 default: break;
             }

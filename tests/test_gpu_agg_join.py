@@ -514,6 +514,31 @@ def test_join_filter_only_probe_matches_full_probe(ch, ctx, strict_name):
         ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, key_dtype=np.uint32, ctx=ctx).probe_columns(left, need_right_rows=False)
 
 
+@pytest.mark.parametrize("dtype", [np.uint16, np.int16, np.int8, np.uint8, np.int32])
+def test_narrow_key_types_join_selector_and_pack(ch, ctx, oracle_mod, dtype):
+    # UInt16 (Date) / Int16 / Int8 keys: raw bits zero-extended into the 64-bit table key, like every other key type
+    O = oracle_mod
+    info = np.iinfo(dtype)
+    rng = np.random.Generator(np.random.PCG64(info.bits))
+    build = rng.integers(info.min, int(info.max) + 1, size=3000).astype(dtype)
+    left = rng.integers(info.min, int(info.max) + 1, size=200_003).astype(dtype)
+    j = ch.HashJoin(ch.JOIN_LEFT, ch.STRICT_SEMI, key_dtype=dtype, ctx=ctx)
+    j.add_block(build)
+    r = j.probe_columns(left, need_right_rows=False)
+    assert np.array_equal(r["filter"].numpy().astype(bool), np.isin(left, build))
+    ja = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, key_dtype=dtype, ctx=ctx)
+    ja.add_block(build)
+    assert ja.probe_columns(left)["n_out"] == int(sum(np.count_nonzero(build == v) * c for v, c in zip(*np.unique(left, return_counts=True))))
+    lc = ctx.upload(left)
+    assert np.array_equal(ch.hash_to_selector(lc, 8).numpy(), O.hash_to_selector(left, 8))
+    assert np.array_equal(lc.get_weak_hash32().numpy(), O.weak_hash32(left))
+    if info.bits <= 16:
+        other = rng.integers(0, 2**32, size=left.shape[0], dtype=np.uint32)
+        packed = ch.pack_fixed_keys([lc, ctx.upload(other)])
+        assert np.array_equal(ch.unpack_fixed_key(packed, 0, dtype).numpy(), left)
+        assert np.array_equal(ch.unpack_fixed_key(packed, info.bits // 8, np.uint32).numpy(), other)
+
+
 def test_join_payload_across_many_right_blocks(ch, ctx, engine):
     # the build side arrives Block by Block (FillingRightJoinSideTransform); payload = concatenated columns + flattened row ids
     rng = np.random.Generator(np.random.PCG64(17))

@@ -18,7 +18,7 @@ def ctx(ch):
     c.close()
 
 
-DTYPES = [np.int64, np.uint64, np.uint32, np.int32, np.float64, np.uint8]
+DTYPES = [np.int64, np.uint64, np.uint32, np.int32, np.float64, np.uint8, np.uint16, np.int16, np.int8]
 
 
 def _rand(rng, dtype, n, lo=0, hi=255):
@@ -92,6 +92,11 @@ def test_cmp_const_all_ops_and_mixed_signedness(ch, ctx, oracle_mod):
         (u32, O.U64, [0, 2**31, 2**32 - 1, 2**40]), (u32, O.I64, [-5, 2**31]),
         (i32, O.I64, [-2**31, 0, 2**31 - 1, -2**40, 2**40]), (i32, O.U64, [0, 5, 2**63]),
     ]
+    u16 = rng.integers(0, 2**16, size=5001).astype(np.uint16)
+    i16 = rng.integers(-2**15, 2**15, size=5003).astype(np.int16)
+    i8 = rng.integers(-128, 128, size=5005).astype(np.int8)
+    cases += [(u16, O.U16, [0, 1, 40000, 65535]), (u16, O.I64, [-1, 65535, 65536]), (i16, O.I16, [-32768, -1, 0, 32767]), (i16, O.U64, [0, 32767, 2**63]),
+              (i8, O.I8, [-128, -1, 0, 127]), (i8, O.I64, [-129, 128, 5]), (u16, O.F64, [0.5, 65535.5, -1.0, float("nan")]), (i8, O.F64, [-128.5, 126.5])]
     for arr, stag, scalars in cases:
         col = ctx.upload(arr)
         for s in scalars:
@@ -128,7 +133,7 @@ def test_cmp_const_all_ops_and_mixed_signedness(ch, ctx, oracle_mod):
                 assert np.array_equal(got, want), (stag, sc, op)
 
 
-@pytest.mark.parametrize("dtype", [np.int64, np.uint64, np.uint32, np.int32, np.uint8])
+@pytest.mark.parametrize("dtype", [np.int64, np.uint64, np.uint32, np.int32, np.uint8, np.uint16, np.int16, np.int8])
 def test_sum_integers_bit_exact_with_wraparound(ch, ctx, oracle_mod, dtype):
     rng = np.random.Generator(np.random.PCG64(6))
     info = np.iinfo(dtype)

@@ -26,8 +26,8 @@ def ctx(ch):
     c.close()
 
 
-KEY_DTYPES = [np.uint32, np.int32, np.uint64, np.int64, np.uint8]
-ARG_DTYPES = [np.int64, np.uint64, np.float64, np.uint32, np.int32, np.uint8]
+KEY_DTYPES = [np.uint32, np.int32, np.uint64, np.int64, np.uint8, np.uint16, np.int16, np.int8]
+ARG_DTYPES = [np.int64, np.uint64, np.float64, np.uint32, np.int32, np.uint8, np.uint16, np.int16, np.int8]
 
 
 def _keys(rng, dtype, n, groups, skew):
