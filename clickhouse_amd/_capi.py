@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "chgpu.h")
 # enums of include/chgpu.h
 OK = 0
 ERR_SIZES_MISMATCH, ERR_NOT_IMPLEMENTED, ERR_OOM, ERR_LOGICAL, ERR_BAD_ARGUMENTS, ERR_DEVICE, ERR_TOO_MANY_ROWS = -1, -2, -3, -4, -5, -6, -7
-I64, U32, U64, F64, U8, I32, U16, I16, I8 = 0, 1, 2, 3, 4, 5, 6, 7, 8
+I64, U32, U64, F64, U8, I32, U16, I16, I8, F32 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 EQ, NE, LT, GT, LE, GE = 0, 1, 2, 3, 4, 5
 AGG_COUNT, AGG_SUM, AGG_AVG = 0, 1, 2
 JOIN_INNER, JOIN_LEFT = 0, 1

@@ -13,7 +13,7 @@ import numpy as np
 from . import _capi as K
 
 NP_OF = {K.I64: np.int64, K.U32: np.uint32, K.U64: np.uint64, K.F64: np.float64, K.U8: np.uint8, K.I32: np.int32,
-         K.U16: np.uint16, K.I16: np.int16, K.I8: np.int8}
+         K.U16: np.uint16, K.I16: np.int16, K.I8: np.int8, K.F32: np.float32}
 TAG_OF = {np.dtype(v): k for k, v in NP_OF.items()}
 
 

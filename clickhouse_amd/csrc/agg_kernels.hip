@@ -126,6 +126,7 @@ __device__ __forceinline__ u64 load_arg_bits(const void * p, int type, u64 i)
         case CHGPU_U16: return ((const u16 *)p)[i];
         case CHGPU_I16: return (u64)(i64)((const i16 *)p)[i];
         case CHGPU_I8: return (u64)(i64)((const i8 *)p)[i];
+        case CHGPU_F32: return (u64)__double_as_longlong((double)((const float *)p)[i]); // Float32 is accumulated as Float64
         default: return 0;
     }
 }
@@ -206,7 +207,7 @@ __device__ __forceinline__ void add_row_global(const AggTable & t, const AggDesc
             global_add_word(w, 1, false);
         else
         {
-            global_add_word(w, load_arg_bits(a.ptr, a.arg_type, i), a.arg_type == CHGPU_F64);
+            global_add_word(w, load_arg_bits(a.ptr, a.arg_type, i), a.arg_type == CHGPU_F64 || a.arg_type == CHGPU_F32);
             if (a.kind == CHGPU_AGG_AVG)
                 global_add_word(w + stride, 1, false); // denominator
         }
@@ -226,7 +227,7 @@ __device__ __forceinline__ void add_vals_global(const AggTable & t, const AggDes
             global_add_word(w, cnt, false);
         else
         {
-            global_add_word(w, a.pre == 0 ? bits0 : bits1, a.arg_type == CHGPU_F64);
+            global_add_word(w, a.pre == 0 ? bits0 : bits1, a.arg_type == CHGPU_F64 || a.arg_type == CHGPU_F32);
             if (a.kind == CHGPU_AGG_AVG)
                 global_add_word(w + stride, cnt, false); // denominator
         }
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, co
                             u64 bits;
                             if (j < PRE) bits = argv[q][j < PRE ? j : 0];
                             else bits = load_arg_bits(a_ptr[j], a_type[j], i);
-                            if (a_type[j] == CHGPU_F64)
+                            if (a_type[j] == CHGPU_F64 || a_type[j] == CHGPU_F32)
                                 atomicAdd((double *)w, __longlong_as_double((long long)bits));
                             else
                                 atomicAdd((unsigned long long *)w, (unsigned long long)bits);
@@ -1249,7 +1250,7 @@ extern "C" int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, 
         a->kinds[j] = kind;
         a->arg_types[j] = at;
         a->word_off[j] = w;
-        if (kind != CHGPU_AGG_COUNT && at == CHGPU_F64)
+        if (kind != CHGPU_AGG_COUNT && chgpu_type_is_float(at))
             a->word_is_f64 |= 1u << w;
         w += kind == CHGPU_AGG_AVG ? 2 : 1;
     }
@@ -1454,7 +1455,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         gc.dst[kk] = pwords + (u64)kk * n;
         // the aggregate pass reads widened 8-byte words: integers were sign/zero-extended, Float64 kept its bits
         d.a[j].ptr = gc.dst[kk];
-        d.a[j].arg_type = a->arg_types[j] == CHGPU_F64 ? CHGPU_F64 : CHGPU_U64;
+        d.a[j].arg_type = chgpu_type_is_float(a->arg_types[j]) ? CHGPU_F64 : CHGPU_U64;
         d.a[j].pre = kk;
         ++kk;
     }
@@ -1539,7 +1540,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
             if (a->kinds[j] == CHGPU_AGG_COUNT || !((agg_mask >> j) & 1))
                 continue;
             ac[c].ctx = ctx;
-            ac[c].type = a->arg_types[j] == CHGPU_F64 ? CHGPU_F64 : CHGPU_U64; // two's complement sums: width is what matters
+            ac[c].type = chgpu_type_is_float(a->arg_types[j]) ? CHGPU_F64 : CHGPU_U64; // two's complement sums: width is what matters
             ac[c].rows = n;
             ac[c].data = pwords + (u64)c * n;
             a->arg_types[j] = ac[c].type;
@@ -1830,7 +1831,7 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
     // instead of one trip through the generic kernel, which is 6x slower per row).
     bool ranged = use_lds && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED") && chgpu_type_size(a->key_type) != 2; // keys of 1, 4 or 8 bytes
     for (u32 j = 0; j < a->n_aggs; ++j) // 2-byte and Int8 arguments (no instantiation / sign extension for them): the generic LDS kernel
-        if (a->kinds[j] != CHGPU_AGG_COUNT && (chgpu_type_size(a->arg_types[j]) == 2 || a->arg_types[j] == CHGPU_I8))
+        if (a->kinds[j] != CHGPU_AGG_COUNT && (chgpu_type_size(a->arg_types[j]) == 2 || a->arg_types[j] == CHGPU_I8 || a->arg_types[j] == CHGPU_F32))
             ranged = false;
     if (ranged)
     {

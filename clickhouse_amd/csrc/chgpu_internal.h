@@ -96,19 +96,20 @@ static inline size_t chgpu_type_size(int type)
     switch (type)
     {
         case CHGPU_I64: case CHGPU_U64: case CHGPU_F64: return 8;
-        case CHGPU_U32: case CHGPU_I32: return 4;
+        case CHGPU_U32: case CHGPU_I32: case CHGPU_F32: return 4;
         case CHGPU_U16: case CHGPU_I16: return 2;
         case CHGPU_U8: case CHGPU_I8: return 1;
         default: return 0;
     }
 }
 
-static inline bool chgpu_type_is_int(int type) { return type != CHGPU_F64 && chgpu_type_size(type) != 0; }
+static inline bool chgpu_type_is_float(int type) { return type == CHGPU_F64 || type == CHGPU_F32; }
+static inline bool chgpu_type_is_int(int type) { return !chgpu_type_is_float(type) && chgpu_type_size(type) != 0; }
 static inline bool chgpu_type_is_signed(int type) { return type == CHGPU_I64 || type == CHGPU_I32 || type == CHGPU_I16 || type == CHGPU_I8; }
 // SumSimple result type (src/AggregateFunctions/AggregateFunctionSum.cpp:19-28)
 static inline int chgpu_sum_result_type(int t)
 {
-    if (t == CHGPU_F64) return CHGPU_F64;
+    if (chgpu_type_is_float(t)) return CHGPU_F64;
     return chgpu_type_is_signed(t) ? CHGPU_I64 : CHGPU_U64;
 }
 

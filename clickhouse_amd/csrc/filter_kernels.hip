@@ -68,7 +68,7 @@ struct TruePred
 
 struct CmpSpec
 {
-    bool is_f64 = false;
+    bool is_f64 = false; // floating-point column (Float64, or Float32 compared after its exact widening to double)
     int op = 0;
     double fs = 0;
     IntRangePred ip{0, 0, 0, 0};
@@ -79,7 +79,7 @@ static int make_cmp_spec(int col_type, int op, int scalar_type, const void * sca
 {
     CHGPU_REQUIRE(op >= CHGPU_EQ && op <= CHGPU_GE, CHGPU_ERR_BAD_ARGUMENTS, "unknown comparison op %d", op);
     CHGPU_REQUIRE(scalar, CHGPU_ERR_BAD_ARGUMENTS, "scalar is NULL");
-    CHGPU_REQUIRE(col_type == CHGPU_F64 || chgpu_type_is_int(col_type), CHGPU_ERR_BAD_ARGUMENTS, "unknown column type %d", col_type);
+    CHGPU_REQUIRE(chgpu_type_is_float(col_type) || chgpu_type_is_int(col_type), CHGPU_ERR_BAD_ARGUMENTS, "unknown column type %d", col_type);
     __int128 s = 0;
     switch (scalar_type)
     {
@@ -91,16 +91,16 @@ static int make_cmp_spec(int col_type, int op, int scalar_type, const void * sca
         case CHGPU_U16: s = *(const u16 *)scalar; break;
         case CHGPU_I16: s = *(const i16 *)scalar; break;
         case CHGPU_I8: s = *(const i8 *)scalar; break;
-        case CHGPU_F64: break;
+        case CHGPU_F64: case CHGPU_F32: break;
         default: return chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "unknown scalar type %d", scalar_type);
     }
-    if (col_type == CHGPU_F64)
+    if (chgpu_type_is_float(col_type))
     {
         spec->is_f64 = true;
         spec->op = op;
-        if (scalar_type == CHGPU_F64)
+        if (chgpu_type_is_float(scalar_type))
         {
-            spec->fs = *(const double *)scalar;
+            spec->fs = scalar_type == CHGPU_F64 ? *(const double *)scalar : (double)*(const float *)scalar;
             return CHGPU_OK;
         }
         // Float64 column vs integer constant s, compared mathematically (accurate::lessOp/equalsOp, AccurateComparison.h:20-130):
@@ -132,12 +132,12 @@ static int make_cmp_spec(int col_type, int op, int scalar_type, const void * sca
         }
         return CHGPU_OK;
     }
-    if (scalar_type == CHGPU_F64)
+    if (chgpu_type_is_float(scalar_type))
     {
-        // integer column vs Float64 constant c, compared mathematically: fold c into the integer threshold of an equivalent
+        // integer column vs Float64 (or Float32) constant c, compared mathematically: fold c into the integer threshold of an equivalent
         // integer comparison (a < c <=> a < ceil(c); a <= c <=> a <= floor(c); a == c needs an integral c); NaN compares
         // false except under != (notEqualsOp = !equalsOp)
-        const double c = *(const double *)scalar;
+        const double c = scalar_type == CHGPU_F64 ? *(const double *)scalar : (double)*(const float *)scalar;
         const __int128 big = (__int128)1 << 65; // beyond both 64-bit domains
         auto to_i128 = [&](double x) -> __int128 { return x >= 0x1p65 ? big : x <= -0x1p65 ? -big : (__int128)x; };
         if (std::isnan(c) || ((op == CHGPU_EQ || op == CHGPU_NE) && (std::isinf(c) || std::floor(c) != c)))
@@ -227,12 +227,14 @@ template <typename T>
 struct AccOf { typedef u64 type; };
 template <>
 struct AccOf<double> { typedef double type; };
+template <>
+struct AccOf<float> { typedef double type; }; // sum(Float32) accumulates in Float64
 
 template <typename T>
 __device__ __forceinline__ typename AccOf<T>::type widen(T a)
 {
-    if constexpr (std::is_same<T, double>::value)
-        return a;
+    if constexpr (std::is_same<T, double>::value || std::is_same<T, float>::value)
+        return (double)a;
     else if constexpr (std::is_signed<T>::value)
         return (u64)(i64)a; // wrap-around two's complement sum (AggregateFunctionSum.h:36-39)
     else
@@ -463,7 +465,7 @@ static int launch_filter_sum_t(chgpu_ctx * ctx, const void * pred, const void * 
         else      { if (same) FS_LAUNCH(1, true, false); else FS_LAUNCH(1, false, false); }
     }
 #undef FS_LAUNCH
-    hipLaunchKernelGGL((k_filter_sum_finish<std::is_same<T, double>::value>), dim3(1), dim3(256), 0, ctx->stream, part_sum, part_cnt, grid, result_dev);
+    hipLaunchKernelGGL((k_filter_sum_finish<std::is_same<typename AccOf<T>::type, double>::value>), dim3(1), dim3(256), 0, ctx->stream, part_sum, part_cnt, grid, result_dev);
     ctx->counters[6] += 2;
     CHGPU_HIP(hipGetLastError());
     return CHGPU_OK;
@@ -493,13 +495,16 @@ static int launch_filter_sum(chgpu_ctx * ctx, int type, const void * pred, const
     {
         if (type == CHGPU_F64)
             return launch_filter_sum_t<double, TruePred>(ctx, pred, val, cond, n, TruePred(), result_dev);
+        if (type == CHGPU_F32)
+            return launch_filter_sum_t<float, TruePred>(ctx, pred, val, cond, n, TruePred(), result_dev);
         return launch_filter_sum_int<TruePred>(ctx, type, pred, val, cond, n, TruePred(), result_dev);
     }
     if (spec->is_f64)
     {
         switch (spec->op)
         {
-#define F64CASE(OP) case OP: return launch_filter_sum_t<double, F64Pred<OP>>(ctx, pred, val, cond, n, F64Pred<OP>{spec->fs}, result_dev);
+#define F64CASE(OP) case OP: return type == CHGPU_F32 ? launch_filter_sum_t<float, F64Pred<OP>>(ctx, pred, val, cond, n, F64Pred<OP>{spec->fs}, result_dev) \
+                                                   : launch_filter_sum_t<double, F64Pred<OP>>(ctx, pred, val, cond, n, F64Pred<OP>{spec->fs}, result_dev);
             F64CASE(CHGPU_EQ) F64CASE(CHGPU_NE) F64CASE(CHGPU_LT) F64CASE(CHGPU_GT) F64CASE(CHGPU_LE) F64CASE(CHGPU_GE)
 #undef F64CASE
         }
@@ -587,7 +592,7 @@ static int sum_add_many_impl(chgpu_ctx * ctx, const chgpu_col * col, const chgpu
     CHGPU_TRY(launch_filter_sum(ctx, col->type, p, p, c, n, nullptr, result_dev));
     u64 res[2];
     CHGPU_TRY(chgpu_read_back(ctx, result_dev, res, sizeof(res)));
-    if (col->type == CHGPU_F64)
+    if (chgpu_type_is_float(col->type))
     {
         double batch, st;
         memcpy(&batch, &res[0], 8);
@@ -727,7 +732,8 @@ extern "C" int chgpu_cmp_const(chgpu_ctx * ctx, const chgpu_col * col, int op, i
         {
             switch (spec.op)
             {
-#define F64CASE(OP) case OP: rc = launch_cmp_t<double, F64Pred<OP>>(ctx, col->data, n, F64Pred<OP>{spec.fs}, c); break;
+#define F64CASE(OP) case OP: rc = col->type == CHGPU_F32 ? launch_cmp_t<float, F64Pred<OP>>(ctx, col->data, n, F64Pred<OP>{spec.fs}, c) \
+                                                       : launch_cmp_t<double, F64Pred<OP>>(ctx, col->data, n, F64Pred<OP>{spec.fs}, c); break;
                 F64CASE(CHGPU_EQ) F64CASE(CHGPU_NE) F64CASE(CHGPU_LT) F64CASE(CHGPU_GT) F64CASE(CHGPU_LE) F64CASE(CHGPU_GE)
 #undef F64CASE
             }

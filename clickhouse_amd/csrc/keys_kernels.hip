@@ -59,7 +59,7 @@ extern "C" int chgpu_pack_fixed_keys(chgpu_ctx * ctx, uint32_t n_cols, const chg
     {
         CHGPU_REQUIRE(cols[j], CHGPU_ERR_BAD_ARGUMENTS, "key column %u is NULL", j);
         CHGPU_REQUIRE(cols[j]->rows == rows, CHGPU_ERR_SIZES_MISMATCH, "key columns have different sizes");
-        CHGPU_REQUIRE(cols[j]->type != CHGPU_F64, CHGPU_ERR_NOT_IMPLEMENTED, "Float64 in a packed key: CPU path");
+        CHGPU_REQUIRE(!chgpu_type_is_float(cols[j]->type), CHGPU_ERR_NOT_IMPLEMENTED, "Float64 in a packed key: CPU path");
         pc.src[j] = cols[j]->data;
         pc.size[j] = (u32)chgpu_type_size(cols[j]->type);
         pc.offset[j] = off;
@@ -83,7 +83,7 @@ extern "C" int chgpu_unpack_fixed_key(chgpu_ctx * ctx, const chgpu_col * packed_
     CHGPU_REQUIRE(ctx && packed_u64 && out_col, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(chgpu_type_size(packed_u64->type) == 8, CHGPU_ERR_BAD_ARGUMENTS, "packed keys must be a 64-bit column");
     const size_t es = chgpu_type_size(type);
-    CHGPU_REQUIRE(es && type != CHGPU_F64, CHGPU_ERR_BAD_ARGUMENTS, "bad key type %d", type);
+    CHGPU_REQUIRE(es && !chgpu_type_is_float(type), CHGPU_ERR_BAD_ARGUMENTS, "bad key type %d", type);
     CHGPU_REQUIRE(byte_offset + es <= 8, CHGPU_ERR_BAD_ARGUMENTS, "key slice [%u,+%zu) outside the 8-byte packed key", byte_offset, es);
     chgpu_col * out = nullptr;
     CHGPU_TRY(chgpu_col_new(ctx, type, packed_u64->rows, &out));

@@ -184,7 +184,7 @@ extern "C" int chgpu_hash_to_selector(chgpu_ctx * ctx, const chgpu_col * keys, u
 {
     CHGPU_REQUIRE(ctx && keys && selector, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_TRY(check_shards(num_shards));
-    CHGPU_REQUIRE(keys->type != CHGPU_F64, CHGPU_ERR_NOT_IMPLEMENTED, "Float64 shard keys: CPU path");
+    CHGPU_REQUIRE(!chgpu_type_is_float(keys->type), CHGPU_ERR_NOT_IMPLEMENTED, "Float64 shard keys: CPU path");
     const u32 * lut = nullptr;
     CHGPU_TRY(chgpu_crc_lut(ctx, &lut));
     chgpu_col * sel = nullptr;

@@ -65,6 +65,7 @@ template <> struct TypeTag<uint16_t> { static constexpr int value = CHGPU_U16; }
 template <> struct TypeTag<int16_t> { static constexpr int value = CHGPU_I16; };
 template <> struct TypeTag<int8_t> { static constexpr int value = CHGPU_I8; };
 template <> struct TypeTag<double> { static constexpr int value = CHGPU_F64; };
+template <> struct TypeTag<float> { static constexpr int value = CHGPU_F32; };
 
 /// One device + one HIP stream: create one per pipeline thread (IProcessor::work() of different processors runs
 /// concurrently, src/Processors/IProcessor.h:176-193).

@@ -43,7 +43,8 @@ enum
 
 /* ---- column element types (the TypeIndex subset of the hot path, src/Core/TypeId.h) ----
    Every entry point takes every type unless it says otherwise; arithmetic (chgpu_arith) and the fused expression kernel
-   (chgpu_expr_filter_sum) are limited to the first six and answer CHGPU_ERR_NOT_IMPLEMENTED for UInt16 / Int16 / Int8. */
+   (chgpu_expr_filter_sum) are limited to the first six and answer CHGPU_ERR_NOT_IMPLEMENTED for UInt16 / Int16 / Int8 /
+   Float32; keys (GROUP BY, join, sharding, packed) are integers. */
 enum
 {
     CHGPU_I64 = 0,
@@ -54,7 +55,8 @@ enum
     CHGPU_I32 = 5,
     CHGPU_U16 = 6, /* also Date (days since epoch) */
     CHGPU_I16 = 7,
-    CHGPU_I8 = 8
+    CHGPU_I8 = 8,
+    CHGPU_F32 = 9  /* sums and averages accumulate in Float64 (SumSimple: NearestFieldType<Float32>) */
 };
 
 /* ---- comparison functions (src/Functions/FunctionsComparison.h: equals..greaterOrEquals) ---- */

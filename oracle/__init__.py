@@ -17,14 +17,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # type tags (same numeric values as include/chgpu.h)
-I64, U32, U64, F64, U8, I32, U16, I16, I8 = 0, 1, 2, 3, 4, 5, 6, 7, 8
+I64, U32, U64, F64, U8, I32, U16, I16, I8, F32 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 EQ, NE, LT, GT, LE, GE = 0, 1, 2, 3, 4, 5
 AGG_COUNT, AGG_SUM, AGG_AVG = 0, 1, 2
 JOIN_INNER, JOIN_LEFT = 0, 1
 STRICT_ANY, STRICT_ALL, STRICT_SEMI, STRICT_ANTI = 0, 1, 2, 3
 DEFAULT_BLOCK_SIZE = 65409
 
-NP_OF = {I64: np.int64, U32: np.uint32, U64: np.uint64, F64: np.float64, U8: np.uint8, I32: np.int32, U16: np.uint16, I16: np.int16, I8: np.int8}
+NP_OF = {I64: np.int64, U32: np.uint32, U64: np.uint64, F64: np.float64, U8: np.uint8, I32: np.int32, U16: np.uint16, I16: np.int16, I8: np.int8, F32: np.float32}
 TAG_OF = {np.dtype(v): k for k, v in NP_OF.items()}
 
 

@@ -84,7 +84,7 @@ static size_t type_size(int type)
     switch (type)
     {
         case CHO_I64: case CHO_U64: case CHO_F64: return 8;
-        case CHO_U32: case CHO_I32: return 4;
+        case CHO_U32: case CHO_I32: case CHO_F32: return 4;
         case CHO_U16: case CHO_I16: return 2;
         case CHO_U8: case CHO_I8: return 1;
         default: return 0;
@@ -157,6 +157,7 @@ static inline num_t load_num(int type, const void * p, size_t idx)
         case CHO_I16: r.i = ((const int16_t *)p)[idx]; break;
         case CHO_I8: r.i = ((const int8_t *)p)[idx]; break;
         case CHO_F64: r.is_float = 1; r.f = ((const double *)p)[idx]; break;
+        case CHO_F32: r.is_float = 1; r.f = (double)((const float *)p)[idx]; break; /* exact */
         default: break;
     }
     return r;
@@ -444,6 +445,35 @@ static void sum_add_many_f64(double * sum, const double * ptr, size_t start, siz
     *sum += local_sum;
 }
 
+/* sum(Float32): the accumulator type is Float64 (SumSimple: NearestFieldType<Float32>), so the loop is the Float64 one with
+   T(ptr[i]) converting every value (AggregateFunctionSum.h:72-101: unroll_count = 128 / sizeof(Float64) = 16) */
+static void sum_add_many_f32(double * sum, const float * ptr, size_t start, size_t end)
+{
+    ptr += start;
+    size_t count = end - start;
+    const float * end_ptr = ptr + count;
+    enum { unroll_count = 16 };
+    double partial_sums[unroll_count];
+    for (int i = 0; i < unroll_count; ++i)
+        partial_sums[i] = 0;
+    const float * unrolled_end = ptr + (count / unroll_count * unroll_count);
+    while (ptr < unrolled_end)
+    {
+        for (int i = 0; i < unroll_count; ++i)
+            partial_sums[i] += (double)ptr[i];
+        ptr += unroll_count;
+    }
+    for (int i = 0; i < unroll_count; ++i)
+        *sum += partial_sums[i];
+    double local_sum = 0;
+    while (ptr < end_ptr)
+    {
+        local_sum += (double)*ptr;
+        ++ptr;
+    }
+    *sum += local_sum;
+}
+
 CHO_MULTITARGET
 static void sum_add_many_i64(void * state, const void * ptr, size_t start, size_t end) SUM_INT_LOOP(int64_t)
 
@@ -460,6 +490,7 @@ void cho_sum_add_many(int type, void * state, const void * ptr, size_t start, si
         case CHO_I16: SUM_INT_LOOP(int16_t) break;
         case CHO_I8: SUM_INT_LOOP(int8_t) break;
         case CHO_F64: sum_add_many_f64((double *)state, (const double *)ptr, start, end); break;
+        case CHO_F32: sum_add_many_f32((double *)state, (const float *)ptr, start, end); break;
         default: break;
     }
 }
@@ -533,6 +564,29 @@ void cho_sum_add_many_conditional(int type, void * state, const void * ptr, cons
             *sum += local_sum;
             break;
         }
+        case CHO_F32:
+        {
+            /* same structure as the Float64 case on converted values */
+            const float * p = (const float *)ptr + start;
+            const uint8_t * cm = cond + start;
+            size_t count = end - start;
+            double partial_sums[16];
+            for (int i = 0; i < 16; ++i)
+                partial_sums[i] = 0;
+            size_t k = 0;
+            for (; k + 16 <= count; k += 16)
+                for (int i = 0; i < 16; ++i)
+                    partial_sums[i] += cm[k + i] ? (double)p[k + i] : 0.0;
+            double * sum = (double *)state;
+            for (int i = 0; i < 16; ++i)
+                *sum += partial_sums[i];
+            double local_sum = 0;
+            for (; k < count; ++k)
+                if (cm[k])
+                    local_sum += (double)p[k];
+            *sum += local_sum;
+            break;
+        }
         default: break;
     }
 }
@@ -544,7 +598,7 @@ double cho_avg_divide(int numerator_type, const void * numerator, uint64_t denom
     {
         case CHO_I64: case CHO_I32: case CHO_I16: case CHO_I8: return (double)(*(const int64_t *)numerator) / (double)denominator;
         case CHO_U64: case CHO_U32: case CHO_U16: case CHO_U8: return (double)(*(const uint64_t *)numerator) / (double)denominator;
-        case CHO_F64: return *(const double *)numerator / (double)denominator;
+        case CHO_F64: case CHO_F32: return *(const double *)numerator / (double)denominator;
         default: return NAN;
     }
 }
@@ -707,7 +761,7 @@ void cho_and_u8(const uint8_t * a, const uint8_t * b, size_t n, uint8_t * out)
    operand, signed if either is or for minus) summed (AggregateFunctionSum: Int64 for signed, UInt64 for unsigned). */
 int cho_arith_sum_type(int value_op, int a_type, int b_type)
 {
-    if (a_type == CHO_F64 || b_type == CHO_F64 || !type_size(a_type) || !type_size(b_type))
+    if (a_type == CHO_F64 || b_type == CHO_F64 || a_type == CHO_F32 || b_type == CHO_F32 || !type_size(a_type) || !type_size(b_type))
         return -1;
     if (a_type > CHO_I32 || b_type > CHO_I32)
         return -1; /* UInt16 / Int16 / Int8 operands: arithmetic is not restated for them */
@@ -1110,6 +1164,7 @@ static inline void agg_add_row(const cho_agg * a, int j, char * place, const voi
                 case CHO_I16: *(uint64_t *)st += (uint64_t)(int64_t)((const int16_t *)arg)[i]; break;
                 case CHO_I8: *(uint64_t *)st += (uint64_t)(int64_t)((const int8_t *)arg)[i]; break;
                 case CHO_F64: *(double *)st += ((const double *)arg)[i]; break;
+                case CHO_F32: *(double *)st += (double)((const float *)arg)[i]; break; /* Impl::add(sum, T(value)), T = Float64 */
                 default: break;
             }
             break;

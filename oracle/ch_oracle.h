@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 /* type tags shared with include/chgpu.h (same numeric values) */
-enum { CHO_I64 = 0, CHO_U32 = 1, CHO_U64 = 2, CHO_F64 = 3, CHO_U8 = 4, CHO_I32 = 5, CHO_U16 = 6, CHO_I16 = 7, CHO_I8 = 8 };
+enum { CHO_I64 = 0, CHO_U32 = 1, CHO_U64 = 2, CHO_F64 = 3, CHO_U8 = 4, CHO_I32 = 5, CHO_U16 = 6, CHO_I16 = 7, CHO_I8 = 8, CHO_F32 = 9 };
 /* comparison ops (FunctionsComparison.h: EqualsOp..GreaterOrEqualsOp) */
 enum { CHO_EQ = 0, CHO_NE = 1, CHO_LT = 2, CHO_GT = 3, CHO_LE = 4, CHO_GE = 5 };
 /* aggregate kinds */

@@ -18,12 +18,12 @@ def ctx(ch):
     c.close()
 
 
-DTYPES = [np.int64, np.uint64, np.uint32, np.int32, np.float64, np.uint8, np.uint16, np.int16, np.int8]
+DTYPES = [np.int64, np.uint64, np.uint32, np.int32, np.float64, np.uint8, np.uint16, np.int16, np.int8, np.float32]
 
 
 def _rand(rng, dtype, n, lo=0, hi=255):
-    if np.dtype(dtype) == np.float64:
-        return rng.random(n) * (hi - lo) + lo
+    if np.dtype(dtype).kind == "f":
+        return (rng.random(n) * (hi - lo) + lo).astype(dtype)
     return rng.integers(lo, hi, size=n).astype(dtype)
 
 
@@ -162,6 +162,37 @@ def test_sum_float64_within_1e6_relative(ch, ctx, oracle_mod):
     assert len({float(ch.sum_add_many(col)[0]) for _ in range(3)}) == 1
     a = np.array([1.0, np.nan, 2.0])
     assert np.isnan(ch.sum_add_many(ctx.upload(a))[0])
+
+
+def test_float32_columns_compare_sum_and_avg(ch, ctx, oracle_mod):
+    # Float32: comparisons after the exact widening to double (against Float32, Float64 and integer constants), sums and
+    # averages accumulated in Float64 (SumSimple: NearestFieldType<Float32>)
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(32))
+    f = np.concatenate([(rng.standard_normal(300_001) * 100).astype(np.float32), np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 16777216.0, 16777218.0], dtype=np.float32)])
+    fc = ctx.upload(f)
+    ops = [ch.EQ, ch.NE, ch.LT, ch.GT, ch.LE, ch.GE]
+    for sc, tag in ((0.5, ch.F32), (0.1, ch.F64), (float(np.float32(0.1)), ch.F64), (np.nan, ch.F32), (16777217, ch.I64), (-3, ch.I32), (2**63, ch.U64), (np.inf, ch.F64)):
+        for op in ops:
+            assert np.array_equal(ch.cmp_const(fc, op, sc, tag).numpy(), O.cmp_const(f, op, sc, tag)), (sc, tag, op)
+    pos = np.abs(f[np.isfinite(f)]).astype(np.float32)
+    pc = ctx.upload(pos)
+    s = ch.sum_add_many(pc)[0]
+    so = O.sum_add_many(pos)[0]
+    assert s.dtype == np.float64 and abs(float(s) - float(so)) <= 1e-6 * abs(float(so))
+    s2, c2 = ch.filter_sum(pc, ch.LT, 50.0, scalar_tag=ch.F64)
+    m = pos.astype(np.float64) < 50.0
+    assert c2 == int(m.sum()) and abs(float(s2) - pos[m].astype(np.float64).sum()) <= 1e-6 * pos[m].astype(np.float64).sum()
+    k = rng.integers(0, 50, size=pos.shape[0]).astype(np.uint32)
+    g = ch.Aggregator(np.uint32, [(ch.AGG_SUM, np.float32), (ch.AGG_AVG, np.float32), (ch.AGG_COUNT, None)], ctx=ctx)
+    g.execute_on_block(k, [pos, pos, None])
+    o = O.Aggregator(np.uint32, [(O.AGG_SUM, np.float32), (O.AGG_AVG, np.float32), (O.AGG_COUNT, None)])
+    o.execute_on_block(k, [pos, pos, None])
+    gk, gr = g.convert_to_block()
+    ok, orr = o.convert_to_block()
+    gi, oi = np.argsort(gk), np.argsort(ok)
+    assert np.array_equal(gk[gi], ok[oi]) and np.array_equal(gr[2][gi], orr[2][oi])
+    assert gr[0].dtype == np.float64 and np.allclose(gr[0][gi], orr[0][oi], rtol=1e-6) and np.allclose(gr[1][gi], orr[1][oi], rtol=1e-6)
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 1000, 65409, 10_000_000])

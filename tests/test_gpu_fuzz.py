@@ -27,7 +27,7 @@ def ctx(ch):
 
 
 KEY_DTYPES = [np.uint32, np.int32, np.uint64, np.int64, np.uint8, np.uint16, np.int16, np.int8]
-ARG_DTYPES = [np.int64, np.uint64, np.float64, np.uint32, np.int32, np.uint8, np.uint16, np.int16, np.int8]
+ARG_DTYPES = [np.int64, np.uint64, np.float64, np.uint32, np.int32, np.uint8, np.uint16, np.int16, np.int8, np.float32]
 
 
 def _keys(rng, dtype, n, groups, skew):
@@ -47,8 +47,8 @@ def _keys(rng, dtype, n, groups, skew):
 
 def _args(rng, dtype, n):
     dt = np.dtype(dtype)
-    if dt == np.float64:
-        return rng.random(n) * 1000 - 500
+    if dt.kind == "f":
+        return (rng.random(n) * 1000 - 500).astype(dt)
     if dt.itemsize == 8:
         return rng.integers(-2**62, 2**62, size=n, dtype=np.int64).astype(dtype)   # sums wrap modulo 2^64
     info = np.iinfo(dt)
@@ -104,9 +104,9 @@ def _agg_case(ch, ctx, oracle_mod, rng, n, groups, use_oracle):
                 assert np.array_equal(got, cnt.astype(np.uint64)), (desc, j)
                 continue
             c = cols[j]
-            if np.dtype(dt) == np.float64:
+            if np.dtype(dt).kind == "f":
                 s = np.zeros(uk.shape[0])
-                np.add.at(s, inv, c)
+                np.add.at(s, inv, c.astype(np.float64))
                 want = s if kind == ch.AGG_SUM else s / cnt
                 assert np.allclose(got, want, rtol=1e-6, atol=1e-6), (desc, j)
             elif kind == ch.AGG_SUM:
