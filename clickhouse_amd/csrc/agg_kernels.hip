@@ -1829,7 +1829,7 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
     // width (8, 4 or 1 B), so the aggregate functions are split into PASSES over the same rows -- each pass re-reads the key
     // column and updates its own state words of the same groups (TPC-H Q1's seven sums and averages: 4 passes x ~20 B/row
     // instead of one trip through the generic kernel, which is 6x slower per row).
-    bool ranged = use_lds && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED") && chgpu_type_size(a->key_type) != 2; // keys of 1, 4 or 8 bytes
+    bool ranged = use_lds && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED"); // keys of 1, 2, 4 or 8 bytes: every key type
     for (u32 j = 0; j < a->n_aggs; ++j) // 2-byte and Int8 arguments (no instantiation / sign extension for them): the generic LDS kernel
         if (a->kinds[j] != CHGPU_AGG_COUNT && (chgpu_type_size(a->arg_types[j]) == 2 || a->arg_types[j] == CHGPU_I8 || a->arg_types[j] == CHGPU_F32))
             ranged = false;
@@ -1862,7 +1862,7 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
         if (n_passes == 0)
             n_passes = 1; // only count(): one pass without argument columns
 
-        const bool key32 = chgpu_type_size(a->key_type) <= 4, key8 = chgpu_type_size(a->key_type) == 1;
+        const bool key32 = chgpu_type_size(a->key_type) <= 4, key8 = chgpu_type_size(a->key_type) == 1, key16 = chgpu_type_size(a->key_type) == 2;
         u32 cnt32 = 0;
         (void)agg_part_cell_bytes(a, n, &cnt32);
         const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
@@ -1922,6 +1922,10 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
             if (key8)
             {
                 if (aw == 8) RANGE_LAUNCH_KS(u32, 8, u8); else if (aw == 4) RANGE_LAUNCH_KS(u32, 4, u8); else RANGE_LAUNCH_KS(u32, 1, u8);
+            }
+            else if (key16) // UInt16 (Date) / Int16 keys
+            {
+                if (aw == 8) RANGE_LAUNCH_KS(u32, 8, u16); else if (aw == 4) RANGE_LAUNCH_KS(u32, 4, u16); else RANGE_LAUNCH_KS(u32, 1, u16);
             }
             else if (key32)
             {
