@@ -782,6 +782,18 @@ __global__ __launch_bounds__(1024) void k_gb_units(const u64 * __restrict__ offs
 // (UInt32 key, sum, count) a cell is 4+8+4 = 16 B, so 8192 cells fit and 256 partitions suffice for 1 M groups --
 // half as many partitions means partition runs twice as long in the scatter, whose cost is dominated by short runs.
 // Layout: keys KT[S+1] (padded to 8 B) | every 8-byte word u64[S+1] in word order | every 4-byte word u32[S+1].
+// widening of a zero-extended narrow argument load (see ex0/ex1 in k_agg_part_lds)
+__device__ __forceinline__ u64 part_extend(u64 raw, int ex)
+{
+    switch (ex)
+    {
+        case 1: return (u64)(i64)(i8)(u8)raw;
+        case 2: return (u64)(i64)(i16)(u16)raw;
+        case 3: return (u64)(i64)(i32)(u32)raw;
+        default: return (u64)__double_as_longlong((double)__uint_as_float((u32)raw));
+    }
+}
+
 struct PartLds
 {
     u32 S1, cnt32, n8, keys_bytes;
@@ -822,7 +834,9 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
     //   op: 0 none, 1 add u64 (integer sum), 2 add f64, 3 count as u32, 4 count as u64
     u32 a_off[AGG_MAX_AGGS], a_off2[AGG_MAX_AGGS];
     int a_op[AGG_MAX_AGGS], a_op2[AGG_MAX_AGGS], a_src[AGG_MAX_AGGS];
-    bool sx0 = false, sx1 = false; // argument word 0 / 1 is an Int32 column: sign-extend the zero-extended load
+    // what to do with the zero-extended load of argument word 0 / 1: 0 nothing, 1/2/3 sign-extend from 8/16/32 bits (Int8/16/32
+    // columns), 4 Float32 -> Float64 bits
+    int ex0 = 0, ex1 = 0;
 #pragma unroll
     for (u32 j = 0; j < AGG_MAX_AGGS; ++j)
     {
@@ -836,10 +850,10 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                 a_op[j] = ((cnt32 >> w) & 1) ? 3 : 4;
             else
             {
-                a_op[j] = d.a[j].arg_type == CHGPU_F64 ? 2 : 1;
+                a_op[j] = (d.a[j].arg_type == CHGPU_F64 || d.a[j].arg_type == CHGPU_F32) ? 2 : 1;
                 a_src[j] = (int)d.a[j].pre;
-                if (AW == 4 && d.a[j].arg_type == CHGPU_I32)
-                    (d.a[j].pre == 0 ? sx0 : sx1) = true;
+                const int ex = d.a[j].arg_type == CHGPU_I8 ? 1 : d.a[j].arg_type == CHGPU_I16 ? 2 : d.a[j].arg_type == CHGPU_I32 ? 3 : d.a[j].arg_type == CHGPU_F32 ? 4 : 0;
+                (d.a[j].pre == 0 ? ex0 : ex1) = ex;
                 if (d.a[j].kind == CHGPU_AGG_AVG)
                 {
                     a_off2[j] = L.off(w + 1);
@@ -910,7 +924,7 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                 i = i < n ? i : n - 1;
                 cv[q] = cond ? (u32)__builtin_nontemporal_load(&cond[i]) : 1u;
                 kv[q] = (u64)__builtin_nontemporal_load(&keys[i]);
-                typedef typename std::conditional<AW == 8, u64, typename std::conditional<AW == 4, u32, u8>::type>::type AT;
+                typedef typename std::conditional<AW == 8, u64, typename std::conditional<AW == 4, u32, typename std::conditional<AW == 2, u16, u8>::type>::type>::type AT;
                 av[q][0] = K > 0 ? (u64)__builtin_nontemporal_load((const AT *)words0 + i) : 0;
                 av[q][1] = K > 1 ? (u64)__builtin_nontemporal_load((const AT *)words1 + i) : 0;
             }
@@ -929,8 +943,11 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                 if (i >= begin && i < end && cv[q] != 0)
                 {
                     const u64 key = keyv[q];
-                    const u64 b0 = sx0 ? (u64)(i64)(i32)(u32)argv[q][0] : argv[q][0];
-                    const u64 b1 = sx1 ? (u64)(i64)(i32)(u32)argv[q][1] : argv[q][1];
+                    u64 b0 = argv[q][0], b1 = argv[q][1];
+                    if (ex0) // wave-uniform
+                        b0 = part_extend(b0, ex0);
+                    if (ex1)
+                        b1 = part_extend(b1, ex1);
                     u32 ls = ~0u;
                     if (key == 0)
                     {
@@ -1830,9 +1847,7 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
     // column and updates its own state words of the same groups (TPC-H Q1's seven sums and averages: 4 passes x ~20 B/row
     // instead of one trip through the generic kernel, which is 6x slower per row).
     bool ranged = use_lds && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED"); // keys of 1, 2, 4 or 8 bytes: every key type
-    for (u32 j = 0; j < a->n_aggs; ++j) // 2-byte and Int8 arguments (no instantiation / sign extension for them): the generic LDS kernel
-        if (a->kinds[j] != CHGPU_AGG_COUNT && (chgpu_type_size(a->arg_types[j]) == 2 || a->arg_types[j] == CHGPU_I8 || a->arg_types[j] == CHGPU_F32))
-            ranged = false;
+
     if (ranged)
     {
         struct Pass
@@ -1921,19 +1936,19 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
 #define RANGE_LAUNCH(KT_, AW_) RANGE_LAUNCH_KS(KT_, AW_, KT_)
             if (key8)
             {
-                if (aw == 8) RANGE_LAUNCH_KS(u32, 8, u8); else if (aw == 4) RANGE_LAUNCH_KS(u32, 4, u8); else RANGE_LAUNCH_KS(u32, 1, u8);
+                if (aw == 8) RANGE_LAUNCH_KS(u32, 8, u8); else if (aw == 4) RANGE_LAUNCH_KS(u32, 4, u8); else if (aw == 2) RANGE_LAUNCH_KS(u32, 2, u8); else RANGE_LAUNCH_KS(u32, 1, u8);
             }
             else if (key16) // UInt16 (Date) / Int16 keys
             {
-                if (aw == 8) RANGE_LAUNCH_KS(u32, 8, u16); else if (aw == 4) RANGE_LAUNCH_KS(u32, 4, u16); else RANGE_LAUNCH_KS(u32, 1, u16);
+                if (aw == 8) RANGE_LAUNCH_KS(u32, 8, u16); else if (aw == 4) RANGE_LAUNCH_KS(u32, 4, u16); else if (aw == 2) RANGE_LAUNCH_KS(u32, 2, u16); else RANGE_LAUNCH_KS(u32, 1, u16);
             }
             else if (key32)
             {
-                if (aw == 8) RANGE_LAUNCH(u32, 8); else if (aw == 4) RANGE_LAUNCH(u32, 4); else RANGE_LAUNCH(u32, 1);
+                if (aw == 8) RANGE_LAUNCH(u32, 8); else if (aw == 4) RANGE_LAUNCH(u32, 4); else if (aw == 2) RANGE_LAUNCH(u32, 2); else RANGE_LAUNCH(u32, 1);
             }
             else
             {
-                if (aw == 8) RANGE_LAUNCH(u64, 8); else if (aw == 4) RANGE_LAUNCH(u64, 4); else RANGE_LAUNCH(u64, 1);
+                if (aw == 8) RANGE_LAUNCH(u64, 8); else if (aw == 4) RANGE_LAUNCH(u64, 4); else if (aw == 2) RANGE_LAUNCH(u64, 2); else RANGE_LAUNCH(u64, 1);
             }
 #undef RANGE_LAUNCH
 #undef RANGE_LAUNCH_KS
