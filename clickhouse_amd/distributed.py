@@ -21,7 +21,8 @@ import torch
 import torch.distributed as dist
 
 _NP2T = {np.dtype(np.int64): torch.int64, np.dtype(np.uint64): torch.int64, np.dtype(np.uint32): torch.int32,
-         np.dtype(np.int32): torch.int32, np.dtype(np.float64): torch.float64, np.dtype(np.uint8): torch.uint8}
+         np.dtype(np.int32): torch.int32, np.dtype(np.float64): torch.float64, np.dtype(np.uint8): torch.uint8,
+         np.dtype(np.uint16): torch.int16, np.dtype(np.int16): torch.int16, np.dtype(np.int8): torch.int8, np.dtype(np.float32): torch.float32}
 
 
 def world_is_power_of_two(world: int) -> bool:
