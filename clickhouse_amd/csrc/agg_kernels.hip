@@ -809,7 +809,9 @@ struct PartLds
 // AW: bytes per element of the argument columns (8 in PARTITION mode -- the buffers hold widened words; 8, 4 or 1 in RANGE mode,
 // where the source columns are read as they are and 4-byte signed arguments are sign-extended after the load)
 // KS: element type of the key column as stored (UInt8 keys are read as they are and held as KT = UInt32 in LDS)
-template <typename KT, int AW, typename KS = KT>
+// EXT: some argument word of this launch needs more than the zero extension its typed load gives (Int8/16/32 sign extension,
+// Float32 -> Float64); compiled out otherwise -- the pass is issue-bound and the extension logic cost it 4-14 % when present
+template <typename KT, int AW, typename KS = KT, bool EXT = false>
 __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const KS * __restrict__ keys, const void * __restrict__ words0, const void * __restrict__ words1,
                                                        const u64 * __restrict__ offsets, u32 G, u32 P, u64 n, u64 * __restrict__ pending, u32 S, u32 K, u32 cnt32,
                                                        u64 rows_per_chunk, const u32 * __restrict__ unit_start, u32 * __restrict__ unit_ctr,
@@ -944,10 +946,13 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                 {
                     const u64 key = keyv[q];
                     u64 b0 = argv[q][0], b1 = argv[q][1];
-                    if (ex0) // wave-uniform
-                        b0 = part_extend(b0, ex0);
-                    if (ex1)
-                        b1 = part_extend(b1, ex1);
+                    if constexpr (EXT)
+                    {
+                        if (ex0) // wave-uniform
+                            b0 = part_extend(b0, ex0);
+                        if (ex1)
+                            b1 = part_extend(b1, ex1);
+                    }
                     u32 ls = ~0u;
                     if (key == 0)
                     {
@@ -1924,15 +1929,22 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
                         dp.a[dp.n_aggs++] = d.a[j];
             const u32 rk = passes[p].n;
             const size_t aw = passes[p].aw;
+            bool need_ext = false; // a signed narrow integer or Float32 argument in this pass
+            for (u32 c = 0; c < passes[p].n; ++c)
+            {
+                const int at = a->arg_types[passes[p].agg[c]];
+                need_ext = need_ext || at == CHGPU_I8 || at == CHGPU_I16 || at == CHGPU_I32 || at == CHGPU_F32;
+            }
             CHGPU_HIP(hipMemsetAsync(pending, 0, n_words64 * sizeof(u64), ctx->stream));
-#define RANGE_LAUNCH_KS(KT_, AW_, KS_)                                                                                                                 \
+#define RANGE_LAUNCH_X(KT_, AW_, KS_, X_)                                                                                                              \
     do                                                                                                                                                \
     {                                                                                                                                                 \
-        CHGPU_HIP(hipFuncSetAttribute((const void *)k_agg_part_lds<KT_, AW_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag));         \
-        hipLaunchKernelGGL((k_agg_part_lds<KT_, AW_, KS_>), dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, dp, (const KS_ *)key_col->data + row_begin, \
+        CHGPU_HIP(hipFuncSetAttribute((const void *)k_agg_part_lds<KT_, AW_, KS_, X_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag));     \
+        hipLaunchKernelGGL((k_agg_part_lds<KT_, AW_, KS_, X_>), dim3((u32)chunks), dim3(1024), lds_ag, ctx->stream, a->t, dp, (const KS_ *)key_col->data + row_begin, \
                            rwords[0], rwords[1], (const u64 *)nullptr, 1u, (u32)chunks, n, pending, S, rk, cnt32, rows_per_chunk, (const u32 *)nullptr,  \
-                           (u32 *)nullptr, cond_ptr);                                                                                                           \
+                           (u32 *)nullptr, cond_ptr);                                                                                                 \
     } while (0)
+#define RANGE_LAUNCH_KS(KT_, AW_, KS_) do { if ((AW_) < 8 && need_ext) RANGE_LAUNCH_X(KT_, AW_, KS_, true); else RANGE_LAUNCH_X(KT_, AW_, KS_, false); } while (0)
 #define RANGE_LAUNCH(KT_, AW_) RANGE_LAUNCH_KS(KT_, AW_, KT_)
             if (key8)
             {
@@ -1952,6 +1964,7 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
             }
 #undef RANGE_LAUNCH
 #undef RANGE_LAUNCH_KS
+#undef RANGE_LAUNCH_X
             ctx->counters[6] += 1;
             CHGPU_HIP(hipGetLastError());
             // rows this pass could not place (table at max fill) are retried with THIS pass's functions only
