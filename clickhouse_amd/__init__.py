@@ -8,6 +8,7 @@ from .columns import (Column, Context, and_, arith, concat, expr_filter_sum, cmp
                       filter_sum_async, hash_to_selector, pack_fixed_keys, partition_by_hash, sum_add_many,
                       sum_add_many_conditional, unpack_fixed_key)
 from .aggregator import Aggregator
+from .expression import ActionsDAG, ExpressionActions
 from .hashjoin import HashJoin
 
 __all__ = [n for n in dir() if not n.startswith("_")]

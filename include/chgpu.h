@@ -182,6 +182,55 @@ int chgpu_expr_filter_sum(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * co
                           const uint64_t * pred_scalar_bits, int value_op, uint32_t val_a, uint32_t val_b,
                           int * result_type_out, void * sum_out, uint64_t * count_out);
 
+/* ------------------------------------------------------------------------------------------------
+ * The general form: an expression DAG compiled at run time into ONE kernel (hiprtc, gfx950) -- ExpressionActions::execute
+ * (src/Interpreters/ExpressionActions.cpp:595-747) without materialised intermediates; the counterpart of the reference's
+ * compile_expressions JIT (src/Interpreters/JIT/CHJIT.cpp, compileFunction.cpp).  A program is an array of nodes in
+ * topological order (operands precede their users); result types follow src/DataTypes/NumberTraits.h, comparisons
+ * src/Core/AccurateComparison.h (mixed-sign and integer-vs-float operands compared mathematically; NaN as there), logical
+ * functions see static_cast<bool>(x) (FunctionsLogical.cpp:81,424), date functions take a Date (CHGPU_U16 day number).
+ * Type combinations the reference answers with a type this path does not carry (128-bit, Float -> integer casts, if() over
+ * UInt64 and a signed type) give CHGPU_ERR_NOT_IMPLEMENTED at compile time: the caller keeps its CPU actions.
+ * ---------------------------------------------------------------------------------------------- */
+enum { CHGPU_EX_INPUT = 0, CHGPU_EX_CONST = 1, CHGPU_EX_FUNC = 2 };
+enum
+{
+    CHGPU_FN_EQUALS = 0, CHGPU_FN_NOT_EQUALS = 1, CHGPU_FN_LESS = 2, CHGPU_FN_GREATER = 3, CHGPU_FN_LESS_OR_EQUALS = 4,
+    CHGPU_FN_GREATER_OR_EQUALS = 5,                                   /* = CHGPU_EQ .. CHGPU_GE; result UInt8 */
+    CHGPU_FN_PLUS = 10, CHGPU_FN_MINUS = 11, CHGPU_FN_MULTIPLY = 12,  /* ResultOfAdditionMultiplication / ResultOfSubtraction */
+    CHGPU_FN_DIVIDE = 13,                                             /* Float64 (ResultOfFloatingPointDivision) */
+    CHGPU_FN_NEGATE = 14,                                             /* ResultOfNegate */
+    CHGPU_FN_AND = 20, CHGPU_FN_OR = 21, CHGPU_FN_XOR = 22, CHGPU_FN_NOT = 23, /* UInt8 */
+    CHGPU_FN_IF = 30,                                                 /* if(cond, then, else): ResultOfIf */
+    CHGPU_FN_BIT_AND = 40, CHGPU_FN_BIT_OR = 41, CHGPU_FN_BIT_XOR = 42, /* integers: ResultOfBit */
+    CHGPU_FN_TO_YEAR = 50, CHGPU_FN_TO_MONTH = 51, CHGPU_FN_TO_DAY_OF_MONTH = 52, CHGPU_FN_TO_YYYYMM = 53, /* Date -> UInt16/UInt8/UInt8/UInt32 */
+    CHGPU_FN_CAST = 64                                                /* CHGPU_FN_CAST + CHGPU_<type>: toInt64(x) ... (static_cast) */
+};
+typedef struct chgpu_expr_node
+{
+    int32_t kind;    /* CHGPU_EX_* */
+    int32_t code;    /* INPUT: index into cols[] (< 8); FUNC: CHGPU_FN_*; CONST: unused */
+    int32_t type;    /* INPUT, CONST: element type; FUNC: ignored (inferred, see chgpu_expr_node_type) */
+    int32_t args[3]; /* FUNC: operand node indices, unused = -1 */
+    uint64_t bits;   /* CONST: the value's raw little-endian bytes */
+} chgpu_expr_node;
+typedef struct chgpu_expr chgpu_expr;
+/* type-checks the DAG and generates its row function; needs no device */
+int chgpu_expr_compile(uint32_t n_nodes, const chgpu_expr_node * nodes, chgpu_expr ** out);
+int chgpu_expr_node_type(const chgpu_expr * expr, uint32_t node, int * type_out);
+/* runs the run-time compiler only (no device): n_outputs > 0 -> the materialising kernel for out_nodes, n_outputs == 0 -> the
+   fused filter + sum kernel for (filter_node, value_node) */
+int chgpu_expr_precompile(const chgpu_expr * expr, uint32_t n_outputs, const uint32_t * out_nodes, int filter_node, int value_node,
+                          uint64_t * code_bytes_out);
+/* materialise out_nodes[n_outputs] (<= 8) as new columns over cols[n_cols] (the INPUT nodes' columns, all of one length) */
+int chgpu_expr_execute(chgpu_ctx * ctx, const chgpu_expr * expr, uint32_t n_cols, const chgpu_col * const * cols,
+                       uint32_t n_outputs, const uint32_t * out_nodes, chgpu_col ** outs);
+/* SELECT sum(value_node), count() WHERE filter_node in one pass, nothing materialised (filter_node < 0: no WHERE;
+   value_node < 0: count only).  sum_out: 8 bytes of the SumSimple type of the value node (*result_type_out). */
+int chgpu_expr_filter_sum_node(chgpu_ctx * ctx, const chgpu_expr * expr, uint32_t n_cols, const chgpu_col * const * cols,
+                               int filter_node, int value_node, int * result_type_out, void * sum_out, uint64_t * count_out);
+int chgpu_expr_free(chgpu_expr * expr);
+
 /* ================================================================================================
  * a22 data movement  —  IColumn::index / replicate (src/Columns/ColumnVector.cpp:1121-1143, 879-907)
  * ============================================================================================== */

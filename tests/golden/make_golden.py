@@ -84,6 +84,34 @@ def main():
     with open(os.path.join(HERE, "hash_kat.json"), "w") as f:
         json.dump(dict(source="src/Common/HashTable/Hash.h compiled in place (oracle/ref_hash_wrapper.cpp)", kat=kat), f, indent=1)
     print("wrote", os.path.join(HERE, "sql_reference_rows.json"), "and hash_kat.json")
+    make_cmp_kat(ref_root)
+
+
+def make_cmp_kat(ref_root):
+    """accurate comparison known answers: 00411_long_accurate_number_comparison_float.  Every query line compares one
+    integer with one Float64 literal as `i op f` and `f op i` (op in =, !=, <, <=, >, >=), first with the bare integer
+    literal and then through every toUInt8 ... toInt64 cast the value fits; the .reference holds the 12 answers per form.
+    Stored: the two literals, the integer types in query order, the answers.  (No SQL text is stored.)"""
+    import re
+    base = os.path.join(ref_root, "tests/queries/0_stateless", "00411_long_accurate_number_comparison_float")
+    with open(base + ".sql") as f:
+        queries = [l for l in f if l.startswith("SELECT")]
+    with open(base + ".reference") as f:
+        answers = [l.rstrip("\n").split("\t") for l in f if l.strip()]
+    assert len(queries) == len(answers)
+    cases = []
+    for q, a in zip(queries, answers):
+        types = []
+        for t in re.findall(r"to(U?Int\d+)\(", q):
+            if t not in types:
+                types.append(t)
+        res = [int(x) for x in a[2:]]
+        assert len(res) == 12 * (1 + len(types)), (a[0], a[1], len(res), types)
+        cases.append(dict(int=a[0], float=a[1], types=["literal"] + types, answers=[res[k * 12:(k + 1) * 12] for k in range(1 + len(types))]))
+    with open(os.path.join(HERE, "expr_cmp_kat.json"), "w") as f:
+        json.dump(dict(source="tests/queries/0_stateless/00411_long_accurate_number_comparison_float.{sql,reference}",
+                       order="i=f i!=f i<f i<=f i>f i>=f f=i f!=i f<i f<=i f>i f>=i", cases=cases), f)
+    print("wrote expr_cmp_kat.json:", len(cases), "cases")
 
 
 if __name__ == "__main__":
