@@ -104,3 +104,120 @@ extern "C" int chgpu_unpack_fixed_key(chgpu_ctx * ctx, const chgpu_col * packed_
     *out_col = out;
     return CHGPU_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// SURVEY §8(f) rank 2 — LowCardinality keys.  A ColumnLowCardinality is a dictionary plus an index column
+// (src/Columns/ColumnLowCardinality.h:27-69); every Block may bring its own dictionary.  The reference's
+// low_cardinality_key* aggregation methods (AggregatedDataVariants.h:119-127) look each DICTIONARY entry up once per block
+// and then walk the rows through a per-position cache (HashMethodSingleLowCardinalityColumn, ColumnsHashing.h:82-260:
+// mapped_cache[row]).  Here the host resolves the block's dictionary against the query-wide one (a few thousand entries,
+// low_cardinality_max_dictionary_size = 8192) and the rows are translated on the device:
+//   k_lc_remap<I>   out[i] = remap[indexes[i]]   — the mapped_cache walk; the table sits in LDS when it fits
+// Streaming geometry: 16 input bytes per lane (16 / 8 / 4 / 2 rows), table lookups from LDS, 16-byte stores.
+// Algorithmic bytes: sizeof(I) + 4 per row.  Out-of-range indexes (a caller bug) read entry 0 instead of faulting.
+// ---------------------------------------------------------------------------------------------
+static constexpr u32 LC_LDS_ENTRIES = 32768; // 128 KiB of UInt32 ids
+
+// VEC: the index column's first row is 16-byte aligned (vector body + scalar tail); otherwise one row per lane throughout
+template <typename I, bool IN_LDS, bool VEC>
+__global__ __launch_bounds__(256) void k_lc_remap(const I * __restrict__ idx, u64 n, const u32 * __restrict__ remap, u32 dict_size, u32 * __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lc_tab[];
+    if constexpr (IN_LDS)
+    {
+        for (u32 k = threadIdx.x; k < dict_size; k += 256)
+            lc_tab[k] = remap[k];
+        __syncthreads();
+    }
+    auto look = [&](u64 j) -> u32 {
+        const u32 k = j < dict_size ? (u32)j : 0u;
+        if constexpr (IN_LDS)
+            return lc_tab[k];
+        else
+            return remap[k];
+    };
+    constexpr u32 R = 16 / sizeof(I); // rows per lane per vector
+    const u64 stride = (u64)gridDim.x * 256;
+    u64 done = 0;
+    if constexpr (VEC && R >= 4)
+    {
+        typedef I vin __attribute__((ext_vector_type(R)));
+        typedef u32 v4u __attribute__((ext_vector_type(4)));
+        const u64 nvec = n / R;
+        for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride)
+        {
+            const vin x = __builtin_nontemporal_load((const vin *)idx + v);
+#pragma unroll
+            for (u32 q = 0; q < R; q += 4)
+            {
+                v4u o;
+                o.x = look((u64)x[q]), o.y = look((u64)x[q + 1]), o.z = look((u64)x[q + 2]), o.w = look((u64)x[q + 3]);
+                *((v4u *)out + v * (R / 4) + q / 4) = o; // result columns are 64-byte aligned
+            }
+        }
+        done = nvec * R;
+    }
+    for (u64 i = done + (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        out[i] = look((u64)idx[i]);
+}
+
+template <typename I>
+static int lc_launch(chgpu_ctx * ctx, const chgpu_col * indexes, const u32 * rm, u32 dict, u32 * o)
+{
+    const u64 n = indexes->rows;
+    const bool in_lds = dict <= LC_LDS_ENTRIES;
+    const size_t lds = in_lds ? (size_t)((dict + 3) & ~3u) * 4 : 0;
+    const bool vec = ((uintptr_t)indexes->data & 15) == 0 && sizeof(I) <= 4;
+    const u32 per_cu = lds > 64 * 1024 ? 1 : lds > 32 * 1024 ? 2 : 4; // LDS bounds the residency
+    const u64 items = vec ? (n + 16 / sizeof(I) - 1) / (16 / sizeof(I)) : n;
+    const u32 grid = chgpu_grid_for(ctx, items, 256, per_cu);
+    const I * ip = (const I *)indexes->data;
+#define LC_GO(L, V)                                                                                                                   \
+    do                                                                                                                                \
+    {                                                                                                                                 \
+        if (lds > 64 * 1024)                                                                                                          \
+            CHGPU_HIP(hipFuncSetAttribute((const void *)k_lc_remap<I, L, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_lc_remap<I, L, V>), dim3(grid), dim3(256), lds, ctx->stream, ip, n, rm, dict, o);                      \
+    } while (0)
+    if (in_lds && vec) LC_GO(true, true);
+    else if (in_lds) LC_GO(true, false);
+    else if (vec) LC_GO(false, true);
+    else LC_GO(false, false);
+#undef LC_GO
+    ctx->counters[6] += 1;
+    CHGPU_HIP(hipGetLastError());
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_lc_remap(chgpu_ctx * ctx, const chgpu_col * indexes, const chgpu_col * remap_u32, chgpu_col ** out_u32)
+{
+    CHGPU_REQUIRE(ctx && indexes && remap_u32 && out_u32, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(remap_u32->type == CHGPU_U32, CHGPU_ERR_BAD_ARGUMENTS, "the remap table must be UInt32");
+    CHGPU_REQUIRE(indexes->type == CHGPU_U8 || indexes->type == CHGPU_U16 || indexes->type == CHGPU_U32 || indexes->type == CHGPU_U64,
+                  CHGPU_ERR_BAD_ARGUMENTS, "LowCardinality indexes are UInt8 / UInt16 / UInt32 / UInt64 (ColumnLowCardinality.h Index)");
+    CHGPU_REQUIRE(remap_u32->rows > 0 || indexes->rows == 0, CHGPU_ERR_BAD_ARGUMENTS, "empty dictionary");
+    CHGPU_REQUIRE(remap_u32->rows < (1ull << 32), CHGPU_ERR_BAD_ARGUMENTS, "dictionary of 2^32 entries");
+    chgpu_col * res = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U32, indexes->rows, &res));
+    int rc = CHGPU_OK;
+    if (indexes->rows)
+    {
+        const u32 * rm = (const u32 *)remap_u32->data;
+        const u32 dict = (u32)remap_u32->rows;
+        u32 * o = (u32 *)res->data;
+        switch (indexes->type)
+        {
+            case CHGPU_U8: rc = lc_launch<u8>(ctx, indexes, rm, dict, o); break;
+            case CHGPU_U16: rc = lc_launch<u16>(ctx, indexes, rm, dict, o); break;
+            case CHGPU_U32: rc = lc_launch<u32>(ctx, indexes, rm, dict, o); break;
+            default: rc = lc_launch<u64>(ctx, indexes, rm, dict, o); break;
+        }
+    }
+    if (rc != CHGPU_OK)
+    {
+        chgpu_col_free(res);
+        return rc;
+    }
+    *out_u32 = res;
+    return CHGPU_OK;
+}

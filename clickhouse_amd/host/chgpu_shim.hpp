@@ -11,6 +11,9 @@
 //                               ISimpleTransform.h:42
 //   FilterTransform             src/Processors/Transforms/FilterTransform.cpp:136-256   chgpu::GpuFilterTransform
 //   IFunction (less, ...)       src/Functions/IFunction.h:426-434              chgpu::FunctionComparisonConst
+//   ActionsDAG / ExpressionActions  src/Interpreters/ActionsDAG.h, ExpressionActions.h:75-134   chgpu::ActionsDAG, chgpu::ExpressionActions (run-time compiled)
+//   ExpressionTransform         src/Processors/Transforms/ExpressionTransform.cpp:22-30      chgpu::GpuExpressionTransform, GpuExpressionFilterTransform
+//   ColumnLowCardinality + low_cardinality_key* methods   src/Columns/ColumnLowCardinality.h:27-69, ColumnsHashing.h:82-260   chgpu::ColumnLowCardinality, LowCardinalityDictionary
 //   IAggregateFunction          src/AggregateFunctions/IAggregateFunction.h:55-399      chgpu::AggregateDescription (closed POD set)
 //   Aggregator                  src/Interpreters/Aggregator.h:179-265          chgpu::GpuAggregator
 //   AggregatingTransform        src/Processors/Transforms/AggregatingTransform.cpp:640-840   chgpu::GpuAggregatingTransform
@@ -30,6 +33,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -307,6 +311,211 @@ protected:
 private:
     size_t filter_arg_position;
     FunctionComparisonConst predicate;
+};
+
+/// ActionsDAG (src/Interpreters/ActionsDAG.h): INPUT / COLUMN (constant) / FUNCTION nodes under the reference's function
+/// names; compile() is ExpressionActions' constructor (ExpressionActions.cpp:71-110) plus the run-time compiler the reference
+/// runs under compile_expressions (src/Interpreters/JIT/compileFunction.cpp): the whole DAG becomes one kernel.
+class ActionsDAG
+{
+public:
+    using Node = uint32_t;
+    Node addInput(size_t position, int type)
+    {
+        chgpu_expr_node n{CHGPU_EX_INPUT, static_cast<int32_t>(position), type, {-1, -1, -1}, 0};
+        nodes.push_back(n);
+        return static_cast<Node>(nodes.size() - 1);
+    }
+    template <typename T>
+    Node addColumn(T constant)
+    {
+        chgpu_expr_node n{CHGPU_EX_CONST, 0, TypeTag<T>::value, {-1, -1, -1}, 0};
+        std::memcpy(&n.bits, &constant, sizeof(T));
+        nodes.push_back(n);
+        return static_cast<Node>(nodes.size() - 1);
+    }
+    Node addFunction(const std::string & name, std::initializer_list<Node> args)
+    {
+        chgpu_expr_node n{CHGPU_EX_FUNC, functionCode(name), 0, {-1, -1, -1}, 0};
+        size_t j = 0;
+        for (Node a : args)
+            n.args[j++] = static_cast<int32_t>(a);
+        nodes.push_back(n);
+        return static_cast<Node>(nodes.size() - 1);
+    }
+    /// FunctionFactory::get(name): unknown names are the caller's cue to keep its CPU actions
+    static int functionCode(const std::string & name)
+    {
+        static const std::pair<const char *, int> table[] = {
+            {"equals", CHGPU_FN_EQUALS}, {"notEquals", CHGPU_FN_NOT_EQUALS}, {"less", CHGPU_FN_LESS}, {"greater", CHGPU_FN_GREATER},
+            {"lessOrEquals", CHGPU_FN_LESS_OR_EQUALS}, {"greaterOrEquals", CHGPU_FN_GREATER_OR_EQUALS}, {"plus", CHGPU_FN_PLUS},
+            {"minus", CHGPU_FN_MINUS}, {"multiply", CHGPU_FN_MULTIPLY}, {"divide", CHGPU_FN_DIVIDE}, {"negate", CHGPU_FN_NEGATE},
+            {"and", CHGPU_FN_AND}, {"or", CHGPU_FN_OR}, {"xor", CHGPU_FN_XOR}, {"not", CHGPU_FN_NOT}, {"if", CHGPU_FN_IF},
+            {"bitAnd", CHGPU_FN_BIT_AND}, {"bitOr", CHGPU_FN_BIT_OR}, {"bitXor", CHGPU_FN_BIT_XOR}, {"toYear", CHGPU_FN_TO_YEAR},
+            {"toMonth", CHGPU_FN_TO_MONTH}, {"toDayOfMonth", CHGPU_FN_TO_DAY_OF_MONTH}, {"toYYYYMM", CHGPU_FN_TO_YYYYMM},
+            {"toInt64", CHGPU_FN_CAST + CHGPU_I64}, {"toUInt64", CHGPU_FN_CAST + CHGPU_U64}, {"toInt32", CHGPU_FN_CAST + CHGPU_I32},
+            {"toUInt32", CHGPU_FN_CAST + CHGPU_U32}, {"toInt16", CHGPU_FN_CAST + CHGPU_I16}, {"toUInt16", CHGPU_FN_CAST + CHGPU_U16},
+            {"toInt8", CHGPU_FN_CAST + CHGPU_I8}, {"toUInt8", CHGPU_FN_CAST + CHGPU_U8}, {"toFloat64", CHGPU_FN_CAST + CHGPU_F64},
+            {"toFloat32", CHGPU_FN_CAST + CHGPU_F32}};
+        for (const auto & e : table)
+            if (name == e.first)
+                return e.second;
+        throw Exception(CHGPU_ERR_NOT_IMPLEMENTED, "Unknown function " + name);
+    }
+    std::vector<chgpu_expr_node> nodes;
+};
+
+/// ExpressionActions (ExpressionActions.h:75-134): execute(Block &) appends the result columns of the requested nodes.
+class ExpressionActions
+{
+public:
+    explicit ExpressionActions(const ActionsDAG & dag) { check(chgpu_expr_compile(static_cast<uint32_t>(dag.nodes.size()), dag.nodes.data(), &h)); }
+    ~ExpressionActions() { chgpu_expr_free(h); }
+    ExpressionActions(const ExpressionActions &) = delete;
+    int resultType(ActionsDAG::Node node) const
+    {
+        int t = 0;
+        check(chgpu_expr_node_type(h, node, &t));
+        return t;
+    }
+    /// columns[position] feeds INPUT(position); one new column per entry of `outputs`
+    Columns execute(const Columns & columns, const std::vector<ActionsDAG::Node> & outputs) const
+    {
+        std::vector<const chgpu_col *> in;
+        ContextPtr ctx;
+        for (auto & c : columns)
+        {
+            in.push_back(c ? c->handle() : nullptr);
+            if (c && !ctx)
+                ctx = c->context();
+        }
+        std::vector<chgpu_col *> out(outputs.size(), nullptr);
+        check(chgpu_expr_execute(ctx->get(), h, static_cast<uint32_t>(in.size()), in.data(), static_cast<uint32_t>(outputs.size()), outputs.data(), out.data()));
+        Columns res;
+        for (chgpu_col * o : out)
+            res.push_back(std::make_shared<ColumnVector>(ctx, o));
+        return res;
+    }
+    /// SELECT sum(value), count() WHERE filter over one chunk, nothing materialised; returns the raw 8 state bytes and the count
+    std::pair<uint64_t, uint64_t> filterSum(const Columns & columns, int filter_node, int value_node, int * result_type = nullptr) const
+    {
+        std::vector<const chgpu_col *> in;
+        ContextPtr ctx;
+        for (auto & c : columns)
+        {
+            in.push_back(c ? c->handle() : nullptr);
+            if (c && !ctx)
+                ctx = c->context();
+        }
+        uint64_t bits = 0, count = 0;
+        check(chgpu_expr_filter_sum_node(ctx->get(), h, static_cast<uint32_t>(in.size()), in.data(), filter_node, value_node, result_type, &bits, &count));
+        return {bits, count};
+    }
+
+private:
+    chgpu_expr * h = nullptr;
+};
+
+/// ExpressionTransform (src/Processors/Transforms/ExpressionTransform.cpp:22-30): the chunk gains the result columns.
+class GpuExpressionTransform : public ISimpleTransform
+{
+public:
+    GpuExpressionTransform(std::shared_ptr<const ExpressionActions> actions_, std::vector<ActionsDAG::Node> outputs_)
+        : actions(std::move(actions_)), outputs(std::move(outputs_)) {}
+    std::string getName() const override { return "GpuExpressionTransform"; }
+
+protected:
+    void transform(Chunk & chunk) override
+    {
+        for (auto & c : actions->execute(chunk.columns, outputs))
+            chunk.columns.push_back(std::move(c));
+    }
+
+private:
+    std::shared_ptr<const ExpressionActions> actions;
+    std::vector<ActionsDAG::Node> outputs;
+};
+
+/// FilterTransform with a whole WHERE expression (FilterTransform.cpp:136-256): the DAG's filter node is evaluated by one
+/// kernel into the UInt8 filter column, then the chunk's columns are filtered as in GpuFilterTransform.
+class GpuExpressionFilterTransform : public ISimpleTransform
+{
+public:
+    GpuExpressionFilterTransform(std::shared_ptr<const ExpressionActions> actions_, ActionsDAG::Node filter_node_)
+        : actions(std::move(actions_)), filter_node(filter_node_) {}
+    std::string getName() const override { return "GpuExpressionFilterTransform"; }
+    uint64_t passed_rows = 0;
+
+protected:
+    void transform(Chunk & chunk) override
+    {
+        auto mask = actions->execute(chunk.columns, {filter_node}).at(0);
+        uint64_t kept = 0;
+        check(chgpu_count_bytes_in_filter(mask->context()->get(), mask->handle(), &kept));
+        if (kept == 0)
+        {
+            chunk.clear();
+            return;
+        }
+        passed_rows += kept;
+        if (kept == chunk.num_rows)
+            return;
+        filterColumns(chunk.columns, *mask, static_cast<ssize_t>(kept));
+        chunk.num_rows = kept;
+    }
+
+private:
+    std::shared_ptr<const ExpressionActions> actions;
+    ActionsDAG::Node filter_node;
+};
+
+/// ColumnLowCardinality (src/Columns/ColumnLowCardinality.h:27-69): the dictionary stays on the host (a few thousand values,
+/// low_cardinality_max_dictionary_size = 8192), the index column lives in HBM.
+struct ColumnLowCardinality
+{
+    std::shared_ptr<const std::vector<std::string>> dictionary; // position -> value (ColumnUnique's nested column)
+    ColumnPtr indexes;                                          // UInt8 / UInt16 / UInt32 / UInt64
+};
+
+/// The query-wide dictionary of one LowCardinality key: what the low_cardinality_key* aggregation methods
+/// (AggregatedDataVariants.h:119-127) achieve by emplacing each Block's dictionary entries once and walking the rows through
+/// HashMethodSingleLowCardinalityColumn's per-position cache (ColumnsHashing.h:82-260).  mapBlock() returns an ordinary UInt32
+/// key column (dense global ids) for GpuAggregator / GpuHashJoin; decode() turns result keys back into values.
+class LowCardinalityDictionary
+{
+public:
+    explicit LowCardinalityDictionary(ContextPtr ctx_) : ctx(std::move(ctx_)) {}
+    ColumnPtr mapBlock(const ColumnLowCardinality & col)
+    {
+        if (col.dictionary != cached_dictionary) // Blocks of one part share their dictionary: resolve it once
+        {
+            std::vector<uint32_t> remap(col.dictionary->size());
+            for (size_t pos = 0; pos < remap.size(); ++pos)
+            {
+                auto it = ids.find((*col.dictionary)[pos]);
+                if (it == ids.end())
+                {
+                    it = ids.emplace((*col.dictionary)[pos], static_cast<uint32_t>(values.size())).first;
+                    values.push_back((*col.dictionary)[pos]);
+                }
+                remap[pos] = it->second;
+            }
+            cached_remap = ColumnVector::fromHost<uint32_t>(ctx, remap.data(), remap.size());
+            cached_dictionary = col.dictionary;
+        }
+        chgpu_col * out = nullptr;
+        check(chgpu_lc_remap(ctx->get(), col.indexes->handle(), cached_remap->handle(), &out));
+        return std::make_shared<ColumnVector>(ctx, out);
+    }
+    const std::string & decode(uint32_t id) const { return values.at(id); }
+    size_t size() const { return values.size(); }
+
+private:
+    ContextPtr ctx;
+    std::vector<std::string> values;
+    std::unordered_map<std::string, uint32_t> ids;
+    std::shared_ptr<const std::vector<std::string>> cached_dictionary;
+    ColumnPtr cached_remap;
 };
 
 /// AggregateDescription (src/Interpreters/AggregateDescription.h): function + argument position.

@@ -164,6 +164,81 @@ int main(int argc, char ** argv)
         }
         REQUIRE(got_rows == want_rows && got_chk == want_chk);
 
+        // ---- WHERE a < thr AND k % ... as an expression DAG: ExpressionActions compiled at run time into one kernel --------
+        {
+            ActionsDAG dag;
+            auto ia = dag.addInput(0, CHGPU_I64), ik = dag.addInput(1, CHGPU_U32);
+            auto p = dag.addFunction("and", {dag.addFunction("less", {ia, dag.addColumn<int64_t>(thr)}),
+                                             dag.addFunction("greaterOrEquals", {ik, dag.addColumn<uint16_t>(500)})});
+            auto v = dag.addFunction("minus", {dag.addFunction("multiply", {ia, ik}), dag.addColumn<uint8_t>(7)});
+            auto actions = std::make_shared<ExpressionActions>(dag);
+            REQUIRE(actions->resultType(p) == CHGPU_U8 && actions->resultType(v) == CHGPU_I64);
+            uint64_t ws = 0, wc = 0;
+            for (size_t i = 0; i < n; ++i)
+                if (a[i] < thr && k[i] >= 500)
+                {
+                    ws += static_cast<uint64_t>(a[i]) * k[i] - 7;
+                    ++wc;
+                }
+            int rt = -1;
+            auto fused = actions->filterSum(stripe.columns, static_cast<int>(p), static_cast<int>(v), &rt); // one pass, nothing materialised
+            REQUIRE(rt == CHGPU_I64 && fused.first == ws && fused.second == wc);
+            // the same through the processors: ExpressionTransform appends v, FilterTransform on the DAG's filter node, sum
+            GpuExpressionTransform project(actions, {v});
+            GpuExpressionFilterTransform where(actions, p);
+            auto ag = std::make_shared<GpuAggregator>(ctx, -1, std::vector<AggregateDescription>{{CHGPU_AGG_SUM, CHGPU_I64, 2}, {CHGPU_AGG_COUNT, CHGPU_U64, 0}});
+            GpuAggregatingTransform at(ag, std::nullopt);
+            project.setInput(stripe);
+            project.work();
+            where.setInput(project.pullOutput());
+            where.work();
+            if (where.hasOutput())
+                at.consume(where.pullOutput());
+            Chunk r = at.generate();
+            REQUIRE(static_cast<uint64_t>(r.columns[0]->getData<int64_t>()[0]) == ws && r.columns[1]->getData<uint64_t>()[0] == wc);
+            REQUIRE(where.passed_rows == wc);
+            bool unknown = false;
+            try { dag.addFunction("cityHash64", {ia}); } catch (const Exception & e) { unknown = e.isNotImplemented(); }
+            REQUIRE(unknown);
+        }
+
+        // ---- GROUP BY a LowCardinality(String) key: two Blocks with different dictionaries ------------------------------
+        {
+            auto d1 = std::make_shared<const std::vector<std::string>>(std::vector<std::string>{"ASIA", "EUROPE", "AFRICA"});
+            auto d2 = std::make_shared<const std::vector<std::string>>(std::vector<std::string>{"EUROPE", "AMERICA", "ASIA"});
+            const size_t m = 100003;
+            std::vector<uint8_t> i1(m), i2(m);
+            std::vector<int64_t> v1(m), v2(m);
+            std::map<std::string, std::pair<int64_t, uint64_t>> want_lc;
+            uint64_t y = 2463534242ull;
+            for (size_t i = 0; i < m; ++i)
+            {
+                y ^= y << 13; y ^= y >> 7; y ^= y << 17;
+                i1[i] = static_cast<uint8_t>(y % 3), i2[i] = static_cast<uint8_t>((y >> 20) % 3);
+                v1[i] = static_cast<int64_t>((y >> 8) % 1000), v2[i] = -static_cast<int64_t>((y >> 30) % 777);
+                auto & w1 = want_lc[(*d1)[i1[i]]];
+                w1.first += v1[i], ++w1.second;
+                auto & w2 = want_lc[(*d2)[i2[i]]];
+                w2.first += v2[i], ++w2.second;
+            }
+            LowCardinalityDictionary dict(ctx);
+            GpuAggregator lc_agg(ctx, CHGPU_U32, {{CHGPU_AGG_SUM, CHGPU_I64, 1}, {CHGPU_AGG_COUNT, CHGPU_U64, 0}});
+            Columns b1 = {dict.mapBlock({d1, ColumnVector::fromHost<uint8_t>(ctx, i1.data(), m)}), ColumnVector::fromHost<int64_t>(ctx, v1.data(), m)};
+            Columns b2 = {dict.mapBlock({d2, ColumnVector::fromHost<uint8_t>(ctx, i2.data(), m)}), ColumnVector::fromHost<int64_t>(ctx, v2.data(), m)};
+            lc_agg.executeOnBlock(b1, 0, m, 0);
+            lc_agg.executeOnBlock(b2, 0, m, 0);
+            Chunk r = lc_agg.convertToBlock();
+            auto ids = r.columns[0]->getData<uint32_t>();
+            auto sums = r.columns[1]->getData<int64_t>();
+            auto cnts = r.columns[2]->getData<uint64_t>();
+            REQUIRE(ids.size() == want_lc.size() && dict.size() == 4);
+            for (size_t g = 0; g < ids.size(); ++g)
+            {
+                const auto & w = want_lc.at(dict.decode(ids[g]));
+                REQUIRE(sums[g] == w.first && cnts[g] == w.second);
+            }
+        }
+
         // ---- threading contract: work() of different processors runs concurrently, each thread with its own Context ----
         {
             std::atomic<int> bad{0};

@@ -1,0 +1,116 @@
+"""LowCardinality keys: ColumnLowCardinality = dictionary + index column
+(src/Columns/ColumnLowCardinality.h:27-69), each Block with its own dictionary.
+
+The reference's low_cardinality_key* aggregation methods (AggregatedDataVariants.h:119-127) resolve every dictionary entry
+once per block and walk the rows through a per-position cache (HashMethodSingleLowCardinalityColumn,
+ColumnsHashing.h:82-260).  Here `LowCardinalityDictionary` is that resolution on the host — the block's few thousand
+dictionary entries against the query-wide dictionary — and `chgpu_lc_remap` walks the rows on the device, producing an
+ordinary UInt32 key column for GROUP BY / join / sharding.  Strings never reach the device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as K
+from .aggregator import Aggregator
+from .columns import Column, Context
+
+
+class ColumnLowCardinality:
+    """dictionary: sequence of values (str / bytes / numbers), position -> value; indexes: UInt8/16/32/64 Column in HBM"""
+
+    def __init__(self, dictionary, indexes: Column):
+        self.dictionary = list(dictionary)
+        self.indexes = indexes
+
+    def size(self) -> int:
+        return self.indexes.size()
+
+    @staticmethod
+    def from_values(ctx: Context, values, index_dtype=None) -> "ColumnLowCardinality":
+        """Build from a full host column (IColumn -> ColumnLowCardinality::insertRangeFromFullColumn): dictionary in order of
+        first appearance, the narrowest index type that holds it (ColumnLowCardinality::Index::check / expandType)."""
+        values = np.asarray(values)
+        uniq, first, inv = np.unique(values, return_index=True, return_inverse=True)
+        order = np.argsort(first, kind="stable")
+        rank = np.empty_like(order)
+        rank[order] = np.arange(order.shape[0])
+        d = uniq[order].tolist()
+        if index_dtype is None:
+            index_dtype = np.uint8 if len(d) <= 2**8 else np.uint16 if len(d) <= 2**16 else np.uint32
+        return ColumnLowCardinality(d, ctx.upload(rank[inv].astype(index_dtype)))
+
+    def filter(self, filt: Column) -> "ColumnLowCardinality":
+        """ColumnLowCardinality::filter: the indexes are filtered, the dictionary is shared"""
+        return ColumnLowCardinality(self.dictionary, self.indexes.filter(filt))
+
+    def cut(self, start: int, length: int) -> "ColumnLowCardinality":
+        return ColumnLowCardinality(self.dictionary, self.indexes.cut(start, length))
+
+    def convert_to_full_column(self) -> list:
+        """convertToFullColumn (:53) on the host, for tests"""
+        idx = self.indexes.numpy()
+        return [self.dictionary[int(i)] for i in idx]
+
+
+class LowCardinalityDictionary:
+    """The query-wide dictionary: value -> global id (insertion order; ids are dense, so they are also ideal GROUP BY keys
+    for the LDS-staged RANGE strategy)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.values = []
+        self._ids = {}
+        self._cache = {}  # id(block dictionary list) -> (len, remap Column): Blocks of one part share their dictionary
+
+    def __len__(self):
+        return len(self.values)
+
+    def remap_table(self, dictionary) -> Column:
+        key = id(dictionary)
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] is dictionary:
+            return hit[1]
+        out = np.empty(len(dictionary), dtype=np.uint32)
+        for pos, v in enumerate(dictionary):
+            g = self._ids.get(v)
+            if g is None:
+                g = len(self.values)
+                self._ids[v] = g
+                self.values.append(v)
+            out[pos] = g
+        col = self.ctx.upload(out)
+        self._cache[key] = (dictionary, col)  # keeps the list alive: id() stays unique
+        return col
+
+    def map_block(self, col: ColumnLowCardinality) -> Column:
+        """-> UInt32 Column of global ids, one per row"""
+        remap = self.remap_table(col.dictionary)
+        h = C.c_void_p()
+        K.check(K.lib().chgpu_lc_remap(self.ctx._h, col.indexes._h, remap._h, C.byref(h)))
+        return Column(self.ctx, h)
+
+    def decode(self, ids: np.ndarray) -> list:
+        return [self.values[int(i)] for i in ids]
+
+
+class LowCardinalityAggregator:
+    """Aggregator over one LowCardinality key column (the low_cardinality_key_string variant): same interface as Aggregator,
+    keys come back as dictionary values."""
+
+    def __init__(self, aggs, ctx: Context | None = None, size_hint: int = 0):
+        self.ctx = ctx if ctx is not None else Context(0)
+        self.dictionary = LowCardinalityDictionary(self.ctx)
+        self.agg = Aggregator(np.uint32, aggs, size_hint=size_hint, ctx=self.ctx)
+
+    def execute_on_block(self, keys: ColumnLowCardinality, args, row_begin: int = 0, row_end: int | None = None, filter=None):
+        self.agg.execute_on_block(self.dictionary.map_block(keys), args, row_begin, row_end, filter=filter)
+
+    def __len__(self):
+        return len(self.agg)
+
+    def convert_to_block(self):
+        ids, res = self.agg.convert_to_block()
+        return self.dictionary.decode(ids), res

@@ -274,6 +274,12 @@ int chgpu_partition_by_hash(chgpu_ctx * ctx, const chgpu_col * keys, uint32_t nu
    inverse used when the key column(s) of the result block are produced (insertKeyIntoColumns). */
 int chgpu_pack_fixed_keys(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, chgpu_col ** packed_u64);
 int chgpu_unpack_fixed_key(chgpu_ctx * ctx, const chgpu_col * packed_u64, uint32_t byte_offset, int type, chgpu_col ** out);
+/* §8(f) rank 2 — LowCardinality keys (src/Columns/ColumnLowCardinality.h:27-69; low_cardinality_key* variants,
+   AggregatedDataVariants.h:119-127; HashMethodSingleLowCardinalityColumn's per-position cache, ColumnsHashing.h:82-260).
+   Every Block brings its own dictionary; the host resolves it against the query-wide dictionary into remap_u32[local position]
+   = global id, and the rows are translated on the device: out_u32[i] = remap_u32[indexes[i]] (indexes: UInt8/16/32/64).
+   The result is an ordinary UInt32 key column for chgpu_agg_* / chgpu_join_* / chgpu_hash_to_selector. */
+int chgpu_lc_remap(chgpu_ctx * ctx, const chgpu_col * indexes, const chgpu_col * remap_u32, chgpu_col ** out_u32);
 int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, const int * agg_kinds, const int * arg_types,
                      uint64_t size_hint, chgpu_agg ** out);
 /* executeOnBlock over rows [row_begin,row_end) of the key column and the argument columns (arg_cols[j] may be NULL

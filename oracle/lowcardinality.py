@@ -1,0 +1,35 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement of GROUP BY over a LowCardinality key column.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+
+The low_cardinality_key* variants (src/Interpreters/AggregatedDataVariants.h:119-127) aggregate by the dictionary VALUE a
+row's index points at: HashMethodSingleLowCardinalityColumn (src/Common/ColumnsHashing.h:82-260) emplaces
+dictionary[index[row]] (through its per-position cache), so rows of different Blocks whose dictionaries hold the same value
+at different positions meet in one group, and the result key column holds each value once.  Restated with a plain Python
+dict over the converted-to-full column (ColumnLowCardinality::convertToFullColumn, ColumnLowCardinality.h:53).
+Parity pinning: the group set and sums are order-free facts of the inputs; no reference vector is needed beyond the
+GROUP BY semantics already pinned in tests/golden/sql_reference_rows.json.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def convert_to_full(dictionary, indexes):
+    return [dictionary[int(i)] for i in indexes]
+
+
+def group_by_sum_count(blocks):
+    """blocks: iterable of (dictionary, indexes ndarray, values ndarray[int64] or None) -> {key value: (sum mod 2^64 as int64, count)}"""
+    out = {}
+    for dictionary, indexes, values in blocks:
+        n = len(indexes)
+        vals = np.zeros(n, dtype=np.int64) if values is None else np.asarray(values)
+        sums = np.zeros(len(dictionary), dtype=np.uint64)
+        cnts = np.zeros(len(dictionary), dtype=np.uint64)
+        np.add.at(sums, indexes.astype(np.int64), vals.astype(np.int64).view(np.uint64))
+        np.add.at(cnts, indexes.astype(np.int64), 1)
+        for pos in np.nonzero(cnts)[0]:
+            k = dictionary[int(pos)]
+            s, c = out.get(k, (np.uint64(0), 0))
+            out[k] = (np.uint64((int(s) + int(sums[pos])) & (2**64 - 1)), c + int(cnts[pos]))
+    return {k: (int(np.array([s], dtype=np.uint64).view(np.int64)[0]), c) for k, (s, c) in out.items()}

@@ -1,0 +1,88 @@
+"""GROUP BY over LowCardinality(String) keys — per-Block dictionaries resolved against a query-wide
+dictionary on the host, rows translated on the device (k_lc_remap), then the ordinary UInt32 GROUP BY."""
+import numpy as np
+import pytest
+
+from oracle import lowcardinality as OL
+
+
+def _blocks(rng, n_blocks, rows, n_values, index_dtype):
+    """Blocks whose dictionaries are different subsets / orders of one value universe"""
+    universe = [f"value-{i:06d}" for i in range(n_values)]
+    out = []
+    for b in range(n_blocks):
+        size = int(rng.integers(max(1, n_values // 2), n_values + 1))
+        d = [universe[i] for i in rng.permutation(n_values)[:size]]
+        idx = rng.integers(0, size, size=rows).astype(index_dtype)
+        vals = rng.integers(-2**40, 2**40, size=rows, dtype=np.int64)
+        out.append((d, idx, vals))
+    return out
+
+
+def test_oracle_groups_by_value_across_block_dictionaries():
+    b1 = (["ASIA", "EUROPE", "AFRICA"], np.array([0, 1, 1, 2], dtype=np.uint8), np.array([1, 10, 100, 1000], dtype=np.int64))
+    b2 = (["EUROPE", "AMERICA", "ASIA"], np.array([0, 2, 1, 2], dtype=np.uint8), np.array([5, 7, -3, 2**63 - 1], dtype=np.int64))
+    got = OL.group_by_sum_count([b1, b2])
+    assert got == {"ASIA": (1 + 7 + 2**63 - 1 - 2**64, 3), "EUROPE": (115, 3), "AFRICA": (1000, 1), "AMERICA": (-3, 1)}
+    assert OL.convert_to_full(b1[0], b1[1]) == ["ASIA", "EUROPE", "EUROPE", "AFRICA"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("index_dtype,n_values,rows", [(np.uint8, 200, 100_003), (np.uint16, 5000, 300_001), (np.uint32, 40_000, 250_000),
+                                                         (np.uint64, 300, 70_001), (np.uint16, 25, 1_000_003)])
+def test_gpu_lowcardinality_group_by_matches_oracle(index_dtype, n_values, rows):
+    import clickhouse_amd as ch
+    from clickhouse_amd.lowcardinality import ColumnLowCardinality, LowCardinalityAggregator
+    rng = np.random.Generator(np.random.PCG64(rows))
+    ctx = ch.Context()
+    blocks = _blocks(rng, 4, rows, n_values, index_dtype)
+    agg = LowCardinalityAggregator([(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], ctx=ctx)
+    for d, idx, vals in blocks:
+        agg.execute_on_block(ColumnLowCardinality(d, ctx.upload(idx)), [ctx.upload(vals), None])
+    keys, (sums, cnts) = agg.convert_to_block()
+    want = OL.group_by_sum_count(blocks)
+    assert len(keys) == len(set(keys)) == len(want) == len(agg)
+    assert {k: (int(s), int(c)) for k, s, c in zip(keys, sums, cnts)} == want
+
+
+@pytest.mark.gpu
+def test_gpu_lc_remap_views_tails_and_big_dictionaries():
+    import clickhouse_amd as ch
+    from clickhouse_amd.lowcardinality import ColumnLowCardinality, LowCardinalityDictionary
+    rng = np.random.Generator(np.random.PCG64(99))
+    ctx = ch.Context()
+    for index_dtype, dict_size in [(np.uint8, 256), (np.uint16, 65_536), (np.uint32, 100_000), (np.uint32, 7), (np.uint64, 33_000)]:
+        d = [int(x) for x in rng.permutation(dict_size)]  # numeric dictionary values: the remap is a permutation
+        gd = LowCardinalityDictionary(ctx)
+        for n in (0, 1, 15, 16, 17, 4097, 200_003):
+            idx = rng.integers(0, dict_size, size=n + 3).astype(index_dtype)
+            col = ctx.upload(idx)
+            for start in (0, 1, 3):  # unaligned views
+                got = gd.map_block(ColumnLowCardinality(d, col.cut(start, n))).numpy()
+                ids = np.array([gd._ids[v] for v in d], dtype=np.uint32)
+                assert got.dtype == np.uint32 and np.array_equal(got, ids[idx[start:start + n].astype(np.int64)])
+        assert len(gd) == dict_size
+
+
+@pytest.mark.gpu
+def test_gpu_lowcardinality_with_where_mask_and_filtered_column():
+    import clickhouse_amd as ch
+    from clickhouse_amd.lowcardinality import ColumnLowCardinality, LowCardinalityAggregator
+    rng = np.random.Generator(np.random.PCG64(5))
+    ctx = ch.Context()
+    n = 400_001
+    nations = ["ALGERIA", "ARGENTINA", "BRAZIL", "CANADA", "EGYPT", "ETHIOPIA", "FRANCE", "GERMANY", "INDIA", "INDONESIA"]
+    lc = ColumnLowCardinality.from_values(ctx, np.array(nations)[rng.integers(0, 10, size=n)])
+    full = np.array(lc.convert_to_full_column())
+    v = rng.integers(0, 1000, size=n, dtype=np.int64)
+    mask = (v % 3 == 0).astype(np.uint8)
+    # (a) WHERE fused into the aggregation  (b) ColumnLowCardinality::filter first
+    a = LowCardinalityAggregator([(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], ctx=ctx)
+    a.execute_on_block(lc, [ctx.upload(v), None], filter=ctx.upload(mask))
+    b = LowCardinalityAggregator([(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], ctx=ctx)
+    m = ctx.upload(mask)
+    b.execute_on_block(lc.filter(m), [ctx.upload(v).filter(m), None])
+    want = {k: (int(v[(full == k) & (mask != 0)].sum()), int(((full == k) & (mask != 0)).sum())) for k in nations}
+    for agg in (a, b):
+        keys, (sums, cnts) = agg.convert_to_block()
+        assert {k: (int(s), int(c)) for k, s, c in zip(keys, sums, cnts)} == want
