@@ -67,6 +67,7 @@ SIGNATURES = {
     "chgpu_expr_free": (_i, [_vp]),
     "chgpu_index": (_i, [_vp, _vp, _vp, _u64, _i, _pp]),
     "chgpu_replicate": (_i, [_vp, _vp, _vp, _pp]),
+    "chgpu_sort_permutation": (_i, [_vp, _vp, _vp, _i, _i, _pp]),
     "chgpu_weak_hash32": (_i, [_vp, _vp, _vp]),
     "chgpu_hash_to_selector": (_i, [_vp, _vp, _u32, _pp]),
     "chgpu_scatter": (_i, [_vp, _vp, _vp, _u32, _pp]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "chgpu_agg_size": (_i, [_vp, _pu64]),
     "chgpu_agg_finalize": (_i, [_vp, _pp, _pp, _pu64]),
     "chgpu_agg_export_states": (_i, [_vp, _pp, _pp, _pu64]),
+    "chgpu_agg_export_states_two_level": (_i, [_vp, _pp, _pp, _pu64, _pu64]),
     "chgpu_agg_free": (_i, [_vp]),
     "chgpu_join_create": (_i, [_vp, _i, _i, _i, _i, _u64, _pp]),
     "chgpu_join_add_block": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_u32)]),

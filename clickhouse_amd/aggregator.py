@@ -89,6 +89,16 @@ class Aggregator:
         keys = Column(self.ctx, kh) if kh.value else None
         return keys, [Column(self.ctx, C.c_void_p(res[w])) for w in range(nw)], int(n.value)
 
+    def export_state_columns_two_level(self):
+        """the partial states ordered by two-level bucket number -> (keys, [state Columns], groups, bucket_counts[256])"""
+        kh = C.c_void_p()
+        nw = self.n_words
+        res = (C.c_void_p * max(1, nw))()
+        n = C.c_uint64(0)
+        counts = (C.c_uint64 * 256)()
+        K.check(K.lib().chgpu_agg_export_states_two_level(self._h, C.byref(kh), res, C.byref(n), counts))
+        return Column(self.ctx, kh), [Column(self.ctx, C.c_void_p(res[w])) for w in range(nw)], int(n.value), [int(x) for x in counts]
+
     def convert_to_block(self):
         """Aggregator::convertToBlocks(final=true) downloaded: (keys ndarray or None, [result ndarrays])."""
         keys, res = self.finalize_columns()

@@ -314,6 +314,26 @@ def expr_filter_sum(cols, preds, value_op: int, val_a: int, val_b: int = 0):
     return out.view(NP_OF[rt.value])[0], int(cnt.value)
 
 
+def sort_permutation(col: Column, perm_in: Column | None = None, descending: bool = False, nan_direction_hint: int = 1) -> Column:
+    """IColumn::getPermutation(direction, Stable, 0, nan_direction_hint) -> UInt64 permutation Column; perm_in composes a previous
+    (less significant) sort: ORDER BY a, b == sort_permutation(a, perm_in=sort_permutation(b))"""
+    h = C.c_void_p()
+    K.check(K.lib().chgpu_sort_permutation(col.ctx._h, col._h, perm_in._h if perm_in is not None else None, 1 if descending else 0,
+                                           nan_direction_hint, C.byref(h)))
+    return Column(col.ctx, h)
+
+
+def sort_block(columns, description, limit: int = 0):
+    """sortBlock (src/Interpreters/sortBlock.cpp): description = [(position, descending, nan_direction_hint), ...] most significant
+    first; every column of the block permuted (IColumn::permute == index), cut to `limit` rows when given."""
+    perm = None
+    for pos, desc, hint in reversed(list(description)):
+        perm = sort_permutation(columns[pos], perm, desc, hint)
+    if limit:
+        perm = perm.cut(0, min(limit, perm.size()))
+    return [c.index(perm) for c in columns], perm
+
+
 def concat(cols) -> Column:
     """glue columns of one type end to end (right-side Blocks -> one payload column)"""
     n = len(cols)

@@ -2280,6 +2280,48 @@ extern "C" int chgpu_agg_export_states(chgpu_agg * a, chgpu_col ** keys_out, chg
     return agg_export(a, keys_out, state_cols, groups);
 }
 
+// Two-level form of the partial states: rows ordered by the reference's bucket number, so that block b of a CPU initiator's
+// MergingAggregatedMemoryEfficientTransform is a row range.  (The device table itself stays single-level)
+extern "C" int chgpu_agg_export_states_two_level(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** state_cols, uint64_t * groups, uint64_t * bucket_counts)
+{
+    CHGPU_REQUIRE(a && keys_out && state_cols && groups && bucket_counts, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(a->key_type >= 0, CHGPU_ERR_BAD_ARGUMENTS, "an aggregation without key has no buckets");
+    chgpu_col * keys = nullptr;
+    chgpu_col * words[AGG_MAX_WORDS] = {nullptr};
+    u64 n = 0;
+    CHGPU_TRY(agg_export(a, &keys, words, &n));
+    const u32 nw = a->n_words;
+    chgpu_col * sorted[AGG_MAX_WORDS + 1] = {nullptr};
+    int rc = CHGPU_OK;
+    // <= 8 columns per partition call; the key column rides in the first
+    for (u32 lo = 0; lo < nw + 1 && rc == CHGPU_OK; lo += 8)
+    {
+        const chgpu_col * in[8];
+        chgpu_col * out[8] = {nullptr};
+        u32 k = 0;
+        for (u32 c = lo; c < nw + 1 && k < 8; ++c, ++k)
+            in[k] = c == 0 ? keys : words[c - 1];
+        rc = chgpu_partition_by_hash(a->ctx, keys, 256, k, in, out, bucket_counts);
+        for (u32 j = 0; j < k && rc == CHGPU_OK; ++j)
+            sorted[lo + j] = out[j];
+    }
+    chgpu_col_free(keys);
+    for (u32 w = 0; w < nw; ++w)
+        chgpu_col_free(words[w]);
+    if (rc != CHGPU_OK)
+    {
+        for (u32 c = 0; c < nw + 1; ++c)
+            if (sorted[c])
+                chgpu_col_free(sorted[c]);
+        return rc;
+    }
+    *keys_out = sorted[0];
+    for (u32 w = 0; w < nw; ++w)
+        state_cols[w] = sorted[w + 1];
+    *groups = n;
+    return CHGPU_OK;
+}
+
 extern "C" int chgpu_agg_finalize(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** res_cols, uint64_t * groups)
 {
     CHGPU_REQUIRE(a && res_cols && groups, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");

@@ -200,7 +200,7 @@ extern "C" int chgpu_hash_to_selector(chgpu_ctx * ctx, const chgpu_col * keys, u
 }
 
 // Stable split of n_cols columns by `sel` into concatenated outputs; counts[num_shards] on the host.
-static int partition_core(chgpu_ctx * ctx, const u32 * sel, u64 n, u32 num_shards, u32 n_cols, const chgpu_col * const * cols,
+int chgpu_partition_core(chgpu_ctx * ctx, const u32 * sel, u64 n, u32 num_shards, u32 n_cols, const chgpu_col * const * cols,
                           chgpu_col ** outs, u64 * counts)
 {
     CHGPU_REQUIRE(n_cols >= 1 && n_cols <= MAX_PART_COLS, CHGPU_ERR_NOT_IMPLEMENTED, "at most %u columns per partition call", MAX_PART_COLS);
@@ -278,7 +278,7 @@ extern "C" int chgpu_partition_by_hash(chgpu_ctx * ctx, const chgpu_col * keys, 
     CHGPU_TRY(check_shards(num_shards));
     chgpu_col * sel = nullptr;
     CHGPU_TRY(chgpu_hash_to_selector(ctx, keys, num_shards, &sel));
-    int rc = partition_core(ctx, (const u32 *)sel->data, keys->rows, num_shards, n_cols, cols, outs, counts);
+    int rc = chgpu_partition_core(ctx, (const u32 *)sel->data, keys->rows, num_shards, n_cols, cols, outs, counts);
     chgpu_col_free(sel); // back to the pool; reuse is ordered behind the kernels above on this stream
     return rc;
 }
@@ -297,7 +297,7 @@ extern "C" int chgpu_scatter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu
     chgpu_col * cat = nullptr;
     u64 counts[MAX_SHARDS];
     const chgpu_col * in[1] = {col};
-    CHGPU_TRY(partition_core(ctx, (const u32 *)selector->data, col->rows, shards_p2, 1, in, &cat, counts));
+    CHGPU_TRY(chgpu_partition_core(ctx, (const u32 *)selector->data, col->rows, shards_p2, 1, in, &cat, counts));
     // hand the concatenated buffer out as num_columns columns sharing one allocation
     int * refs = new int(0);
     u64 pos = 0;

@@ -1,0 +1,148 @@
+// sort_kernels.hip — SURVEY §8(f) rank 4: ordered output.  IColumn::getPermutation for ColumnVector<T>
+// (src/Columns/ColumnVector.cpp:245-330) — the step under sortBlock / MergeSortingTransform / PartialSortingTransform
+// (src/Interpreters/sortBlock.cpp, src/Processors/Transforms/MergeSortingTransform.cpp) — as an LSD radix sort on the device.
+//
+// The reference already radix-sorts here (RadixSort<RadixSortTraits<T>>::executeLSD, ColumnVector.cpp:294-316) but only for the
+// cases its CPU radix sort handles (not stable-descending, not stable floats) and falls back to comparison sorts otherwise;
+// this path is one algorithm for every case, with the STABLE semantics of less_stable / greater_stable (:120-166): equal values —
+// including -0.0 == 0.0 and NaN with NaN — keep their original order, in both directions.  NaN placement follows
+// CompareHelper (nan_direction_hint > 0: NaN greater than every number, < 0: smaller; ColumnVector.h FloatCompareHelper).
+//   k_sort_keys     value -> order-preserving unsigned key of the same width (sign flip; IEEE total-order fold with -0.0 and NaN
+//                   canonicalised; bitwise complement for descending), optionally gathered through an incoming permutation
+//                   (ORDER BY a, b = sort by b, then stably by a), and the initial permutation
+//   k_digit_sel     8-bit digit of the key -> selector
+//   chgpu_partition_core (partition_kernels.hip): stable 256-way split of (key, permutation) by the digit — one pass per key byte
+// Algorithmic bytes: per pass (sizeof(key) + 8) read and written, sizeof(T) passes.
+#include "chgpu_internal.h"
+
+template <typename T>
+struct SortKey;
+template <> struct SortKey<u8> { typedef u8 K; static __device__ K key(u8 v, int) { return v; } };
+template <> struct SortKey<u16> { typedef u16 K; static __device__ K key(u16 v, int) { return v; } };
+template <> struct SortKey<u32> { typedef u32 K; static __device__ K key(u32 v, int) { return v; } };
+template <> struct SortKey<u64> { typedef u64 K; static __device__ K key(u64 v, int) { return v; } };
+template <> struct SortKey<i8> { typedef u8 K; static __device__ K key(i8 v, int) { return (u8)v ^ 0x80u; } };
+template <> struct SortKey<i16> { typedef u16 K; static __device__ K key(i16 v, int) { return (u16)v ^ 0x8000u; } };
+template <> struct SortKey<i32> { typedef u32 K; static __device__ K key(i32 v, int) { return (u32)v ^ 0x80000000u; } };
+template <> struct SortKey<i64> { typedef u64 K; static __device__ K key(i64 v, int) { return (u64)v ^ 0x8000000000000000ull; } };
+template <> struct SortKey<float>
+{
+    typedef u32 K;
+    static __device__ K key(float v, int nan_hint)
+    {
+        if (v != v)
+            return nan_hint > 0 ? 0xFFFFFFFFu : 0u;
+        if (v == 0.0f)
+            v = 0.0f; // -0.0 == 0.0 (less_stable compares with ==)
+        const u32 b = __float_as_uint(v);
+        const u32 k = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+        // keep the extremes free for NaN: -inf folds to 0x007FFFFF, +inf to 0xFF800000 -- neither is 0 nor all-ones
+        return k;
+    }
+};
+template <> struct SortKey<double>
+{
+    typedef u64 K;
+    static __device__ K key(double v, int nan_hint)
+    {
+        if (v != v)
+            return nan_hint > 0 ? ~0ull : 0ull;
+        if (v == 0.0)
+            v = 0.0;
+        const u64 b = (u64)__double_as_longlong(v);
+        return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_sort_keys(const T * __restrict__ data, u64 rows, const u64 * __restrict__ perm_in, u64 n, int descending, int nan_hint,
+                                                   typename SortKey<T>::K * __restrict__ keys, u64 * __restrict__ perm)
+{
+    typedef typename SortKey<T>::K K;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        u64 src = perm_in ? perm_in[i] : i;
+        if (src >= rows)
+            src = 0; // a caller bug in the reference too (no bounds check in IColumn::permute); no fault here
+        K k = SortKey<T>::key(data[src], nan_hint);
+        keys[i] = descending ? (K)~k : k;
+        perm[i] = src;
+    }
+}
+
+template <typename K>
+__global__ __launch_bounds__(256) void k_digit_sel(const K * __restrict__ keys, u64 n, u32 shift, u32 * __restrict__ sel)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+        sel[i] = (u32)(keys[i] >> shift) & 0xFFu;
+}
+
+template <typename T>
+static int sort_impl(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * perm_in, int descending, int nan_hint, chgpu_col ** perm_out)
+{
+    typedef typename SortKey<T>::K K;
+    const u64 n = perm_in ? perm_in->rows : col->rows;
+    constexpr int key_type = sizeof(K) == 8 ? CHGPU_U64 : sizeof(K) == 4 ? CHGPU_U32 : sizeof(K) == 2 ? CHGPU_U16 : CHGPU_U8;
+    chgpu_col * keys = nullptr, * perm = nullptr, * sel = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, key_type, n, &keys));
+    int rc = chgpu_col_new(ctx, CHGPU_U64, n, &perm);
+    if (rc == CHGPU_OK)
+        rc = chgpu_col_new(ctx, CHGPU_U32, n, &sel);
+    if (rc == CHGPU_OK && n)
+    {
+        const u32 grid = chgpu_grid_for(ctx, n, 256, 8);
+        hipLaunchKernelGGL(k_sort_keys<T>, dim3(grid), dim3(256), 0, ctx->stream, (const T *)col->data, (u64)col->rows,
+                           perm_in ? (const u64 *)perm_in->data : nullptr, n, descending, nan_hint, (K *)keys->data, (u64 *)perm->data);
+        ctx->counters[6] += 1;
+        for (u32 pass = 0; pass < sizeof(K) && rc == CHGPU_OK; ++pass)
+        {
+            hipLaunchKernelGGL(k_digit_sel<K>, dim3(grid), dim3(256), 0, ctx->stream, (const K *)keys->data, n, pass * 8, (u32 *)sel->data);
+            ctx->counters[6] += 1;
+            const chgpu_col * in[2] = {keys, perm};
+            chgpu_col * out[2] = {nullptr, nullptr};
+            u64 counts[256];
+            rc = chgpu_partition_core(ctx, (const u32 *)sel->data, n, 256, 2, in, out, counts);
+            if (rc == CHGPU_OK)
+            {
+                chgpu_col_free(keys);
+                chgpu_col_free(perm);
+                keys = out[0], perm = out[1];
+            }
+        }
+    }
+    if (keys)
+        chgpu_col_free(keys);
+    if (sel)
+        chgpu_col_free(sel);
+    if (rc != CHGPU_OK)
+    {
+        if (perm)
+            chgpu_col_free(perm);
+        return rc;
+    }
+    *perm_out = perm;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_sort_permutation(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * perm_in_u64, int descending, int nan_direction_hint,
+                                      chgpu_col ** perm_out_u64)
+{
+    CHGPU_REQUIRE(ctx && col && perm_out_u64, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(!perm_in_u64 || perm_in_u64->type == CHGPU_U64, CHGPU_ERR_BAD_ARGUMENTS, "a permutation is a UInt64 column (IColumn::Permutation)");
+    CHGPU_REQUIRE(!perm_in_u64 || perm_in_u64->rows <= col->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of permutation (%llu) is greater than the column (%llu)",
+                  (unsigned long long)(perm_in_u64 ? perm_in_u64->rows : 0), (unsigned long long)col->rows);
+    switch (col->type)
+    {
+        case CHGPU_I64: return sort_impl<i64>(ctx, col, perm_in_u64, descending, nan_direction_hint, perm_out_u64);
+        case CHGPU_U64: return sort_impl<u64>(ctx, col, perm_in_u64, descending, nan_direction_hint, perm_out_u64);
+        case CHGPU_I32: return sort_impl<i32>(ctx, col, perm_in_u64, descending, nan_direction_hint, perm_out_u64);
+        case CHGPU_U32: return sort_impl<u32>(ctx, col, perm_in_u64, descending, nan_direction_hint, perm_out_u64);
+        case CHGPU_I16: return sort_impl<i16>(ctx, col, perm_in_u64, descending, nan_direction_hint, perm_out_u64);
+        case CHGPU_U16: return sort_impl<u16>(ctx, col, perm_in_u64, descending, nan_direction_hint, perm_out_u64);
+        case CHGPU_I8: return sort_impl<i8>(ctx, col, perm_in_u64, descending, nan_direction_hint, perm_out_u64);
+        case CHGPU_U8: return sort_impl<u8>(ctx, col, perm_in_u64, descending, nan_direction_hint, perm_out_u64);
+        case CHGPU_F64: return sort_impl<double>(ctx, col, perm_in_u64, descending, nan_direction_hint, perm_out_u64);
+        case CHGPU_F32: return sort_impl<float>(ctx, col, perm_in_u64, descending, nan_direction_hint, perm_out_u64);
+        default: return chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "unsupported column type");
+    }
+}

@@ -241,6 +241,15 @@ int chgpu_index(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * indexe
 /* offsets: CHGPU_U64 cumulative (IColumn::Offsets) */
 int chgpu_replicate(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * offsets_u64, chgpu_col ** out);
 
+/* §8(f) rank 4 — ordered output: IColumn::getPermutation(direction, Stable, limit = 0, nan_direction_hint, res) for
+   ColumnVector<T> (src/Columns/ColumnVector.cpp:245-330), the step under sortBlock / MergeSortingTransform.  LSD radix sort on
+   the device with the stable semantics of less_stable / greater_stable (:120-166): equal values (-0.0 == 0.0, NaN with NaN) keep
+   their original order in both directions; NaN is greater than every number when nan_direction_hint > 0, smaller otherwise.
+   perm_in_u64 (may be NULL): sort the rows col[perm_in[i]] instead and return the composed permutation -- ORDER BY a, b is
+   sort by b, then by a with b's permutation as perm_in.  Apply the result with chgpu_index (IColumn::permute), cut it for LIMIT. */
+int chgpu_sort_permutation(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * perm_in_u64, int descending,
+                           int nan_direction_hint, chgpu_col ** perm_out_u64);
+
 /* ================================================================================================
  * a11/a21 hashing & sharding  —  ColumnVector::getWeakHash32 (ColumnVector.cpp:78-95), ConcurrentHashJoin
  * hashToSelector (src/Interpreters/ConcurrentHashJoin.cpp:426-440), IColumn::scatter (src/Columns/IColumn.cpp:245-269).
@@ -304,6 +313,12 @@ int chgpu_agg_size(chgpu_agg * agg, uint64_t * groups);
 int chgpu_agg_finalize(chgpu_agg * agg, chgpu_col ** keys_out, chgpu_col ** res_cols, uint64_t * groups);
 /* convertToBlockImplNotFinal: raw states (sum/count 8 B; avg -> numerator, denominator as two columns) */
 int chgpu_agg_export_states(chgpu_agg * agg, chgpu_col ** keys_out, chgpu_col ** state_cols, uint64_t * groups);
+/* convertToBlockImplNotFinal for a two-level result (Aggregator::prepareBlocksAndFillTwoLevelImpl, Aggregator.cpp:2790-2860): the
+   same states ordered by bucket = (crc32c(key) >> 24) & 0xFF (TwoLevelHashTable.h:53 getBucketFromHash over HashCRC32<Key>,
+   Hash.h:280-288), bucket_counts[256] rows each -- bucket b is rows [sum(counts[:b]), +counts[b]): the 256 blocks with
+   BlockInfo::bucket_num (src/Core/BlockInfo.h:21-29) a CPU initiator's MergingAggregatedMemoryEfficientTransform expects. */
+int chgpu_agg_export_states_two_level(chgpu_agg * agg, chgpu_col ** keys_out, chgpu_col ** state_cols, uint64_t * groups,
+                                      uint64_t * bucket_counts);
 int chgpu_agg_free(chgpu_agg * agg);
 
 /* ================================================================================================
