@@ -136,6 +136,7 @@ int chgpu_scan_exclusive_u32_u64(chgpu_ctx * ctx, const u32 * in, u64 * out, u64
 int chgpu_scan_inclusive_u32_u64(chgpu_ctx * ctx, const u32 * in, u64 * out, u64 n, u64 * total_dev, void * tmp, size_t tmp_bytes);
 size_t chgpu_scan_tmp_bytes(u64 n);
 // stable split of n_cols columns by sel[i] < num_shards (<= 256) into concatenated outputs (partition_kernels.hip); counts[num_shards] on the host
+int chgpu_partition_by_key_byte(chgpu_ctx * ctx, const chgpu_col * keys, u32 shift, u32 n_cols, const chgpu_col * const * cols, chgpu_col ** outs);
 int chgpu_partition_core(chgpu_ctx * ctx, const u32 * sel, u64 n, u32 num_shards, u32 n_cols, const chgpu_col * const * cols, chgpu_col ** outs, u64 * counts);
 
 // ---------------------------------------------------------------------------------------------

@@ -13,9 +13,17 @@
 // wave ballots, so each shard's rows keep their input order exactly like the reference's sequential insertFrom loop.
 #include "chgpu_internal.h"
 
+#include <algorithm>
+
 static constexpr u32 PT = 256;
 static constexpr u32 MAX_SHARDS = 256;
 static constexpr u32 MAX_PART_COLS = 8;
+
+static u32 tune_env_part(const char * name, u32 dflt)
+{
+    const char * v = getenv(name);
+    return v ? (u32)atoi(v) : dflt;
+}
 
 __device__ __forceinline__ u64 pload_key(const void * keys, int type, u64 i)
 {
@@ -146,6 +154,203 @@ __global__ __launch_bounds__(PT) void k_part_scatter(const u32 * __restrict__ se
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-staged stable partition (the default).  The wave-per-tile kernel above writes every row to its own destination
+// line (64 scattered 4-8 byte stores per wave instruction) and is bound by the rate of partial-line writes; here a
+// workgroup sorts a tile of PL_TILE rows by shard in LDS and writes each shard's run with consecutive lanes on consecutive
+// addresses.  Stability: rows are taken wave-striped (step j of wave w covers 64 consecutive rows), a row's rank inside
+// its wave = the wave's running per-shard counter + the number of lower lanes of this step with the same shard (per-bit
+// ballots), and waves are ordered by an exclusive prefix over their per-shard totals.
+// The shard of a row comes from a UInt32 selector column or, for the radix sort, straight from a key byte (SelSrc).
+// ---------------------------------------------------------------------------------------------
+struct SelSrc
+{
+    const void * p;
+    u32 mode;  // 0: UInt32 selector column; 1/2/4/8: key column of that many bytes, shard = (key >> shift) & 0xFF
+    u32 shift;
+};
+__device__ __forceinline__ u32 sel_at(const SelSrc & s, u64 i, u32 num_shards)
+{
+    u32 v;
+    switch (s.mode)
+    {
+        case 0: v = ((const u32 *)s.p)[i]; break;
+        case 1: v = ((const u8 *)s.p)[i]; break;
+        case 2: v = (((const u16 *)s.p)[i] >> s.shift) & 0xFFu; break;
+        case 4: v = (((const u32 *)s.p)[i] >> s.shift) & 0xFFu; break;
+        default: v = (u32)(((const u64 *)s.p)[i] >> s.shift) & 0xFFu; break;
+    }
+    return v < num_shards ? v : 0; // a selector beyond the shard count is a caller bug: folded into shard 0
+}
+
+static constexpr u32 PL_RPT = 32;             // rows per thread
+static constexpr u32 PL_TILE = PT * PL_RPT;   // 8192 rows per workgroup tile
+static constexpr u32 PL_WAVE_ROWS = PL_TILE / (PT / 64);
+
+__global__ __launch_bounds__(PT) void k_part_hist_lds(SelSrc sel, u64 n, u32 num_shards, u64 n_tiles, u32 * __restrict__ counts)
+{
+    __shared__ u32 hist[MAX_SHARDS];
+    for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+    {
+        for (u32 s = threadIdx.x; s < num_shards; s += PT)
+            hist[s] = 0;
+        __syncthreads();
+        const u64 base = tile * PL_TILE;
+        u32 v[PL_RPT];
+#pragma unroll
+        for (u32 j = 0; j < PL_RPT; ++j)
+        {
+            const u64 i = base + (u64)j * PT + threadIdx.x;
+            v[j] = i < n ? sel_at(sel, i, num_shards) : ~0u;
+        }
+#pragma unroll
+        for (u32 j = 0; j < PL_RPT; ++j)
+            if (v[j] != ~0u)
+                atomicAdd(&hist[v[j]], 1u);
+        __syncthreads();
+        for (u32 s = threadIdx.x; s < num_shards; s += PT)
+            counts[(u64)s * n_tiles + tile] = hist[s];
+        __syncthreads();
+    }
+}
+
+// one column of the tile: rows (64 apart per step, from `src`) -> LDS at their destination position -> runs written with
+// consecutive lanes on consecutive addresses.  Loads go eight at a time (the whole 32 at once cost 256 VGPRs).
+template <typename T>
+__device__ __forceinline__ void part_move_column(const T * __restrict__ src, T * __restrict__ dst, const u32 (&pos)[PL_RPT], T * stage, const u8 * dig,
+                                                 const u64 * gdelta, u32 tile_rows)
+{
+#pragma unroll
+    for (u32 j0 = 0; j0 < PL_RPT; j0 += 8)
+    {
+        T v[8];
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q)
+            if (pos[j0 + q] != ~0u)
+                v[q] = src[(j0 + q) * 64];
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q)
+            if (pos[j0 + q] != ~0u)
+                stage[pos[j0 + q]] = v[q];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads(); // (first column: also publishes dig[])
+    for (u32 p = threadIdx.x; p < tile_rows; p += PT)
+        dst[gdelta[dig[p]] + p] = stage[p];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(PT) void k_part_scatter_lds(SelSrc sel, u64 n, u32 num_shards, u32 shard_bits, u64 n_tiles,
+                                                         const u64 * __restrict__ offsets, PartCols cols)
+{
+    __shared__ __attribute__((aligned(16))) u64 stage[PL_TILE]; // one column of the tile in destination order (64 KiB)
+    __shared__ u8 dig[PL_TILE];                                 // shard of the row at each destination position
+    __shared__ u32 wcnt[PT / 64][MAX_SHARDS];                   // per wave: running count, then exclusive prefix over waves
+    __shared__ u32 doff[MAX_SHARDS];                            // first position of each shard inside the sorted tile
+    __shared__ u64 gdelta[MAX_SHARDS];                          // global row of (shard, tile) minus doff
+    __shared__ u32 wave_sum[PT / 64];
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+    {
+        const u64 base = tile * PL_TILE;
+        const u32 tile_rows = (u32)(n - base < PL_TILE ? n - base : PL_TILE);
+        for (u32 s = threadIdx.x; s < (PT / 64) * MAX_SHARDS; s += PT)
+            (&wcnt[0][0])[s] = 0;
+        __syncthreads(); // also: the previous tile's write-out has finished with stage / dig / gdelta
+        // A. ranks inside the wave's 2048-row strip, 64 rows per step
+        u32 sr[PL_RPT]; // shard << 16 | rank in wave's strip   (rank < 2048)
+        u32 sv[PL_RPT];
+#pragma unroll
+        for (u32 j = 0; j < PL_RPT; ++j)
+        {
+            const u32 r = wave * PL_WAVE_ROWS + j * 64 + lane;
+            sv[j] = r < tile_rows ? sel_at(sel, base + r, num_shards) : ~0u;
+        }
+#pragma unroll
+        for (u32 j = 0; j < PL_RPT; ++j)
+        {
+            const bool in = sv[j] != ~0u;
+            const u32 s = in ? sv[j] : 0;
+            u64 peers = __ballot(in);
+            for (u32 b = 0; b < shard_bits; ++b)
+            {
+                const u64 bal = __ballot((s >> b) & 1);
+                peers &= ((s >> b) & 1) ? bal : ~bal;
+            }
+            const u32 before = mbcnt(peers);
+            u32 rank = 0;
+            if (in)
+                rank = wcnt[wave][s] + before; // LDS operations of one wave complete in order
+            __builtin_amdgcn_wave_barrier();
+            if (in && before == 0)
+                wcnt[wave][s] += (u32)__popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+            sr[j] = in ? ((s << 16) | rank) : ~0u;
+        }
+        __syncthreads();
+        // B. per shard: exclusive prefix over the waves, tile total; exclusive scan of the totals over the shards
+        {
+            const u32 d = threadIdx.x;
+            u32 tot = 0;
+            if (d < num_shards)
+            {
+#pragma unroll
+                for (u32 w = 0; w < PT / 64; ++w)
+                {
+                    const u32 c = wcnt[w][d];
+                    wcnt[w][d] = tot;
+                    tot += c;
+                }
+            }
+            u32 inc = tot;
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1)
+            {
+                const u32 o = __shfl_up(inc, dlt, WAVE);
+                if (lane >= (u32)dlt)
+                    inc += o;
+            }
+            if (lane == 63)
+                wave_sum[wave] = inc;
+            __syncthreads();
+            u32 ex = inc - tot;
+            for (u32 w = 0; w < wave; ++w)
+                ex += wave_sum[w];
+            if (d < num_shards)
+            {
+                doff[d] = ex;
+                gdelta[d] = offsets[(u64)d * n_tiles + tile] - ex;
+            }
+        }
+        __syncthreads();
+        // C. destination position of every row inside the sorted tile
+        u32 pos[PL_RPT];
+#pragma unroll
+        for (u32 j = 0; j < PL_RPT; ++j)
+        {
+            pos[j] = ~0u;
+            if (sr[j] != ~0u)
+            {
+                const u32 s = sr[j] >> 16;
+                pos[j] = doff[s] + wcnt[wave][s] + (sr[j] & 0xFFFFu);
+                dig[pos[j]] = (u8)s;
+            }
+        }
+        // D. column by column: rows -> LDS in destination order -> coalesced runs
+        for (u32 c = 0; c < cols.n_cols; ++c)
+        {
+            const u64 first = base + wave * PL_WAVE_ROWS + lane;
+            switch (cols.elem_size[c])
+            {
+                case 8: part_move_column<u64>((const u64 *)cols.src[c] + first, (u64 *)cols.dst[c], pos, (u64 *)stage, dig, gdelta, tile_rows); break;
+                case 4: part_move_column<u32>((const u32 *)cols.src[c] + first, (u32 *)cols.dst[c], pos, (u32 *)stage, dig, gdelta, tile_rows); break;
+                case 2: part_move_column<u16>((const u16 *)cols.src[c] + first, (u16 *)cols.dst[c], pos, (u16 *)stage, dig, gdelta, tile_rows); break;
+                default: part_move_column<u8>((const u8 *)cols.src[c] + first, (u8 *)cols.dst[c], pos, (u8 *)stage, dig, gdelta, tile_rows); break;
+            }
+        }
+    }
+}
+
 __global__ void k_part_shard_starts(const u64 * __restrict__ offsets, u64 n_tiles, u32 num_shards, u64 * __restrict__ starts)
 {
     const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -199,9 +404,10 @@ extern "C" int chgpu_hash_to_selector(chgpu_ctx * ctx, const chgpu_col * keys, u
     return CHGPU_OK;
 }
 
-// Stable split of n_cols columns by `sel` into concatenated outputs; counts[num_shards] on the host.
-int chgpu_partition_core(chgpu_ctx * ctx, const u32 * sel, u64 n, u32 num_shards, u32 n_cols, const chgpu_col * const * cols,
-                          chgpu_col ** outs, u64 * counts)
+// Stable split of n_cols columns by shard into concatenated outputs; counts[num_shards] on the host (counts == nullptr: no
+// read-back, no host synchronisation -- the radix sort's passes).
+static int partition_core_src(chgpu_ctx * ctx, SelSrc sel, u64 n, u32 num_shards, u32 n_cols, const chgpu_col * const * cols,
+                              chgpu_col ** outs, u64 * counts)
 {
     CHGPU_REQUIRE(n_cols >= 1 && n_cols <= MAX_PART_COLS, CHGPU_ERR_NOT_IMPLEMENTED, "at most %u columns per partition call", MAX_PART_COLS);
     for (u32 c = 0; c < n_cols; ++c)
@@ -211,9 +417,13 @@ int chgpu_partition_core(chgpu_ctx * ctx, const u32 * sel, u64 n, u32 num_shards
                       (unsigned long long)n, (unsigned long long)cols[c]->rows); // IColumn.cpp:249-251
         outs[c] = nullptr;
     }
+    static const bool old_kernels = tune_env_part("CHGPU_PART_OLD", 0) != 0; // A/B: the wave-per-tile kernels (selector column only)
+    const bool lds_path = !(old_kernels && sel.mode == 0);
     u32 tile_rows = 2048;
     if (tile_rows < num_shards * 64)
         tile_rows = num_shards * 64;
+    if (lds_path)
+        tile_rows = PL_TILE;
     const u64 n_tiles = (n + tile_rows - 1) / tile_rows;
     const u64 m = (u64)num_shards * (n_tiles ? n_tiles : 1);
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -237,16 +447,13 @@ int chgpu_partition_core(chgpu_ctx * ctx, const u32 * sel, u64 n, u32 num_shards
     }
     if (n == 0)
     {
-        memset(counts, 0, sizeof(u64) * num_shards);
+        if (counts)
+            memset(counts, 0, sizeof(u64) * num_shards);
         return CHGPU_OK;
     }
     u32 shard_bits = 0;
     while ((1u << shard_bits) < num_shards)
         ++shard_bits;
-    const u32 grid = chgpu_grid_for(ctx, n_tiles * 64, PT, 8);
-    hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(PT), 0, ctx->stream, sel, n, num_shards, tile_rows, n_tiles, cnt);
-    CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, cnt, offs, m, starts + num_shards, tmp, tmp_b));
-    hipLaunchKernelGGL(k_part_shard_starts, dim3((num_shards + 63) / 64), dim3(64), 0, ctx->stream, (const u64 *)offs, n_tiles, num_shards, starts);
     PartCols pc;
     pc.n_cols = n_cols;
     for (u32 c = 0; c < n_cols; ++c)
@@ -255,20 +462,50 @@ int chgpu_partition_core(chgpu_ctx * ctx, const u32 * sel, u64 n, u32 num_shards
         pc.src[c] = cols[c]->data;
         pc.dst[c] = outs[c]->data;
     }
-    hipLaunchKernelGGL(k_part_scatter, dim3(grid), dim3(PT), 0, ctx->stream, sel, n, num_shards, shard_bits, tile_rows, n_tiles, (const u64 *)offs, pc);
+    if (lds_path)
+    {
+        const u32 grid = (u32)std::min<u64>(n_tiles, (u64)ctx->num_cus * 2); // 79 KiB of LDS per workgroup: two per CU
+        hipLaunchKernelGGL(k_part_hist_lds, dim3((u32)std::min<u64>(n_tiles, (u64)ctx->num_cus * 8)), dim3(PT), 0, ctx->stream, sel, n, num_shards, n_tiles, cnt);
+        CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, cnt, offs, m, starts + num_shards, tmp, tmp_b));
+        hipLaunchKernelGGL(k_part_scatter_lds, dim3(grid), dim3(PT), 0, ctx->stream, sel, n, num_shards, shard_bits, n_tiles, (const u64 *)offs, pc);
+    }
+    else
+    {
+        const u32 grid = chgpu_grid_for(ctx, n_tiles * 64, PT, 8);
+        hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(PT), 0, ctx->stream, (const u32 *)sel.p, n, num_shards, tile_rows, n_tiles, cnt);
+        CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, cnt, offs, m, starts + num_shards, tmp, tmp_b));
+        hipLaunchKernelGGL(k_part_scatter, dim3(grid), dim3(PT), 0, ctx->stream, (const u32 *)sel.p, n, num_shards, shard_bits, tile_rows, n_tiles, (const u64 *)offs, pc);
+    }
     ctx->counters[6] += 3;
-    u64 host_starts[MAX_SHARDS + 1];
-    int rc = chgpu_read_back(ctx, starts, host_starts, sizeof(u64) * (num_shards + 1));
     hipError_t e = hipGetLastError();
+    int rc = CHGPU_OK;
+    if (counts)
+    {
+        hipLaunchKernelGGL(k_part_shard_starts, dim3((num_shards + 63) / 64), dim3(64), 0, ctx->stream, (const u64 *)offs, n_tiles, num_shards, starts);
+        u64 host_starts[MAX_SHARDS + 1];
+        rc = chgpu_read_back(ctx, starts, host_starts, sizeof(u64) * (num_shards + 1));
+        if (rc == CHGPU_OK)
+            for (u32 s = 0; s < num_shards; ++s)
+                counts[s] = (s + 1 < num_shards ? host_starts[s + 1] : host_starts[num_shards]) - host_starts[s];
+    }
     if (rc != CHGPU_OK || e != hipSuccess)
     {
         for (u32 c = 0; c < n_cols; ++c)
             chgpu_col_free(outs[c]);
         return rc != CHGPU_OK ? rc : chgpu_set_error(CHGPU_ERR_DEVICE, "partition launch: %s", hipGetErrorString(e));
     }
-    for (u32 s = 0; s < num_shards; ++s)
-        counts[s] = (s + 1 < num_shards ? host_starts[s + 1] : host_starts[num_shards]) - host_starts[s];
     return CHGPU_OK;
+}
+
+int chgpu_partition_core(chgpu_ctx * ctx, const u32 * sel, u64 n, u32 num_shards, u32 n_cols, const chgpu_col * const * cols, chgpu_col ** outs, u64 * counts)
+{
+    return partition_core_src(ctx, SelSrc{sel, 0, 0}, n, num_shards, n_cols, cols, outs, counts);
+}
+
+// one radix pass: stable 256-way split of cols[] by byte `shift / 8` of the key column (no selector column, no host synchronisation)
+int chgpu_partition_by_key_byte(chgpu_ctx * ctx, const chgpu_col * keys, u32 shift, u32 n_cols, const chgpu_col * const * cols, chgpu_col ** outs)
+{
+    return partition_core_src(ctx, SelSrc{keys->data, (u32)chgpu_type_size(keys->type), shift}, keys->rows, 256, n_cols, cols, outs, nullptr);
 }
 
 extern "C" int chgpu_partition_by_hash(chgpu_ctx * ctx, const chgpu_col * keys, uint32_t num_shards, uint32_t n_cols,

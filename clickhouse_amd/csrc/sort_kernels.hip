@@ -10,8 +10,8 @@
 //   k_sort_keys     value -> order-preserving unsigned key of the same width (sign flip; IEEE total-order fold with -0.0 and NaN
 //                   canonicalised; bitwise complement for descending), optionally gathered through an incoming permutation
 //                   (ORDER BY a, b = sort by b, then stably by a), and the initial permutation
-//   k_digit_sel     8-bit digit of the key -> selector
-//   chgpu_partition_core (partition_kernels.hip): stable 256-way split of (key, permutation) by the digit — one pass per key byte
+//   chgpu_partition_by_key_byte (partition_kernels.hip): LDS-staged stable 256-way split of (key, permutation) by one key byte per
+//                   pass; the digit is read straight from the key column, no selector column, no host synchronisation
 // Algorithmic bytes: per pass (sizeof(key) + 8) read and written, sizeof(T) passes.
 #include "chgpu_internal.h"
 
@@ -70,24 +70,15 @@ __global__ __launch_bounds__(256) void k_sort_keys(const T * __restrict__ data, 
     }
 }
 
-template <typename K>
-__global__ __launch_bounds__(256) void k_digit_sel(const K * __restrict__ keys, u64 n, u32 shift, u32 * __restrict__ sel)
-{
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
-        sel[i] = (u32)(keys[i] >> shift) & 0xFFu;
-}
-
 template <typename T>
 static int sort_impl(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * perm_in, int descending, int nan_hint, chgpu_col ** perm_out)
 {
     typedef typename SortKey<T>::K K;
     const u64 n = perm_in ? perm_in->rows : col->rows;
     constexpr int key_type = sizeof(K) == 8 ? CHGPU_U64 : sizeof(K) == 4 ? CHGPU_U32 : sizeof(K) == 2 ? CHGPU_U16 : CHGPU_U8;
-    chgpu_col * keys = nullptr, * perm = nullptr, * sel = nullptr;
+    chgpu_col * keys = nullptr, * perm = nullptr;
     CHGPU_TRY(chgpu_col_new(ctx, key_type, n, &keys));
     int rc = chgpu_col_new(ctx, CHGPU_U64, n, &perm);
-    if (rc == CHGPU_OK)
-        rc = chgpu_col_new(ctx, CHGPU_U32, n, &sel);
     if (rc == CHGPU_OK && n)
     {
         const u32 grid = chgpu_grid_for(ctx, n, 256, 8);
@@ -96,12 +87,9 @@ static int sort_impl(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * p
         ctx->counters[6] += 1;
         for (u32 pass = 0; pass < sizeof(K) && rc == CHGPU_OK; ++pass)
         {
-            hipLaunchKernelGGL(k_digit_sel<K>, dim3(grid), dim3(256), 0, ctx->stream, (const K *)keys->data, n, pass * 8, (u32 *)sel->data);
-            ctx->counters[6] += 1;
             const chgpu_col * in[2] = {keys, perm};
             chgpu_col * out[2] = {nullptr, nullptr};
-            u64 counts[256];
-            rc = chgpu_partition_core(ctx, (const u32 *)sel->data, n, 256, 2, in, out, counts);
+            rc = chgpu_partition_by_key_byte(ctx, keys, pass * 8, 2, in, out); // no host synchronisation between the passes
             if (rc == CHGPU_OK)
             {
                 chgpu_col_free(keys);
@@ -112,8 +100,6 @@ static int sort_impl(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * p
     }
     if (keys)
         chgpu_col_free(keys);
-    if (sel)
-        chgpu_col_free(sel);
     if (rc != CHGPU_OK)
     {
         if (perm)
