@@ -183,8 +183,11 @@ __device__ __forceinline__ u32 sel_at(const SelSrc & s, u64 i, u32 num_shards)
     return v < num_shards ? v : 0; // a selector beyond the shard count is a caller bug: folded into shard 0
 }
 
-static constexpr u32 PL_RPT = 32;             // rows per thread
-static constexpr u32 PL_TILE = PT * PL_RPT;   // 8192 rows per workgroup tile
+#ifndef PL_RPT_V
+#define PL_RPT_V 16
+#endif
+static constexpr u32 PL_RPT = PL_RPT_V;       // rows per thread
+static constexpr u32 PL_TILE = PT * PL_RPT;   // 4096 rows per workgroup tile (A/B on 1e8-row sorts: 16 rows/thread 13.1 ms, 32: 14.7 ms, 8: 14.1 ms)
 static constexpr u32 PL_WAVE_ROWS = PL_TILE / (PT / 64);
 
 __global__ __launch_bounds__(PT) void k_part_hist_lds(SelSrc sel, u64 n, u32 num_shards, u64 n_tiles, u32 * __restrict__ counts)
@@ -243,7 +246,7 @@ __device__ __forceinline__ void part_move_column(const T * __restrict__ src, T *
 __global__ __launch_bounds__(PT) void k_part_scatter_lds(SelSrc sel, u64 n, u32 num_shards, u32 shard_bits, u64 n_tiles,
                                                          const u64 * __restrict__ offsets, PartCols cols)
 {
-    __shared__ __attribute__((aligned(16))) u64 stage[PL_TILE]; // one column of the tile in destination order (64 KiB)
+    __shared__ __attribute__((aligned(16))) u64 stage[PL_TILE]; // one column of the tile in destination order (32 KiB)
     __shared__ u8 dig[PL_TILE];                                 // shard of the row at each destination position
     __shared__ u32 wcnt[PT / 64][MAX_SHARDS];                   // per wave: running count, then exclusive prefix over waves
     __shared__ u32 doff[MAX_SHARDS];                            // first position of each shard inside the sorted tile
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(PT) void k_part_scatter_lds(SelSrc sel, u64 n, u32 
         for (u32 s = threadIdx.x; s < (PT / 64) * MAX_SHARDS; s += PT)
             (&wcnt[0][0])[s] = 0;
         __syncthreads(); // also: the previous tile's write-out has finished with stage / dig / gdelta
-        // A. ranks inside the wave's 2048-row strip, 64 rows per step
+        // A. ranks inside the wave's strip of PL_WAVE_ROWS rows, 64 rows per step
         u32 sr[PL_RPT]; // shard << 16 | rank in wave's strip   (rank < 2048)
         u32 sv[PL_RPT];
 #pragma unroll
@@ -464,7 +467,8 @@ static int partition_core_src(chgpu_ctx * ctx, SelSrc sel, u64 n, u32 num_shards
     }
     if (lds_path)
     {
-        const u32 grid = (u32)std::min<u64>(n_tiles, (u64)ctx->num_cus * 2); // 79 KiB of LDS per workgroup: two per CU
+        constexpr u32 wg_per_cu = PL_RPT >= 32 ? 2 : PL_RPT >= 16 ? 3 : 5; // what LDS (9 B per tile row + 7 KiB) and the VGPR count allow
+        const u32 grid = (u32)std::min<u64>(n_tiles, (u64)ctx->num_cus * wg_per_cu);
         hipLaunchKernelGGL(k_part_hist_lds, dim3((u32)std::min<u64>(n_tiles, (u64)ctx->num_cus * 8)), dim3(PT), 0, ctx->stream, sel, n, num_shards, n_tiles, cnt);
         CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, cnt, offs, m, starts + num_shards, tmp, tmp_b));
         hipLaunchKernelGGL(k_part_scatter_lds, dim3(grid), dim3(PT), 0, ctx->stream, sel, n, num_shards, shard_bits, n_tiles, (const u64 *)offs, pc);

@@ -15,8 +15,8 @@ ALG = [
     ("k_count_nonzero", 1 * R, "countBytesInFilter (1 B/row; a 0.4 GB input at R = 4e8: ramp-up dominated)"),
     ("k_selector", 12 * R, "CRC32-C shard selector (8 B key in, 4 B out)"),
     ("k_weak_hash32", 16 * R, "getWeakHash32 (8 B key + 4 B hash in, 4 B out)"),
-    ("k_part_hist", 4 * R, "partition histogram (4 B selector)"),
-    ("k_part_scatter", 36 * R, "stable 8-way partition of 2 Int64 columns (4 + 2*(8+8) B/row)"),
+    ("k_part_hist_lds", 4 * R, "partition histogram (4 B selector)"),
+    ("k_part_scatter_lds", 36 * R, "stable 8-way partition of 2 Int64 columns, LDS-staged (4 + 2*(8+8) B/row)"),
     ("k_index<unsigned long, unsigned long>", (8 + 8 + 8) * (R // 4), "random gather of R/4 rows (8 idx + 8 data + 8 out)"),
     ("k_gb_hist_wide<unsigned int>", 4 * R, "GROUP BY partition histogram (4 B key)"),
     ("k_gb_scatter<12288u, unsigned int, true>", (12 + 12) * R, "GROUP BY partition scatter (12 B in, 12 B out)"),
