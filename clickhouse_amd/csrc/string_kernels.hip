@@ -1,0 +1,245 @@
+// string_kernels.hip — SURVEY §8(f) rank 2: String keys.  A ColumnString (src/Columns/ColumnString.h:40-49: `chars` with a
+// terminating zero after every value, `offsets[i]` = end of value i including that zero) is dictionary-encoded on the device:
+// every row gets the dense id of its value, ids numbered by first appearance — what ColumnUnique::uniqueInsertRangeFrom builds
+// when a String column is turned into a LowCardinality one (src/Columns/ColumnUnique.h:520-620), and what the reference's
+// key_string / StringHashMap aggregation (AggregatedDataVariants.h:96, Common/HashTable/StringHashTable.h) achieves per row with
+// a CPU hash table keyed by the bytes.  The ids then take the ordinary UInt32 GROUP BY / join path (through
+// LowCardinalityDictionary when several stripes or Blocks must agree on ids).
+//
+//   k_str_hash      64-bit hash of every value (8 bytes per step, unaligned loads inside the column's padding)
+//   k_str_insert    open-addressing table of hash tags; every row lowers `first_row` of its tag's cell (atomicMin): the
+//                   representative of a value is its FIRST row, independent of scheduling
+//   k_str_resolve   every row compares its bytes with its representative's (length + content): equal -> it belongs to that value;
+//                   different bytes under one 64-bit tag -> the collision flag (the call answers NOT_IMPLEMENTED: exactness is
+//                   never traded; the reference's `hashed` method accepts 128-bit collisions, this path accepts none)
+//   scan of the "I am a first row" flags -> dense ids in order of first appearance; k_str_ids gathers them per row
+// The hash is internal (placement only).  Algorithmic bytes: chars once + 8 B offsets + 4 B id per row; the table traffic is
+// random 16-byte cells, two touches per row.
+#include "chgpu_internal.h"
+
+__device__ __forceinline__ u64 str_load8(const u8 * p)
+{
+    u64 v;
+    __builtin_memcpy(&v, p, 8); // unaligned: global memory allows it; the column's 64-byte pad covers the over-read
+    return v;
+}
+
+__device__ __forceinline__ u64 str_hash_bytes(const u8 * p, u64 len)
+{
+    u64 h = 0x9E3779B97F4A7C15ull ^ (len * 0xff51afd7ed558ccdull);
+    u64 i = 0;
+    for (; i + 8 <= len; i += 8)
+    {
+        h = (h ^ str_load8(p + i)) * 0xc4ceb9fe1a85ec53ull;
+        h ^= h >> 29;
+    }
+    if (i < len)
+    {
+        const u64 tail = str_load8(p + i) & (~0ull >> (8 * (8 - (len - i))));
+        h = (h ^ tail) * 0xc4ceb9fe1a85ec53ull;
+        h ^= h >> 29;
+    }
+    h = dev_intHash64(h);
+    return h | 1ull; // 0 marks an empty cell
+}
+
+__device__ __forceinline__ bool str_equal(const u8 * a, const u8 * b, u64 len)
+{
+    u64 i = 0;
+    for (; i + 8 <= len; i += 8)
+        if (str_load8(a + i) != str_load8(b + i))
+            return false;
+    if (i < len)
+    {
+        const u64 m = ~0ull >> (8 * (8 - (len - i)));
+        return ((str_load8(a + i) ^ str_load8(b + i)) & m) == 0;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_str_hash(const u64 * __restrict__ offsets, const u8 * __restrict__ chars, u64 n, u64 * __restrict__ hash)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        const u64 begin = i ? offsets[i - 1] : 0;
+        const u64 len = offsets[i] - begin - 1; // without the terminating zero (ColumnString.h:48-52)
+        hash[i] = str_hash_bytes(chars + begin, len);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_str_insert(const u64 * __restrict__ hash, u64 n, u64 * __restrict__ tags, unsigned long long * __restrict__ first_row, u64 mask,
+                                                    u32 * __restrict__ fail)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        const u64 h = hash[i];
+        u64 s = (h >> 1) & mask;
+        bool placed = false;
+        for (u64 probe = 0; probe <= mask; ++probe) // bounded: the table has >= 2 cells per row
+        {
+            u64 t = tags[s];
+            if (t == 0)
+            {
+                t = atomicCAS((unsigned long long *)&tags[s], 0ull, (unsigned long long)h);
+                if (t == 0)
+                    t = h;
+            }
+            if (t == h)
+            {
+                // first_row only ever decreases, so a (possibly stale) value <= i proves the atomic would change nothing; without
+                // this test a low-cardinality column sends every row's atomic to a few thousand addresses (same-address atomics
+                // serialise: 1e8 rows over 2500 values took 414 ms, all of it here)
+                if (__builtin_nontemporal_load(&first_row[s]) > (unsigned long long)i)
+                    atomicMin(&first_row[s], (unsigned long long)i);
+                placed = true;
+                break;
+            }
+            s = (s + 1) & mask;
+        }
+        if (!placed)
+            *fail = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_str_resolve(const u64 * __restrict__ offsets, const u8 * __restrict__ chars, const u64 * __restrict__ hash, u64 n,
+                                                     const u64 * __restrict__ tags, const unsigned long long * __restrict__ first_row, u64 mask,
+                                                     u64 * __restrict__ rep_row, u32 * __restrict__ is_first, u32 * __restrict__ fail)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        const u64 h = hash[i];
+        u64 s = (h >> 1) & mask;
+        u64 r = ~0ull;
+        for (u64 probe = 0; probe <= mask; ++probe)
+        {
+            const u64 t = tags[s];
+            if (t == h)
+            {
+                r = first_row[s];
+                break;
+            }
+            if (t == 0)
+                break;
+            s = (s + 1) & mask;
+        }
+        if (r >= n)
+        {
+            *fail = 1;
+            r = i;
+        }
+        if (r != i)
+        {
+            const u64 b0 = i ? offsets[i - 1] : 0, l0 = offsets[i] - b0 - 1;
+            const u64 b1 = r ? offsets[r - 1] : 0, l1 = offsets[r] - b1 - 1;
+            if (l0 != l1 || !str_equal(chars + b0, chars + b1, l0))
+                *fail = 2; // two different values under one 64-bit tag
+        }
+        rep_row[i] = r;
+        is_first[i] = r == i ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_str_ids(const u64 * __restrict__ rep_row, const u32 * __restrict__ is_first, const u64 * __restrict__ prefix, u64 n,
+                                                 u32 * __restrict__ ids, u64 * __restrict__ dict_rows)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        ids[i] = (u32)prefix[rep_row[i]]; // exclusive prefix of the first-row flags = number of values that appeared earlier
+        if (is_first[i])
+            dict_rows[prefix[i]] = i;
+    }
+}
+
+extern "C" int chgpu_string_dictionary_encode(chgpu_ctx * ctx, const chgpu_col * offsets_u64, const chgpu_col * chars_u8, chgpu_col ** ids_u32,
+                                              chgpu_col ** first_rows_u64, uint64_t * n_distinct)
+{
+    CHGPU_REQUIRE(ctx && offsets_u64 && chars_u8 && ids_u32 && first_rows_u64 && n_distinct, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(offsets_u64->type == CHGPU_U64 && chars_u8->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "ColumnString = UInt64 offsets + UInt8 chars");
+    const u64 n = offsets_u64->rows;
+    CHGPU_REQUIRE(n < (1ull << 32), CHGPU_ERR_NOT_IMPLEMENTED, "more than 2^32 rows per call");
+    chgpu_col * ids = nullptr, * dict = nullptr;
+    *n_distinct = 0;
+    if (n == 0)
+    {
+        CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U32, 0, &ids));
+        CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U64, 0, &dict));
+        *ids_u32 = ids, *first_rows_u64 = dict;
+        return CHGPU_OK;
+    }
+    // the last offset must equal the size of chars (ColumnString invariant); checked with one read-back
+    u64 last = 0;
+    CHGPU_TRY(chgpu_read_back(ctx, (const u64 *)offsets_u64->data + (n - 1), &last, sizeof(last)));
+    CHGPU_REQUIRE(last == chars_u8->rows, CHGPU_ERR_SIZES_MISMATCH, "offsets.back() (%llu) != chars.size() (%llu)", (unsigned long long)last,
+                  (unsigned long long)chars_u8->rows);
+    u64 cap = 1024;
+    while (cap < 2 * n)
+        cap <<= 1;
+    // temporaries: hash u64[n] | rep_row u64[n] | is_first u32[n] | prefix u64[n] | tags u64[cap] | first_row u64[cap] | fail u32 | scan tmp
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_hash = al(n * 8), b_rep = al(n * 8), b_first = al(n * 4), b_prefix = al(n * 8), b_tags = al(cap * 8), b_rows = al(cap * 8), b_flag = 256;
+    const size_t b_tmp = chgpu_scan_tmp_bytes(n);
+    void * mem = nullptr;
+    size_t mem_class = 0;
+    CHGPU_TRY(chgpu_pool_alloc(ctx, b_hash + b_rep + b_first + b_prefix + b_tags + b_rows + b_flag + 256 + b_tmp, &mem, &mem_class));
+    char * p = (char *)mem;
+    u64 * hash = (u64 *)p; p += b_hash;
+    u64 * rep = (u64 *)p; p += b_rep;
+    u32 * isf = (u32 *)p; p += b_first;
+    u64 * prefix = (u64 *)p; p += b_prefix;
+    u64 * tags = (u64 *)p; p += b_tags;
+    unsigned long long * rows = (unsigned long long *)p; p += b_rows;
+    u32 * fail = (u32 *)p; p += b_flag;
+    u64 * total_dev = (u64 *)p; p += 256;
+    void * tmp = p;
+    int rc = CHGPU_OK;
+    auto done = [&](int code) {
+        chgpu_pool_free(ctx, mem, mem_class);
+        if (code != CHGPU_OK)
+        {
+            if (ids)
+                chgpu_col_free(ids);
+            if (dict)
+                chgpu_col_free(dict);
+        }
+        return code;
+    };
+    if (hipMemsetAsync(tags, 0, b_tags, ctx->stream) != hipSuccess || hipMemsetAsync(rows, 0xFF, b_rows, ctx->stream) != hipSuccess ||
+        hipMemsetAsync(fail, 0, b_flag, ctx->stream) != hipSuccess)
+        return done(chgpu_set_error(CHGPU_ERR_DEVICE, "memset failed"));
+    const u32 grid = chgpu_grid_for(ctx, n, 256, 8);
+    const u64 * offs = (const u64 *)offsets_u64->data;
+    const u8 * chars = (const u8 *)chars_u8->data;
+    hipLaunchKernelGGL(k_str_hash, dim3(grid), dim3(256), 0, ctx->stream, offs, chars, n, hash);
+    hipLaunchKernelGGL(k_str_insert, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)hash, n, tags, rows, cap - 1, fail);
+    hipLaunchKernelGGL(k_str_resolve, dim3(grid), dim3(256), 0, ctx->stream, offs, chars, (const u64 *)hash, n, (const u64 *)tags, (const unsigned long long *)rows,
+                       cap - 1, rep, isf, fail);
+    ctx->counters[6] += 3;
+    rc = chgpu_scan_exclusive_u32_u64(ctx, isf, prefix, n, total_dev, tmp, b_tmp);
+    if (rc != CHGPU_OK)
+        return done(rc);
+    struct { u64 total; } hb;
+    rc = chgpu_read_back(ctx, total_dev, &hb.total, sizeof(u64));
+    if (rc != CHGPU_OK)
+        return done(rc);
+    u32 failed = 0;
+    rc = chgpu_read_back(ctx, fail, &failed, sizeof(failed));
+    if (rc != CHGPU_OK)
+        return done(rc);
+    if (failed == 2)
+        return done(chgpu_set_error(CHGPU_ERR_NOT_IMPLEMENTED, "two different strings share a 64-bit hash tag in this block: CPU path"));
+    if (failed)
+        return done(chgpu_set_error(CHGPU_ERR_LOGICAL, "string table probe did not terminate"));
+    rc = chgpu_col_new(ctx, CHGPU_U32, n, &ids);
+    if (rc == CHGPU_OK)
+        rc = chgpu_col_new(ctx, CHGPU_U64, hb.total, &dict);
+    if (rc != CHGPU_OK)
+        return done(rc);
+    hipLaunchKernelGGL(k_str_ids, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)rep, (const u32 *)isf, (const u64 *)prefix, n, (u32 *)ids->data, (u64 *)dict->data);
+    ctx->counters[6] += 1;
+    if (hipGetLastError() != hipSuccess)
+        return done(chgpu_set_error(CHGPU_ERR_DEVICE, "string dictionary kernels failed to launch"));
+    *ids_u32 = ids;
+    *first_rows_u64 = dict;
+    *n_distinct = hb.total;
+    return done(CHGPU_OK);
+}

@@ -14,6 +14,7 @@
 //   ActionsDAG / ExpressionActions  src/Interpreters/ActionsDAG.h, ExpressionActions.h:75-134   chgpu::ActionsDAG, chgpu::ExpressionActions (run-time compiled)
 //   ExpressionTransform         src/Processors/Transforms/ExpressionTransform.cpp:22-30      chgpu::GpuExpressionTransform, GpuExpressionFilterTransform
 //   ColumnLowCardinality + low_cardinality_key* methods   src/Columns/ColumnLowCardinality.h:27-69, ColumnsHashing.h:82-260   chgpu::ColumnLowCardinality, LowCardinalityDictionary
+//   ColumnString as a key       src/Columns/ColumnString.h:40-49, ColumnUnique.h:520-620     chgpu::ColumnString::dictionaryEncode
 //   IAggregateFunction          src/AggregateFunctions/IAggregateFunction.h:55-399      chgpu::AggregateDescription (closed POD set)
 //   Aggregator                  src/Interpreters/Aggregator.h:179-265          chgpu::GpuAggregator
 //   AggregatingTransform        src/Processors/Transforms/AggregatingTransform.cpp:640-840   chgpu::GpuAggregatingTransform
@@ -475,6 +476,31 @@ struct ColumnLowCardinality
 {
     std::shared_ptr<const std::vector<std::string>> dictionary; // position -> value (ColumnUnique's nested column)
     ColumnPtr indexes;                                          // UInt8 / UInt16 / UInt32 / UInt64
+};
+
+/// ColumnString (src/Columns/ColumnString.h:40-49) pinned into HBM: chars (every value followed by a zero byte) + cumulative offsets.
+/// dictionaryEncode() turns it into a ColumnLowCardinality on the device (ids by first appearance, ColumnUnique.h:520-620); the
+/// dictionary's strings are read from the caller's own Block at the returned first rows, so no string leaves the device.
+struct ColumnString
+{
+    ColumnPtr offsets; // UInt64
+    ColumnPtr chars;   // UInt8
+
+    /// value_of(row) -> the string at `row` of the host Block this column was pinned from
+    template <typename ValueOf>
+    ColumnLowCardinality dictionaryEncode(ValueOf && value_of) const
+    {
+        chgpu_col * ids = nullptr, * rows = nullptr;
+        uint64_t n = 0;
+        check(chgpu_string_dictionary_encode(offsets->context()->get(), offsets->handle(), chars->handle(), &ids, &rows, &n));
+        ColumnVector first(offsets->context(), rows);
+        auto first_rows = first.getData<uint64_t>();
+        auto dict = std::make_shared<std::vector<std::string>>();
+        dict->reserve(first_rows.size());
+        for (uint64_t r : first_rows)
+            dict->push_back(value_of(r));
+        return ColumnLowCardinality{dict, std::make_shared<ColumnVector>(offsets->context(), ids)};
+    }
 };
 
 /// The query-wide dictionary of one LowCardinality key: what the low_cardinality_key* aggregation methods

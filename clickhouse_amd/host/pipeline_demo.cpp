@@ -221,6 +221,23 @@ int main(int argc, char ** argv)
                 auto & w2 = want_lc[(*d2)[i2[i]]];
                 w2.first += v2[i], ++w2.second;
             }
+            // a String key column: dictionary-encoded on the device, then the same path
+            {
+                std::vector<std::string> names = {"FRANCE", "", "PERU", "FRANCE", "PERU", "FRANCE", std::string("a\0b", 3), "PERU"};
+                std::vector<uint8_t> chars;
+                std::vector<uint64_t> offs;
+                for (auto & v : names)
+                {
+                    chars.insert(chars.end(), v.begin(), v.end());
+                    chars.push_back(0);
+                    offs.push_back(chars.size());
+                }
+                ColumnString col{ColumnVector::fromHost<uint64_t>(ctx, offs.data(), offs.size()), ColumnVector::fromHost<uint8_t>(ctx, chars.data(), chars.size())};
+                ColumnLowCardinality enc = col.dictionaryEncode([&](uint64_t r) { return names[r]; });
+                auto got_ids = enc.indexes->getData<uint32_t>();
+                REQUIRE((*enc.dictionary == std::vector<std::string>{"FRANCE", "", "PERU", std::string("a\0b", 3)}));
+                REQUIRE((got_ids == std::vector<uint32_t>{0, 1, 2, 0, 2, 0, 3, 2}));
+            }
             LowCardinalityDictionary dict(ctx);
             GpuAggregator lc_agg(ctx, CHGPU_U32, {{CHGPU_AGG_SUM, CHGPU_I64, 1}, {CHGPU_AGG_COUNT, CHGPU_U64, 0}});
             Columns b1 = {dict.mapBlock({d1, ColumnVector::fromHost<uint8_t>(ctx, i1.data(), m)}), ColumnVector::fromHost<int64_t>(ctx, v1.data(), m)};

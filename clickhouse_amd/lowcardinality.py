@@ -55,6 +55,51 @@ class ColumnLowCardinality:
         return [self.dictionary[int(i)] for i in idx]
 
 
+class ColumnString:
+    """ColumnString (src/Columns/ColumnString.h:40-49) in HBM: chars (every value followed by a zero byte) + cumulative offsets."""
+
+    def __init__(self, offsets: Column, chars: Column, host_values=None):
+        self.offsets = offsets
+        self.chars = chars
+        self._host_values = host_values  # the caller's Block, when it is at hand (saves the download in dictionary())
+
+    @staticmethod
+    def from_values(ctx: Context, values) -> "ColumnString":
+        vals = [v.encode() if isinstance(v, str) else bytes(v) for v in values]
+        lens = np.fromiter((len(v) + 1 for v in vals), dtype=np.uint64, count=len(vals))
+        chars = np.frombuffer(b"".join(v + b"\0" for v in vals), dtype=np.uint8) if vals else np.zeros(0, dtype=np.uint8)
+        return ColumnString(ctx.upload(np.cumsum(lens, dtype=np.uint64)), ctx.upload(chars), vals)
+
+    def size(self) -> int:
+        return self.offsets.size()
+
+    def value_at(self, rows) -> list:
+        if self._host_values is not None:
+            return [self._host_values[int(r)] for r in rows]
+        # ColumnString::index over a few rows, on the device: only the requested values cross PCIe
+        rows = np.asarray(rows, dtype=np.uint64)
+        if rows.shape[0] == 0:
+            return []
+        ctx = self.offsets.ctx
+        ends = self.offsets.index(ctx.upload(rows)).numpy()
+        prev = np.where(rows > 0, rows - np.uint64(1), np.uint64(0))
+        begins = np.where(rows > 0, self.offsets.index(ctx.upload(prev)).numpy(), np.uint64(0))
+        lens = (ends - begins - np.uint64(1)).astype(np.int64)
+        flat = np.repeat(begins.astype(np.int64) - np.concatenate(([0], np.cumsum(lens)[:-1])), lens) + np.arange(int(lens.sum()), dtype=np.int64)
+        data = self.chars.index(ctx.upload(flat.astype(np.uint64))).numpy().tobytes() if flat.shape[0] else b""
+        cuts = np.concatenate(([0], np.cumsum(lens)))
+        return [data[int(cuts[k]):int(cuts[k + 1])] for k in range(rows.shape[0])]
+
+    def dictionary_encode(self) -> "ColumnLowCardinality":
+        """String -> LowCardinality(String) on the device: ids by first appearance; the dictionary's strings are read on the host"""
+        ids, rows = C.c_void_p(), C.c_void_p()
+        n = C.c_uint64(0)
+        ctx = self.offsets.ctx
+        K.check(K.lib().chgpu_string_dictionary_encode(ctx._h, self.offsets._h, self.chars._h, C.byref(ids), C.byref(rows), C.byref(n)))
+        first_rows = Column(ctx, rows).numpy()
+        return ColumnLowCardinality(self.value_at(first_rows), Column(ctx, ids))
+
+
 class LowCardinalityDictionary:
     """The query-wide dictionary: value -> global id (insertion order; ids are dense, so they are also ideal GROUP BY keys
     for the LDS-staged RANGE strategy)."""

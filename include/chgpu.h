@@ -289,6 +289,14 @@ int chgpu_unpack_fixed_key(chgpu_ctx * ctx, const chgpu_col * packed_u64, uint32
    = global id, and the rows are translated on the device: out_u32[i] = remap_u32[indexes[i]] (indexes: UInt8/16/32/64).
    The result is an ordinary UInt32 key column for chgpu_agg_* / chgpu_join_* / chgpu_hash_to_selector. */
 int chgpu_lc_remap(chgpu_ctx * ctx, const chgpu_col * indexes, const chgpu_col * remap_u32, chgpu_col ** out_u32);
+/* §8(f) rank 2 — String keys.  ColumnString (src/Columns/ColumnString.h:40-49) = chars_u8 (every value followed by a zero byte) +
+   offsets_u64 (offsets[i] = end of value i including that zero).  Every row gets the dense id of its value, ids numbered by
+   first appearance (ColumnUnique::uniqueInsertRangeFrom, src/Columns/ColumnUnique.h:520-620); first_rows_u64[id] = the row where
+   the value first appears (the caller reads the dictionary's strings from its own Block there).  Exact: values are compared
+   byte by byte; a 64-bit tag shared by two different values answers CHGPU_ERR_NOT_IMPLEMENTED (CPU path).  ids + dictionary
+   are a ColumnLowCardinality: chgpu_lc_remap / GROUP BY / join as above. */
+int chgpu_string_dictionary_encode(chgpu_ctx * ctx, const chgpu_col * offsets_u64, const chgpu_col * chars_u8, chgpu_col ** ids_u32,
+                                   chgpu_col ** first_rows_u64, uint64_t * n_distinct);
 int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, const int * agg_kinds, const int * arg_types,
                      uint64_t size_hint, chgpu_agg ** out);
 /* executeOnBlock over rows [row_begin,row_end) of the key column and the argument columns (arg_cols[j] may be NULL

@@ -33,3 +33,20 @@ def group_by_sum_count(blocks):
             s, c = out.get(k, (np.uint64(0), 0))
             out[k] = (np.uint64((int(s) + int(sums[pos])) & (2**64 - 1)), c + int(cnts[pos]))
     return {k: (int(np.array([s], dtype=np.uint64).view(np.int64)[0]), c) for k, (s, c) in out.items()}
+
+
+def dictionary_encode(values):
+    """ColumnUnique::uniqueInsertRangeFrom (src/Columns/ColumnUnique.h:520-620) over a full String column: every row gets the
+    position of its value in a dictionary that holds each distinct value once, in order of first appearance.
+    -> (ids ndarray[uint32], dictionary list, first_rows ndarray[uint64])"""
+    pos, d, first = {}, [], []
+    ids = np.empty(len(values), dtype=np.uint32)
+    for i, v in enumerate(values):
+        k = pos.get(v)
+        if k is None:
+            k = len(d)
+            pos[v] = k
+            d.append(v)
+            first.append(i)
+        ids[i] = k
+    return ids, d, np.array(first, dtype=np.uint64)

@@ -86,3 +86,55 @@ def test_gpu_lowcardinality_with_where_mask_and_filtered_column():
     for agg in (a, b):
         keys, (sums, cnts) = agg.convert_to_block()
         assert {k: (int(s), int(c)) for k, s, c in zip(keys, sums, cnts)} == want
+
+
+def _strings(rng, n, n_distinct, max_len):
+    pool = []
+    for k in range(n_distinct):
+        ln = int(rng.integers(0, max_len + 1))
+        b = rng.integers(0, 256, size=ln, dtype=np.uint8).tobytes() if k % 3 else bytes(rng.integers(97, 100, size=ln, dtype=np.uint8))  # zero bytes inside; tiny alphabets
+        pool.append(b)
+    pool = list(dict.fromkeys(pool + [b"", b"a", b"ab", b"ab\0", b"abc", b"x" * 64, b"x" * 65, b"x" * 63 + b"y"]))
+    return [pool[int(i)] for i in rng.integers(0, len(pool), size=n)]
+
+
+def test_oracle_dictionary_encode_first_appearance_order():
+    ids, d, first = OL.dictionary_encode([b"b", b"a", b"b", b"", b"a", b"c"])
+    assert ids.tolist() == [0, 1, 0, 2, 1, 3] and d == [b"b", b"a", b"", b"c"] and first.tolist() == [0, 1, 3, 5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,n_distinct,max_len", [(0, 1, 4), (1, 1, 8), (1000, 3, 5), (100_003, 500, 40), (200_001, 150_000, 12), (50_000, 50, 300)])
+def test_gpu_string_dictionary_encode_matches_oracle(n, n_distinct, max_len):
+    import clickhouse_amd as ch
+    rng = np.random.Generator(np.random.PCG64(n + 17))
+    ctx = ch.Context()
+    vals = _strings(rng, n, n_distinct, max_len)
+    lc = ch.ColumnString.from_values(ctx, vals).dictionary_encode()
+    ids, d, _ = OL.dictionary_encode(vals)
+    assert lc.dictionary == d and np.array_equal(lc.indexes.numpy(), ids)
+    # without the host copy of the Block: dictionary strings read back from the device column
+    cs = ch.ColumnString.from_values(ctx, vals)
+    cs._host_values = None
+    assert cs.dictionary_encode().dictionary == d
+
+
+@pytest.mark.gpu
+def test_gpu_group_by_string_key_over_stripes():
+    """GROUP BY a String key: each stripe dictionary-encoded on the device, ids unified by LowCardinalityDictionary"""
+    import clickhouse_amd as ch
+    rng = np.random.Generator(np.random.PCG64(23))
+    ctx = ch.Context()
+    cities = [f"CITY-{i:04d}".encode() for i in range(2500)]
+    agg = ch.LowCardinalityAggregator([(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], ctx=ctx)
+    blocks = []
+    for stripe in range(3):
+        n = 150_000 + stripe
+        vals = [cities[int(i)] for i in rng.integers(stripe * 500, 1500 + stripe * 500, size=n)]
+        v = rng.integers(-10**9, 10**9, size=n, dtype=np.int64)
+        lc = ch.ColumnString.from_values(ctx, vals).dictionary_encode()
+        agg.execute_on_block(lc, [ctx.upload(v), None])
+        ids, d, _ = OL.dictionary_encode(vals)
+        blocks.append((d, ids, v))
+    keys, (sums, cnts) = agg.convert_to_block()
+    assert {k: (int(s), int(c)) for k, s, c in zip(keys, sums, cnts)} == OL.group_by_sum_count(blocks)

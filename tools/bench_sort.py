@@ -59,4 +59,21 @@ gd = LowCardinalityDictionary(ctx)
 dt = best_of(lambda: gd.map_block(lc), reps=5)
 res.append({"case": "k_lc_remap UInt8 -> UInt32 ids, 25-entry dictionary", "rows": n, "ms": dt * 1e3, "rows_per_s": n / dt,
             "algorithmic_B_per_row": 5, "GBps": 5 * n / dt / 1e9, "roofline_frac": 5 * n / dt / 8e12})
+# String key dictionary encode: n values "CITY-dddd" (9 bytes + terminating zero), 2500 distinct
+from clickhouse_amd.lowcardinality import ColumnString
+m = rows
+cid = torch.randint(0, 2500, (m,), dtype=torch.int64, device=dev, generator=g)
+chars = torch.empty((m, 10), dtype=torch.uint8, device=dev)
+for k, ch_ in enumerate(b"CITY-"):
+    chars[:, k] = ch_
+for k, div in enumerate((1000, 100, 10, 1)):
+    chars[:, 5 + k] = ((cid // div) % 10 + 48).to(torch.uint8)
+chars[:, 9] = 0
+offs = (torch.arange(1, m + 1, dtype=torch.int64, device=dev) * 10)
+cs = ColumnString(ctx.wrap(offs.data_ptr(), np.uint64, m, keepalive=offs), ctx.wrap(chars.data_ptr(), np.uint8, m * 10, keepalive=chars))
+dt = best_of(lambda: cs.dictionary_encode(), reps=3)
+lc2 = cs.dictionary_encode()
+assert len(lc2.dictionary) == 2500 and lc2.dictionary[0] == bytes(chars[0, :9].cpu().numpy())
+res.append({"case": "chgpu_string_dictionary_encode, 10-byte values, 2500 distinct", "rows": m, "ms": dt * 1e3, "rows_per_s": m / dt,
+            "algorithmic_B_per_row": 22, "GBps": 22 * m / dt / 1e9, "roofline_frac": 22 * m / dt / 8e12})
 print(json.dumps({"results": res}))
