@@ -1,0 +1,344 @@
+// compress_kernels.hip — SURVEY §8(f) rank 3: the feed side.  A MergeTree column file / a compressed Native stream is a sequence of
+// frames (src/Compression/CompressedReadBufferBase.cpp:175-222, CompressionInfo.h:10-51): 16-byte CityHash128 checksum, method byte,
+// compressed size, decompressed size, payload.  The reference decompresses every frame on a CPU core
+// (LZ4_decompress_faster.cpp, ~2-5 GB/s per core) into host memory which then has to cross PCIe uncompressed; here the compressed
+// bytes cross PCIe and the frames are decoded in HBM, one wavefront per frame, straight into the column's buffer.
+//
+//   k_lz4_decode    LZ4 block format (token | literal length bytes | literals | 2-byte offset | match length bytes).  The wave parses
+//                   the sequence headers uniformly (values broadcast with readfirstlane -> scalar branches) and all 64 lanes copy:
+//                   literals byte-per-lane, matches from the output already written -- an overlapping match (offset < length) is
+//                   the `offset` bytes before it repeated, so byte k reads position (k mod offset) of that window and no lane
+//                   depends on another lane of the same copy.  Input window and recent output are kept in LDS (see the kernel).
+//                   Every input and output position is bounds-checked: a malformed frame sets the error flag, never faults.
+//   k_frame_copy    method NONE (0x02): payload copied as is
+// Algorithmic bytes: compressed size read + decompressed size written (match sources are re-reads of fresh output: L1/L2).
+#include "chgpu_internal.h"
+
+struct FrameJob
+{
+    u64 src_off;  // payload begin in the compressed buffer
+    u64 dst_off;  // begin in the output buffer
+    u32 src_size; // payload bytes
+    u32 dst_size; // decompressed bytes
+    u32 method;   // 0x82 LZ4, 0x02 NONE
+    u32 pad;
+};
+
+__device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+
+// Per wave: a window of the compressed input and a ring of the most recent output live in LDS, so the serial part of the format --
+// token, length bytes, offset -- and the short-distance matches that dominate column data (zero bytes 8 back, the previous value 8
+// back, runs) never wait for a global load: the first version read everything through global memory and spent ~1.7 us per
+// sequence in three dependent round trips (64 KiB frames of C2's column: 29 GB/s for the whole GPU).
+static constexpr u32 LZ_IN = 1024;    // input window bytes per wave
+static constexpr u32 LZ_RING = 4096;  // output ring bytes per wave (matches up to LZ_RING / 2 back are served from it); 20 KiB of LDS per
+                                      // workgroup keeps 8 workgroups = 32 frames per CU in flight (8 KiB rings: 3 workgroups, two rounds for 6 K frames)
+static constexpr u32 LZ_CHUNK = LZ_RING / 2;
+
+__global__ __launch_bounds__(256) void k_lz4_decode(const u8 * __restrict__ src, u8 * dst, const FrameJob * __restrict__ jobs, u32 n_jobs, u32 * __restrict__ err)
+{
+    __shared__ __attribute__((aligned(16))) u8 lds_in[4][LZ_IN + 16];
+    __shared__ __attribute__((aligned(16))) u8 lds_ring[4][LZ_RING];
+    const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u8 * lin = lds_in[w];
+    u8 * ring = lds_ring[w];
+    const u32 wave0 = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
+    for (u32 j = wave0; j < n_jobs; j += n_waves)
+    {
+        const FrameJob job = jobs[j];
+        const u8 * in = src + job.src_off;
+        u8 * out = dst + job.dst_off;
+        const u32 isz = job.src_size, osz = job.dst_size;
+        if (job.method == 0x02u)
+        {
+            if (isz != osz)
+            {
+                if (lane == 0)
+                    atomicOr(err, 1u);
+                continue;
+            }
+            for (u32 k = lane; k < osz; k += 64)
+                out[k] = in[k];
+            continue;
+        }
+        u32 ip = 0, op = 0;
+        u32 in_base = 0, in_len = 0; // lin[0 .. in_len) = in[in_base .. in_base + in_len)
+        bool bad = false;
+        // make in[pos .. pos + need) available in the window (need <= 16); false at the end of the frame
+        auto window = [&](u32 pos, u32 need) -> bool {
+            if (pos + need > isz)
+                return false;
+            if (pos < in_base || pos + need > in_base + in_len)
+            {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                in_base = pos;
+                in_len = isz - pos < LZ_IN ? isz - pos : LZ_IN;
+                for (u32 k = lane * 8; k < in_len; k += 64 * 8)
+                {
+                    if (k + 8 <= in_len)
+                    {
+                        u64 v;
+                        __builtin_memcpy(&v, in + pos + k, 8); // unaligned 8-byte global load
+                        *(u64 *)(lin + k) = v;
+                    }
+                    else
+                        for (u32 q = k; q < in_len; ++q) // never read past the frame (a wrapped buffer may end right there)
+                            lin[q] = in[pos + q];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            return true;
+        };
+        while (true)
+        {
+            if (!window(ip, 1))
+            {
+                bad = true;
+                break;
+            }
+            const u32 token = uni(lin[ip - in_base]);
+            ++ip;
+            u32 lit = token >> 4;
+            if (lit == 15)
+            {
+                u32 b;
+                do
+                {
+                    if (!window(ip, 1))
+                    {
+                        bad = true;
+                        break;
+                    }
+                    b = uni(lin[ip - in_base]);
+                    ++ip;
+                    lit += b;
+                } while (b == 255);
+                if (bad)
+                    break;
+            }
+            if (lit > isz - ip || lit > osz - op)
+            {
+                bad = true;
+                break;
+            }
+            if (lit)
+            {
+                if (ip >= in_base && ip + lit <= in_base + in_len)
+                {
+                    for (u32 k = lane; k < lit; k += 64) // literals out of the LDS window
+                    {
+                        const u8 v = lin[ip - in_base + k];
+                        out[op + k] = v;
+                        ring[(op + k) & (LZ_RING - 1)] = v;
+                    }
+                }
+                else
+                {
+                    for (u32 k = lane; k < lit; k += 64) // a long literal run: straight from the compressed buffer
+                    {
+                        const u8 v = in[ip + k];
+                        out[op + k] = v;
+                        if (lit - k <= LZ_RING) // only the last LZ_RING bytes matter (and each ring byte is written once)
+                            ring[(op + k) & (LZ_RING - 1)] = v;
+                    }
+                }
+                ip += lit;
+                op += lit;
+            }
+            if (ip >= isz)
+                break; // the last sequence ends after its literals
+            if (!window(ip, 2))
+            {
+                bad = true;
+                break;
+            }
+            const u32 offset = uni((u32)lin[ip - in_base] | ((u32)lin[ip - in_base + 1] << 8));
+            ip += 2;
+            u32 ml = token & 15;
+            if (ml == 15)
+            {
+                u32 b;
+                do
+                {
+                    if (!window(ip, 1))
+                    {
+                        bad = true;
+                        break;
+                    }
+                    b = uni(lin[ip - in_base]);
+                    ++ip;
+                    ml += b;
+                } while (b == 255);
+                if (bad)
+                    break;
+            }
+            ml += 4;
+            if (offset == 0 || offset > op || ml > osz - op)
+            {
+                bad = true;
+                break;
+            }
+            if (offset <= LZ_CHUNK)
+            {
+                // from the ring, at most LZ_CHUNK bytes at a time: a chunk never overwrites ring bytes it still has to read, and
+                // because the output repeats with period `offset`, the window "offset bytes before the current position" is
+                // the right source for every chunk
+                while (ml)
+                {
+                    const u32 c = ml < LZ_CHUNK ? ml : LZ_CHUNK;
+                    const u32 wbase = op - offset;
+                    if (offset >= c)
+                    {
+                        for (u32 k = lane; k < c; k += 64)
+                        {
+                            const u8 v = ring[(wbase + k) & (LZ_RING - 1)];
+                            out[op + k] = v;
+                            ring[(op + k) & (LZ_RING - 1)] = v;
+                        }
+                    }
+                    else
+                    {
+                        for (u32 k = lane; k < c; k += 64)
+                        {
+                            const u8 v = ring[(wbase + k % offset) & (LZ_RING - 1)];
+                            out[op + k] = v;
+                            ring[(op + k) & (LZ_RING - 1)] = v;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    op += c;
+                    ml -= c;
+                }
+            }
+            else
+            {
+                // a far match: its source left the ring; read the output buffer itself (a wave's memory operations execute in
+                // order, so its own earlier stores are visible; the fences only pin the compiler)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const u8 * win = out + (op - offset);
+                if (offset >= ml)
+                {
+                    for (u32 k = lane; k < ml; k += 64)
+                    {
+                        const u8 v = win[k];
+                        out[op + k] = v;
+                        if (ml - k <= LZ_RING)
+                            ring[(op + k) & (LZ_RING - 1)] = v;
+                    }
+                }
+                else
+                {
+                    for (u32 k = lane; k < ml; k += 64)
+                    {
+                        const u8 v = win[k % offset];
+                        out[op + k] = v;
+                        if (ml - k <= LZ_RING)
+                            ring[(op + k) & (LZ_RING - 1)] = v;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                op += ml;
+            }
+        }
+        if (!bad && op != osz)
+            bad = true;
+        if (bad && lane == 0)
+            atomicOr(err, 2u);
+    }
+}
+
+/* Decompress n_frames frames of `compressed_u8` into one new UInt8 column of sum(dst_sizes) bytes.  Host arrays describe the frames
+   (payload offset / size inside compressed_u8, decompressed size, method byte).  CANNOT_DECOMPRESS -> CHGPU_ERR_BAD_ARGUMENTS. */
+extern "C" int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compressed_u8, uint32_t n_frames, const uint64_t * payload_offsets,
+                                       const uint32_t * payload_sizes, const uint32_t * decompressed_sizes, const uint8_t * methods, chgpu_col ** out_u8)
+{
+    CHGPU_REQUIRE(ctx && compressed_u8 && out_u8, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(compressed_u8->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "compressed data is a UInt8 column");
+    CHGPU_REQUIRE(n_frames == 0 || (payload_offsets && payload_sizes && decompressed_sizes && methods), CHGPU_ERR_BAD_ARGUMENTS, "NULL frame arrays");
+    std::vector<FrameJob> jobs(n_frames);
+    u64 total = 0;
+    for (u32 f = 0; f < n_frames; ++f)
+    {
+        CHGPU_REQUIRE(methods[f] == 0x82 || methods[f] == 0x02, CHGPU_ERR_NOT_IMPLEMENTED, "compression method 0x%02x: CPU path", methods[f]);
+        CHGPU_REQUIRE(payload_offsets[f] + payload_sizes[f] <= compressed_u8->rows, CHGPU_ERR_BAD_ARGUMENTS, "frame %u lies outside the compressed buffer", f);
+        jobs[f] = FrameJob{payload_offsets[f], total, payload_sizes[f], decompressed_sizes[f], methods[f], 0};
+        total += decompressed_sizes[f];
+    }
+    chgpu_col * res = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U8, total, &res));
+    if (n_frames && total)
+    {
+        void * scratch = nullptr;
+        int rc = chgpu_scratch(ctx, sizeof(FrameJob) * (size_t)n_frames + 256, &scratch);
+        if (rc != CHGPU_OK)
+        {
+            chgpu_col_free(res);
+            return rc;
+        }
+        u32 * err = (u32 *)scratch;
+        FrameJob * jd = (FrameJob *)((char *)scratch + 256);
+        hipError_t e = hipMemsetAsync(err, 0, 256, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(jd, jobs.data(), sizeof(FrameJob) * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream); // `jobs` is pageable host memory: it must outlive the copy
+        if (e != hipSuccess)
+        {
+            chgpu_col_free(res);
+            return chgpu_set_error(CHGPU_ERR_DEVICE, "frame table upload: %s", hipGetErrorString(e));
+        }
+        const u32 grid = chgpu_grid_for(ctx, (u64)n_frames * 64, 256, 8);
+        hipLaunchKernelGGL(k_lz4_decode, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)compressed_u8->data, (u8 *)res->data, (const FrameJob *)jd, n_frames, err);
+        ctx->counters[6] += 1;
+        u32 failed = 0;
+        rc = chgpu_read_back(ctx, err, &failed, sizeof(failed));
+        if (rc == CHGPU_OK && failed)
+            rc = chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "Cannot decompress: malformed frame (CANNOT_DECOMPRESS)");
+        if (rc != CHGPU_OK)
+        {
+            chgpu_col_free(res);
+            return rc;
+        }
+    }
+    *out_u8 = res;
+    return CHGPU_OK;
+}
+
+/* typed view of `rows` elements starting at byte `byte_offset` of a UInt8 column, copied into a new aligned column (decompressed
+   column files are plain little-endian arrays: SerializationNumber::deserializeBinaryBulk) */
+__global__ __launch_bounds__(256) void k_bytes_copy(const u8 * __restrict__ src, u64 nbytes, u8 * __restrict__ dst)
+{
+    const u64 stride = (u64)gridDim.x * 256;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0)
+    {
+        typedef u32 v4u __attribute__((ext_vector_type(4)));
+        const u64 nv = nbytes / 16;
+        for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride)
+            ((v4u *)dst)[i] = __builtin_nontemporal_load((const v4u *)src + i);
+        for (u64 i = nv * 16 + (u64)blockIdx.x * 256 + threadIdx.x; i < nbytes; i += stride)
+            dst[i] = src[i];
+    }
+    else
+        for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nbytes; i += stride)
+            dst[i] = src[i];
+}
+
+extern "C" int chgpu_col_from_bytes(chgpu_ctx * ctx, const chgpu_col * bytes_u8, uint64_t byte_offset, int type, uint64_t rows, chgpu_col ** out)
+{
+    CHGPU_REQUIRE(ctx && bytes_u8 && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    const size_t es = chgpu_type_size(type);
+    CHGPU_REQUIRE(es && bytes_u8->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "bad type");
+    CHGPU_REQUIRE(byte_offset + rows * es <= bytes_u8->rows, CHGPU_ERR_SIZES_MISMATCH, "Cannot read all data: %llu rows of %zu bytes at %llu, %llu available",
+                  (unsigned long long)rows, es, (unsigned long long)byte_offset, (unsigned long long)bytes_u8->rows);
+    chgpu_col * res = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, type, rows, &res));
+    if (rows)
+    {
+        const u64 nbytes = rows * es;
+        hipLaunchKernelGGL(k_bytes_copy, dim3(chgpu_grid_for(ctx, (nbytes + 15) / 16, 256, 8)), dim3(256), 0, ctx->stream,
+                           (const u8 *)bytes_u8->data + byte_offset, nbytes, (u8 *)res->data);
+        ctx->counters[6] += 1;
+    }
+    *out = res;
+    return CHGPU_OK;
+}

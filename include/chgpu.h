@@ -115,6 +115,21 @@ void * chgpu_col_device_ptr(const chgpu_col * col);
 int chgpu_col_free(chgpu_col * col);
 
 /* ================================================================================================
+ * §8(f) rank 3 — the feed side: compressed frames decoded in HBM.  A MergeTree column file / compressed Native stream is a
+ * sequence of frames: 16-byte checksum, method byte, compressed size (incl. the 9-byte header), decompressed size, payload
+ * (src/Compression/CompressedReadBufferBase.cpp:175-222, CompressionInfo.h:10-51).  The host walks the frame headers (the caller
+ * verifies checksums if it wants them verified: CityHash128 is not carried), uploads the compressed bytes once and names the
+ * frames; every frame is decoded by one wavefront straight into the output buffer (LZ4 block format as in
+ * LZ4_decompress_faster.cpp:470-684; method 0x02 NONE copies).  Other methods -> CHGPU_ERR_NOT_IMPLEMENTED; a malformed frame ->
+ * CHGPU_ERR_BAD_ARGUMENTS (CANNOT_DECOMPRESS), never a fault.  chgpu_col_from_bytes turns a byte range of the result into a typed
+ * column (SerializationNumber::deserializeBinaryBulk: plain little-endian arrays).
+ * ============================================================================================== */
+int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compressed_u8, uint32_t n_frames, const uint64_t * payload_offsets,
+                            const uint32_t * payload_sizes, const uint32_t * decompressed_sizes, const uint8_t * methods,
+                            chgpu_col ** out_u8);
+int chgpu_col_from_bytes(chgpu_ctx * ctx, const chgpu_col * bytes_u8, uint64_t byte_offset, int type, uint64_t rows, chgpu_col ** out);
+
+/* ================================================================================================
  * a3 comparison  —  IFunction::executeImpl for less/greater/equals... with a constant right argument:
  * NumComparisonImpl<A,B,Op>::vectorConstant (src/Functions/FunctionsComparison.h:204-245), semantics
  * accurate::lessOp/equalsOp (src/Core/AccurateComparison.h:20-130).  mask[i] = Op(col[i], scalar) ? 1 : 0.
