@@ -537,6 +537,62 @@ extern "C" __global__ __launch_bounds__(64) void k_fin(Args a)
     return s;
 }
 
+// WHERE + projection in one step (FilterTransform behind an ExpressionTransform): k_fcount evaluates the filter node and counts
+// the surviving rows of every 1024-row chunk (one wave per chunk, 64 consecutive rows per step); after the scan of the counts
+// k_femit evaluates filter and outputs again and writes the survivors compacted, in order (rank inside a step from the wave
+// ballot).  The inputs are read twice; no mask, no unfiltered intermediate column is ever written.
+constexpr u32 FE_CHUNK = 1024;
+
+std::string gen_filter_source(const chgpu_expr * e, const KernelSpec & ks)
+{
+    std::string s = PRELUDE;
+    s += "struct Args { const void * in[8]; void * out[8]; u64 n; u64 * part; u32 n_parts; u32 pad; };\n";
+    s += "struct Row {";
+    for (size_t j = 0; j < e->input_types.size(); ++j)
+        if (e->input_types[j] >= 0)
+            s += std::string(" ") + ctype(e->input_types[j]) + " c" + std::to_string(j) + ";";
+    s += " };\nstruct Res { bool keep;";
+    for (size_t o = 0; o < ks.out_nodes.size(); ++o)
+        s += std::string(" ") + ctype(e->types[ks.out_nodes[o]]) + " o" + std::to_string(o) + ";";
+    s += " };\nDEV void eval(const Row & r, Res & o)\n{\n" + e->body;
+    s += "    o.keep = n" + std::to_string(ks.filter_node) + " != 0;\n";
+    for (size_t o = 0; o < ks.out_nodes.size(); ++o)
+        s += "    o.o" + std::to_string(o) + " = n" + std::to_string(ks.out_nodes[o]) + ";\n";
+    s += "}\n";
+    std::string load;
+    for (size_t j = 0; j < e->input_types.size(); ++j)
+        if (e->input_types[j] >= 0)
+            load += "            r.c" + std::to_string(j) + " = ((const " + ctype(e->input_types[j]) + " *)a.in[" + std::to_string(j) + "])[in ? i : 0];\n";
+    const std::string C = std::to_string(FE_CHUNK);
+    // a.part: u32 counts[n_chunks] (k_fcount writes) ; a.out[7]: const u64 offsets[n_chunks] (k_femit reads)
+    s += "extern \"C\" __global__ __launch_bounds__(256) void k_fcount(Args a)\n{\n"
+         "    const u32 lane = threadIdx.x & 63;\n"
+         "    const u64 n_chunks = (a.n + " + C + " - 1) / " + C + ";\n"
+         "    for (u64 ch = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6; ch < n_chunks; ch += ((u64)gridDim.x * 256) >> 6)\n    {\n"
+         "        u32 cnt = 0;\n"
+         "#pragma unroll 4\n"
+         "        for (u32 st = 0; st < " + C + " / 64; ++st)\n        {\n"
+         "            const u64 i = ch * " + C + " + st * 64 + lane;\n            const bool in = i < a.n;\n            Row r; Res o;\n" + load +
+         "            eval(r, o);\n            cnt += (u32)__popcll(__ballot(in && o.keep));\n        }\n"
+         "        if (lane == 0) ((u32 *)a.part)[ch] = cnt;\n    }\n}\n";
+    s += "extern \"C\" __global__ __launch_bounds__(256) void k_femit(Args a)\n{\n"
+         "    const u32 lane = threadIdx.x & 63;\n"
+         "    const u64 n_chunks = (a.n + " + C + " - 1) / " + C + ";\n"
+         "    const u64 * offsets = (const u64 *)a.part;\n"
+         "    for (u64 ch = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6; ch < n_chunks; ch += ((u64)gridDim.x * 256) >> 6)\n    {\n"
+         "        u64 pos = offsets[ch];\n"
+         "#pragma unroll 4\n"
+         "        for (u32 st = 0; st < " + C + " / 64; ++st)\n        {\n"
+         "            const u64 i = ch * " + C + " + st * 64 + lane;\n            const bool in = i < a.n;\n            Row r; Res o;\n" + load +
+         "            eval(r, o);\n            const bool keep = in && o.keep;\n            const u64 b = __ballot(keep);\n"
+         "            const u64 dst = pos + __builtin_amdgcn_mbcnt_hi((u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((u32)b, 0u));\n"
+         "            if (keep)\n            {\n";
+    for (size_t o = 0; o < ks.out_nodes.size(); ++o)
+        s += "                ((" + std::string(ctype(e->types[ks.out_nodes[o]])) + " *)a.out[" + std::to_string(o) + "])[dst] = o.o" + std::to_string(o) + ";\n";
+    s += "            }\n            pos += (u64)__popcll(b);\n        }\n    }\n}\n";
+    return s;
+}
+
 int jit_compile(const std::string & src, const std::vector<char> ** code_out)
 {
     std::lock_guard<std::mutex> g(g_jit_mutex);
@@ -724,7 +780,14 @@ extern "C" int chgpu_expr_precompile(const chgpu_expr * e, uint32_t n_outputs, c
     KernelSpec ks;
     CHGPU_TRY(make_spec(e, n_outputs == 0, n_outputs, out_nodes, filter_node, value_node, true, &ks));
     const std::vector<char> * code = nullptr;
-    CHGPU_TRY(jit_compile(gen_source(e, ks), &code));
+    if (n_outputs > 0 && filter_node >= 0) // the WHERE + projection pair (k_fcount, k_femit)
+    {
+        CHGPU_REQUIRE((size_t)filter_node < e->types.size() && n_outputs <= 7, CHGPU_ERR_BAD_ARGUMENTS, "bad filter node / more than 7 outputs");
+        ks.filter_node = filter_node;
+        CHGPU_TRY(jit_compile(gen_filter_source(e, ks), &code));
+    }
+    else
+        CHGPU_TRY(jit_compile(gen_source(e, ks), &code));
     if (code_bytes_out)
         *code_bytes_out = code->size();
     return CHGPU_OK;
@@ -818,5 +881,85 @@ extern "C" int chgpu_expr_filter_sum_node(chgpu_ctx * ctx, const chgpu_expr * e,
         memcpy(sum_out, &res[0], 8);
     if (count_out)
         *count_out = res[1];
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_expr_filter_execute(chgpu_ctx * ctx, const chgpu_expr * e, uint32_t n_cols, const chgpu_col * const * cols, uint32_t filter_node,
+                                         uint32_t n_outputs, const uint32_t * out_nodes, chgpu_col ** outs, uint64_t * rows_out)
+{
+    CHGPU_REQUIRE(ctx && e && cols && outs && rows_out && out_nodes, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(n_outputs >= 1 && n_outputs <= 7, CHGPU_ERR_BAD_ARGUMENTS, "1..7 outputs");
+    CHGPU_REQUIRE(filter_node < e->types.size() && chgpu_type_is_int(e->types[filter_node]), CHGPU_ERR_BAD_ARGUMENTS,
+                  "Illegal type for filter: the WHERE node must be an integer (FilterDescription.cpp:86-92)");
+    u64 rows = 0;
+    CHGPU_TRY(check_spec(e, n_cols, cols, &rows));
+    KernelSpec ks;
+    ks.filter_node = (int)filter_node;
+    for (uint32_t o = 0; o < n_outputs; ++o)
+    {
+        CHGPU_REQUIRE(out_nodes[o] < e->types.size(), CHGPU_ERR_BAD_ARGUMENTS, "bad output node");
+        ks.out_nodes.push_back(out_nodes[o]);
+    }
+    std::vector<chgpu_col *> res(n_outputs, nullptr);
+    auto fail = [&](int rc) {
+        for (chgpu_col * c : res)
+            if (c)
+                chgpu_col_free(c);
+        return rc;
+    };
+    u64 total = 0;
+    if (rows)
+    {
+        hipModule_t mod = nullptr;
+        CHGPU_TRY(jit_module(ctx, gen_filter_source(e, ks), &mod));
+        hipFunction_t fcount = nullptr, femit = nullptr;
+        CHGPU_HIP(hipModuleGetFunction(&fcount, mod, "k_fcount"));
+        CHGPU_HIP(hipModuleGetFunction(&femit, mod, "k_femit"));
+        const u64 n_chunks = (rows + FE_CHUNK - 1) / FE_CHUNK;
+        auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+        const size_t b_cnt = al(n_chunks * 4), b_off = al(n_chunks * 8), b_tmp = chgpu_scan_tmp_bytes(n_chunks);
+        void * scratch = nullptr;
+        CHGPU_TRY(chgpu_scratch(ctx, b_cnt + b_off + 256 + b_tmp, &scratch));
+        u32 * counts = (u32 *)scratch;
+        u64 * offsets = (u64 *)((char *)scratch + b_cnt);
+        u64 * total_dev = (u64 *)((char *)scratch + b_cnt + b_off);
+        void * tmp = (char *)scratch + b_cnt + b_off + 256;
+        JitArgs a;
+        memset(&a, 0, sizeof(a));
+        for (size_t j = 0; j < e->input_types.size(); ++j)
+            a.in[j] = e->input_types[j] >= 0 ? cols[j]->data : nullptr;
+        a.n = rows;
+        a.part = (u64 *)counts;
+        const u32 grid = chgpu_grid_for(ctx, n_chunks * 64, 256, 8);
+        void * params[] = {&a};
+        CHGPU_HIP(hipModuleLaunchKernel(fcount, grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
+        CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, n_chunks, total_dev, tmp, b_tmp));
+        CHGPU_TRY(chgpu_read_back(ctx, total_dev, &total, sizeof(total)));
+        for (uint32_t o = 0; o < n_outputs; ++o)
+        {
+            const int rc = chgpu_col_new(ctx, e->types[out_nodes[o]], total, &res[o]);
+            if (rc != CHGPU_OK)
+                return fail(rc);
+            a.out[o] = res[o]->data;
+        }
+        if (total)
+        {
+            a.part = offsets;
+            if (hipModuleLaunchKernel(femit, grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr) != hipSuccess)
+                return fail(chgpu_set_error(CHGPU_ERR_DEVICE, "k_femit launch failed"));
+        }
+        ctx->counters[6] += 2;
+        ctx->counters[0] += total; // FilterTransformPassedRows
+    }
+    else
+        for (uint32_t o = 0; o < n_outputs; ++o)
+        {
+            const int rc = chgpu_col_new(ctx, e->types[out_nodes[o]], 0, &res[o]);
+            if (rc != CHGPU_OK)
+                return fail(rc);
+        }
+    for (uint32_t o = 0; o < n_outputs; ++o)
+        outs[o] = res[o];
+    *rows_out = total;
     return CHGPU_OK;
 }

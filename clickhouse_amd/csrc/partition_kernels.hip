@@ -9,8 +9,8 @@
 //
 // CDNA has no crc32c instruction: CRC32-C of a 64-bit key is computed from eight 256-entry byte tables staged in LDS
 // (crc is GF(2)-affine in the message).  The partition is a stable three-pass split (per-tile histogram -> scan ->
-// ordered scatter); one wave owns one tile and keeps its per-shard cursors in LDS, ranks inside a 64-row step come from
-// wave ballots, so each shard's rows keep their input order exactly like the reference's sequential insertFrom loop.
+// ordered scatter through LDS, see k_part_scatter_lds), so each shard's rows keep their input order exactly like the
+// reference's sequential insertFrom loop.
 #include "chgpu_internal.h"
 
 #include <algorithm>
@@ -19,11 +19,6 @@ static constexpr u32 PT = 256;
 static constexpr u32 MAX_SHARDS = 256;
 static constexpr u32 MAX_PART_COLS = 8;
 
-static u32 tune_env_part(const char * name, u32 dflt)
-{
-    const char * v = getenv(name);
-    return v ? (u32)atoi(v) : dflt;
-}
 
 __device__ __forceinline__ u64 pload_key(const void * keys, int type, u64 i)
 {
@@ -67,32 +62,6 @@ __global__ __launch_bounds__(PT) void k_selector(const void * __restrict__ keys,
     }
 }
 
-// pass 1: counts[shard * n_tiles + tile]
-__global__ __launch_bounds__(PT) void k_part_hist(const u32 * __restrict__ sel, u64 n, u32 num_shards, u32 tile_rows, u64 n_tiles, u32 * __restrict__ counts)
-{
-    __shared__ u32 hist[PT / 64][MAX_SHARDS];
-    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u64 wave0 = ((u64)blockIdx.x * PT + threadIdx.x) >> 6;
-    const u64 n_waves = ((u64)gridDim.x * PT) >> 6;
-    for (u64 tile = wave0; tile < n_tiles; tile += n_waves)
-    {
-        for (u32 s = lane; s < num_shards; s += 64)
-            hist[wave][s] = 0;
-        const u64 base = tile * tile_rows;
-        for (u32 r = lane; r < tile_rows; r += 64)
-        {
-            const u64 i = base + r;
-            if (i < n)
-            {
-                const u32 s = sel[i];
-                atomicAdd(&hist[wave][s < num_shards ? s : 0], 1u);
-            }
-        }
-        for (u32 s = lane; s < num_shards; s += 64)
-            counts[(u64)s * n_tiles + tile] = hist[wave][s];
-    }
-}
-
 struct PartCols
 {
     u32 n_cols;
@@ -101,62 +70,10 @@ struct PartCols
     void * dst[MAX_PART_COLS];
 };
 
-// pass 3: ordered scatter.  offsets[shard * n_tiles + tile] = global position (in the concatenated output) of the first
-// row of (shard, tile).
-__global__ __launch_bounds__(PT) void k_part_scatter(const u32 * __restrict__ sel, u64 n, u32 num_shards, u32 shard_bits, u32 tile_rows, u64 n_tiles,
-                                                     const u64 * __restrict__ offsets, PartCols cols)
-{
-    __shared__ u64 cursor_s[PT / 64][MAX_SHARDS];
-    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    volatile u64 * cursor = cursor_s[wave];
-    const u64 wave0 = ((u64)blockIdx.x * PT + threadIdx.x) >> 6;
-    const u64 n_waves = ((u64)gridDim.x * PT) >> 6;
-    for (u64 tile = wave0; tile < n_tiles; tile += n_waves)
-    {
-        for (u32 s = lane; s < num_shards; s += 64)
-            cursor[s] = offsets[(u64)s * n_tiles + tile];
-        const u64 base = tile * tile_rows;
-        for (u32 r0 = 0; r0 < tile_rows; r0 += 64)
-        {
-            const u64 i = base + r0 + lane;
-            const bool in = i < n;
-            u32 s = in ? sel[i] : 0;
-            if (s >= num_shards)
-                s = 0;
-            // lanes holding the same shard id: AND of per-bit ballots
-            u64 peers = __ballot(in);
-            for (u32 b = 0; b < shard_bits; ++b)
-            {
-                const u64 bal = __ballot((s >> b) & 1);
-                peers &= ((s >> b) & 1) ? bal : ~bal;
-            }
-            u64 pos = 0;
-            if (in)
-                pos = cursor[s] + mbcnt(peers); // LDS reads of this wave complete before its later LDS writes
-            __builtin_amdgcn_wave_barrier();
-            if (in && mbcnt(peers) == 0)
-                cursor[s] += (u64)__popcll(peers); // the lowest lane of each peer group advances the shard cursor
-            __builtin_amdgcn_wave_barrier();
-            if (in)
-            {
-                for (u32 c = 0; c < cols.n_cols; ++c)
-                {
-                    switch (cols.elem_size[c])
-                    {
-                        case 8: ((u64 *)cols.dst[c])[pos] = ((const u64 *)cols.src[c])[i]; break;
-                        case 4: ((u32 *)cols.dst[c])[pos] = ((const u32 *)cols.src[c])[i]; break;
-                        case 2: ((u16 *)cols.dst[c])[pos] = ((const u16 *)cols.src[c])[i]; break;
-                        default: ((u8 *)cols.dst[c])[pos] = ((const u8 *)cols.src[c])[i]; break;
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// LDS-staged stable partition (the default).  The wave-per-tile kernel above writes every row to its own destination
-// line (64 scattered 4-8 byte stores per wave instruction) and is bound by the rate of partial-line writes; here a
+// LDS-staged stable partition.  A first version (one wave per tile, every row stored straight to its destination: 64 scattered
+// 4-8 byte stores per wave instruction) was bound by the rate of partial-line writes (3.06 ms per 256-way pass over 1e8 16-byte
+// rows against 1.6 ms); here a
 // workgroup sorts a tile of PL_TILE rows by shard in LDS and writes each shard's run with consecutive lanes on consecutive
 // addresses.  Stability: rows are taken wave-striped (step j of wave w covers 64 consecutive rows), a row's rank inside
 // its wave = the wave's running per-shard counter + the number of lower lanes of this step with the same shard (per-bit
@@ -420,13 +337,7 @@ static int partition_core_src(chgpu_ctx * ctx, SelSrc sel, u64 n, u32 num_shards
                       (unsigned long long)n, (unsigned long long)cols[c]->rows); // IColumn.cpp:249-251
         outs[c] = nullptr;
     }
-    static const bool old_kernels = tune_env_part("CHGPU_PART_OLD", 0) != 0; // A/B: the wave-per-tile kernels (selector column only)
-    const bool lds_path = !(old_kernels && sel.mode == 0);
-    u32 tile_rows = 2048;
-    if (tile_rows < num_shards * 64)
-        tile_rows = num_shards * 64;
-    if (lds_path)
-        tile_rows = PL_TILE;
+    const u32 tile_rows = PL_TILE;
     const u64 n_tiles = (n + tile_rows - 1) / tile_rows;
     const u64 m = (u64)num_shards * (n_tiles ? n_tiles : 1);
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -465,20 +376,12 @@ static int partition_core_src(chgpu_ctx * ctx, SelSrc sel, u64 n, u32 num_shards
         pc.src[c] = cols[c]->data;
         pc.dst[c] = outs[c]->data;
     }
-    if (lds_path)
     {
         constexpr u32 wg_per_cu = PL_RPT >= 32 ? 2 : PL_RPT >= 16 ? 3 : 5; // what LDS (9 B per tile row + 7 KiB) and the VGPR count allow
         const u32 grid = (u32)std::min<u64>(n_tiles, (u64)ctx->num_cus * wg_per_cu);
         hipLaunchKernelGGL(k_part_hist_lds, dim3((u32)std::min<u64>(n_tiles, (u64)ctx->num_cus * 8)), dim3(PT), 0, ctx->stream, sel, n, num_shards, n_tiles, cnt);
         CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, cnt, offs, m, starts + num_shards, tmp, tmp_b));
         hipLaunchKernelGGL(k_part_scatter_lds, dim3(grid), dim3(PT), 0, ctx->stream, sel, n, num_shards, shard_bits, n_tiles, (const u64 *)offs, pc);
-    }
-    else
-    {
-        const u32 grid = chgpu_grid_for(ctx, n_tiles * 64, PT, 8);
-        hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(PT), 0, ctx->stream, (const u32 *)sel.p, n, num_shards, tile_rows, n_tiles, cnt);
-        CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, cnt, offs, m, starts + num_shards, tmp, tmp_b));
-        hipLaunchKernelGGL(k_part_scatter, dim3(grid), dim3(PT), 0, ctx->stream, (const u32 *)sel.p, n, num_shards, shard_bits, tile_rows, n_tiles, (const u64 *)offs, pc);
     }
     ctx->counters[6] += 3;
     hipError_t e = hipGetLastError();

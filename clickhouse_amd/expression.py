@@ -108,6 +108,15 @@ class ExpressionActions:
         K.check(K.lib().chgpu_expr_execute(ctx._h, self._h, len(cols), arr, len(out_nodes), outs_n, outs))
         return [Column(ctx, C.c_void_p(h)) for h in outs]
 
+    def filter_execute(self, ctx: Context, cols, filter_node: int, out_nodes):
+        """WHERE filter_node + projection of out_nodes in one step -> ([Columns of the surviving rows, in order], rows)"""
+        arr = (C.c_void_p * len(cols))(*[c._h if c is not None else None for c in cols])
+        outs_n = (C.c_uint32 * len(out_nodes))(*out_nodes)
+        outs = (C.c_void_p * len(out_nodes))()
+        rows = C.c_uint64(0)
+        K.check(K.lib().chgpu_expr_filter_execute(ctx._h, self._h, len(cols), arr, filter_node, len(out_nodes), outs_n, outs, C.byref(rows)))
+        return [Column(ctx, C.c_void_p(h)) for h in outs], int(rows.value)
+
     def filter_sum(self, ctx: Context, cols, filter_node: int = -1, value_node: int = -1):
         """(sum(value_node), count()) over the rows where filter_node != 0, one pass"""
         arr = (C.c_void_p * len(cols))(*[c._h if c is not None else None for c in cols])

@@ -233,8 +233,8 @@ typedef struct chgpu_expr chgpu_expr;
 /* type-checks the DAG and generates its row function; needs no device */
 int chgpu_expr_compile(uint32_t n_nodes, const chgpu_expr_node * nodes, chgpu_expr ** out);
 int chgpu_expr_node_type(const chgpu_expr * expr, uint32_t node, int * type_out);
-/* runs the run-time compiler only (no device): n_outputs > 0 -> the materialising kernel for out_nodes, n_outputs == 0 -> the
-   fused filter + sum kernel for (filter_node, value_node) */
+/* runs the run-time compiler only (no device): n_outputs > 0 -> the materialising kernel for out_nodes (with filter_node >= 0: the
+   WHERE + projection pair of chgpu_expr_filter_execute), n_outputs == 0 -> the fused filter + sum kernel for (filter_node, value_node) */
 int chgpu_expr_precompile(const chgpu_expr * expr, uint32_t n_outputs, const uint32_t * out_nodes, int filter_node, int value_node,
                           uint64_t * code_bytes_out);
 /* materialise out_nodes[n_outputs] (<= 8) as new columns over cols[n_cols] (the INPUT nodes' columns, all of one length) */
@@ -244,6 +244,12 @@ int chgpu_expr_execute(chgpu_ctx * ctx, const chgpu_expr * expr, uint32_t n_cols
    value_node < 0: count only).  sum_out: 8 bytes of the SumSimple type of the value node (*result_type_out). */
 int chgpu_expr_filter_sum_node(chgpu_ctx * ctx, const chgpu_expr * expr, uint32_t n_cols, const chgpu_col * const * cols,
                                int filter_node, int value_node, int * result_type_out, void * sum_out, uint64_t * count_out);
+/* WHERE filter_node + projection of out_nodes (<= 7; INPUT nodes pass columns through) in one step: only the rows whose filter value
+   is non-zero are written, in order -- FilterTransform (FilterTransform.cpp:136-256) fused behind the ExpressionTransform, no mask
+   and no unfiltered intermediate in HBM.  *rows_out = surviving rows (0: the chunk is dropped; the outputs are empty columns). */
+int chgpu_expr_filter_execute(chgpu_ctx * ctx, const chgpu_expr * expr, uint32_t n_cols, const chgpu_col * const * cols,
+                              uint32_t filter_node, uint32_t n_outputs, const uint32_t * out_nodes, chgpu_col ** outs,
+                              uint64_t * rows_out);
 int chgpu_expr_free(chgpu_expr * expr);
 
 /* ================================================================================================

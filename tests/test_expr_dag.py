@@ -286,6 +286,16 @@ def test_gpu_random_dags_match_oracle_bit_exact(seed):
             assert ex.node_type(k) == types[k]
             got = o.numpy()
             assert _same(got, vals[k]), (seed, k, d.nodes[k], got[:8], vals[k][:8])
+    # WHERE + projection in one step: the surviving rows of up to 7 nodes, in order
+    ints0 = [k for k in range(len(d.nodes)) if types[k] not in (OE.F64, OE.F32)]
+    if ints0:
+        fn0 = ints0[int(rng.integers(0, len(ints0)))]
+        outs_k = [int(x) for x in rng.choice(len(d.nodes), size=min(len(d.nodes), 1 + int(rng.integers(0, 7))), replace=False)]
+        got, nrows = ex.filter_execute(ctx, cols_d, fn0, outs_k)
+        keep = vals[fn0] != 0
+        assert nrows == int(keep.sum())
+        for k, o in zip(outs_k, got):
+            assert _same(o.numpy(), vals[k][keep]), (seed, "filter_execute", fn0, k)
     # fused WHERE + sum + count over a random (filter, value) pair
     ints = [k for k in fnodes if types[k] not in (OE.F64, OE.F32)]
     if ints:

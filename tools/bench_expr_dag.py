@@ -58,7 +58,23 @@ dt_m, outs = best_of(lambda: ex.execute(ctx, [ca], [p]), reps=5)
 dt_c, m2 = best_of(lambda: ch.cmp_const(ca, ch.LT, 214748365), reps=5)
 res.append(line("less(a, C) -> UInt8 mask: JIT DAG", dt_m, 9))
 res.append(line("less(a, C) -> UInt8 mask: hand-written k_cmp_mask", dt_c, 9))
-del outs, m2, a, ca
+# WHERE a < C (10 % pass) + projection (a, a * 3): fused k_fcount + k_femit against mask -> filter_columns -> arithmetic
+d2 = ch.ActionsDAG()
+ja = d2.add_input(0, np.int64)
+jp = d2.add_function("less", ja, d2.add_column(214748365, np.uint32))
+jv = d2.add_function("multiply", ja, d2.add_column(3, np.uint8))
+ex2 = d2.compile()
+ex2.filter_execute(ctx, [ca.cut(0, 4096)], jp, [ja, jv])
+dt_f, (fo, frows) = best_of(lambda: ex2.filter_execute(ctx, [ca], jp, [ja, jv]), reps=5)
+def unfused_project():
+    mk = ch.cmp_const(ca, ch.LT, 214748365)
+    fa = ch.filter_columns([ca], mk)[0]
+    return fa, ex2.execute(ctx, [fa], [jv])[0]
+dt_u2, (ua, uv) = best_of(unfused_project, reps=5)
+assert frows == ua.size() and int(ch.sum_add_many(fo[1])[0]) == int(ch.sum_add_many(uv)[0])
+res.append(line("WHERE a < C + projection (a, a*3), 10 % pass: JIT k_fcount + k_femit", dt_f, 8 + 1.6, {"rows_out": frows}))
+res.append(line("WHERE a < C + projection: k_cmp_mask + filter_columns + JIT multiply", dt_u2, 8 + 1.6))
+del outs, m2, a, ca, fo, ua, uv
 ctx.trim()
 torch.cuda.empty_cache()
 # --- SSB Q1.1 over the real widths (UInt32, UInt8, UInt8, UInt32: 10 B/row) ------------------------------------------------
