@@ -47,7 +47,7 @@ SIGNATURES = {
     "chgpu_col_type": (_i, [_vp]),
     "chgpu_col_device_ptr": (_vp, [_vp]),
     "chgpu_col_free": (_i, [_vp]),
-    "chgpu_decompress_frames": (_i, [_vp, _vp, _u32, _pu64, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.c_uint8), _pp]),
+    "chgpu_decompress_frames": (_i, [_vp, _vp, _u32, _pu64, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(_u32), _pp]),
     "chgpu_col_from_bytes": (_i, [_vp, _vp, _u64, _i, _u64, _pp]),
     "chgpu_cmp_const": (_i, [_vp, _vp, _i, _i, _vp, _pp]),
     "chgpu_count_bytes_in_filter": (_i, [_vp, _vp, _pu64]),

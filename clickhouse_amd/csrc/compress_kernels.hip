@@ -10,7 +10,8 @@
 //                   the `offset` bytes before it repeated, so byte k reads position (k mod offset) of that window and no lane
 //                   depends on another lane of the same copy.  Input window and recent output are kept in LDS (see the kernel).
 //                   Every input and output position is bounds-checked: a malformed frame sets the error flag, never faults.
-//   k_frame_copy    method NONE (0x02): payload copied as is
+//                   method NONE (0x02): payload copied as is
+//   k_delta_decode  the Delta stage of CODEC(Delta, LZ4): running sums of 1/2/4/8-byte elements, wave scan + uniform carry
 // Algorithmic bytes: compressed size read + decompressed size written (match sources are re-reads of fresh output: L1/L2).
 #include "chgpu_internal.h"
 
@@ -21,6 +22,9 @@ struct FrameJob
     u32 src_size; // payload bytes
     u32 dst_size; // decompressed bytes
     u32 method;   // 0x82 LZ4, 0x02 NONE
+    u32 post;     // 0: dst is the output buffer; 0x92: dst is the stage buffer and a Delta stage follows (CODEC(Delta, LZ4))
+    u64 out_off;  // post != 0: where the Delta stage writes in the output buffer
+    u32 out_size; // post != 0: final decompressed size
     u32 pad;
 };
 
@@ -35,7 +39,7 @@ static constexpr u32 LZ_RING = 4096;  // output ring bytes per wave (matches up 
                                       // workgroup keeps 8 workgroups = 32 frames per CU in flight (8 KiB rings: 3 workgroups, two rounds for 6 K frames)
 static constexpr u32 LZ_CHUNK = LZ_RING / 2;
 
-__global__ __launch_bounds__(256) void k_lz4_decode(const u8 * __restrict__ src, u8 * dst, const FrameJob * __restrict__ jobs, u32 n_jobs, u32 * __restrict__ err)
+__global__ __launch_bounds__(256) void k_lz4_decode(const u8 * __restrict__ src, u8 * dst_out, u8 * dst_stage, const FrameJob * __restrict__ jobs, u32 n_jobs, u32 * __restrict__ err)
 {
     __shared__ __attribute__((aligned(16))) u8 lds_in[4][LZ_IN + 16];
     __shared__ __attribute__((aligned(16))) u8 lds_ring[4][LZ_RING];
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) void k_lz4_decode(const u8 * __restrict__ src,
     {
         const FrameJob job = jobs[j];
         const u8 * in = src + job.src_off;
-        u8 * out = dst + job.dst_off;
+        u8 * out = (job.post ? dst_stage : dst_out) + job.dst_off;
         const u32 isz = job.src_size, osz = job.dst_size;
         if (job.method == 0x02u)
         {
@@ -247,29 +251,142 @@ __global__ __launch_bounds__(256) void k_lz4_decode(const u8 * __restrict__ src,
     }
 }
 
-/* Decompress n_frames frames of `compressed_u8` into one new UInt8 column of sum(dst_sizes) bytes.  Host arrays describe the frames
-   (payload offset / size inside compressed_u8, decompressed size, method byte).  CANNOT_DECOMPRESS -> CHGPU_ERR_BAD_ARGUMENTS. */
+// CompressionCodecDelta::doDecompressData (src/Compression/CompressionCodecDelta.cpp:84-175) as the second stage of
+// CODEC(Delta, LZ4) (CompressionCodecMultiple.cpp:68-130: the LZ4 stage yields the Delta stage's own 9-byte header + payload):
+// payload = [element width][bytes_to_skip][skipped bytes][deltas]; the values are the running sums, wrap-around.  One wave per
+// frame: 64 deltas per step, wave inclusive scan by shuffles, the carry travels in a uniform register.  Loads and stores are
+// unaligned by construction (9 + 2 header bytes in front of the payload).
+template <typename T>
+__device__ __forceinline__ void delta_frame(const u8 * __restrict__ pay, u32 n_el, u8 * __restrict__ out, u32 lane)
+{
+    T carry = 0;
+    for (u32 base = 0; base < n_el; base += 64)
+    {
+        const u32 i = base + lane;
+        T v = 0;
+        if (i < n_el)
+            __builtin_memcpy(&v, pay + (size_t)i * sizeof(T), sizeof(T));
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1)
+        {
+            T o;
+            if constexpr (sizeof(T) == 8)
+                o = (T)(((u64)__shfl_up((u32)((u64)v >> 32), d, 64) << 32) | __shfl_up((u32)(u64)v, d, 64));
+            else
+                o = (T)__shfl_up((u32)v, d, 64);
+            if (lane >= (u32)d)
+                v += o;
+        }
+        v += carry;
+        if (i < n_el)
+            __builtin_memcpy(out + (size_t)i * sizeof(T), &v, sizeof(T));
+        T last;
+        if constexpr (sizeof(T) == 8)
+            last = (T)(((u64)__shfl((u32)((u64)v >> 32), 63, 64) << 32) | __shfl((u32)(u64)v, 63, 64));
+        else
+            last = (T)__shfl((u32)v, 63, 64);
+        carry = last; // lanes beyond n_el hold the running sum too (their delta is 0)
+    }
+}
+
+__global__ __launch_bounds__(256) void k_delta_decode(const u8 * __restrict__ stage, u8 * __restrict__ dst_out, const FrameJob * __restrict__ jobs, u32 n_jobs,
+                                                      u32 * __restrict__ err)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave0 = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
+    for (u32 j = wave0; j < n_jobs; j += n_waves)
+    {
+        const FrameJob job = jobs[j];
+        if (job.post != 0x92u)
+            continue;
+        const u8 * in = stage + job.dst_off; // the LZ4 stage's output: [method][compressed size][decompressed size][payload]
+        const u32 ssz = job.dst_size;
+        bool bad = ssz < 11;
+        u32 w = 0, skip = 0, n_bytes = 0;
+        if (!bad)
+        {
+            u32 csize, dsize;
+            __builtin_memcpy(&csize, in + 1, 4);
+            __builtin_memcpy(&dsize, in + 5, 4);
+            w = in[9], skip = in[10];
+            bad = in[0] != 0x92 || csize != ssz || dsize != job.out_size || !(w == 1 || w == 2 || w == 4 || w == 8) || 11 + skip > ssz || skip > job.out_size;
+            if (!bad)
+            {
+                n_bytes = ssz - 11 - skip;
+                bad = n_bytes != job.out_size - skip || n_bytes % w != 0;
+            }
+        }
+        if (__builtin_amdgcn_readfirstlane((int)bad))
+        {
+            if (lane == 0)
+                atomicOr(err, 4u);
+            continue;
+        }
+        u8 * out = dst_out + job.out_off;
+        if (lane < skip)
+            out[lane] = in[11 + lane];
+        const u8 * pay = in + 11 + skip;
+        switch (w)
+        {
+            case 1: delta_frame<u8>(pay, n_bytes, out + skip, lane); break;
+            case 2: delta_frame<u16>(pay, n_bytes / 2, out + skip, lane); break;
+            case 4: delta_frame<u32>(pay, n_bytes / 4, out + skip, lane); break;
+            default: delta_frame<u64>(pay, n_bytes / 8, out + skip, lane); break;
+        }
+    }
+}
+
+/* Decompress n_frames frames of `compressed_u8` into one new UInt8 column of sum(decompressed_sizes) bytes.  Host arrays describe the
+   frames: payload offset / size inside compressed_u8 and method byte of the (last applied) general-purpose stage, its output size
+   (stage_sizes; NULL = decompressed_sizes) and, for CODEC(Delta, LZ4), post_methods[f] = 0x92 (NULL / 0 = single stage).
+   CANNOT_DECOMPRESS -> CHGPU_ERR_BAD_ARGUMENTS. */
 extern "C" int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compressed_u8, uint32_t n_frames, const uint64_t * payload_offsets,
-                                       const uint32_t * payload_sizes, const uint32_t * decompressed_sizes, const uint8_t * methods, chgpu_col ** out_u8)
+                                       const uint32_t * payload_sizes, const uint32_t * decompressed_sizes, const uint8_t * methods,
+                                       const uint8_t * post_methods, const uint32_t * stage_sizes, chgpu_col ** out_u8)
 {
     CHGPU_REQUIRE(ctx && compressed_u8 && out_u8, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(compressed_u8->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "compressed data is a UInt8 column");
     CHGPU_REQUIRE(n_frames == 0 || (payload_offsets && payload_sizes && decompressed_sizes && methods), CHGPU_ERR_BAD_ARGUMENTS, "NULL frame arrays");
     std::vector<FrameJob> jobs(n_frames);
-    u64 total = 0;
+    u64 total = 0, stage_total = 0;
     for (u32 f = 0; f < n_frames; ++f)
     {
         CHGPU_REQUIRE(methods[f] == 0x82 || methods[f] == 0x02, CHGPU_ERR_NOT_IMPLEMENTED, "compression method 0x%02x: CPU path", methods[f]);
         CHGPU_REQUIRE(payload_offsets[f] + payload_sizes[f] <= compressed_u8->rows, CHGPU_ERR_BAD_ARGUMENTS, "frame %u lies outside the compressed buffer", f);
-        jobs[f] = FrameJob{payload_offsets[f], total, payload_sizes[f], decompressed_sizes[f], methods[f], 0};
+        const u32 post = post_methods ? post_methods[f] : 0;
+        CHGPU_REQUIRE(post == 0 || post == 0x92, CHGPU_ERR_NOT_IMPLEMENTED, "codec 0x%02x in front of the general-purpose stage: CPU path", post);
+        CHGPU_REQUIRE(post == 0 || stage_sizes, CHGPU_ERR_BAD_ARGUMENTS, "stage_sizes is NULL");
+        FrameJob jb{};
+        jb.src_off = payload_offsets[f];
+        jb.src_size = payload_sizes[f];
+        jb.method = methods[f];
+        jb.post = post;
+        if (post)
+        {
+            jb.dst_off = stage_total;
+            jb.dst_size = stage_sizes[f];
+            jb.out_off = total;
+            jb.out_size = decompressed_sizes[f];
+            stage_total += (stage_sizes[f] + 15u) & ~15ull;
+        }
+        else
+        {
+            jb.dst_off = total;
+            jb.dst_size = decompressed_sizes[f];
+        }
+        jobs[f] = jb;
         total += decompressed_sizes[f];
     }
     chgpu_col * res = nullptr;
     CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U8, total, &res));
     if (n_frames && total)
     {
+        void * stage = nullptr;
+        size_t stage_class = 0;
         void * scratch = nullptr;
         int rc = chgpu_scratch(ctx, sizeof(FrameJob) * (size_t)n_frames + 256, &scratch);
+        if (rc == CHGPU_OK && stage_total)
+            rc = chgpu_pool_alloc(ctx, stage_total + 64, &stage, &stage_class);
         if (rc != CHGPU_OK)
         {
             chgpu_col_free(res);
@@ -282,17 +399,27 @@ extern "C" int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compre
             e = hipMemcpyAsync(jd, jobs.data(), sizeof(FrameJob) * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess)
             e = hipStreamSynchronize(ctx->stream); // `jobs` is pageable host memory: it must outlive the copy
-        if (e != hipSuccess)
+        if (e == hipSuccess)
         {
-            chgpu_col_free(res);
-            return chgpu_set_error(CHGPU_ERR_DEVICE, "frame table upload: %s", hipGetErrorString(e));
+            const u32 grid = chgpu_grid_for(ctx, (u64)n_frames * 64, 256, 8);
+            hipLaunchKernelGGL(k_lz4_decode, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)compressed_u8->data, (u8 *)res->data, (u8 *)stage, (const FrameJob *)jd,
+                               n_frames, err);
+            ctx->counters[6] += 1;
+            if (stage_total)
+            {
+                hipLaunchKernelGGL(k_delta_decode, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)stage, (u8 *)res->data, (const FrameJob *)jd, n_frames, err);
+                ctx->counters[6] += 1;
+            }
+            e = hipGetLastError();
         }
-        const u32 grid = chgpu_grid_for(ctx, (u64)n_frames * 64, 256, 8);
-        hipLaunchKernelGGL(k_lz4_decode, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)compressed_u8->data, (u8 *)res->data, (const FrameJob *)jd, n_frames, err);
-        ctx->counters[6] += 1;
         u32 failed = 0;
-        rc = chgpu_read_back(ctx, err, &failed, sizeof(failed));
-        if (rc == CHGPU_OK && failed)
+        if (e == hipSuccess)
+            rc = chgpu_read_back(ctx, err, &failed, sizeof(failed));
+        if (stage)
+            chgpu_pool_free(ctx, stage, stage_class);
+        if (e != hipSuccess)
+            rc = chgpu_set_error(CHGPU_ERR_DEVICE, "frame decode: %s", hipGetErrorString(e));
+        else if (rc == CHGPU_OK && failed)
             rc = chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "Cannot decompress: malformed frame (CANNOT_DECOMPRESS)");
         if (rc != CHGPU_OK)
         {

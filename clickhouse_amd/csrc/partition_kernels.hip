@@ -112,7 +112,7 @@ __global__ __launch_bounds__(PT) void k_part_hist_lds(SelSrc sel, u64 n, u32 num
     __shared__ u32 hist[MAX_SHARDS];
     for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
     {
-        for (u32 s = threadIdx.x; s < num_shards; s += PT)
+        for (u32 s = threadIdx.x; s < (num_shards < 8 ? 8u : num_shards); s += PT)
             hist[s] = 0;
         __syncthreads();
         const u64 base = tile * PL_TILE;
@@ -123,10 +123,30 @@ __global__ __launch_bounds__(PT) void k_part_hist_lds(SelSrc sel, u64 n, u32 num
             const u64 i = base + (u64)j * PT + threadIdx.x;
             v[j] = i < n ? sel_at(sel, i, num_shards) : ~0u;
         }
+        if (num_shards <= 8)
+        {
+            // few shards (the 2/4/8-GPU split): 256 lanes hammering 8 LDS counters serialise; count in registers, reduce per wave
+            u32 c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (u32 j = 0; j < PL_RPT; ++j)
-            if (v[j] != ~0u)
-                atomicAdd(&hist[v[j]], 1u);
+            for (u32 j = 0; j < PL_RPT; ++j)
+#pragma unroll
+                for (u32 q = 0; q < 8; ++q)
+                    c[q] += v[j] == q ? 1u : 0u;
+#pragma unroll
+            for (u32 q = 0; q < 8; ++q)
+            {
+                const u32 t = wave_reduce_add_u32(c[q]);
+                if ((threadIdx.x & 63) == 0 && t)
+                    atomicAdd(&hist[q], t);
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (u32 j = 0; j < PL_RPT; ++j)
+                if (v[j] != ~0u)
+                    atomicAdd(&hist[v[j]], 1u);
+        }
         __syncthreads();
         for (u32 s = threadIdx.x; s < num_shards; s += PT)
             counts[(u64)s * n_tiles + tile] = hist[s];

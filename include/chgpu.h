@@ -120,13 +120,16 @@ int chgpu_col_free(chgpu_col * col);
  * (src/Compression/CompressedReadBufferBase.cpp:175-222, CompressionInfo.h:10-51).  The host walks the frame headers (the caller
  * verifies checksums if it wants them verified: CityHash128 is not carried), uploads the compressed bytes once and names the
  * frames; every frame is decoded by one wavefront straight into the output buffer (LZ4 block format as in
- * LZ4_decompress_faster.cpp:470-684; method 0x02 NONE copies).  Other methods -> CHGPU_ERR_NOT_IMPLEMENTED; a malformed frame ->
+ * LZ4_decompress_faster.cpp:470-684; method 0x02 NONE copies).  CODEC(Delta, LZ4) -- a Multiple frame (0x91,
+ * CompressionCodecMultiple.cpp:68-130) whose methods are {0x92, 0x82} -- is two stages: the host names the inner LZ4 stage's payload
+ * and output size (stage_sizes) and sets post_methods[f] = 0x92; the Delta stage (CompressionCodecDelta.cpp:84-175: running sums) checks
+ * its own header on the device.  post_methods / stage_sizes may be NULL.  Other methods -> CHGPU_ERR_NOT_IMPLEMENTED; a malformed frame ->
  * CHGPU_ERR_BAD_ARGUMENTS (CANNOT_DECOMPRESS), never a fault.  chgpu_col_from_bytes turns a byte range of the result into a typed
  * column (SerializationNumber::deserializeBinaryBulk: plain little-endian arrays).
  * ============================================================================================== */
 int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compressed_u8, uint32_t n_frames, const uint64_t * payload_offsets,
                             const uint32_t * payload_sizes, const uint32_t * decompressed_sizes, const uint8_t * methods,
-                            chgpu_col ** out_u8);
+                            const uint8_t * post_methods, const uint32_t * stage_sizes, chgpu_col ** out_u8);
 int chgpu_col_from_bytes(chgpu_ctx * ctx, const chgpu_col * bytes_u8, uint64_t byte_offset, int type, uint64_t rows, chgpu_col ** out);
 
 /* ================================================================================================

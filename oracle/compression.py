@@ -20,7 +20,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-METHOD_NONE, METHOD_LZ4, METHOD_DELTA = 0x02, 0x82, 0x92
+METHOD_NONE, METHOD_LZ4, METHOD_DELTA, METHOD_MULTIPLE = 0x02, 0x82, 0x92, 0x91
+DELTA_LZ4 = "delta+lz4"  # CODEC(Delta(w), LZ4)
 HEADER = 9
 CHECKSUM = 16
 _lib = None
@@ -57,14 +58,34 @@ def delta_decode(payload: bytes, dst_size: int) -> bytes:
     return dst.tobytes()
 
 
-def write_frames(raw: bytes, block_size: int = 65536, method: int = METHOD_LZ4) -> bytes:
-    """CompressedWriteBuffer: one frame per `block_size` bytes of input (checksum bytes are left zero: unverified)"""
+def _stage(method: int, payload: bytes, decompressed_size: int) -> bytes:
+    """one codec application as ICompressionCodec::compress lays it out: 9-byte header + payload"""
+    return struct.pack("<BII", method, HEADER + len(payload), decompressed_size) + payload
+
+
+def delta_encode(raw: bytes, width: int) -> bytes:
+    """CompressionCodecDelta::doCompressData (CompressionCodecDelta.cpp:109-133): [width][bytes_to_skip][skipped][deltas]"""
+    skip = len(raw) % width
+    x = np.frombuffer(raw[skip:], dtype={1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[width])
+    d = np.diff(np.concatenate((np.zeros(1, dtype=x.dtype), x))) if x.size else x
+    return bytes([width, skip]) + raw[:skip] + d.astype(x.dtype).tobytes()
+
+
+def write_frames(raw: bytes, block_size: int = 65536, method=METHOD_LZ4, delta_width: int = 8) -> bytes:
+    """CompressedWriteBuffer: one frame per `block_size` bytes of input (checksum bytes are left zero: unverified).
+    method DELTA_LZ4 = CODEC(Delta(delta_width), LZ4): a Multiple frame (CompressionCodecMultiple.cpp:40-66) -- the method list, then
+    the stages applied in order, each with its own header."""
     import pyarrow as pa
     out = bytearray()
     for lo in range(0, len(raw), block_size):
         chunk = raw[lo:lo + block_size]
+        if method == DELTA_LZ4:
+            st1 = _stage(METHOD_DELTA, delta_encode(chunk, delta_width), len(chunk))
+            st2 = _stage(METHOD_LZ4, pa.compress(st1, codec="lz4_raw", asbytes=True), len(st1))
+            out += bytes(CHECKSUM) + _stage(METHOD_MULTIPLE, bytes([2, METHOD_DELTA, METHOD_LZ4]) + st2, len(chunk))
+            continue
         payload = pa.compress(chunk, codec="lz4_raw", asbytes=True) if method == METHOD_LZ4 else chunk
-        out += bytes(CHECKSUM) + struct.pack("<BII", method, HEADER + len(payload), len(chunk)) + payload
+        out += bytes(CHECKSUM) + _stage(method, payload, len(chunk))
     return bytes(out)
 
 
@@ -93,6 +114,33 @@ def read_frames(buf: bytes) -> bytes:
             out += payload
         elif method == METHOD_DELTA:
             out += delta_decode(payload, dsize)
+        elif method == METHOD_MULTIPLE:
+            out += _multiple_decode(payload, dsize)
         else:
             raise NotImplementedError(hex(method))
     return bytes(out)
+
+
+def _decode_stage(buf: bytes) -> bytes:
+    method, csize, dsize = struct.unpack_from("<BII", buf, 0)
+    payload = buf[HEADER:csize]
+    if method == METHOD_LZ4:
+        return lz4_decompress(payload, dsize)
+    if method == METHOD_DELTA:
+        return delta_decode(payload, dsize)
+    if method == METHOD_NONE:
+        return payload
+    raise NotImplementedError(hex(method))
+
+
+def _multiple_decode(payload: bytes, dsize: int) -> bytes:
+    """CompressionCodecMultiple::doDecompressData (CompressionCodecMultiple.cpp:68-130): undo the stages from the last to the first"""
+    n = payload[0]
+    if n == 0:
+        raise ValueError("Wrong compression methods list")
+    buf = payload[1 + n:]
+    for _ in range(n):
+        buf = _decode_stage(buf)
+    if len(buf) != dsize:
+        raise ValueError("Wrong final decompressed size in codec Multiple")
+    return buf

@@ -23,10 +23,10 @@ res = []
 cases = [("Int64 uniform in [0, 2^31) (C2's column)", rng.integers(0, 2**31, size=rows, dtype=np.int64)),
          ("Int64 ascending ids, small steps", np.cumsum(rng.integers(0, 4, size=rows)).astype(np.int64)),
          ("UInt8 discount 0..10", rng.integers(0, 11, size=rows * 4).astype(np.uint8))]
-for name, arr in cases:
+for name, arr, method in [(n_, a_, OC.METHOD_LZ4) for n_, a_ in cases] + [("Int64 ascending ids, CODEC(Delta(8), LZ4)", cases[1][1], OC.DELTA_LZ4)]:
     raw = arr.tobytes()
     for bs in (65536, 1 << 20):
-        buf = OC.write_frames(raw, bs)
+        buf = OC.write_frames(raw, bs, method)
         frames = CC.parse_frames(buf)
         host = np.frombuffer(buf, dtype=np.uint8)
         up = ctx.upload(host)
@@ -45,12 +45,12 @@ for name, arr in cases:
         # CPU: Arrow's liblz4 (the library the reference links) and the plain-C restatement, one thread, first 64 frames
         sample = frames[:64]
         t0 = time.perf_counter()
-        for m, off, size, dsize in sample:
-            pa.decompress(buf[off:off + size], dsize, codec="lz4_raw", asbytes=True)
+        for m, off, size, dsize, post, stage in sample:
+            pa.decompress(buf[off:off + size], stage, codec="lz4_raw", asbytes=True)
         t_arrow = time.perf_counter() - t0
         t0 = time.perf_counter()
-        for m, off, size, dsize in sample:
-            OC.lz4_decompress(buf[off:off + size], dsize)
+        for m, off, size, dsize, post, stage in sample:
+            OC.lz4_decompress(buf[off:off + size], stage)
         t_port = time.perf_counter() - t0
         sbytes = sum(f[3] for f in sample)
         res.append({"case": name, "frame_bytes": bs, "frames": len(frames), "raw_bytes": len(raw), "compressed_bytes": len(buf),
