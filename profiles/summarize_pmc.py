@@ -48,6 +48,12 @@ main = [k for k in res["kernels"] if "k_filter_sum<" in k]
 if main:
     k = res["kernels"][main[0]]
     res["k_filter_sum_hbm_bytes_per_launch"] = k["hbm_read_bytes_per_launch_corrected"] + k["hbm_write_bytes_per_launch"]
+# the workload the counters were collected on (bench.py only quotes `traffic` for the same row count)
+try:
+    bj = json.loads(open(os.path.join(out, f"prof_{tag}_bench.json")).read().strip().splitlines()[-1])
+    res["rows"] = bj["config"]["rows_per_gpu"]
+except Exception:
+    res["rows"] = None
 with open(os.path.join(out, f"{tag}_traffic.json"), "w") as fo:
     json.dump(res, fo, indent=1)
 print(json.dumps(res, indent=1)[:3000])
