@@ -9,7 +9,7 @@ from .columns import (Column, Context, and_, arith, concat, expr_filter_sum, cmp
                       sum_add_many_conditional, unpack_fixed_key, sort_permutation, sort_block)
 from .aggregator import Aggregator
 from .expression import ActionsDAG, ExpressionActions
-from .lowcardinality import ColumnString, ColumnLowCardinality, LowCardinalityAggregator, LowCardinalityDictionary
+from .lowcardinality import ColumnString, ColumnLowCardinality, LowCardinalityAggregator, LowCardinalityDictionary, PackedKeysAggregator
 from .hashjoin import HashJoin
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -159,3 +159,53 @@ class LowCardinalityAggregator:
     def convert_to_block(self):
         ids, res = self.agg.convert_to_block()
         return self.dictionary.decode(ids), res
+
+
+class PackedKeysAggregator:
+    """GROUP BY several key columns, any of them LowCardinality / dictionary-encoded String — the keys16/32/64 variants
+    (chooseAggregationMethod, Aggregator.cpp:773-778: all keys fixed-width and <= 8 bytes together -> packFixed<UInt64>) with
+    LowCardinality keys contributing their dictionary positions, which is how the reference's `low_cardinality_keys128/256` treat them
+    (AggregatedDataVariants.h:128-131, HashMethodKeysFixed with has_low_cardinality).  A LowCardinality key takes 2 bytes of the packed
+    key (query-wide ids cast to UInt16 by a run-time compiled kernel); more than 65 536 distinct values or more than 8 key bytes ->
+    CHGPU_ERR_NOT_IMPLEMENTED (the caller keeps its CPU method).  SSB Q3.1's `GROUP BY c_nation, s_nation, d_year` is 2 + 2 + 2 bytes."""
+
+    def __init__(self, key_kinds, aggs, ctx: Context | None = None, size_hint: int = 0):
+        """key_kinds: one entry per key column, either "lc" or a numpy dtype"""
+        from .expression import ActionsDAG
+        self.ctx = ctx if ctx is not None else Context(0)
+        self.kinds = [k if k == "lc" else np.dtype(k) for k in key_kinds]
+        self.dicts = [LowCardinalityDictionary(self.ctx) if k == "lc" else None for k in self.kinds]
+        self.widths = [2 if k == "lc" else k.itemsize for k in self.kinds]
+        if sum(self.widths) > 8:
+            raise K.ChgpuError(K.ERR_NOT_IMPLEMENTED, "more than 8 key bytes: keys128/256 stay on the CPU")
+        d = ActionsDAG()
+        d.add_function("toUInt16", d.add_input(0, np.uint32))
+        self._narrow = d.compile()
+        self.agg = Aggregator(np.uint64, aggs, size_hint=size_hint, ctx=self.ctx)
+
+    def execute_on_block(self, keys, args, filter=None):
+        from .columns import pack_fixed_keys
+        cols = []
+        for k, kind, dic in zip(keys, self.kinds, self.dicts):
+            if kind == "lc":
+                ids = dic.map_block(k)
+                if len(dic) > 65536:
+                    raise K.ChgpuError(K.ERR_NOT_IMPLEMENTED, "a LowCardinality key with more than 65536 values does not fit its 2 key bytes")
+                cols.append(self._narrow.execute(self.ctx, [ids], [1])[0])
+            else:
+                cols.append(self.ctx.column(k))
+        self.agg.execute_on_block(pack_fixed_keys(cols), args, filter=filter)
+
+    def __len__(self):
+        return len(self.agg)
+
+    def convert_to_block(self):
+        """-> ([one list / ndarray per key column], [result ndarrays])"""
+        from .columns import unpack_fixed_key
+        keys, res = self.agg.finalize_columns()
+        out, off = [], 0
+        for kind, dic, w in zip(self.kinds, self.dicts, self.widths):
+            part = unpack_fixed_key(keys, off, np.uint16 if kind == "lc" else kind).numpy()
+            out.append(dic.decode(part) if kind == "lc" else part)
+            off += w
+        return out, [r.numpy() for r in res]

@@ -138,3 +138,35 @@ def test_gpu_group_by_string_key_over_stripes():
         blocks.append((d, ids, v))
     keys, (sums, cnts) = agg.convert_to_block()
     assert {k: (int(s), int(c)) for k, s, c in zip(keys, sums, cnts)} == OL.group_by_sum_count(blocks)
+
+
+@pytest.mark.gpu
+def test_gpu_ssb_q31_shape_group_by_two_string_keys_and_year():
+    """SELECT c_nation, s_nation, d_year, sum(lo_revenue) ... GROUP BY c_nation, s_nation, d_year with real String keys:
+    each stripe's String columns dictionary-encoded on the device, ids unified per key, 2 + 2 + 2 key bytes packed"""
+    import clickhouse_amd as ch
+    rng = np.random.Generator(np.random.PCG64(31))
+    ctx = ch.Context()
+    nations = [n.encode() for n in ("CHINA", "INDIA", "INDONESIA", "JAPAN", "VIETNAM", "FRANCE", "GERMANY", "PERU", "BRAZIL", "UNITED KINGDOM")]
+    agg = ch.PackedKeysAggregator(["lc", "lc", np.uint16], [(ch.AGG_SUM, np.uint32), (ch.AGG_COUNT, None)], ctx=ctx)
+    want = {}
+    for stripe in range(3):
+        n = 120_000 + 7 * stripe
+        c = rng.integers(0, 10, size=n)
+        s = rng.integers(0, 10, size=n)
+        y = rng.integers(1992, 1999, size=n).astype(np.uint16)
+        rev = rng.integers(1, 10_000_000, size=n).astype(np.uint32)
+        order = rng.permutation(10)  # every stripe meets the values in another order: different local dictionaries
+        cs = ch.ColumnString.from_values(ctx, [nations[order[i]] for i in c]).dictionary_encode()
+        ss = ch.ColumnString.from_values(ctx, [nations[order[i]] for i in s]).dictionary_encode()
+        agg.execute_on_block([cs, ss, ctx.upload(y)], [ctx.upload(rev), None])
+        for cn, sn, yy, r in zip(order[c], order[s], y, rev):
+            k = (nations[cn], nations[sn], int(yy))
+            a = want.get(k, (0, 0))
+            want[k] = (a[0] + int(r), a[1] + 1)
+    (kc, ks, ky), (sums, cnts) = agg.convert_to_block()
+    got = {(a, b, int(yv)): (int(sv), int(cv)) for a, b, yv, sv, cv in zip(kc, ks, ky, sums, cnts)}
+    assert len(got) == len(kc) == len(agg) and got == want
+    with pytest.raises(ch.ChgpuError) as ei:
+        ch.PackedKeysAggregator(["lc", np.uint64], [(ch.AGG_COUNT, None)], ctx=ctx)  # 10 key bytes
+    assert ei.value.code == ch._capi.ERR_NOT_IMPLEMENTED
