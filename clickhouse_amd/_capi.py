@@ -78,6 +78,7 @@ SIGNATURES = {
     "chgpu_pack_fixed_keys": (_i, [_vp, _u32, _pp, _pp]),
     "chgpu_unpack_fixed_key": (_i, [_vp, _vp, _u32, _i, _pp]),
     "chgpu_string_dictionary_encode": (_i, [_vp, _vp, _vp, _pp, _pp, _pu64]),
+    "chgpu_string_filter": (_i, [_vp, _vp, _vp, _vp, _pp, _pp, _pu64]),
     "chgpu_lc_remap": (_i, [_vp, _vp, _vp, _pp]),
     "chgpu_agg_create": (_i, [_vp, _i, _u32, C.POINTER(_i), C.POINTER(_i), _u64, _pp]),
     "chgpu_agg_add_block": (_i, [_vp, _vp, _pp, _u64, _u64]),

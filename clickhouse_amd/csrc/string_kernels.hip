@@ -243,3 +243,134 @@ extern "C" int chgpu_string_dictionary_encode(chgpu_ctx * ctx, const chgpu_col *
     *n_distinct = hb.total;
     return done(CHGPU_OK);
 }
+
+// ---------------------------------------------------------------------------------------------
+// ColumnString::filter (src/Columns/ColumnString.cpp:270-290 -> filterArraysImpl<UInt8>, src/Columns/ColumnsCommon.cpp:191-286):
+// the kept values' bytes are moved together and the offsets rebuilt.  The reference walks the mask 64 rows at a time and memcpy's
+// runs of kept values; here two scans (kept rows, kept bytes) give every surviving value its new row and its new byte position,
+// and one pass copies the values (8 bytes per step per lane, unaligned; the terminating zero travels with the value).
+//   k_str_filter_sizes   flag[i] = mask[i] != 0, bytes[i] = flag ? size of value i incl. its zero : 0
+//   k_str_filter_move    out_offsets[row'] = pos' + size;  out_chars[pos' ..] = chars[begin ..]
+// Algorithmic bytes: 8 (offset) + 1 (mask) per row + kept bytes read and written + 8 per kept row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_str_filter_sizes(const u64 * __restrict__ offsets, const u8 * __restrict__ mask, u64 n, u32 * __restrict__ flag,
+                                                          u32 * __restrict__ bytes, u32 * __restrict__ too_long)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        const u32 f = mask[i] != 0;
+        const u64 sz = offsets[i] - (i ? offsets[i - 1] : 0);
+        if (f && sz >= (1ull << 32))
+            *too_long = 1;
+        flag[i] = f;
+        bytes[i] = f ? (u32)sz : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_str_filter_move(const u64 * __restrict__ offsets, const u8 * __restrict__ chars, const u32 * __restrict__ flag,
+                                                         const u64 * __restrict__ row_pos, const u64 * __restrict__ byte_pos, u64 n,
+                                                         u64 * __restrict__ out_offsets, u8 * __restrict__ out_chars)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        if (!flag[i])
+            continue;
+        const u64 begin = i ? offsets[i - 1] : 0;
+        const u64 sz = offsets[i] - begin;
+        const u64 dst = byte_pos[i];
+        out_offsets[row_pos[i]] = dst + sz;
+        u64 k = 0;
+        for (; k + 8 <= sz; k += 8)
+        {
+            const u64 v = str_load8(chars + begin + k);
+            __builtin_memcpy(out_chars + dst + k, &v, 8);
+        }
+        for (; k < sz; ++k)
+            out_chars[dst + k] = chars[begin + k];
+    }
+}
+
+extern "C" int chgpu_string_filter(chgpu_ctx * ctx, const chgpu_col * offsets_u64, const chgpu_col * chars_u8, const chgpu_col * filter_u8,
+                                   chgpu_col ** out_offsets_u64, chgpu_col ** out_chars_u8, uint64_t * rows_out)
+{
+    CHGPU_REQUIRE(ctx && offsets_u64 && chars_u8 && filter_u8 && out_offsets_u64 && out_chars_u8 && rows_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(offsets_u64->type == CHGPU_U64 && chars_u8->type == CHGPU_U8 && filter_u8->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS,
+                  "ColumnString = UInt64 offsets + UInt8 chars; the filter is a UInt8 column");
+    const u64 n = offsets_u64->rows;
+    CHGPU_REQUIRE(filter_u8->rows == n, CHGPU_ERR_SIZES_MISMATCH, "Size of filter (%llu) doesn't match size of column (%llu)",
+                  (unsigned long long)filter_u8->rows, (unsigned long long)n); // ColumnsCommon.cpp:199-200
+    chgpu_col * oo = nullptr, * oc = nullptr;
+    u64 kept_rows = 0, kept_bytes = 0;
+    if (n)
+    {
+        auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+        const size_t b_flag = al(n * 4), b_bytes = al(n * 4), b_rpos = al(n * 8), b_bpos = al(n * 8), b_tmp = chgpu_scan_tmp_bytes(n);
+        void * mem = nullptr;
+        size_t mem_class = 0;
+        CHGPU_TRY(chgpu_pool_alloc(ctx, b_flag + b_bytes + b_rpos + b_bpos + 512 + b_tmp, &mem, &mem_class));
+        char * p = (char *)mem;
+        u32 * flag = (u32 *)p; p += b_flag;
+        u32 * bytes = (u32 *)p; p += b_bytes;
+        u64 * rpos = (u64 *)p; p += b_rpos;
+        u64 * bpos = (u64 *)p; p += b_bpos;
+        u64 * totals = (u64 *)p; p += 256; // [0] rows, [1] bytes
+        u32 * too_long = (u32 *)p; p += 256;
+        void * tmp = p;
+        auto done = [&](int code) {
+            chgpu_pool_free(ctx, mem, mem_class);
+            if (code != CHGPU_OK)
+            {
+                if (oo)
+                    chgpu_col_free(oo);
+                if (oc)
+                    chgpu_col_free(oc);
+            }
+            return code;
+        };
+        if (hipMemsetAsync(too_long, 0, 256, ctx->stream) != hipSuccess)
+            return done(chgpu_set_error(CHGPU_ERR_DEVICE, "memset failed"));
+        const u32 grid = chgpu_grid_for(ctx, n, 256, 8);
+        hipLaunchKernelGGL(k_str_filter_sizes, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)offsets_u64->data, (const u8 *)filter_u8->data, n, flag, bytes, too_long);
+        int rc = chgpu_scan_exclusive_u32_u64(ctx, flag, rpos, n, totals, tmp, b_tmp);
+        if (rc == CHGPU_OK)
+            rc = chgpu_scan_exclusive_u32_u64(ctx, bytes, bpos, n, totals + 1, tmp, b_tmp);
+        u64 host_totals[2] = {0, 0};
+        u32 host_long = 0;
+        if (rc == CHGPU_OK)
+            rc = chgpu_read_back(ctx, totals, host_totals, sizeof(host_totals));
+        if (rc == CHGPU_OK)
+            rc = chgpu_read_back(ctx, too_long, &host_long, sizeof(host_long));
+        if (rc == CHGPU_OK && host_long)
+            rc = chgpu_set_error(CHGPU_ERR_NOT_IMPLEMENTED, "a value of 4 GiB or more");
+        if (rc != CHGPU_OK)
+            return done(rc);
+        kept_rows = host_totals[0], kept_bytes = host_totals[1];
+        rc = chgpu_col_new(ctx, CHGPU_U64, kept_rows, &oo);
+        if (rc == CHGPU_OK)
+            rc = chgpu_col_new(ctx, CHGPU_U8, kept_bytes, &oc);
+        if (rc != CHGPU_OK)
+            return done(rc);
+        if (kept_rows)
+            hipLaunchKernelGGL(k_str_filter_move, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)offsets_u64->data, (const u8 *)chars_u8->data, (const u32 *)flag,
+                               (const u64 *)rpos, (const u64 *)bpos, n, (u64 *)oo->data, (u8 *)oc->data);
+        ctx->counters[6] += 2;
+        ctx->counters[0] += kept_rows;
+        if (hipGetLastError() != hipSuccess)
+            return done(chgpu_set_error(CHGPU_ERR_DEVICE, "string filter kernels failed to launch"));
+        done(CHGPU_OK);
+    }
+    else
+    {
+        CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U64, 0, &oo));
+        int rc = chgpu_col_new(ctx, CHGPU_U8, 0, &oc);
+        if (rc != CHGPU_OK)
+        {
+            chgpu_col_free(oo);
+            return rc;
+        }
+    }
+    *out_offsets_u64 = oo;
+    *out_chars_u8 = oc;
+    *rows_out = kept_rows;
+    return CHGPU_OK;
+}

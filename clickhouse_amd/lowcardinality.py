@@ -90,6 +90,20 @@ class ColumnString:
         cuts = np.concatenate(([0], np.cumsum(lens)))
         return [data[int(cuts[k]):int(cuts[k + 1])] for k in range(rows.shape[0])]
 
+    def filter(self, filt: Column) -> "ColumnString":
+        """ColumnString::filter (ColumnString.cpp:270-290): the kept values, in order"""
+        oo, oc = C.c_void_p(), C.c_void_p()
+        rows = C.c_uint64(0)
+        ctx = self.offsets.ctx
+        K.check(K.lib().chgpu_string_filter(ctx._h, self.offsets._h, self.chars._h, filt._h, C.byref(oo), C.byref(oc), C.byref(rows)))
+        return ColumnString(Column(ctx, oo), Column(ctx, oc))
+
+    def to_list(self) -> list:
+        """the values on the host (tests)"""
+        offs = self.offsets.numpy()
+        chars = self.chars.numpy().tobytes()
+        return [chars[(int(offs[i - 1]) if i else 0):int(offs[i]) - 1] for i in range(offs.shape[0])]
+
     def dictionary_encode(self) -> "ColumnLowCardinality":
         """String -> LowCardinality(String) on the device: ids by first appearance; the dictionary's strings are read on the host"""
         ids, rows = C.c_void_p(), C.c_void_p()

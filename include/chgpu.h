@@ -321,6 +321,10 @@ int chgpu_lc_remap(chgpu_ctx * ctx, const chgpu_col * indexes, const chgpu_col *
    are a ColumnLowCardinality: chgpu_lc_remap / GROUP BY / join as above. */
 int chgpu_string_dictionary_encode(chgpu_ctx * ctx, const chgpu_col * offsets_u64, const chgpu_col * chars_u8, chgpu_col ** ids_u32,
                                    chgpu_col ** first_rows_u64, uint64_t * n_distinct);
+/* ColumnString::filter (src/Columns/ColumnString.cpp:270-290 -> filterArraysImpl, src/Columns/ColumnsCommon.cpp:191-286): the values
+   whose filter byte is non-zero, in order, as a new ColumnString (offsets rebuilt, bytes moved together). */
+int chgpu_string_filter(chgpu_ctx * ctx, const chgpu_col * offsets_u64, const chgpu_col * chars_u8, const chgpu_col * filter_u8,
+                        chgpu_col ** out_offsets_u64, chgpu_col ** out_chars_u8, uint64_t * rows_out);
 int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, const int * agg_kinds, const int * arg_types,
                      uint64_t size_hint, chgpu_agg ** out);
 /* executeOnBlock over rows [row_begin,row_end) of the key column and the argument columns (arg_cols[j] may be NULL

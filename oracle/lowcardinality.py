@@ -50,3 +50,20 @@ def dictionary_encode(values):
             first.append(i)
         ids[i] = k
     return ids, d, np.array(first, dtype=np.uint64)
+
+
+def string_filter(offsets: np.ndarray, chars: np.ndarray, filt: np.ndarray):
+    """filterArraysImpl<UInt8> for a ColumnString (src/Columns/ColumnsCommon.cpp:191-286): result offsets and chars hold the values
+    whose filter byte is non-zero, in order; SIZES_OF_COLUMNS_DOESNT_MATCH when the sizes differ (:199-200)."""
+    if filt.shape[0] != offsets.shape[0]:
+        raise ValueError("SIZES_OF_COLUMNS_DOESNT_MATCH")
+    res_offsets, res_chars, pos, begin = [], bytearray(), 0, 0
+    raw = chars.tobytes()
+    for i in range(offsets.shape[0]):
+        end = int(offsets[i])
+        if filt[i]:
+            res_chars += raw[begin:end]
+            pos += end - begin
+            res_offsets.append(pos)
+        begin = end
+    return np.array(res_offsets, dtype=np.uint64), np.frombuffer(bytes(res_chars), dtype=np.uint8)

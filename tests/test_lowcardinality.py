@@ -170,3 +170,47 @@ def test_gpu_ssb_q31_shape_group_by_two_string_keys_and_year():
     with pytest.raises(ch.ChgpuError) as ei:
         ch.PackedKeysAggregator(["lc", np.uint64], [(ch.AGG_COUNT, None)], ctx=ctx)  # 10 key bytes
     assert ei.value.code == ch._capi.ERR_NOT_IMPLEMENTED
+
+
+def test_oracle_string_filter():
+    vals = [b"ab", b"", b"xyz", b"q\0r"]
+    chars = np.frombuffer(b"".join(v + b"\0" for v in vals), dtype=np.uint8)
+    offs = np.cumsum([len(v) + 1 for v in vals]).astype(np.uint64)
+    o, c = OL.string_filter(offs, chars, np.array([0, 1, 0, 7], dtype=np.uint8))
+    assert o.tolist() == [1, 5] and c.tobytes() == b"\0q\0r\0"
+    with pytest.raises(ValueError):
+        OL.string_filter(offs, chars, np.zeros(3, dtype=np.uint8))
+
+
+@pytest.mark.gpu
+def test_gpu_string_filter_matches_oracle():
+    import clickhouse_amd as ch
+    rng = np.random.Generator(np.random.PCG64(41))
+    ctx = ch.Context()
+    for n, max_len, keep in [(1, 5, 1.0), (1000, 0, 0.5), (50_003, 40, 0.1), (70_001, 300, 0.9), (20_000, 12, 0.0), (20_000, 12, 1.0)]:
+        vals = _strings(rng, n, max(1, n // 3), max_len)
+        cs = ch.ColumnString.from_values(ctx, vals)
+        mask = (rng.random(n) < keep).astype(np.uint8) * rng.integers(1, 256, size=n).astype(np.uint8)
+        got = cs.filter(ctx.upload(mask))
+        eo, ec = OL.string_filter(cs.offsets.numpy(), cs.chars.numpy(), mask)
+        assert np.array_equal(got.offsets.numpy(), eo) and np.array_equal(got.chars.numpy(), ec), (n, max_len, keep)
+        assert got.to_list() == [v for v, m in zip(vals, mask) if m]
+    with pytest.raises(ch.ChgpuError) as ei:
+        cs.filter(ctx.upload(np.ones(3, dtype=np.uint8)))
+    assert ei.value.code == ch._capi.ERR_SIZES_MISMATCH
+    # WHERE on a numeric column, String column filtered by the same mask, then GROUP BY the String key
+    n = 100_000
+    names = [f"BRAND#{i % 40}".encode() for i in rng.integers(0, 1000, size=n)]
+    qty = rng.integers(0, 50, size=n).astype(np.int64)
+    m = ch.cmp_const(ctx.upload(qty), ch.LT, 25)
+    fs = ch.ColumnString.from_values(ctx, names).filter(m)
+    fq = ctx.upload(qty).filter(m)
+    agg = ch.LowCardinalityAggregator([(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], ctx=ctx)
+    agg.execute_on_block(fs.dictionary_encode(), [fq, None])
+    keys, (sums, cnts) = agg.convert_to_block()
+    want = {}
+    for nm, q in zip(names, qty):
+        if q < 25:
+            a = want.get(nm, (0, 0))
+            want[nm] = (a[0] + int(q), a[1] + 1)
+    assert {k: (int(s), int(c)) for k, s, c in zip(keys, sums, cnts)} == want
