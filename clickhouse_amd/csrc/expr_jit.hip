@@ -146,6 +146,10 @@ int infer_type(int fn, int a, int b, int c)
             const bool dbl = (has_float && has_integer && max_i >= max_f) || (has_signed && has_unsigned && max_u >= max_s);
             return construct(has_signed, has_float, dbl ? m * 2 : m); // UInt64 with Int<x>, Float<x> with [U]Int64 -> size 16 -> -1 (Error)
         }
+        case CHGPU_FN_INT_DIV: // ResultOfIntegerDivision; integers only here (the float forms throw on NaN / infinities)
+            return (sa && sb && !fa && !fb) ? construct(is_sgn(a) || is_sgn(b), false, sa) : -1;
+        case CHGPU_FN_MODULO: // ResultOfModulo; integers only here
+            return (sa && sb && !fa && !fb) ? construct(is_sgn(a), false, is_sgn(a) ? next_size(sb) : sb) : -1;
         case CHGPU_FN_TO_YEAR: return a == CHGPU_U16 ? CHGPU_U16 : -1;
         case CHGPU_FN_TO_MONTH: return a == CHGPU_U16 ? CHGPU_U8 : -1;
         case CHGPU_FN_TO_DAY_OF_MONTH: return a == CHGPU_U16 ? CHGPU_U8 : -1;
@@ -350,6 +354,22 @@ int build_body(chgpu_expr * e)
                 const char * op = fn == CHGPU_FN_BIT_AND ? "&" : fn == CHGPU_FN_BIT_OR ? "|" : "^";
                 rhs = std::string("(") + ct + ")((u64)" + N(0) + " " + op + " (u64)" + N(1) + ")";
             }
+            else if (fn == CHGPU_FN_INT_DIV)
+            {
+                // DivideIntegralImpl::apply (src/Functions/DivisionUtils.h:66-105).  The operands keep their exact C types, so the
+                // division is performed in the same promoted type as on the host (usual arithmetic conversions, LP64).
+                const int ta = T(0), tb = T(1);
+                if (chgpu_type_is_signed(ta) || chgpu_type_is_signed(tb))
+                {
+                    const int sa_t = construct(true, false, chgpu_type_size(ta));
+                    const int sb_t = chgpu_type_size(ta) <= chgpu_type_size(tb) ? construct(true, false, chgpu_type_size(tb)) : sa_t;
+                    rhs = std::string("(") + ct + ")((" + ctype(sa_t) + ")" + N(0) + " / (" + ctype(sb_t) + ")" + N(1) + ")";
+                }
+                else
+                    rhs = std::string("(") + ct + ")(" + N(0) + " / " + N(1) + ")";
+            }
+            else if (fn == CHGPU_FN_MODULO) // ModuloImpl::apply (:126-170): IntegerAType(a) % IntegerBType(b), then the cast
+                rhs = std::string("(") + ct + ")(" + N(0) + " % " + N(1) + ")";
             else if (fn == CHGPU_FN_IF)
                 rhs = truth(N(0)) + " ? (" + ct + ")" + N(1) + " : (" + ct + ")" + N(2);
             else if (fn == CHGPU_FN_TO_YEAR)
@@ -708,6 +728,27 @@ extern "C" int chgpu_expr_compile(uint32_t n_nodes, const chgpu_expr_node * node
                     rc = chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "node %u: operand %d is not an earlier node", k, j);
                 else
                     at[j] = e->types[nd.args[j]];
+            }
+            if (rc == CHGPU_OK && (nd.code == CHGPU_FN_INT_DIV || nd.code == CHGPU_FN_MODULO))
+            {
+                // intDiv / modulo throw ILLEGAL_DIVISION on a zero divisor and on min / -1 (throwIfDivisionLeadsToFPE,
+                // DivisionUtils.h:15-26): a kernel cannot throw per row, so only constant divisors that can never throw are
+                // compiled; everything else stays on the CPU
+                const chgpu_expr_node & dn = nodes[nd.args[1]];
+                bool ok = dn.kind == CHGPU_EX_CONST && at[0] >= 0 && at[1] >= 0 && chgpu_type_is_int(at[0]) && chgpu_type_is_int(at[1]);
+                if (ok)
+                {
+                    const size_t sb = chgpu_type_size(at[1]);
+                    const u64 mask = sb == 8 ? ~0ull : ((1ull << (8 * sb)) - 1);
+                    const u64 bits = dn.bits & mask;
+                    if (bits == 0)
+                        ok = false; // division by zero
+                    // all-ones divisor: -1 once it is (or is cast to) a signed type of its own width -- min / -1 would throw
+                    if (bits == mask && (chgpu_type_is_signed(at[1]) || (nd.code == CHGPU_FN_INT_DIV && chgpu_type_is_signed(at[0]) && chgpu_type_size(at[0]) <= sb)))
+                        ok = false;
+                }
+                if (!ok)
+                    rc = chgpu_set_error(CHGPU_ERR_NOT_IMPLEMENTED, "node %u: intDiv / modulo need a constant integer divisor that cannot raise ILLEGAL_DIVISION", k);
             }
             if (rc == CHGPU_OK)
             {

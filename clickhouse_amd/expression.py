@@ -17,7 +17,7 @@ from .columns import NP_OF, TAG_OF, Column, Context, sum_result_dtype
 # reference function name -> CHGPU_FN_* (include/chgpu.h)
 FUNCTIONS = {
     "equals": 0, "notEquals": 1, "less": 2, "greater": 3, "lessOrEquals": 4, "greaterOrEquals": 5,
-    "plus": 10, "minus": 11, "multiply": 12, "divide": 13, "negate": 14,
+    "plus": 10, "minus": 11, "multiply": 12, "divide": 13, "negate": 14, "intDiv": 15, "modulo": 16,
     "and": 20, "or": 21, "xor": 22, "not": 23,
     "if": 30,
     "bitAnd": 40, "bitOr": 41, "bitXor": 42,

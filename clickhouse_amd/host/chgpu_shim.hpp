@@ -350,7 +350,7 @@ public:
         static const std::pair<const char *, int> table[] = {
             {"equals", CHGPU_FN_EQUALS}, {"notEquals", CHGPU_FN_NOT_EQUALS}, {"less", CHGPU_FN_LESS}, {"greater", CHGPU_FN_GREATER},
             {"lessOrEquals", CHGPU_FN_LESS_OR_EQUALS}, {"greaterOrEquals", CHGPU_FN_GREATER_OR_EQUALS}, {"plus", CHGPU_FN_PLUS},
-            {"minus", CHGPU_FN_MINUS}, {"multiply", CHGPU_FN_MULTIPLY}, {"divide", CHGPU_FN_DIVIDE}, {"negate", CHGPU_FN_NEGATE},
+            {"minus", CHGPU_FN_MINUS}, {"multiply", CHGPU_FN_MULTIPLY}, {"divide", CHGPU_FN_DIVIDE}, {"negate", CHGPU_FN_NEGATE}, {"intDiv", CHGPU_FN_INT_DIV}, {"modulo", CHGPU_FN_MODULO},
             {"and", CHGPU_FN_AND}, {"or", CHGPU_FN_OR}, {"xor", CHGPU_FN_XOR}, {"not", CHGPU_FN_NOT}, {"if", CHGPU_FN_IF},
             {"bitAnd", CHGPU_FN_BIT_AND}, {"bitOr", CHGPU_FN_BIT_OR}, {"bitXor", CHGPU_FN_BIT_XOR}, {"toYear", CHGPU_FN_TO_YEAR},
             {"toMonth", CHGPU_FN_TO_MONTH}, {"toDayOfMonth", CHGPU_FN_TO_DAY_OF_MONTH}, {"toYYYYMM", CHGPU_FN_TO_YYYYMM},

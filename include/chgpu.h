@@ -218,6 +218,7 @@ enum
     CHGPU_FN_PLUS = 10, CHGPU_FN_MINUS = 11, CHGPU_FN_MULTIPLY = 12,  /* ResultOfAdditionMultiplication / ResultOfSubtraction */
     CHGPU_FN_DIVIDE = 13,                                             /* Float64 (ResultOfFloatingPointDivision) */
     CHGPU_FN_NEGATE = 14,                                             /* ResultOfNegate */
+    CHGPU_FN_INT_DIV = 15, CHGPU_FN_MODULO = 16,                      /* integers, constant divisor that cannot raise ILLEGAL_DIVISION */
     CHGPU_FN_AND = 20, CHGPU_FN_OR = 21, CHGPU_FN_XOR = 22, CHGPU_FN_NOT = 23, /* UInt8 */
     CHGPU_FN_IF = 30,                                                 /* if(cond, then, else): ResultOfIf */
     CHGPU_FN_BIT_AND = 40, CHGPU_FN_BIT_OR = 41, CHGPU_FN_BIT_XOR = 42, /* integers: ResultOfBit */

@@ -12,9 +12,11 @@ whole columns, materialising every intermediate: `evaluate` does exactly that, o
   logical         FunctionsLogical.cpp:81,424: operands through static_cast<bool>
   dates           DateTimeTransforms.h ToYearImpl / ToMonthImpl / ToDayOfMonthImpl / ToYYYYMMImpl over DayNum — restated with
                   numpy's datetime64 calendar (independent of the product's civil-from-days arithmetic)
-Parity pinning: the reference has no golden vectors for typed intermediate columns; pinned by tests/golden/expr_dag_kat.json
-(hand-derived from the reference's documented examples, e.g. NumberTraits.h:66-70 "UInt8 + Int32 = Int64",
-:103 "toInt32(-199) % toUInt8(200)" is NOT carried) and by the SQL rows of 00120 / SSB Q1.1 shapes already in tests/golden.
+  intDiv, modulo  src/Functions/DivisionUtils.h:66-170 for integer operands, in the type C++'s usual arithmetic conversions choose
+                  (restated on Python integers); the product compiles them only for constant divisors that cannot throw
+Parity pinning: comparisons by tests/golden/expr_cmp_kat.json (the reference's 00411_long_accurate_number_comparison_float answers);
+the calendar by Python's datetime; result types by the documented NumberTraits.h examples.  Arithmetic values have no reference
+vector beyond their definitions (static_cast<Result>(a) OP b).
 """
 from __future__ import annotations
 
@@ -26,7 +28,7 @@ NP_OF = {I64: np.int64, U32: np.uint32, U64: np.uint64, F64: np.float64, U8: np.
 TAG_OF = {np.dtype(v): k for k, v in NP_OF.items()}
 EX_INPUT, EX_CONST, EX_FUNC = 0, 1, 2
 FN = {"equals": 0, "notEquals": 1, "less": 2, "greater": 3, "lessOrEquals": 4, "greaterOrEquals": 5, "plus": 10, "minus": 11,
-      "multiply": 12, "divide": 13, "negate": 14, "and": 20, "or": 21, "xor": 22, "not": 23, "if": 30, "bitAnd": 40,
+      "multiply": 12, "divide": 13, "negate": 14, "intDiv": 15, "modulo": 16, "and": 20, "or": 21, "xor": 22, "not": 23, "if": 30, "bitAnd": 40,
       "bitOr": 41, "bitXor": 42, "toYear": 50, "toMonth": 51, "toDayOfMonth": 52, "toYYYYMM": 53}
 FN_CAST = 64
 
@@ -68,6 +70,14 @@ def result_type(fn, a=None, b=None, c=None):
         return F64
     if fn == 14:
         return _construct(True, _is_float(a), _size(a) if _is_signed(a) else _next_size(_size(a)))
+    if fn == 15:  # ResultOfIntegerDivision (integers only on this path)
+        if _is_float(a) or _is_float(b):
+            return None
+        return _construct(_is_signed(a) or _is_signed(b), False, _size(a))
+    if fn == 16:  # ResultOfModulo
+        if _is_float(a) or _is_float(b):
+            return None
+        return _construct(_is_signed(a), False, _next_size(_size(b)) if _is_signed(a) else _size(b))
     if fn in (20, 21, 22, 23):
         return U8
     if fn in (40, 41, 42):
@@ -159,6 +169,8 @@ def apply_function(fn, args, types):
             a, b = _wide_u64(x), _wide_u64(y)
             r = a + b if fn == 10 else a - b if fn == 11 else a * b
             return r.astype(np.dtype(out).str.replace("i", "u")).view(out) if np.dtype(out).kind == "i" else r.astype(out)
+    if fn in (15, 16):
+        return _int_div_mod(fn, x, args[1], types[0], types[1], rt)
     if fn == 13:
         with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
             return x.astype(np.float64) / args[1].astype(np.float64)
@@ -183,6 +195,57 @@ def apply_function(fn, args, types):
         y, m, d = _civil(x)
         return (y if fn == 50 else m if fn == 51 else d if fn == 52 else y * 100 + m).astype(out)
     return _cast(x, rt)
+
+
+def _promote(t):
+    """C++ integer promotion on LP64: everything narrower than int becomes int"""
+    return I32 if _size(t) < 4 else t
+
+
+def _usual_arithmetic_conversion(ta, tb):
+    """the common type of `a OP b` for integer operands ([expr.arith.conv]; int = 32, long = 64 bits)"""
+    ta, tb = _promote(ta), _promote(tb)
+    if ta == tb:
+        return ta
+    if _is_signed(ta) == _is_signed(tb):
+        return ta if _size(ta) >= _size(tb) else tb
+    u, sg = (ta, tb) if not _is_signed(ta) else (tb, ta)
+    return u if _size(u) >= _size(sg) else sg
+
+
+def _to_type(v: int, t) -> int:
+    """static_cast of a mathematical integer to type t (two's complement wrap)"""
+    bits = 8 * _size(t)
+    v &= (1 << bits) - 1
+    if _is_signed(t) and v >> (bits - 1):
+        v -= 1 << bits
+    return v
+
+
+def _int_div_mod(fn, x, y, tx, ty, rt):
+    """DivideIntegralImpl / ModuloImpl for integer operands (src/Functions/DivisionUtils.h:66-170) on Python integers: exact C++
+    semantics (truncation toward zero, remainder with the dividend's sign) in the type the usual arithmetic conversions choose."""
+    out = np.empty(x.shape[0], dtype=NP_OF[rt])
+    if fn == 15 and (_is_signed(tx) or _is_signed(ty)):
+        sa = _construct(True, False, _size(tx))
+        sb = _construct(True, False, _size(ty)) if _size(tx) <= _size(ty) else sa
+        cast_a, cast_b = sa, sb
+    else:
+        cast_a, cast_b = tx, ty
+    ct = _usual_arithmetic_conversion(cast_a, cast_b)
+    res = []
+    for a, b in zip(x.tolist(), y.tolist()):
+        a = _to_type(_to_type(int(a), cast_a), ct)
+        b = _to_type(_to_type(int(b), cast_b), ct)
+        if b == 0:
+            raise ZeroDivisionError("ILLEGAL_DIVISION")
+        q = abs(a) // abs(b)
+        if (a < 0) != (b < 0):
+            q = -q
+        r = q if fn == 15 else a - q * b
+        res.append(_to_type(_to_type(r, ct), rt))
+    out[:] = np.array(res, dtype=object).astype(NP_OF[rt]) if res else []
+    return out
 
 
 def _cast(x, to):

@@ -124,6 +124,8 @@ def test_product_type_inference_equals_oracle_for_every_combination():
     for fn, types in _all_function_cases():
         d = ch.ActionsDAG()
         ins = [d.add_input(j, NP_OF[t]) for j, t in enumerate(types)]
+        if fn in (OE.FN["intDiv"], OE.FN["modulo"]) and types[1] not in (OE.F64, OE.F32):
+            ins[1] = d.add_column(3, NP_OF[types[1]])  # compiled only for constant divisors that cannot throw
         d.nodes.append((OE.EX_FUNC, fn, 0, tuple(ins) + (-1,) * (3 - len(ins)), 0))
         want = OE.result_type(fn, *types)
         if want is None:
@@ -131,7 +133,7 @@ def test_product_type_inference_equals_oracle_for_every_combination():
                 d.compile()
             assert ei.value.code == ch._capi.ERR_NOT_IMPLEMENTED, (fn, types)
         else:
-            assert d.compile().node_type(len(ins)) == want, (fn, types)
+            assert d.compile().node_type(len(d.nodes) - 1) == want, (fn, types)
         n += 1
     assert n > 1500
 
@@ -143,6 +145,15 @@ def test_compile_errors():
     with pytest.raises(ch.ChgpuError) as ei:
         d.compile()
     assert ei.value.code == ch._capi.ERR_BAD_ARGUMENTS
+    for build in (lambda d, a: d.add_function("intDiv", a, d.add_input(1, np.int64)),          # a column divisor can be zero
+                  lambda d, a: d.add_function("modulo", a, d.add_column(0, np.uint8)),         # division by zero
+                  lambda d, a: d.add_function("intDiv", a, d.add_column(-1, np.int64)),        # min / -1
+                  lambda d, a: d.add_function("intDiv", a, d.add_column(2**64 - 1, np.uint64))):  # -1 once cast to Int64
+        d = ch.ActionsDAG()
+        build(d, d.add_input(0, np.int64))
+        with pytest.raises(ch.ChgpuError) as ei:
+            d.compile()
+        assert ei.value.code == ch._capi.ERR_NOT_IMPLEMENTED
     d = ch.ActionsDAG()
     a = d.add_input(0, np.float64)
     d.add_function("toInt64", a)  # Float -> integer: not carried
@@ -205,6 +216,7 @@ def _random_dag(ch, rng, col_dtypes, n_funcs):
     for j, dt in enumerate(col_dtypes):
         d.add_input(j, dt)
         types.append(TAG_OF[np.dtype(dt)])
+    consts = {}
     for _ in range(3):
         dt = ALL_TYPES[rng.integers(0, len(ALL_TYPES))]
         val = rng.choice(np.array(SPECIAL_F64)) if np.dtype(dt).kind == "f" else int(rng.integers(-5, 300))
@@ -212,7 +224,7 @@ def _random_dag(ch, rng, col_dtypes, n_funcs):
             val = abs(int(val))
         if np.dtype(dt).kind != "f":
             val = int(np.clip(val, np.iinfo(dt).min, np.iinfo(dt).max))
-        d.add_column(val, dt)
+        consts[d.add_column(val, dt)] = val
         types.append(TAG_OF[np.dtype(dt)])
     names = list(OE.FN.keys()) + ["cast"]
     made = 0
@@ -221,6 +233,11 @@ def _random_dag(ch, rng, col_dtypes, n_funcs):
         fn = OE.FN_CAST + int(rng.integers(0, 10)) if name == "cast" else OE.FN[name]
         ar = 3 if name == "if" else 1 if name in ("negate", "not", "toYear", "toMonth", "toDayOfMonth", "toYYYYMM", "cast") else 2
         args = [int(rng.integers(0, len(types))) for _ in range(ar)]
+        if name in ("intDiv", "modulo"):  # only constant divisors that cannot throw are compiled
+            ok = [c for c, v in consts.items() if types[c] not in (OE.F64, OE.F32) and v not in (0, -1) and v != np.iinfo(OE.NP_OF[types[c]]).max]
+            if not ok or types[args[0]] in (OE.F64, OE.F32):
+                continue
+            args[1] = ok[int(rng.integers(0, len(ok)))]
         at = [types[a] for a in args]
         if name == "if" and at[0] in (OE.F64, OE.F32):
             continue
@@ -388,3 +405,34 @@ def test_gpu_dag_linearity_at_2_pow_27_rows():
     assert cnt == c_all and tot == int(s_all) & (2**64 - 1)
     ref = int((a * b.to(torch.int64))[b < 100].sum().item()) & (2**64 - 1)
     assert ref == int(s_all) & (2**64 - 1)
+
+
+@pytest.mark.gpu
+def test_gpu_intdiv_modulo_by_constants_every_integer_type_pair():
+    """DivideIntegralImpl / ModuloImpl (DivisionUtils.h:66-170) for every (dividend type, divisor type) and a few constant divisors,
+    negative ones included: the kernel divides in the type C++'s usual arithmetic conversions give on the host"""
+    import clickhouse_amd as ch
+    ctx = ch.Context()
+    rng = np.random.Generator(np.random.PCG64(15))
+    ints = [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64]
+    n = 3001
+    for ta in ints:
+        x = _random_column(rng, ta, n)
+        col = ctx.upload(x)
+        for tb in ints:
+            info = np.iinfo(tb)
+            divs = [1, 2, 3, 7, 100, int(info.max) - 1] + ([-2, -3, int(info.min)] if info.min < 0 else [])
+            d = ch.ActionsDAG()
+            a = d.add_input(0, ta)
+            outs = []
+            for v in divs:
+                c = d.add_column(v, tb)
+                outs.append(d.add_function("intDiv", a, c))
+                outs.append(d.add_function("modulo", a, c))
+            ex = d.compile()
+            vals, types = OE.evaluate(d.nodes, [x])
+            for lo in range(0, len(outs), 8):
+                part = outs[lo:lo + 8]
+                for k, o in zip(part, ex.execute(ctx, [col], part)):
+                    assert ex.node_type(k) == types[k]
+                    assert _same(o.numpy(), vals[k]), (ta, tb, d.nodes[k], d.nodes[d.nodes[k][3][1]])
