@@ -436,3 +436,30 @@ def test_gpu_intdiv_modulo_by_constants_every_integer_type_pair():
                 for k, o in zip(part, ex.execute(ctx, [col], part)):
                     assert ex.node_type(k) == types[k]
                     assert _same(o.numpy(), vals[k]), (ta, tb, d.nodes[k], d.nodes[d.nodes[k][3][1]])
+
+
+@pytest.mark.gpu
+def test_gpu_01300_group_by_modulo_expression_reference_rows(golden):
+    """tests/queries/0_stateless/01300_group_by_other_keys: SELECT round(avg(log(2) * number), 6) FROM numbers(1e7) GROUP BY number % 5
+    with BOTH expressions computed on the device by the run-time compiled DAG (key = modulo(number, 5) -> UInt8, the reference's key
+    type; value = multiply(Float64 constant, number)), then the GROUP BY; expected rows are the reference's .reference lines."""
+    import clickhouse_amd as ch
+    ctx = ch.Context()
+    want = sorted(float(r[0]) for r in golden["rows"]["01300_avg_group_by_mod5"]["rows"])
+    d = ch.ActionsDAG()
+    num = d.add_input(0, np.uint64)
+    key = d.add_function("modulo", num, d.add_column(5, np.uint8))
+    val = d.add_function("multiply", d.add_column(np.log(2.0), np.float64), num)
+    ex = d.compile()
+    assert ex.node_dtype(key) == np.uint8 and ex.node_dtype(val) == np.float64
+    agg = ch.Aggregator(np.uint8, [(ch.AGG_AVG, np.float64)], ctx=ctx)
+    rows, stripe = 10_000_000, 2_500_000
+    for lo in range(0, rows, stripe):
+        k, v = ex.execute(ctx, [ctx.upload(np.arange(lo, lo + stripe, dtype=np.uint64))], [key, val])
+        agg.execute_on_block(k, [v])
+    keys, (avg,) = agg.convert_to_block()
+    assert sorted(keys.tolist()) == [0, 1, 2, 3, 4]
+    got = sorted(float(x) for x in avg)
+    for g, w in zip(got, want):
+        assert abs(g - w) <= 1e-6 * abs(w)  # BASELINE: 1e-6 relative for avg(Float64)
+    assert sum(round(g, 6) == w for g, w in zip(got, want)) >= 3
