@@ -18,7 +18,7 @@ ERR_SIZES_MISMATCH, ERR_NOT_IMPLEMENTED, ERR_OOM, ERR_LOGICAL, ERR_BAD_ARGUMENTS
 I64, U32, U64, F64, U8, I32, U16, I16, I8, F32 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 EQ, NE, LT, GT, LE, GE = 0, 1, 2, 3, 4, 5
 AGG_COUNT, AGG_SUM, AGG_AVG = 0, 1, 2
-JOIN_INNER, JOIN_LEFT = 0, 1
+JOIN_INNER, JOIN_LEFT, JOIN_RIGHT, JOIN_FULL = 0, 1, 2, 3
 STRICT_ANY, STRICT_ALL, STRICT_SEMI, STRICT_ANTI = 0, 1, 2, 3
 N_COUNTERS = 8
 VAL_COL, VAL_MUL, VAL_PLUS, VAL_MINUS = 0, 1, 2, 3
@@ -96,6 +96,7 @@ SIGNATURES = {
     "chgpu_join_total_rows": (_i, [_vp, _pu64, _pu64]),
     "chgpu_join_probe": (_i, [_vp, _vp, _vp, _u64, _pp, _pp, _pp, _pu64, _pu64]),
     "chgpu_join_flatten_rowids": (_i, [_vp, _vp, _pp]),
+    "chgpu_join_non_joined_rows": (_i, [_vp, _pp, _pu64]),
     "chgpu_join_free": (_i, [_vp]),
 }
 

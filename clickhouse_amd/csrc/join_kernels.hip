@@ -108,15 +108,24 @@ struct chgpu_join
     u64 n_keys = 0;
     u64 inserted = 0;
     u64 left_seq = 0; // running left-row sequence across joinBlock calls (INNER ANY)
+    // RIGHT / FULL: JoinUsedFlags (src/Interpreters/HashJoin/JoinUsedFlags.h) -- one byte per build row in insertion order
+    u8 * used = nullptr;
+    size_t used_class = 0;
+    u64 * block_base_dev = nullptr; // [n_blocks] first flat row of every build block
+    size_t base_class = 0;
 };
+
+// the left-side behaviour of the four kinds: RIGHT probes like INNER, FULL like LEFT (JoinFeatures.h:20-40: add_missing for LEFT / FULL)
+static inline int jf_left_kind(const chgpu_join * j) { return (j->kind == CHGPU_JOIN_LEFT || j->kind == CHGPU_JOIN_FULL) ? CHGPU_JOIN_LEFT : CHGPU_JOIN_INNER; }
+static inline bool jf_track_used(const chgpu_join * j) { return j->kind == CHGPU_JOIN_RIGHT || j->kind == CHGPU_JOIN_FULL; }
 
 static inline bool jf_need_replication(const chgpu_join * j) { return j->strictness == CHGPU_STRICT_ALL; } // JoinFeatures.h:29
 static inline bool jf_need_filter(const chgpu_join * j)
 {
     return !jf_need_replication(j)
-        && (j->kind == CHGPU_JOIN_INNER || j->strictness == CHGPU_STRICT_SEMI || j->strictness == CHGPU_STRICT_ANTI); // JoinFeatures.h:32
+        && (jf_left_kind(j) == CHGPU_JOIN_INNER || j->strictness == CHGPU_STRICT_SEMI || j->strictness == CHGPU_STRICT_ANTI); // JoinFeatures.h:32
 }
-static inline bool jf_add_missing(const chgpu_join * j) { return j->kind == CHGPU_JOIN_LEFT && j->strictness != CHGPU_STRICT_SEMI; } // :35
+static inline bool jf_add_missing(const chgpu_join * j) { return jf_left_kind(j) == CHGPU_JOIN_LEFT && j->strictness != CHGPU_STRICT_SEMI; } // :35
 
 // ---------------------------------------------------------------------------------------------
 // device
@@ -500,6 +509,49 @@ __global__ __launch_bounds__(JT) void k_join_emit(JoinTable t, int variant, cons
 // Table capacity for `rows` build rows: a power of two with load factor in (0.35, 0.7].  Denser than the reference's
 // 0.5 cap on purpose: the table is immutable after the build and a 1e7-row build then needs 2^24 cells (134 MB of keys),
 // which stays resident in the 256 MB Infinity Cache, where 2^25 cells would not.
+__global__ __launch_bounds__(JT) void k_join_mark_used(const u64 * __restrict__ rowid, u64 n, const u64 * __restrict__ block_base, u64 n_blocks, u64 total_rows,
+                                                       u8 * __restrict__ used)
+{
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+    {
+        const u64 r = rowid[i];
+        const u64 b = r >> 32;
+        if (r == NO_ROW || b >= n_blocks)
+            continue; // the default row of a LEFT / FULL miss
+        const u64 f = block_base[b] + (r & 0xFFFFFFFFull);
+        if (f < total_rows)
+            used[f] = 1; // plain store: every writer stores the same value
+    }
+}
+
+// NotJoinedHash (src/Interpreters/HashJoin/HashJoin.cpp:1280-1420): the build rows no probe row ever matched -- rows whose key was
+// NULL or whose ON mask was 0 included (they were never inserted, so they are never used) -- as (block << 32 | row) ids
+__global__ __launch_bounds__(JT) void k_join_unused_flags(const u8 * __restrict__ used, u64 n, u32 * __restrict__ flag)
+{
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+        flag[i] = used[i] ? 0u : 1u;
+}
+
+__global__ __launch_bounds__(JT) void k_join_unused_emit(const u32 * __restrict__ flag, const u64 * __restrict__ pos, u64 n, const u64 * __restrict__ block_base,
+                                                         u64 n_blocks, u64 * __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+    {
+        if (!flag[i])
+            continue;
+        u64 lo = 0, hi = n_blocks - 1; // largest block with base <= i
+        while (lo < hi)
+        {
+            const u64 mid = (lo + hi + 1) >> 1;
+            if (block_base[mid] <= i)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        out[pos[i]] = (lo << 32) | (i - block_base[lo]);
+    }
+}
+
 static u64 jpow2_ceil(u64 x)
 {
     u64 p = 256;
@@ -515,7 +567,9 @@ extern "C" int chgpu_join_create(chgpu_ctx * ctx, int key_type, int kind, int st
     CHGPU_REQUIRE(ctx && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(chgpu_type_is_int(key_type),
                   CHGPU_ERR_NOT_IMPLEMENTED, "join key type %d: CPU path", key_type);
-    CHGPU_REQUIRE(kind == CHGPU_JOIN_INNER || kind == CHGPU_JOIN_LEFT, CHGPU_ERR_NOT_IMPLEMENTED, "join kind %d (RIGHT/FULL need non-joined rows): CPU path", kind);
+    CHGPU_REQUIRE(kind >= CHGPU_JOIN_INNER && kind <= CHGPU_JOIN_FULL, CHGPU_ERR_NOT_IMPLEMENTED, "join kind %d: CPU path", kind);
+    CHGPU_REQUIRE((kind != CHGPU_JOIN_RIGHT && kind != CHGPU_JOIN_FULL) || strictness == CHGPU_STRICT_ALL, CHGPU_ERR_NOT_IMPLEMENTED,
+                  "RIGHT / FULL joins are carried for strictness ALL only (RIGHT ANY / SEMI / ANTI use per-key flags, joinDispatch.h:30-68): CPU path");
     CHGPU_REQUIRE(strictness >= CHGPU_STRICT_ANY && strictness <= CHGPU_STRICT_ANTI, CHGPU_ERR_NOT_IMPLEMENTED, "join strictness %d: CPU path", strictness);
     CHGPU_REQUIRE(!((strictness == CHGPU_STRICT_SEMI || strictness == CHGPU_STRICT_ANTI) && kind != CHGPU_JOIN_LEFT), CHGPU_ERR_NOT_IMPLEMENTED,
                   "only SEMI LEFT / ANTI LEFT are valid here (joinDispatch.h:52-64)");
@@ -540,6 +594,10 @@ extern "C" int chgpu_join_free(chgpu_join * j)
     }
     if (j->table_mem)
         chgpu_pool_free(j->ctx, j->table_mem, j->table_class);
+    if (j->used)
+        chgpu_pool_free(j->ctx, j->used, j->used_class);
+    if (j->block_base_dev)
+        chgpu_pool_free(j->ctx, j->block_base_dev, j->base_class);
     delete j;
     return CHGPU_OK;
 }
@@ -675,7 +733,69 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
     JoinCtrl c;
     CHGPU_TRY(chgpu_read_back(ctx, t.ctrl, &c, sizeof(c)));
     j->n_keys = c.n_keys;
+    if (jf_track_used(j))
+    {
+        const u64 nb = j->blocks.size();
+        std::vector<u64> bases(nb ? nb : 1, 0);
+        for (u64 b = 0; b < nb; ++b)
+            bases[b] = j->blocks[b].base;
+        void * um = nullptr, * bm = nullptr;
+        CHGPU_TRY(chgpu_pool_alloc(ctx, j->total_rows + 64, &um, &j->used_class));
+        j->used = (u8 *)um;
+        CHGPU_TRY(chgpu_pool_alloc(ctx, bases.size() * sizeof(u64), &bm, &j->base_class));
+        j->block_base_dev = (u64 *)bm;
+        CHGPU_HIP(hipMemsetAsync(j->used, 0, j->total_rows + 64, ctx->stream));
+        CHGPU_HIP(hipMemcpyAsync(j->block_base_dev, bases.data(), bases.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        CHGPU_HIP(hipStreamSynchronize(ctx->stream)); // `bases` is a host temporary
+    }
     j->finished = true;
+    return CHGPU_OK;
+}
+
+/* IJoin::getNonJoinedBlocks (src/Interpreters/IJoin.h:133-134; NotJoinedHash, HashJoin.cpp:1280-1420) for RIGHT / FULL joins: after the
+   last joinBlock, the build rows no left row matched, as (block << 32 | row) ids in insertion order; the caller gathers the right
+   columns there and pads the left columns with defaults. */
+extern "C" int chgpu_join_non_joined_rows(chgpu_join * j, chgpu_col ** right_rowid_u64, uint64_t * rows_out)
+{
+    CHGPU_REQUIRE(j && right_rowid_u64 && rows_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(jf_track_used(j), CHGPU_ERR_LOGICAL, "non-joined rows exist for RIGHT / FULL joins only");
+    if (!j->finished)
+        CHGPU_TRY(chgpu_join_finish_build(j));
+    chgpu_ctx * ctx = j->ctx;
+    const u64 n = j->total_rows;
+    chgpu_col * out = nullptr;
+    u64 total = 0;
+    if (n)
+    {
+        auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+        const size_t b_flag = al(n * 4), b_pos = al(n * 8), b_tmp = chgpu_scan_tmp_bytes(n);
+        void * mem = nullptr;
+        size_t mem_class = 0;
+        CHGPU_TRY(chgpu_pool_alloc(ctx, b_flag + b_pos + 256 + b_tmp, &mem, &mem_class));
+        u32 * flag = (u32 *)mem;
+        u64 * pos = (u64 *)((char *)mem + b_flag);
+        u64 * total_dev = (u64 *)((char *)mem + b_flag + b_pos);
+        void * tmp = (char *)mem + b_flag + b_pos + 256;
+        const u32 grid = chgpu_grid_for(ctx, n, JT, 8);
+        hipLaunchKernelGGL(k_join_unused_flags, dim3(grid), dim3(JT), 0, ctx->stream, (const u8 *)j->used, n, flag);
+        int rc = chgpu_scan_exclusive_u32_u64(ctx, flag, pos, n, total_dev, tmp, b_tmp);
+        if (rc == CHGPU_OK)
+            rc = chgpu_read_back(ctx, total_dev, &total, sizeof(total));
+        if (rc == CHGPU_OK)
+            rc = chgpu_col_new(ctx, CHGPU_U64, total, &out);
+        if (rc == CHGPU_OK && total)
+            hipLaunchKernelGGL(k_join_unused_emit, dim3(grid), dim3(JT), 0, ctx->stream, (const u32 *)flag, (const u64 *)pos, n, (const u64 *)j->block_base_dev,
+                               (u64)j->blocks.size(), (u64 *)out->data);
+        ctx->counters[6] += 2;
+        chgpu_pool_free(ctx, mem, mem_class);
+        if (rc != CHGPU_OK)
+            return rc;
+        CHGPU_HIP(hipGetLastError());
+    }
+    else
+        CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U64, 0, &out));
+    *right_rowid_u64 = out;
+    *rows_out = total;
     return CHGPU_OK;
 }
 
@@ -751,10 +871,10 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
     if (offsets_out) *offsets_out = nullptr;
     if (right_rowid_out) *right_rowid_out = nullptr;
     int variant;
-    if (j->strictness == CHGPU_STRICT_ALL) variant = j->kind == CHGPU_JOIN_LEFT ? PV_ALL_LEFT : PV_ALL_INNER;
+    if (j->strictness == CHGPU_STRICT_ALL) variant = jf_left_kind(j) == CHGPU_JOIN_LEFT ? PV_ALL_LEFT : PV_ALL_INNER;
     else if (j->strictness == CHGPU_STRICT_SEMI) variant = PV_SEMI_LEFT;
     else if (j->strictness == CHGPU_STRICT_ANTI) variant = PV_ANTI_LEFT;
-    else variant = j->kind == CHGPU_JOIN_LEFT ? PV_ANY_LEFT : PV_ANY_INNER;
+    else variant = jf_left_kind(j) == CHGPU_JOIN_LEFT ? PV_ANY_LEFT : PV_ANY_INNER;
     if (!need_repl)
         max_joined_block_rows = 0; // the early stop only exists for need_replication (HashJoinMethodsImpl.h:434-444)
 
@@ -848,6 +968,13 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
     {
         hipLaunchKernelGGL(k_join_emit, dim3(grid), dim3(JT), 0, ctx->stream, j->t, variant, (const u64 *)val_of_left, (const u32 *)counts,
                            (const u64 *)offsets->data, c.consumed, (u64 *)rowid->data);
+        ctx->counters[6] += 1;
+    }
+    if (c.n_out && jf_track_used(j))
+    {
+        // used_flags.setUsed for every emitted right row (HashJoinMethodsImpl.h addFoundRowAll with flag_per_row)
+        hipLaunchKernelGGL(k_join_mark_used, dim3(chgpu_grid_for(ctx, c.n_out, JT, 8)), dim3(JT), 0, ctx->stream, (const u64 *)rowid->data, (u64)c.n_out,
+                           (const u64 *)j->block_base_dev, (u64)j->blocks.size(), j->total_rows, j->used);
         ctx->counters[6] += 1;
     }
     hipError_t e = hipGetLastError();

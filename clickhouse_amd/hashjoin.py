@@ -37,7 +37,7 @@ class HashJoin:
 
     @property
     def need_filter(self):  # JoinFeatures.h:32
-        return not self.need_replication and (self.kind == K.JOIN_INNER or self.strictness in (K.STRICT_SEMI, K.STRICT_ANTI))
+        return not self.need_replication and (self.kind in (K.JOIN_INNER, K.JOIN_RIGHT) or self.strictness in (K.STRICT_SEMI, K.STRICT_ANTI))
 
     def _col(self, x, dtype=None):
         if isinstance(x, Column):
@@ -85,6 +85,15 @@ class HashJoin:
                     filter=Column(self.ctx, fh) if fh.value else None,
                     offsets=Column(self.ctx, oh) if oh.value else None,
                     right_rowid=Column(self.ctx, rh) if need_right_rows else None)
+
+    def non_joined_rows(self):
+        """IJoin::getNonJoinedBlocks for RIGHT / FULL joins: (right_block, right_row) of the build rows no left row matched,
+        in insertion order (call after the last probe)"""
+        h = C.c_void_p()
+        n = C.c_uint64(0)
+        K.check(K.lib().chgpu_join_non_joined_rows(self._h, C.byref(h), C.byref(n)))
+        rid = Column(self.ctx, h).numpy()
+        return (rid >> np.uint64(32)).astype(np.int64), (rid & np.uint64(0xFFFFFFFF)).astype(np.int64)
 
     def flatten_rowids(self, right_rowid: Column) -> Column:
         """(block << 32 | row) -> ordinal over all right blocks (index into concatenated payload columns)"""

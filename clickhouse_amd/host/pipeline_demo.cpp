@@ -304,7 +304,7 @@ int main(int argc, char ** argv)
         bool fell_back = false;
         try
         {
-            GpuHashJoin right_join(ctx, CHGPU_U64, /*RIGHT*/ 2, CHGPU_STRICT_ALL);
+            GpuHashJoin right_join(ctx, CHGPU_U64, CHGPU_JOIN_RIGHT, CHGPU_STRICT_ANY); // RIGHT ANY uses per-key flags: not carried
         }
         catch (const Exception & e)
         {

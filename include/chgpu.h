@@ -66,7 +66,7 @@ enum { CHGPU_EQ = 0, CHGPU_NE = 1, CHGPU_LT = 2, CHGPU_GT = 3, CHGPU_LE = 4, CHG
 enum { CHGPU_AGG_COUNT = 0, CHGPU_AGG_SUM = 1, CHGPU_AGG_AVG = 2 };
 
 /* ---- JoinKind / JoinStrictness subset (src/Core/Joins.h) ---- */
-enum { CHGPU_JOIN_INNER = 0, CHGPU_JOIN_LEFT = 1 };
+enum { CHGPU_JOIN_INNER = 0, CHGPU_JOIN_LEFT = 1, CHGPU_JOIN_RIGHT = 2, CHGPU_JOIN_FULL = 3 }; /* RIGHT / FULL: strictness ALL only */
 enum { CHGPU_STRICT_ANY = 0, CHGPU_STRICT_ALL = 1, CHGPU_STRICT_SEMI = 2, CHGPU_STRICT_ANTI = 3 };
 
 typedef struct chgpu_ctx chgpu_ctx;
@@ -388,6 +388,11 @@ int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const chgpu_col 
    all-ones): the index into payload columns concatenated with chgpu_col_concat, i.e. fillFromBlocksAndRowNumbers
    (src/Columns/IColumn.cpp:515-526) for many right Blocks */
 int chgpu_join_flatten_rowids(chgpu_join * j, const chgpu_col * right_rowid_u64, chgpu_col ** flat_u64);
+/* IJoin::getNonJoinedBlocks (src/Interpreters/IJoin.h:133-134; NotJoinedHash, HashJoin.cpp:1280-1420) for RIGHT / FULL joins (strictness
+   ALL): every right row a joinBlock emitted is flagged (JoinUsedFlags); after the last joinBlock this returns the build rows no left row
+   matched -- rows with a NULL key or a zero ON mask included -- as (block << 32 | row) ids in insertion order.  RIGHT probes like INNER,
+   FULL like LEFT. */
+int chgpu_join_non_joined_rows(chgpu_join * j, chgpu_col ** right_rowid_u64, uint64_t * rows_out);
 int chgpu_join_free(chgpu_join * j);
 
 #ifdef __cplusplus

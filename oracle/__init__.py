@@ -521,3 +521,24 @@ def hash_to_selector(keys: np.ndarray, num_shards: int) -> np.ndarray:
     out = np.empty(keys.shape[0], dtype=np.uint64)
     lib().cho_hash_to_selector(tag_of(keys), _p(keys), keys.shape[0], num_shards, _p(out))
     return out
+
+
+def non_joined_rows(build_blocks, probe_key_batches):
+    """RIGHT / FULL join with strictness ALL: the build rows NotJoinedHash emits after the probe phase (HashJoin.cpp:1280-1420) are
+    those whose JoinUsedFlags bit was never set (JoinUsedFlags.h; set in addFoundRowAll for every matching right row).  With ALL
+    strictness every right row whose key equals some probed left key is emitted, so by definition a right row is non-joined iff its
+    key is NULL, its ON mask is 0, or no probed (non-NULL) left key equals it.  Restated directly from that definition (numpy set
+    membership), independently of any join implementation.
+    build_blocks: [(keys, null_map or None, join_mask or None)]; probe_key_batches: [(keys, null_map or None)] -> sorted [(block, row)]"""
+    seen = [k[(nm == 0) if nm is not None else slice(None)] for k, nm in probe_key_batches]
+    left = np.unique(np.concatenate(seen)) if seen else np.zeros(0, dtype=np.uint64)
+    out = []
+    for b, (keys, nm, jm) in enumerate(build_blocks):
+        inserted = np.ones(keys.shape[0], dtype=bool)
+        if nm is not None:
+            inserted &= nm == 0
+        if jm is not None:
+            inserted &= jm != 0
+        matched = inserted & np.isin(keys, left)
+        out += [(b, int(r)) for r in np.nonzero(~matched)[0]]
+    return out

@@ -247,7 +247,7 @@ def test_join_empty_sides_and_errors(ch, engine):
         j.add_block(np.array([6], dtype=np.uint64))                         # addBlockToJoin after the build phase finished
     assert e.value.code == ch._capi.ERR_LOGICAL
     with pytest.raises(ch.ChgpuError) as e:
-        ch.HashJoin(2, ch.STRICT_ALL)                                       # RIGHT join: explicit CPU fallback signal
+        ch.HashJoin(ch.JOIN_RIGHT, ch.STRICT_SEMI)                          # RIGHT SEMI: explicit CPU fallback signal
     assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED
 
 
@@ -564,3 +564,63 @@ def test_join_payload_across_many_right_blocks(ch, ctx, engine):
         start = int(cnt[:i].sum())
         want = sorted(sv[lo[i]:hi[i]].tolist()) if hi[i] > lo[i] else [0]
         assert sorted(got_v[start:start + int(cnt[i])].tolist()) == want
+
+
+@pytest.mark.parametrize("kind_name", ["RIGHT", "FULL"])
+def test_right_and_full_join_all_with_non_joined_rows(ch, ctx, oracle_mod, kind_name):
+    """RIGHT / FULL × ALL: joinBlock behaves like INNER / LEFT ALL (compared with the oracle's INNER / LEFT ALL, pair by pair) and sets
+    the used flags; getNonJoinedBlocks returns exactly the right rows the definition gives (NULL keys, zero ON masks, keys no left
+    row had), in insertion order."""
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(len(kind_name)))
+    kind = ch.JOIN_RIGHT if kind_name == "RIGHT" else ch.JOIN_FULL
+    g = ch.HashJoin(kind, ch.STRICT_ALL, ctx=ctx)
+    o = O.HashJoin(O.JOIN_INNER if kind_name == "RIGHT" else O.JOIN_LEFT, O.STRICT_ALL)
+    build = []
+    for b in range(4):
+        n = [5000, 1, 0, 7001][b]
+        keys = rng.integers(0, 3000, size=n).astype(np.uint64)
+        keys[: min(n, 3)] = 0  # the zero key
+        nm = (rng.random(n) < 0.05).astype(np.uint8) if b % 2 == 0 else None
+        jm = (rng.random(n) < 0.9).astype(np.uint8) if b == 3 else None
+        g.add_block(keys, nm, jm)
+        o.add_block(keys, nm, jm)
+        build.append((keys, nm, jm))
+    probes = []
+    for batch in range(3):
+        n = [4000, 0, 2500][batch]
+        left = rng.integers(0, 2000, size=n).astype(np.uint64)  # keys 2000..2999 of the build side are never probed
+        lnm = (rng.random(n) < 0.1).astype(np.uint8) if batch == 0 else None
+        gl, gb, gr, gc = g.joined_pairs(left, lnm)
+        ol, ob, orow, oc = o.joined_pairs(left, lnm)
+        assert gc == oc == n
+        assert sorted(zip(gl.tolist(), gb.tolist(), gr.tolist())) == sorted(zip(ol.tolist(), ob.tolist(), orow.tolist()))
+        probes.append((left, lnm))
+    nb, nr = g.non_joined_rows()
+    got = list(zip(nb.tolist(), nr.tolist()))
+    assert got == sorted(got)  # insertion order
+    assert got == O.non_joined_rows(build, probes)
+    # matched + non-joined partition the build side
+    assert len(got) + len({(b, r) for b, r in zip(gb.tolist(), gr.tolist()) if b >= 0}) <= g.total_rows
+
+
+def test_right_join_restrictions_and_empty_cases(ch, ctx):
+    with pytest.raises(ch.ChgpuError) as ei:
+        ch.HashJoin(ch.JOIN_RIGHT, ch.STRICT_ANY, ctx=ctx)
+    assert ei.value.code == ch._capi.ERR_NOT_IMPLEMENTED
+    j = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, ctx=ctx)
+    j.add_block(np.array([1, 2], dtype=np.uint64))
+    with pytest.raises(ch.ChgpuError) as ei:
+        j.non_joined_rows()
+    assert ei.value.code == ch._capi.ERR_LOGICAL
+    f = ch.HashJoin(ch.JOIN_FULL, ch.STRICT_ALL, ctx=ctx)
+    f.add_block(np.array([7, 8, 7], dtype=np.uint64))
+    b, r = f.non_joined_rows()  # nothing probed yet: every right row is non-joined
+    assert list(zip(b.tolist(), r.tolist())) == [(0, 0), (0, 1), (0, 2)]
+    l, bb, rr, c = f.joined_pairs(np.array([7, 9], dtype=np.uint64))
+    assert sorted(zip(l.tolist(), bb.tolist(), rr.tolist())) == [(0, 0, 0), (0, 0, 2), (1, -1, -1)]  # FULL keeps the unmatched left row
+    b, r = f.non_joined_rows()
+    assert list(zip(b.tolist(), r.tolist())) == [(0, 1)]
+    e = ch.HashJoin(ch.JOIN_RIGHT, ch.STRICT_ALL, ctx=ctx)
+    b, r = e.non_joined_rows()  # empty right table
+    assert b.shape[0] == 0
