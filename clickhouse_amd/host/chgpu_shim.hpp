@@ -688,6 +688,34 @@ public:
         return !needReplication() && (kind == CHGPU_JOIN_INNER || strictness == CHGPU_STRICT_SEMI || strictness == CHGPU_STRICT_ANTI);
     }
 
+    /// getNonJoinedBlocks (IJoin.h:133-134; NotJoinedBlocks::nextImpl, src/Interpreters/NotJoinedBlocks.cpp) for RIGHT / FULL joins, after
+    /// the last joinBlock: the right payload columns of the build rows no left row matched, in insertion order.  The caller prepends
+    /// default-filled left columns of `num_rows` rows (insertManyDefaults).
+    Chunk getNonJoinedBlock()
+    {
+        if (right_payload.empty() && !right_blocks.empty())
+            onBuildPhaseFinish();
+        chgpu_col * rowid = nullptr;
+        uint64_t n = 0;
+        check(chgpu_join_non_joined_rows(h, &rowid, &n));
+        ColumnPtr ids = std::make_shared<ColumnVector>(ctx, rowid);
+        if (right_blocks.size() > 1)
+        {
+            chgpu_col * flat = nullptr;
+            check(chgpu_join_flatten_rowids(h, ids->handle(), &flat));
+            ids = std::make_shared<ColumnVector>(ctx, flat);
+        }
+        Chunk res;
+        res.num_rows = n;
+        for (auto & col : right_payload)
+        {
+            chgpu_col * out = nullptr;
+            check(chgpu_index(ctx->get(), col->handle(), ids->handle(), 0, 0, &out));
+            res.columns.push_back(std::make_shared<ColumnVector>(ctx, out));
+        }
+        return res;
+    }
+
     /// joinBlock(block, not_processed): the left chunk is replaced by [left columns..., right payload columns...];
     /// the unprocessed tail (max_joined_block_rows) comes back in not_processed (HashJoin.cpp:1090-1093).
     /// Right payloads are gathered on the device (fillFromBlocksAndRowNumbers, IColumn.cpp:515-526) from the glued columns.

@@ -300,6 +300,36 @@ int main(int argc, char ** argv)
             REQUIRE(bad == 0);
         }
 
+        // ---- FULL JOIN: the LEFT probe + used flags, then getNonJoinedBlocks ------------------------------------------------
+        {
+            auto full = std::make_shared<GpuHashJoin>(ctx, CHGPU_U64, CHGPU_JOIN_FULL, CHGPU_STRICT_ALL);
+            std::vector<uint64_t> rk1 = {1, 2, 3}, rk2 = {2, 9};
+            std::vector<int64_t> rv1 = {10, 20, 30}, rv2 = {21, 90};
+            Chunk r1, r2;
+            r1.columns = {ColumnVector::fromHost<uint64_t>(ctx, rk1.data(), 3), ColumnVector::fromHost<int64_t>(ctx, rv1.data(), 3)};
+            r1.num_rows = 3;
+            r2.columns = {ColumnVector::fromHost<uint64_t>(ctx, rk2.data(), 2), ColumnVector::fromHost<int64_t>(ctx, rv2.data(), 2)};
+            r2.num_rows = 2;
+            full->addBlockToJoin(r1, 0);
+            full->addBlockToJoin(r2, 0);
+            full->onBuildPhaseFinish();
+            std::vector<uint64_t> lk = {2, 5};
+            Chunk l;
+            l.columns = {ColumnVector::fromHost<uint64_t>(ctx, lk.data(), 2)};
+            l.num_rows = 2;
+            std::shared_ptr<Chunk> rest;
+            full->joinBlock(l, 0, rest);
+            REQUIRE(l.num_rows == 3); // (2,20) (2,21) (5,default)
+            int64_t joined_sum = 0;
+            for (int64_t v : l.columns.back()->getData<int64_t>())
+                joined_sum += v;
+            REQUIRE(joined_sum == 41);
+            Chunk nj = full->getNonJoinedBlock(); // right rows 1, 3 (block 0) and 9 (block 1), in insertion order
+            REQUIRE(nj.num_rows == 3);
+            REQUIRE((nj.columns[0]->getData<uint64_t>() == std::vector<uint64_t>{1, 3, 9}));
+            REQUIRE((nj.columns[1]->getData<int64_t>() == std::vector<int64_t>{10, 30, 90}));
+        }
+
         // unsupported surface -> NOT_IMPLEMENTED (CPU fallback signal), not a crash
         bool fell_back = false;
         try
