@@ -103,3 +103,47 @@ class Aggregator:
         """Aggregator::convertToBlocks(final=true) downloaded: (keys ndarray or None, [result ndarrays])."""
         keys, res = self.finalize_columns()
         return (keys.numpy() if keys is not None else None), [r.numpy() for r in res]
+
+
+class NullableKeyAggregator:
+    """GROUP BY a Nullable(T) key: AggregationDataWithNullKey (src/Interpreters/AggregatedData.h:71-95) keeps the NULL group's state
+    out of the hash table (has_null_key_data / null_key_data), and the key extraction sends rows whose null-map byte is set there
+    (ColumnsHashingImpl.h:196-240) whatever their nested value is.  Here: the hash table aggregates the rows whose null-map byte is 0
+    (the WHERE-fused form of add_block, mask = NOT null), an aggregation without key takes the rows whose byte is set."""
+
+    def __init__(self, key_dtype, aggs, ctx: Context | None = None, size_hint: int = 0):
+        self.ctx = ctx if ctx is not None else Context(0)
+        self.keyed = Aggregator(key_dtype, aggs, size_hint=size_hint, ctx=self.ctx)
+        self.null_group = Aggregator(None, aggs, ctx=self.ctx)
+        self.has_null_key_data = False
+        from .expression import ActionsDAG
+        d = ActionsDAG()
+        d.add_function("not", d.add_input(0, np.uint8))
+        self._not = d.compile()
+
+    def execute_on_block(self, keys, null_map, args):
+        """keys: the nested column of the ColumnNullable, null_map: its UInt8 null map (ColumnNullable.h)"""
+        from .columns import count_bytes_in_filter
+        k = self.ctx.column(keys)
+        nm = self.ctx.column(null_map)
+        acols = [self.ctx.column(a) if a is not None else None for a in args]
+        not_null = self._not.execute(self.ctx, [nm], [1])[0]
+        self.keyed.execute_on_block(k, acols, filter=not_null)
+        if count_bytes_in_filter(nm):
+            self.has_null_key_data = True
+            self.null_group.execute_on_block(None, acols, filter=nm)
+
+    def __len__(self):
+        return len(self.keyed) + (1 if self.has_null_key_data else 0)
+
+    def convert_to_block(self):
+        """-> (keys ndarray, key null map ndarray[uint8], [result ndarrays]); the NULL group, when present, is the last row (the
+        reference appends it the same way: insertDefault into the key column + 1 in the null map)"""
+        keys, res = self.keyed.convert_to_block()
+        nulls = np.zeros(keys.shape[0], dtype=np.uint8)
+        if self.has_null_key_data:
+            _, nres = self.null_group.convert_to_block()
+            keys = np.concatenate([keys, np.zeros(1, dtype=keys.dtype)])
+            nulls = np.concatenate([nulls, np.ones(1, dtype=np.uint8)])
+            res = [np.concatenate([r, n.astype(r.dtype)]) for r, n in zip(res, nres)]
+        return keys, nulls, res

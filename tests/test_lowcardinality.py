@@ -214,3 +214,57 @@ def test_gpu_string_filter_matches_oracle():
             a = want.get(nm, (0, 0))
             want[nm] = (a[0] + int(q), a[1] + 1)
     assert {k: (int(s), int(c)) for k, s, c in zip(keys, sums, cnts)} == want
+
+
+@pytest.mark.gpu
+def test_gpu_group_by_nullable_key():
+    """GROUP BY a Nullable(UInt32) key: the NULL group is kept out of the table (AggregationDataWithNullKey); nested values under a
+    set null-map byte are ignored"""
+    import clickhouse_amd as ch
+    rng = np.random.Generator(np.random.PCG64(12))
+    ctx = ch.Context()
+    agg = ch.NullableKeyAggregator(np.uint32, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None), (ch.AGG_AVG, np.float64)], ctx=ctx)
+    want, null_state = {}, [0, 0, 0.0]
+    for block in range(3):
+        n = 100_000 + block
+        k = rng.integers(0, 500, size=n).astype(np.uint32)
+        nm = (rng.random(n) < (0.0 if block == 0 else 0.2)).astype(np.uint8)
+        k[nm != 0] = rng.integers(0, 2**32, size=int(nm.sum()), dtype=np.uint32)  # garbage under the null map
+        v = rng.integers(-1000, 1000, size=n, dtype=np.int64)
+        f = rng.random(n)
+        agg.execute_on_block(k, nm, [v, None, f])
+        for kk in np.unique(k[nm == 0]):
+            m = (k == kk) & (nm == 0)
+            a = want.get(int(kk), [0, 0, 0.0])
+            want[int(kk)] = [a[0] + int(v[m].sum()), a[1] + int(m.sum()), a[2] + float(f[m].sum())]
+        null_state = [null_state[0] + int(v[nm != 0].sum()), null_state[1] + int((nm != 0).sum()), null_state[2] + float(f[nm != 0].sum())]
+    keys, nulls, (s, c, a) = agg.convert_to_block()
+    assert len(agg) == len(want) + 1 == keys.shape[0] and nulls[-1] == 1 and int(nulls[:-1].sum()) == 0
+    for kk, ss, cc, aa in zip(keys[:-1].tolist(), s[:-1].tolist(), c[:-1].tolist(), a[:-1].tolist()):
+        w = want[kk]
+        assert (ss, cc) == (w[0], w[1]) and abs(aa - w[2] / w[1]) <= 1e-6 * abs(w[2] / w[1])
+    assert (int(s[-1]), int(c[-1])) == (null_state[0], null_state[1]) and abs(a[-1] - null_state[2] / null_state[1]) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_gpu_join_on_string_keys_through_a_shared_dictionary():
+    """INNER ALL JOIN ON l.name = r.name with String keys: both sides dictionary-encoded on the device and mapped through ONE
+    query-wide dictionary, then the ordinary UInt32 hash join"""
+    import clickhouse_amd as ch
+    rng = np.random.Generator(np.random.PCG64(4))
+    ctx = ch.Context()
+    names = [f"SUPPLIER#{i:05d}".encode() for i in range(3000)]
+    right = [names[int(i)] for i in rng.integers(0, 2000, size=5000)]     # duplicates on the build side
+    left = [names[int(i)] for i in rng.integers(1000, 3000, size=20_000)]  # half of them have no partner
+    d = ch.LowCardinalityDictionary(ctx)
+    rk = d.map_block(ch.ColumnString.from_values(ctx, right).dictionary_encode())
+    lk = d.map_block(ch.ColumnString.from_values(ctx, left).dictionary_encode())
+    j = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, key_dtype=np.uint32, ctx=ctx)
+    j.add_block(rk)
+    l, b, r, c = j.joined_pairs(lk)
+    got = sorted(zip(l.tolist(), r.tolist()))
+    pos = {}
+    for i, v in enumerate(right):
+        pos.setdefault(v, []).append(i)
+    want = sorted((i, rr) for i, v in enumerate(left) for rr in pos.get(v, []))
+    assert c == len(left) and got == want
