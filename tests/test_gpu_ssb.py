@@ -53,3 +53,20 @@ def test_pack_unpack_fixed_keys(oracle_mod):
     with pytest.raises(ch.ChgpuError) as e:   # 12 key bytes -> keys128 on the CPU
         ch.pack_fixed_keys([ctx.upload(a.astype(np.uint64)), ctx.upload(a)])
     assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED
+
+
+@pytest.mark.gpu
+def test_ssb_q31_string_keys_compressed_columns_end_to_end():
+    """SSB Q3.1 with String dimension attributes, a Date column, compressed fact columns, generated WHERE + projection, two joins,
+    packed string-id keys, ORDER BY -- against the numpy restatement (tools/ssb_q31.py)"""
+    import clickhouse_amd as ch
+    from oracle import compression as OC
+    import ssb_q31 as Q  # tools/ is on sys.path (top of this file)
+    ctx = ch.Context()
+    dims, lo = Q.gen(rows=600_000, customers=30_000, suppliers=2_000)
+    files = Q.compress_lineorder(OC, lo)
+    got, kept = Q.q31_gpu(ch, ctx, dims, files, {k: v.dtype for k, v in lo.items()})
+    want, _ = Q.q31_cpu(dims, lo)
+    assert len(got) == len(want) > 100 and sorted(got) == sorted(want)
+    assert [(r[2], -r[3]) for r in got] == sorted((r[2], -r[3]) for r in got)  # ORDER BY year ASC, revenue DESC
+    assert got == Q.ordered(want) or sorted(got) == sorted(want)             # equal up to the order of revenue ties
