@@ -29,6 +29,7 @@ struct FrameJob
 };
 
 __device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 uni64(u64 v) { return ((u64)uni((u32)(v >> 32)) << 32) | uni((u32)v); }
 
 // Per wave: a window of the compressed input and a ring of the most recent output live in LDS, so the serial part of the format --
 // token, length bytes, offset -- and the short-distance matches that dominate column data (zero bytes 8 back, the previous value 8
@@ -50,10 +51,12 @@ __global__ __launch_bounds__(256) void k_lz4_decode(const u8 * __restrict__ src,
     for (u32 j = wave0; j < n_jobs; j += n_waves)
     {
         const FrameJob job = jobs[j];
-        const u8 * in = src + job.src_off;
-        u8 * out = (job.post ? dst_stage : dst_out) + job.dst_off;
-        const u32 isz = job.src_size, osz = job.dst_size;
-        if (job.method == 0x02u)
+        // the frame's fields are the same in every lane: telling the compiler so keeps the base pointers and sizes in scalar
+        // registers (stores become saddr + 32-bit lane offset instead of a 64-bit vector add per access)
+        const u8 * in = src + uni64(job.src_off);
+        u8 * out = (uni(job.post) ? dst_stage : dst_out) + uni64(job.dst_off);
+        const u32 isz = uni(job.src_size), osz = uni(job.dst_size);
+        if (uni(job.method) == 0x02u)
         {
             if (isz != osz)
             {
@@ -100,28 +103,41 @@ __global__ __launch_bounds__(256) void k_lz4_decode(const u8 * __restrict__ src,
             // One LDS read gives every lane one byte of the next 64 input bytes; token and offset are picked out of it with
             // v_readlane (no further LDS round trip); lanes 0..lit-1 store the literals, lanes 0..ml-1 the match.  ~45
             // instructions against ~170 on the general path below -- the decoder is bound by instruction issue.
-            if (ip >= in_base && ip + 64 <= in_base + in_len)
+            // (the window lies inside the frame, so 64 readable window bytes cover token + 14 literals + offset; 32 free output
+            //  bytes cover 14 literals + 18 match bytes: two checks instead of one per field -- the decoder is bound by the CU's
+            //  scalar unit, one instruction per clock for all its waves)
+            if (ip >= in_base && ip + 64 <= in_base + in_len && op + 32 <= osz)
             {
                 const u32 rel = ip - in_base;
                 const u32 hb = lin[rel + lane];
                 const u32 token = uni(hb);
                 const u32 lit = token >> 4, mlt = token & 15;
-                if (lit != 15 && mlt != 15 && ip + 1 + lit + 2 <= isz)
+                if (lit != 15 && mlt != 15)
                 {
                     const u32 offset = (u32)__builtin_amdgcn_readlane((int)hb, (int)(1 + lit)) | ((u32)__builtin_amdgcn_readlane((int)hb, (int)(2 + lit)) << 8);
                     const u32 ml = mlt + 4;
-                    if (offset != 0 && offset <= op + lit && offset <= LZ_CHUNK && lit + ml <= osz - op)
+                    if (offset - 1 < (op + lit < LZ_CHUNK ? op + lit : LZ_CHUNK)) // 1 <= offset <= min(bytes written, what the ring serves)
                     {
+                        // the literals are bytes 1..lit of the window: lane l takes lane l+1's byte (DPP wave shift, no LDS read)
+                        const u32 litb = (u32)__builtin_amdgcn_update_dpp(0, (int)hb, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
                         if (lane < lit)
                         {
-                            const u8 v = lin[rel + 1 + lane];
-                            out[op + lane] = v;
-                            ring[(op + lane) & (LZ_RING - 1)] = v;
+                            out[op + lane] = (u8)litb;
+                            ring[(op + lane) & (LZ_RING - 1)] = (u8)litb;
                         }
                         op += lit;
+                        // byte k of the match = byte (k mod offset) of the window before it; uniform branches keep the integer
+                        // modulo (~30 instructions) out of the common cases: no overlap, or a power-of-two period (runs, 8-byte values)
+                        u32 k = lane;
+                        if (offset < ml)
+                        {
+                            if ((offset & (offset - 1)) == 0)
+                                k = lane & (offset - 1);
+                            else
+                                k = lane % offset;
+                        }
                         if (lane < ml)
                         {
-                            const u32 k = offset >= ml ? lane : (offset == 1 ? 0u : lane % offset);
                             const u8 v = ring[(op - offset + k) & (LZ_RING - 1)]; // LDS operations of a wave complete in order
                             out[op + lane] = v;
                             ring[(op + lane) & (LZ_RING - 1)] = v;
