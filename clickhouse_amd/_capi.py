@@ -71,6 +71,8 @@ SIGNATURES = {
     "chgpu_index": (_i, [_vp, _vp, _vp, _u64, _i, _pp]),
     "chgpu_replicate": (_i, [_vp, _vp, _vp, _pp]),
     "chgpu_sort_permutation": (_i, [_vp, _vp, _vp, _i, _i, _pp]),
+    "chgpu_sort_permutation_limit": (_i, [_vp, _vp, _i, _i, _u64, _pp]),
+    "chgpu_filter_to_indices": (_i, [_vp, _vp, _pp, _pu64]),
     "chgpu_weak_hash32": (_i, [_vp, _vp, _vp]),
     "chgpu_hash_to_selector": (_i, [_vp, _vp, _u32, _pp]),
     "chgpu_scatter": (_i, [_vp, _vp, _vp, _u32, _pp]),

@@ -323,11 +323,31 @@ def sort_permutation(col: Column, perm_in: Column | None = None, descending: boo
     return Column(col.ctx, h)
 
 
+def sort_permutation_limit(col: Column, limit: int, descending: bool = False, nan_direction_hint: int = 1) -> Column:
+    """the first `limit` entries of the stable sorted permutation (ORDER BY ... LIMIT n over one column)"""
+    h = C.c_void_p()
+    K.check(K.lib().chgpu_sort_permutation_limit(col.ctx._h, col._h, 1 if descending else 0, nan_direction_hint, limit, C.byref(h)))
+    return Column(col.ctx, h)
+
+
+def filter_to_indices(filt: Column) -> Column:
+    """filterToIndices: ascending row numbers of the non-zero filter bytes"""
+    h = C.c_void_p()
+    n = C.c_uint64(0)
+    K.check(K.lib().chgpu_filter_to_indices(filt.ctx._h, filt._h, C.byref(h), C.byref(n)))
+    return Column(filt.ctx, h)
+
+
 def sort_block(columns, description, limit: int = 0):
     """sortBlock (src/Interpreters/sortBlock.cpp): description = [(position, descending, nan_direction_hint), ...] most significant
     first; every column of the block permuted (IColumn::permute == index), cut to `limit` rows when given."""
+    description = list(description)
+    if limit and len(description) == 1:
+        pos, desc, hint = description[0]
+        perm = sort_permutation_limit(columns[pos], limit, desc, hint)  # one sort column + LIMIT: only the candidate rows are sorted
+        return [c.index(perm) for c in columns], perm
     perm = None
-    for pos, desc, hint in reversed(list(description)):
+    for pos, desc, hint in reversed(description):
         perm = sort_permutation(columns[pos], perm, desc, hint)
     if limit:
         perm = perm.cut(0, min(limit, perm.size()))

@@ -1065,6 +1065,58 @@ extern "C" int chgpu_filter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_
     return CHGPU_OK;
 }
 
+// filterToIndices (src/Columns/ColumnsCommon.cpp:384-470): the row numbers whose filter byte is non-zero, ascending -- the form
+// ORDER BY ... LIMIT uses to name its candidate rows.  Same chunk counts + scan as chgpu_filter; one wave per 1024-row chunk.
+__global__ __launch_bounds__(256) void k_filter_emit_indices(const u8 * __restrict__ mask, u64 n, const u64 * __restrict__ chunk_offsets, u64 n_chunks, u64 * __restrict__ out)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave0 = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u64 n_waves = ((u64)gridDim.x * 256) >> 6;
+    for (u64 chunk = wave0; chunk < n_chunks; chunk += n_waves)
+    {
+        u64 pos = chunk_offsets[chunk];
+        for (u32 st = 0; st < CHUNK_ROWS / 64; ++st)
+        {
+            const u64 i = chunk * CHUNK_ROWS + st * 64 + lane;
+            const bool keep = i < n && mask[i] != 0;
+            const u64 b = __ballot(keep);
+            if (keep)
+                out[pos + mbcnt(b)] = i;
+            pos += (u64)__popcll(b);
+        }
+    }
+}
+
+extern "C" int chgpu_filter_to_indices(chgpu_ctx * ctx, const chgpu_col * mask, chgpu_col ** indexes_u64, uint64_t * rows_out)
+{
+    CHGPU_REQUIRE(ctx && mask && indexes_u64 && rows_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(mask->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "filter must be a UInt8 column");
+    chgpu_col * res = nullptr;
+    if (mask->rows == 0)
+    {
+        CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U64, 0, &res));
+        *indexes_u64 = res;
+        *rows_out = 0;
+        return CHGPU_OK;
+    }
+    FilterPlan fp;
+    CHGPU_TRY(filter_plan(ctx, mask, &fp));
+    CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U64, fp.total, &res));
+    if (fp.total)
+    {
+        hipLaunchKernelGGL(k_filter_emit_indices, dim3(fp.grid), dim3(256), 0, ctx->stream, (const u8 *)mask->data, fp.n, (const u64 *)fp.offsets, fp.n_chunks, (u64 *)res->data);
+        ctx->counters[6] += 1;
+        if (hipGetLastError() != hipSuccess)
+        {
+            chgpu_col_free(res);
+            return chgpu_set_error(CHGPU_ERR_DEVICE, "filter_to_indices launch failed");
+        }
+    }
+    *indexes_u64 = res;
+    *rows_out = fp.total;
+    return CHGPU_OK;
+}
+
 extern "C" int chgpu_filter_columns(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, const chgpu_col * mask,
                                     int64_t result_size_hint, chgpu_col ** outs, uint64_t * out_rows)
 {

@@ -132,3 +132,127 @@ extern "C" int chgpu_sort_permutation(chgpu_ctx * ctx, const chgpu_col * col, co
         default: return chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "unsupported column type");
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// ORDER BY ... LIMIT n (getPermutation with limit, ColumnVector.cpp:254-281: the reference switches to a partial sort).  Here the
+// k-th order statistic is bracketed from a sample: a strided sample of the column is sorted, the value at (about four times) the
+// limit's quantile becomes a threshold, `col <= t` (>= for descending) names the candidate rows (filterToIndices), and only those are
+// radix-sorted.  The result is EXACT: every row not among the candidates is greater than t, hence after at least `limit` candidates in
+// the order, and the candidates keep their row order, so ties break as in the full stable sort.  Too few candidates (an unlucky
+// sample), too many (a heavily repeated value) or NaNs that sort first fall back to the full sort.
+// Traffic: one comparison pass + two mask passes instead of sizeof(T) partition passes -- 1e8 Int64 rows, LIMIT 10: see DESIGN.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_sample_strided(const T * __restrict__ data, u64 n, u64 stride, u64 m, T * __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < m; i += (u64)gridDim.x * 256)
+    {
+        const u64 r = i * stride;
+        out[i] = data[r < n ? r : n - 1];
+    }
+}
+
+extern "C" int chgpu_sort_permutation_limit(chgpu_ctx * ctx, const chgpu_col * col, int descending, int nan_direction_hint, uint64_t limit,
+                                            chgpu_col ** perm_out_u64)
+{
+    CHGPU_REQUIRE(ctx && col && perm_out_u64, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    const u64 n = col->rows;
+    const bool is_float = chgpu_type_is_float(col->type);
+    // NaNs sort last when they compare greater in an ascending order or smaller in a descending one; otherwise they would have to lead
+    // the result and no value threshold describes that
+    const bool nan_last = !is_float || (descending ? nan_direction_hint < 0 : nan_direction_hint > 0);
+    constexpr u64 SAMPLE = 1u << 16;
+    auto full = [&]() -> int {
+        chgpu_col * p = nullptr;
+        CHGPU_TRY(chgpu_sort_permutation(ctx, col, nullptr, descending, nan_direction_hint, &p));
+        if (limit && limit < p->rows)
+            p->rows = limit; // IColumn::Permutation is simply cut (the buffer keeps its size class)
+        *perm_out_u64 = p;
+        return CHGPU_OK;
+    };
+    if (limit == 0 || limit >= n || n < (1u << 20) || limit * 64 > n || !nan_last)
+        return full();
+    const size_t es = chgpu_type_size(col->type);
+    const u64 stride = n / SAMPLE;
+    chgpu_col * sample = nullptr, * sperm = nullptr, * mask = nullptr, * ids = nullptr, * cand = nullptr, * cperm = nullptr, * res = nullptr;
+    auto cleanup = [&]() {
+        for (chgpu_col * c : {sample, sperm, mask, ids, cand, cperm})
+            if (c)
+                chgpu_col_free(c);
+    };
+    int rc = chgpu_col_new(ctx, col->type, SAMPLE, &sample);
+    if (rc == CHGPU_OK)
+    {
+        const u32 grid = chgpu_grid_for(ctx, SAMPLE, 256, 8);
+        switch (es)
+        {
+            case 8: hipLaunchKernelGGL(k_sample_strided<u64>, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)col->data, n, stride, SAMPLE, (u64 *)sample->data); break;
+            case 4: hipLaunchKernelGGL(k_sample_strided<u32>, dim3(grid), dim3(256), 0, ctx->stream, (const u32 *)col->data, n, stride, SAMPLE, (u32 *)sample->data); break;
+            case 2: hipLaunchKernelGGL(k_sample_strided<u16>, dim3(grid), dim3(256), 0, ctx->stream, (const u16 *)col->data, n, stride, SAMPLE, (u16 *)sample->data); break;
+            default: hipLaunchKernelGGL(k_sample_strided<u8>, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)col->data, n, stride, SAMPLE, (u8 *)sample->data); break;
+        }
+        ctx->counters[6] += 1;
+        rc = chgpu_sort_permutation(ctx, sample, nullptr, descending, nan_direction_hint, &sperm);
+    }
+    u64 threshold_bits = 0;
+    if (rc == CHGPU_OK)
+    {
+        // rank of the limit inside the sample, with a 4x margin + 32 (the sample's quantiles wobble by ~sqrt(rank))
+        u64 rank = (limit * SAMPLE + n - 1) / n;
+        rank = rank * 4 + 32;
+        if (rank >= SAMPLE)
+        {
+            cleanup();
+            return full();
+        }
+        u64 srow = 0;
+        rc = chgpu_read_back(ctx, (const u64 *)sperm->data + rank, &srow, sizeof(srow));
+        if (rc == CHGPU_OK)
+            rc = chgpu_read_back(ctx, (const char *)sample->data + srow * es, &threshold_bits, es);
+    }
+    if (rc == CHGPU_OK && is_float)
+    {
+        const bool is_nan = col->type == CHGPU_F64 ? ((threshold_bits & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull)
+                                                   : ((threshold_bits & 0x7FFFFFFFull) > 0x7F800000ull);
+        if (is_nan)
+        {
+            cleanup();
+            return full();
+        }
+    }
+    u64 n_cand = 0;
+    if (rc == CHGPU_OK)
+    {
+        int scalar_type = col->type;
+        if (col->type == CHGPU_F32) // Float32 columns compare after their exact widening: hand the threshold over as Float64
+        {
+            float f;
+            memcpy(&f, &threshold_bits, 4);
+            const double d = (double)f;
+            memcpy(&threshold_bits, &d, 8);
+            scalar_type = CHGPU_F64;
+        }
+        rc = chgpu_cmp_const(ctx, col, descending ? CHGPU_GE : CHGPU_LE, scalar_type, &threshold_bits, &mask);
+    }
+    if (rc == CHGPU_OK)
+        rc = chgpu_filter_to_indices(ctx, mask, &ids, &n_cand);
+    if (rc == CHGPU_OK && (n_cand < limit || n_cand > n / 8))
+    {
+        cleanup();
+        return full();
+    }
+    if (rc == CHGPU_OK)
+        rc = chgpu_index(ctx, col, ids, 0, 0, &cand);
+    if (rc == CHGPU_OK)
+        rc = chgpu_sort_permutation(ctx, cand, nullptr, descending, nan_direction_hint, &cperm);
+    if (rc == CHGPU_OK)
+    {
+        cperm->rows = limit;
+        rc = chgpu_index(ctx, ids, cperm, 0, 0, &res); // candidate positions -> row numbers
+    }
+    cleanup();
+    if (rc != CHGPU_OK)
+        return rc;
+    *perm_out_u64 = res;
+    return CHGPU_OK;
+}

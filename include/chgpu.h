@@ -275,6 +275,14 @@ int chgpu_replicate(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * of
 int chgpu_sort_permutation(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * perm_in_u64, int descending,
                            int nan_direction_hint, chgpu_col ** perm_out_u64);
 
+/* getPermutation with a limit (ColumnVector.cpp:254-281: ORDER BY ... LIMIT n): the first `limit` entries of the stable sorted
+   permutation.  A threshold from a sorted sample names the candidate rows (one comparison pass + filterToIndices); only they are
+   sorted.  Exact; falls back to the full sort when the sample misleads, a value repeats massively or NaNs must come first. */
+int chgpu_sort_permutation_limit(chgpu_ctx * ctx, const chgpu_col * col, int descending, int nan_direction_hint, uint64_t limit,
+                                 chgpu_col ** perm_out_u64);
+/* filterToIndices (src/Columns/ColumnsCommon.cpp:384-470): row numbers whose filter byte is non-zero, ascending */
+int chgpu_filter_to_indices(chgpu_ctx * ctx, const chgpu_col * filter_u8, chgpu_col ** indexes_u64, uint64_t * rows_out);
+
 /* ================================================================================================
  * a11/a21 hashing & sharding  —  ColumnVector::getWeakHash32 (ColumnVector.cpp:78-95), ConcurrentHashJoin
  * hashToSelector (src/Interpreters/ConcurrentHashJoin.cpp:426-440), IColumn::scatter (src/Columns/IColumn.cpp:245-269).

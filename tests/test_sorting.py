@@ -125,3 +125,49 @@ def test_gpu_two_level_export_buckets_match_reference_hash(golden, oracle_mod):
     wc = np.bincount(inv, minlength=uk.shape[0])
     assert np.array_equal(k[order], uk) and np.array_equal(s[order].view(np.int64), ws) and np.array_equal(c[order], wc.astype(np.uint64))
     assert np.array_equal(num[order].view(np.int64), ws) and np.array_equal(den[order], wc.astype(np.uint64))
+
+
+def _stable_order(x, descending):
+    """numpy restatement of the stable order for large inputs (NaN last in both directions): order-preserving unsigned keys"""
+    dt = x.dtype
+    if dt.kind == "f":
+        key = np.where(np.isnan(x), 0.0, x).astype(np.float64)
+        # primary: NaN last; then the value (-0.0 == 0.0); ties by row number
+        order = np.lexsort((np.arange(x.shape[0]), -key if descending else key, np.isnan(x)))
+        return order.astype(np.uint64)
+    u = x.astype(np.int64).view(np.uint64) ^ np.uint64(1 << 63) if dt.kind == "i" else x.astype(np.uint64)
+    return np.argsort(~u if descending else u, kind="stable").astype(np.uint64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.int64, np.uint32, np.float64, np.float32, np.int16, np.uint64])
+def test_gpu_sort_permutation_limit_is_the_prefix_of_the_full_stable_sort(dtype):
+    """ORDER BY x LIMIT n: sampled threshold + candidates, or one of its fallbacks -- always the exact prefix"""
+    import clickhouse_amd as ch
+    ctx = ch.Context()
+    rng = np.random.Generator(np.random.PCG64(np.dtype(dtype).itemsize + 100))
+    n = (1 << 21) + 12345
+    for flavour in ("wide", "few values", "one value repeated", "nans"):
+        if flavour == "nans" and np.dtype(dtype).kind != "f":
+            continue
+        x = _column(rng, dtype, n, few_values=(flavour == "few values"))
+        if flavour == "one value repeated":
+            x[rng.random(n) < 0.6] = x[0]
+        if flavour == "nans":
+            x[rng.random(n) < 0.3] = np.nan
+        col = ctx.upload(x)
+        for desc in (False, True):
+            want = _stable_order(x, desc)
+            hint = -1 if desc else 1  # NaN last
+            for limit in (1, 10, 1000, 30_000, n // 2, n + 5):
+                got = ch.sort_permutation_limit(col, limit, desc, hint).numpy()
+                assert np.array_equal(got, want[:limit]), (dtype, flavour, desc, limit)
+        if np.dtype(dtype).kind == "f":  # NaN first: no threshold describes it -> the full sort, still exact
+            got = ch.sort_permutation_limit(col, 100, False, -1).numpy()
+            full = ch.sort_permutation(col, None, False, -1).numpy()
+            assert np.array_equal(got, full[:100])
+    # sortBlock with one sort column and LIMIT takes this path; filterToIndices
+    (o,), perm = ch.sort_block([col], [(0, False, 1)], limit=7)
+    assert o.size() == 7 and np.array_equal(perm.numpy(), _stable_order(x, False)[:7])
+    m = (rng.random(n) < 0.01).astype(np.uint8)
+    assert np.array_equal(ch.filter_to_indices(ctx.upload(m)).numpy(), np.nonzero(m)[0].astype(np.uint64))

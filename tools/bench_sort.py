@@ -48,6 +48,9 @@ for name, t, npdt, width in [("Int64", torch.randint(-2**62, 2**62, (rows,), dty
                 "algorithmic_B_per_row": passes * 2 * (width + 8), "GBps": passes * 2 * (width + 8) * rows / dt / 1e9,
                 "roofline_frac": passes * 2 * (width + 8) * rows / dt / 8e12,
                 "cpu_numpy_stable_argsort_rows_per_s_1thread": m / tc, "cpu_sample_rows": m})
+    dl = best_of(lambda: ch.sort_permutation_limit(col, 10, False, 1))
+    res.append({"case": f"ORDER BY {name} LIMIT 10 (sampled threshold + candidates)", "rows": rows, "ms": dl * 1e3, "rows_per_s": rows / dl,
+                "algorithmic_B_per_row": width + 2, "GBps": (width + 2) * rows / dl / 1e9, "roofline_frac": (width + 2) * rows / dl / 8e12})
     del col, t
     ctx.trim()
     torch.cuda.empty_cache()
