@@ -6,8 +6,9 @@
  * bytes, match of length + 4 copied from `offset` bytes back, overlap allowed (copyOverlap*, :41-420) — without the reference's
  * wide-copy over-writes (which only touch padding).  Returns 0 on success, -1 where the reference returns false
  * (CANNOT_DECOMPRESS).  The byte-wise match copy is the definition of an overlapping LZ4 match.
- * Pinned by an independent implementation: tests compress with Apache Arrow's bundled liblz4 (pyarrow codec "lz4_raw") and
- * require this decoder — and the device decoder — to return the original bytes.
+ * PARITY UNPINNED by the reference's own fixtures (it ships no small compressed column files); cross-checked instead against an
+ * independent implementation of the same format: tests compress with Apache Arrow's bundled liblz4 (pyarrow codec "lz4_raw", the
+ * library the reference links as contrib/lz4) and require this decoder — and the device decoder — to return the original bytes.
  * cho_delta_decode follows CompressionCodecDelta::doDecompressData (src/Compression/CompressionCodecDelta.cpp:84-175).
  */
 #include <stddef.h>

@@ -6,8 +6,9 @@ row's index points at: HashMethodSingleLowCardinalityColumn (src/Common/ColumnsH
 dictionary[index[row]] (through its per-position cache), so rows of different Blocks whose dictionaries hold the same value
 at different positions meet in one group, and the result key column holds each value once.  Restated with a plain Python
 dict over the converted-to-full column (ColumnLowCardinality::convertToFullColumn, ColumnLowCardinality.h:53).
-Parity pinning: the group set and sums are order-free facts of the inputs; no reference vector is needed beyond the
-GROUP BY semantics already pinned in tests/golden/sql_reference_rows.json.
+Parity pinning: PARITY UNPINNED by reference vectors of their own (the reference's LowCardinality / String tests need a server); the
+group set and sums are order-free facts of the inputs, and the GROUP BY semantics underneath are the ones pinned in
+tests/golden/sql_reference_rows.json.
 """
 from __future__ import annotations
 
