@@ -15,9 +15,10 @@ whole columns, materialising every intermediate: `evaluate` does exactly that, o
   intDiv, modulo  src/Functions/DivisionUtils.h:66-170 for integer operands, in the type C++'s usual arithmetic conversions choose
                   (restated on Python integers); the product compiles them only for constant divisors that cannot throw
 Parity pinning: comparisons are PINNED by tests/golden/expr_cmp_kat.json (the reference's 00411_long_accurate_number_comparison_float
-answers); modulo + multiply + avg end to end by the reference rows of 01300_group_by_other_keys (tests/golden/sql_reference_rows.json).
+answers); modulo values AND result types by 01700_mod_negative_type_promotion and 00516_modulo, intDiv by 00977_int_div
+(tests/golden/expr_mod_kat.json); modulo + multiply + avg end to end by 01300_group_by_other_keys (tests/golden/sql_reference_rows.json).
 Everything else here is PARITY UNPINNED by reference vectors: the calendar is checked against Python's datetime, result types against the
-documented NumberTraits.h examples, arithmetic / logical / if / bit / cast / intDiv values only against their definitions
+documented NumberTraits.h examples, plus / minus / multiply / divide / logical / if / bit / cast values only against their definitions
 (static_cast<Result>(a) OP b) as restated here.
 """
 from __future__ import annotations

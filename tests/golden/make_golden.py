@@ -85,6 +85,21 @@ def main():
         json.dump(dict(source="src/Common/HashTable/Hash.h compiled in place (oracle/ref_hash_wrapper.cpp)", kat=kat), f, indent=1)
     print("wrote", os.path.join(HERE, "sql_reference_rows.json"), "and hash_kat.json")
     make_cmp_kat(ref_root)
+    make_mod_kat(ref_root)
+
+
+def make_mod_kat(ref_root):
+    """modulo known answers: the expected rows of 01700_mod_negative_type_promotion (value + result type name; the integer forms,
+    i.e. its first seven lines) and of 00516_modulo (values).  The operands are restated as typed inputs in tests/test_expr_dag.py."""
+    out = {"01700_mod_negative_type_promotion": dict(source="tests/queries/0_stateless/01700_mod_negative_type_promotion.reference",
+                                                      rows=rows_of(ref_root, "01700_mod_negative_type_promotion", 0, 7)),
+           "00516_modulo": dict(source="tests/queries/0_stateless/00516_modulo.reference", rows=rows_of(ref_root, "00516_modulo")),
+           # 00977_int_div: four intDiv forms over numbers(1, 10), ten result lines each (lines 4-13, 24-33, 44-53, 64-73 of the .reference)
+           "00977_int_div": dict(source="tests/queries/0_stateless/00977_int_div.reference",
+                                 rows=[rows_of(ref_root, "00977_int_div", lo, lo + 10) for lo in (3, 23, 43, 63)])}
+    with open(os.path.join(HERE, "expr_mod_kat.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote expr_mod_kat.json")
 
 
 def make_cmp_kat(ref_root):

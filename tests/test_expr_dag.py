@@ -463,3 +463,69 @@ def test_gpu_01300_group_by_modulo_expression_reference_rows(golden):
     for g, w in zip(got, want):
         assert abs(g - w) <= 1e-6 * abs(w)  # BASELINE: 1e-6 relative for avg(Float64)
     assert sum(round(g, 6) == w for g, w in zip(got, want)) >= 3
+
+
+# the operands of the reference's modulo tests, restated: (dividend, its type, divisor, its type); integer literals take the narrowest
+# type, unsigned unless negative (_literal_dtype)
+_MOD_01700 = [(-199, np.int32, 200, np.uint8), (-199, np.int32, 200, np.uint16), (-199, np.int32, 200, np.uint32), (-199, np.int32, 200, np.uint64),
+              (-199, np.int32, -200, np.int16), (199, np.uint8, -10, np.int8), (199, np.uint8, -200, np.int16)]
+_MOD_00516 = [(1000, 32), (7, 3), (255, 510), (255, 512), (255, 1000000009), (0, 255), (2147483647, 255), (-1, -1), (-1, -2), (255, 99), (42, 13),
+              (42, 22), (1234567, 123)]
+_TYPE_NAME = {"Int8": np.int8, "Int16": np.int16, "Int32": np.int32, "Int64": np.int64, "UInt8": np.uint8, "UInt16": np.uint16, "UInt32": np.uint32,
+              "UInt64": np.uint64}
+
+
+def _mod_cases():
+    with open(os.path.join(HERE, "golden", "expr_mod_kat.json")) as f:
+        kat = json.load(f)
+    cases = []
+    for (a, ta, b, tb), row in zip(_MOD_01700, kat["01700_mod_negative_type_promotion"]["rows"]):
+        cases.append((a, ta, b, tb, int(row[0]), _TYPE_NAME[row[1]]))
+    for (a, b), row in zip(_MOD_00516, kat["00516_modulo"]["rows"]):
+        cases.append((a, _literal_dtype(a), b, _literal_dtype(b), int(row[0]), None))
+    assert len(cases) == 20
+    return cases
+
+
+def test_oracle_modulo_reference_rows():
+    """01700_mod_negative_type_promotion (values AND result types, e.g. toInt32(-199) % toUInt32(200) = 97 :: Int64 -- the unsigned
+    remainder of the usual arithmetic conversions) and 00516_modulo"""
+    for a, ta, b, tb, want, want_type in _mod_cases():
+        r = OE.apply_function(OE.FN["modulo"], [np.array([a], dtype=ta), np.array([b], dtype=tb)], [OE.TAG_OF[np.dtype(ta)], OE.TAG_OF[np.dtype(tb)]])
+        assert int(r[0]) == want, (a, ta, b, tb)
+        if want_type is not None:
+            assert r.dtype == np.dtype(want_type), (a, ta, b, tb, r.dtype)
+
+
+@pytest.mark.gpu
+def test_gpu_modulo_reference_rows():
+    import clickhouse_amd as ch
+    ctx = ch.Context()
+    done = 0
+    for a, ta, b, tb, want, want_type in _mod_cases():
+        d = ch.ActionsDAG()
+        x = d.add_input(0, ta)
+        try:
+            m = d.add_function("modulo", x, d.add_column(b, tb))
+            ex = d.compile()
+        except ch.ChgpuError as e:  # a divisor of -1 could raise ILLEGAL_DIVISION for the minimal dividend: left to the CPU
+            assert e.code == ch._capi.ERR_NOT_IMPLEMENTED and b == -1
+            continue
+        out = ex.execute(ctx, [ctx.upload(np.array([a, a, a], dtype=ta))], [m])[0].numpy()
+        assert out.tolist() == [want] * 3 and (want_type is None or out.dtype == np.dtype(want_type)), (a, ta, b, tb, out)
+        done += 1
+    assert done == 19
+
+
+def test_oracle_intdiv_reference_rows():
+    """00977_int_div: intDiv(-1, number), intDiv(toInt32(number), -1), intDiv(toInt64(number), -1), intDiv(number, -number) over
+    numbers(1, 10) -- column divisors and -1 (forms the device path leaves to the CPU; they pin the restated DivideIntegralImpl)"""
+    with open(os.path.join(HERE, "golden", "expr_mod_kat.json")) as f:
+        rows = json.load(f)["00977_int_div"]["rows"]
+    number = np.arange(1, 11, dtype=np.uint64)
+    neg = OE.apply_function(OE.FN["negate"], [number], [OE.U64])  # -number: Int64
+    forms = [(np.full(10, -1, dtype=np.int8), number), (number.astype(np.int32), np.full(10, -1, dtype=np.int8)),
+             (number.astype(np.int64), np.full(10, -1, dtype=np.int8)), (number, neg)]
+    for (a, b), want in zip(forms, rows):
+        r = OE.apply_function(OE.FN["intDiv"], [a, b], [OE.TAG_OF[a.dtype], OE.TAG_OF[b.dtype]])
+        assert r.tolist() == [int(w[0]) for w in want], (a.dtype, b.dtype)
