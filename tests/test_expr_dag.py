@@ -77,6 +77,11 @@ def test_oracle_calendar_against_python_datetime():
     for i, d in enumerate(days.tolist()):
         c = datetime.date(1970, 1, 1) + datetime.timedelta(days=d)
         assert (int(vals[1][i]), int(vals[2][i]), int(vals[3][i]), int(vals[4][i])) == (c.year, c.month, c.day, c.year * 100 + c.month)
+    # the reference's own answer: 00479_date_and_datetime_to_number, toYYYYMM(toDate('2017-07-21')) = 201707
+    with open(os.path.join(HERE, "golden", "expr_mod_kat.json")) as f:
+        want = int(json.load(f)["00479_toYYYYMM_of_date_2017_07_21"]["rows"][0][0])
+    d0 = np.array([(datetime.date(2017, 7, 21) - datetime.date(1970, 1, 1)).days], dtype=np.uint16)
+    assert int(OE.evaluate(nodes, [d0])[0][4][0]) == want == 201707
 
 
 def test_oracle_result_types_documented_examples():
