@@ -8,8 +8,9 @@ against NaN is neither less nor greater), ties — a == b, or both NaN — broke
 directions.  Restated as Python's sorted() (stable) over row numbers with exactly that three-way comparator, which is an
 independent route from the product's radix keys.  Multi-column ORDER BY = sortBlock's lexicographic comparator
 (src/Interpreters/sortBlock.cpp:33-80), restated the same way.
-Parity pinning: PARITY UNPINNED by reference vectors (the reference's tests hold no permutation fixtures for this); a total order with
-index tie-break has exactly one valid permutation, so the restated definition determines the expected output completely.
+Parity pinning: NaN placement and direction are PINNED by the 16 output blocks of 03447_float_nan_order (tests/golden/sort_nan_order.json:
+ASC / DESC x NULLS FIRST / LAST over 3 and 256 rows); tie-breaking by row number has no reference vector -- a total order with index
+tie-break has exactly one valid permutation, so the restated definition determines the expected output completely.
 """
 from __future__ import annotations
 

@@ -86,6 +86,25 @@ def main():
     print("wrote", os.path.join(HERE, "sql_reference_rows.json"), "and hash_kat.json")
     make_cmp_kat(ref_root)
     make_mod_kat(ref_root)
+    make_sort_kat(ref_root)
+
+
+def make_sort_kat(ref_root):
+    """NaN placement in ORDER BY: the expected output blocks of 03447_float_nan_order (the .reference echoes a '--- <name>' line before
+    each block).  The sorted column -- number + number / number over numbers(3) / numbers(256) -- is restated in tests/test_sorting.py."""
+    path = os.path.join(ref_root, "tests/queries/0_stateless", "03447_float_nan_order.reference")
+    blocks, name = {}, None
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if line.startswith("--- "):
+                name = line[4:]
+                blocks[name] = []
+            elif name is not None and line:
+                blocks[name].append(line)
+    with open(os.path.join(HERE, "sort_nan_order.json"), "w") as f:
+        json.dump(dict(source="tests/queries/0_stateless/03447_float_nan_order.reference", blocks=blocks), f)
+    print("wrote sort_nan_order.json:", len(blocks), "blocks")
 
 
 def make_mod_kat(ref_root):

@@ -171,3 +171,45 @@ def test_gpu_sort_permutation_limit_is_the_prefix_of_the_full_stable_sort(dtype)
     assert o.size() == 7 and np.array_equal(perm.numpy(), _stable_order(x, False)[:7])
     m = (rng.random(n) < 0.01).astype(np.uint8)
     assert np.array_equal(ch.filter_to_indices(ctx.upload(m)).numpy(), np.nonzero(m)[0].astype(np.uint64))
+
+
+def _nan_order_cases():
+    """03447_float_nan_order: a = number + number / number (NaN for number = 0) over numbers(3) and numbers(256), ORDER BY a ASC | DESC
+    NULLS FIRST | LAST.  nulls_direction: NaN counts as greater than every number when it is +1 -- ASC NULLS LAST and DESC NULLS FIRST."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sort_nan_order.json")) as f:
+        blocks = json.load(f)["blocks"]
+    for size, n in (("short", 3), ("long", 256)):
+        number = np.arange(n, dtype=np.uint64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            a = number.astype(np.float64) + number.astype(np.float64) / number.astype(np.float64)
+        for direction, desc in (("ASC", False), ("DESC", True)):
+            for nulls, hint in (("FIRST", 1 if desc else -1), ("LAST", -1 if desc else 1)):
+                for partial in ("", "partial "):
+                    want = [float(x) for x in blocks[f"{size} array {partial}{direction} NULLS {nulls}"]]
+                    yield a, desc, hint, want
+
+
+def _same_floats(got, want):
+    return len(got) == len(want) and all((g == w) or (g != g and w != w) for g, w in zip(got, want))
+
+
+def test_oracle_sort_nan_order_reference_blocks():
+    n = 0
+    for a, desc, hint, want in _nan_order_cases():
+        assert _same_floats(a[OS.get_permutation(a, desc, hint).astype(np.int64)].tolist(), want), (a.shape, desc, hint)
+        n += 1
+    assert n == 16
+
+
+@pytest.mark.gpu
+def test_gpu_sort_nan_order_reference_blocks():
+    import clickhouse_amd as ch
+    ctx = ch.Context()
+    for a, desc, hint, want in _nan_order_cases():
+        col = ctx.upload(a)
+        perm = ch.sort_permutation(col, None, desc, hint)
+        assert _same_floats(col.index(perm).numpy().tolist(), want), (a.shape, desc, hint)
+        f32 = ctx.upload(a.astype(np.float32))
+        assert _same_floats(f32.index(ch.sort_permutation(f32, None, desc, hint)).numpy().astype(np.float64).tolist(), want)
