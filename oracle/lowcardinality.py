@@ -6,8 +6,9 @@ row's index points at: HashMethodSingleLowCardinalityColumn (src/Common/ColumnsH
 dictionary[index[row]] (through its per-position cache), so rows of different Blocks whose dictionaries hold the same value
 at different positions meet in one group, and the result key column holds each value once.  Restated with a plain Python
 dict over the converted-to-full column (ColumnLowCardinality::convertToFullColumn, ColumnLowCardinality.h:53).
-Parity pinning: PARITY UNPINNED by reference vectors of their own (the reference's LowCardinality / String tests need a server); the
-group set and sums are order-free facts of the inputs, and the GROUP BY semantics underneath are the ones pinned in
+Parity pinning: the String-key paths are checked end to end against the reference's expected rows of 00054_join_string and
+00127_group_by_concat (tests/golden/string_key_rows.json); the helpers in this file have no reference vectors of their own -- the group
+set and sums are order-free facts of the inputs, and the GROUP BY semantics underneath are the ones pinned in
 tests/golden/sql_reference_rows.json.
 """
 from __future__ import annotations

@@ -87,6 +87,17 @@ def main():
     make_cmp_kat(ref_root)
     make_mod_kat(ref_root)
     make_sort_kat(ref_root)
+    make_string_kat(ref_root)
+
+
+def make_string_kat(ref_root):
+    """String keys: expected rows of 00054_join_string (ALL LEFT JOIN USING a String key) and 00127_group_by_concat (GROUP BY a String
+    and a number).  The inputs are restated in tests/test_lowcardinality.py."""
+    out = {"00054_join_string": dict(source="tests/queries/0_stateless/00054_join_string.reference", rows=rows_of(ref_root, "00054_join_string")),
+           "00127_group_by_concat": dict(source="tests/queries/0_stateless/00127_group_by_concat.reference", rows=rows_of(ref_root, "00127_group_by_concat"))}
+    with open(os.path.join(HERE, "string_key_rows.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote string_key_rows.json")
 
 
 def make_sort_kat(ref_root):

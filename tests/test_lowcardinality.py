@@ -268,3 +268,54 @@ def test_gpu_join_on_string_keys_through_a_shared_dictionary():
         pos.setdefault(v, []).append(i)
     want = sorted((i, rr) for i, v in enumerate(left) for rr in pos.get(v, []))
     assert c == len(left) and got == want
+
+
+def _string_rows():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "string_key_rows.json")) as f:
+        return json.load(f)
+
+
+def test_oracle_string_key_reference_rows():
+    """00127_group_by_concat restated over the oracle: GROUP BY ('' as a String key, number % 123) over numbers(1000)"""
+    want = [(r[0].encode(), int(r[1]), int(r[2])) for r in _string_rows()["00127_group_by_concat"]["rows"]]
+    number = np.arange(1000, dtype=np.uint64)
+    k2 = (number % 123).astype(np.uint8)
+    got = OL.group_by_sum_count([([b""], np.zeros(1000, dtype=np.uint8) + 0 * k2, None)])  # one String group ...
+    assert got == {b"": (0, 1000)}
+    cnt = np.bincount(k2, minlength=123)                                                   # ... times the numeric key
+    assert [(b"", int(k), int(c)) for k, c in enumerate(cnt)] == want
+
+
+@pytest.mark.gpu
+def test_gpu_string_key_reference_rows():
+    """00054_join_string (ALL LEFT JOIN USING a String key, defaults for the misses) and 00127_group_by_concat (GROUP BY a String and
+    number % 123, the modulo computed on the device) against the reference's expected rows"""
+    import clickhouse_amd as ch
+    ctx = ch.Context()
+    rows = _string_rows()
+    # ---- 00054: left k = 'A'..'J'; right k = char('A' + number div 2), joined = number; ALL LEFT JOIN USING k ORDER BY k, joined ----
+    left = [bytes([65 + i]) for i in range(10)]
+    right = [bytes([65 + i // 2]) for i in range(10)]
+    joined = np.arange(10, dtype=np.uint64)
+    d = ch.LowCardinalityDictionary(ctx)
+    rk = d.map_block(ch.ColumnString.from_values(ctx, right).dictionary_encode())
+    lk = d.map_block(ch.ColumnString.from_values(ctx, left).dictionary_encode())
+    j = ch.HashJoin(ch.JOIN_LEFT, ch.STRICT_ALL, key_dtype=np.uint32, ctx=ctx)
+    j.add_block(rk)
+    r = j.probe_columns(lk)
+    k_out = lk.replicate(r["offsets"])
+    joined_out = ctx.upload(joined).index(r["right_rowid"], default_for_missing=True)
+    got = sorted(zip(d.decode(k_out.numpy()), joined_out.numpy().tolist()))
+    assert [(k.decode(), str(v)) for k, v in got] == [tuple(x) for x in rows["00054_join_string"]["rows"]]
+    # ---- 00127: GROUP BY materialize('') AS k1, number % 123 AS k2 over numbers(1000), count() ----
+    dag = ch.ActionsDAG()
+    k2n = dag.add_function("modulo", dag.add_input(0, np.uint64), dag.add_column(123, np.uint8))
+    k2 = dag.compile().execute(ctx, [ctx.upload(np.arange(1000, dtype=np.uint64))], [k2n])[0]
+    k1 = ch.ColumnString.from_values(ctx, [b""] * 1000).dictionary_encode()
+    agg = ch.PackedKeysAggregator(["lc", np.uint8], [(ch.AGG_COUNT, None)], ctx=ctx)
+    agg.execute_on_block([k1, k2], [None])
+    (g1, g2), (cnt,) = agg.convert_to_block()
+    got = sorted(zip(g1, g2.tolist(), cnt.tolist()))
+    assert [[a.decode(), str(b), str(c)] for a, b, c in got] == rows["00127_group_by_concat"]["rows"]
