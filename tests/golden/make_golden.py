@@ -94,7 +94,8 @@ def make_string_kat(ref_root):
     """String keys: expected rows of 00054_join_string (ALL LEFT JOIN USING a String key) and 00127_group_by_concat (GROUP BY a String
     and a number).  The inputs are restated in tests/test_lowcardinality.py."""
     out = {"00054_join_string": dict(source="tests/queries/0_stateless/00054_join_string.reference", rows=rows_of(ref_root, "00054_join_string")),
-           "00127_group_by_concat": dict(source="tests/queries/0_stateless/00127_group_by_concat.reference", rows=rows_of(ref_root, "00127_group_by_concat"))}
+           "00127_group_by_concat": dict(source="tests/queries/0_stateless/00127_group_by_concat.reference", rows=rows_of(ref_root, "00127_group_by_concat")),
+           "00056_join_number_string": dict(source="tests/queries/0_stateless/00056_join_number_string.reference", rows=rows_of(ref_root, "00056_join_number_string"))}
     with open(os.path.join(HERE, "string_key_rows.json"), "w") as f:
         json.dump(out, f)
     print("wrote string_key_rows.json")

@@ -290,8 +290,9 @@ def test_oracle_string_key_reference_rows():
 
 @pytest.mark.gpu
 def test_gpu_string_key_reference_rows():
-    """00054_join_string (ALL LEFT JOIN USING a String key, defaults for the misses) and 00127_group_by_concat (GROUP BY a String and
-    number % 123, the modulo computed on the device) against the reference's expected rows"""
+    """00054_join_string (ALL LEFT JOIN USING a String key, defaults for the misses), 00056_join_number_string (USING a number and a
+    String key, packed) and 00127_group_by_concat (GROUP BY a String and number % 123, the modulo computed on the device) against the
+    reference's expected rows"""
     import clickhouse_amd as ch
     ctx = ch.Context()
     rows = _string_rows()
@@ -309,6 +310,25 @@ def test_gpu_string_key_reference_rows():
     joined_out = ctx.upload(joined).index(r["right_rowid"], default_for_missing=True)
     got = sorted(zip(d.decode(k_out.numpy()), joined_out.numpy().tolist()))
     assert [(k.decode(), str(v)) for k, v in got] == [tuple(x) for x in rows["00054_join_string"]["rows"]]
+    # ---- 00056: ALL LEFT JOIN USING (k1 = number % 4 | % 2, k2 = toString(number % 3 | % 6)): a number and a String key packed ----
+    n10 = np.arange(10, dtype=np.uint64)
+    d2 = ch.LowCardinalityDictionary(ctx)
+    narrow = ch.ActionsDAG()
+    narrow.add_function("toUInt16", narrow.add_input(0, np.uint32))
+    narrow = narrow.compile()
+
+    def packed(k1, strings):
+        ids = d2.map_block(ch.ColumnString.from_values(ctx, strings).dictionary_encode())
+        return ch.pack_fixed_keys([ctx.upload(k1.astype(np.uint8)), narrow.execute(ctx, [ids], [1])[0]])
+    rkey = packed(n10 % 2, [str(int(x)).encode() for x in n10 % 6])
+    lkey = packed(n10 % 4, [str(int(x)).encode() for x in n10 % 3])
+    j2 = ch.HashJoin(ch.JOIN_LEFT, ch.STRICT_ALL, key_dtype=np.uint64, ctx=ctx)
+    j2.add_block(rkey)
+    r2 = j2.probe_columns(lkey)
+    left_out = ctx.upload(n10).replicate(r2["offsets"])
+    right_out = ctx.upload(n10).index(r2["right_rowid"], default_for_missing=True)
+    got = sorted(zip(left_out.numpy().tolist(), right_out.numpy().tolist()))
+    assert [[str(a), str(b)] for a, b in got] == rows["00056_join_number_string"]["rows"]
     # ---- 00127: GROUP BY materialize('') AS k1, number % 123 AS k2 over numbers(1000), count() ----
     dag = ch.ActionsDAG()
     k2n = dag.add_function("modulo", dag.add_input(0, np.uint64), dag.add_column(123, np.uint8))
