@@ -95,6 +95,8 @@ def make_string_kat(ref_root):
     and a number).  The inputs are restated in tests/test_lowcardinality.py."""
     out = {"00054_join_string": dict(source="tests/queries/0_stateless/00054_join_string.reference", rows=rows_of(ref_root, "00054_join_string")),
            "00127_group_by_concat": dict(source="tests/queries/0_stateless/00127_group_by_concat.reference", rows=rows_of(ref_root, "00127_group_by_concat")),
+           # ALL FULL OUTER JOIN with non-joined right rows padded with defaults (Date 1970-01-01, 0)
+           "00974_full_outer_join": dict(source="tests/queries/0_stateless/00974_full_outer_join.reference", rows=rows_of(ref_root, "00974_full_outer_join")),
            "00056_join_number_string": dict(source="tests/queries/0_stateless/00056_join_number_string.reference", rows=rows_of(ref_root, "00056_join_number_string"))}
     with open(os.path.join(HERE, "string_key_rows.json"), "w") as f:
         json.dump(out, f)

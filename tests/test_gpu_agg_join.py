@@ -624,3 +624,32 @@ def test_right_join_restrictions_and_empty_cases(ch, ctx):
     e = ch.HashJoin(ch.JOIN_RIGHT, ch.STRICT_ALL, ctx=ctx)
     b, r = e.non_joined_rows()  # empty right table
     assert b.shape[0] == 0
+
+
+def test_00974_full_outer_join_reference_rows(ch, ctx):
+    """tests/queries/0_stateless/00974_full_outer_join: two GROUP BY results joined ALL FULL OUTER on a Date key; the right rows without
+    a partner come back through getNonJoinedBlocks with default left columns (Date 0 = 1970-01-01, cnt 0)"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "string_key_rows.json")) as f:
+        want = [tuple(r) for r in json.load(f)["00974_full_outer_join"]["rows"]]
+    day0 = int((np.datetime64("2015-12-01") - np.datetime64("1970-01-01")).astype(np.int64))
+
+    def grouped(n):  # SELECT toDate(addDays(toDate('2015-12-01'), number)) AS dt, sum(number) FROM numbers(n) GROUP BY dt
+        number = np.arange(n, dtype=np.uint64)
+        agg = ch.Aggregator(np.uint16, [(ch.AGG_SUM, np.uint64)], ctx=ctx)
+        agg.execute_on_block((day0 + number).astype(np.uint16), [number])
+        k, (s,) = agg.convert_to_block()
+        o = np.argsort(k)
+        return k[o], s[o]
+    ldt, lcnt = grouped(2)
+    rdt, rcnt = grouped(5)
+    j = ch.HashJoin(ch.JOIN_FULL, ch.STRICT_ALL, key_dtype=np.uint16, ctx=ctx)
+    j.add_block(rdt)
+    l, b, r, c = j.joined_pairs(ldt)
+    rows = [(int(ldt[i]), int(lcnt[i]), int(rcnt[rr]) if rr >= 0 else 0) for i, rr in zip(l.tolist(), r.tolist())]
+    nb, nr = j.non_joined_rows()
+    rows += [(0, 0, int(rcnt[rr])) for rr in nr.tolist()]  # insertManyDefaults for q0.dt, q0.cnt
+    rows.sort(key=lambda t: t[2])  # ORDER BY q1.cnt2
+    fmt = [(str(np.datetime64("1970-01-01") + np.timedelta64(d, "D")), str(a), str(b2)) for d, a, b2 in rows]
+    assert fmt == want
