@@ -14,11 +14,12 @@ whole columns, materialising every intermediate: `evaluate` does exactly that, o
                   numpy's datetime64 calendar (independent of the product's civil-from-days arithmetic)
   intDiv, modulo  src/Functions/DivisionUtils.h:66-170 for integer operands, in the type C++'s usual arithmetic conversions choose
                   (restated on Python integers); the product compiles them only for constant divisors that cannot throw
-Parity pinning: comparisons are PINNED by tests/golden/expr_cmp_kat.json (the reference's 00411_long_accurate_number_comparison_float
-answers); modulo values AND result types by 01700_mod_negative_type_promotion and 00516_modulo, intDiv by 00977_int_div
+Parity pinning: comparisons and result types are PINNED by the reference itself -- src/Core/AccurateComparison.h and
+src/DataTypes/NumberTraits.h compiled in place into oracle/_ref/libchref_expr.so (ref_expr_wrapper.cpp; every type pair, adversarial
+values; Int8 operands excepted in the type rules, see the wrapper) -- and by tests/golden/expr_cmp_kat.json (the reference's
+00411_long_accurate_number_comparison_float answers); modulo values AND result types by 01700_mod_negative_type_promotion and 00516_modulo, intDiv by 00977_int_div
 (tests/golden/expr_mod_kat.json); modulo + multiply + avg end to end by 01300_group_by_other_keys (tests/golden/sql_reference_rows.json).
-Everything else here is PARITY UNPINNED by reference vectors: the calendar is checked against Python's datetime, result types against the
-documented NumberTraits.h examples, plus / minus / multiply / divide / logical / if / bit / cast values only against their definitions
+Everything else here is PARITY UNPINNED by reference vectors: the calendar is checked against Python's datetime (and one 00479 row), plus / minus / multiply / divide / logical / if / bit / cast values only against their definitions
 (static_cast<Result>(a) OP b) as restated here.
 """
 from __future__ import annotations
@@ -302,3 +303,34 @@ def filter_sum(nodes, cols, filter_node=-1, value_node=-1):
         return np.float64(np.sum(v.astype(np.float64))), cnt
     s = np.add.reduce(_wide_u64(v), dtype=np.uint64) if v.size else np.uint64(0)
     return (np.array([s], dtype=np.uint64).view(np.int64)[0] if v.dtype.kind == "i" else np.uint64(s)), cnt
+
+
+_ref_expr = None
+
+
+def ref_expr():
+    """The reference's own AccurateComparison.h + NumberTraits.h compiled in place (oracle/_ref/libchref_expr.so, oracle/Makefile);
+    None when it was never built (no reference checkout and no prebuilt file)."""
+    global _ref_expr
+    if _ref_expr is None:
+        import ctypes as C
+        import os
+        so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libchref_expr.so")
+        if not os.path.exists(so):
+            return None
+        L = C.CDLL(so)
+        L.ref_result_type.restype = C.c_int
+        L.ref_result_type.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.ref_compare.restype = C.c_int
+        L.ref_compare.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        _ref_expr = L
+    return _ref_expr
+
+
+def ref_compare(fn, x, y):
+    """accurate::*Op of the compiled reference over two arrays"""
+    x, y = np.ascontiguousarray(x), np.ascontiguousarray(y)
+    out = np.empty(x.shape[0], dtype=np.uint8)
+    rc = ref_expr().ref_compare(fn, TAG_OF[x.dtype], TAG_OF[y.dtype], x.ctypes.data, y.ctypes.data, x.shape[0], out.ctypes.data)
+    assert rc == 0
+    return out

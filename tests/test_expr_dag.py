@@ -534,3 +534,64 @@ def test_oracle_intdiv_reference_rows():
     for (a, b), want in zip(forms, rows):
         r = OE.apply_function(OE.FN["intDiv"], [a, b], [OE.TAG_OF[a.dtype], OE.TAG_OF[b.dtype]])
         assert r.tolist() == [int(w[0]) for w in want], (a.dtype, b.dtype)
+
+
+def test_result_types_and_comparisons_against_the_compiled_reference():
+    """oracle/_ref/libchref_expr.so = the reference's own NumberTraits.h and AccurateComparison.h compiled in place: every result type
+    of plus / minus / multiply / divide / negate / intDiv / modulo / bit* / if over all 100 operand-type pairs -- oracle AND product --
+    and all six comparisons over adversarial values of every type pair"""
+    R = OE.ref_expr()
+    if R is None:
+        pytest.skip("oracle/_ref/libchref_expr.so was never built (no reference checkout)")
+    import clickhouse_amd as ch
+    from clickhouse_amd.columns import NP_OF
+    tags = list(range(10))
+    checked = 0
+    # the reference's Int8 is `signed _BitInt(8)`; its type traits rest on std::is_signed_v, which this image's libstdc++ answers false for
+    # _BitInt (the reference builds against libc++) -- so the in-place build cannot speak for Int8 operands in the TYPE rules; the
+    # comparisons are fed plain int8_t and cover Int8 fully
+    typed = [t for t in tags if t != OE.I8]
+    for name, ref_fn in (("plus", 10), ("minus", 11), ("multiply", 12), ("divide", 13), ("intDiv", 15), ("modulo", 16), ("bitAnd", 40), ("if", 30)):
+        for a in typed:
+            for b in typed:
+                want = R.ref_result_type(ref_fn, a, b)
+                args = (OE.U8, a, b) if name == "if" else (a, b)
+                got = OE.result_type(OE.FN[name], *args)
+                floats = a in (OE.F64, OE.F32) or b in (OE.F64, OE.F32)
+                if name in ("intDiv", "modulo", "bitAnd") and floats:
+                    assert got is None  # the float forms of these are not carried (they throw / need float -> int casts)
+                    continue
+                assert (got if got is not None else -1) == want, (name, a, b, got, want)
+                # the product's inference through the C ABI
+                d = ch.ActionsDAG()
+                ins = [d.add_input(j, NP_OF[t]) for j, t in enumerate(args)]
+                if name in ("intDiv", "modulo"):
+                    ins[1] = d.add_column(3, NP_OF[b])
+                d.nodes.append((OE.EX_FUNC, OE.FN[name], 0, tuple(ins) + (-1,) * (3 - len(ins)), 0))
+                if want < 0:
+                    with pytest.raises(ch.ChgpuError):
+                        d.compile()
+                else:
+                    assert d.compile().node_type(len(d.nodes) - 1) == want, (name, a, b)
+                checked += 1
+    for a in typed:
+        assert (OE.result_type(OE.FN["negate"], a) if OE.result_type(OE.FN["negate"], a) is not None else -1) == R.ref_result_type(14, a, 0)
+    assert checked > 500
+    rng = np.random.Generator(np.random.PCG64(99))
+    n = 20_000
+    cols = {t: _random_column(rng, ALL_TYPES[t], n) for t in tags}
+    for t in tags:  # make cross-type equalities common
+        if np.dtype(ALL_TYPES[t]).kind == "f":
+            idx = rng.integers(0, n, size=n // 3)
+            cols[t][idx] = cols[OE.I64][idx].astype(ALL_TYPES[t])
+            idx = rng.integers(0, n, size=n // 3)
+            cols[t][idx] = cols[OE.U64][idx].astype(ALL_TYPES[t])
+    assert all(TAG_OF_NP(c.dtype) == t for t, c in cols.items())
+    for a in tags:
+        for b in tags:
+            for fn in range(6):
+                assert np.array_equal(OE._compare(fn, cols[a], cols[b]), OE.ref_compare(fn, cols[a], cols[b])), (fn, a, b)
+
+
+def TAG_OF_NP(dt):
+    return OE.TAG_OF[np.dtype(dt)]
