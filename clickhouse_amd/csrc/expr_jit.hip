@@ -154,6 +154,10 @@ int infer_type(int fn, int a, int b, int c)
         case CHGPU_FN_TO_MONTH: return a == CHGPU_U16 ? CHGPU_U8 : -1;
         case CHGPU_FN_TO_DAY_OF_MONTH: return a == CHGPU_U16 ? CHGPU_U8 : -1;
         case CHGPU_FN_TO_YYYYMM: return a == CHGPU_U16 ? CHGPU_U32 : -1;
+        case CHGPU_FN_TO_YYYYMMDD: return a == CHGPU_U16 ? CHGPU_U32 : -1;
+        case CHGPU_FN_TO_DAY_OF_WEEK: return a == CHGPU_U16 ? CHGPU_U8 : -1;
+        case CHGPU_FN_TO_QUARTER: return a == CHGPU_U16 ? CHGPU_U8 : -1;
+        case CHGPU_FN_TO_START_OF_MONTH: return a == CHGPU_U16 ? CHGPU_U16 : -1; // a Date again
         default: break;
     }
     if (fn >= CHGPU_FN_CAST && fn < CHGPU_FN_CAST + 16)
@@ -172,7 +176,7 @@ int fn_arity(int fn)
 {
     if (fn == CHGPU_FN_IF)
         return 3;
-    if (fn == CHGPU_FN_NEGATE || fn == CHGPU_FN_NOT || (fn >= CHGPU_FN_TO_YEAR && fn <= CHGPU_FN_TO_YYYYMM) || (fn >= CHGPU_FN_CAST && fn < CHGPU_FN_CAST + 16))
+    if (fn == CHGPU_FN_NEGATE || fn == CHGPU_FN_NOT || (fn >= CHGPU_FN_TO_YEAR && fn <= CHGPU_FN_TO_START_OF_MONTH) || (fn >= CHGPU_FN_CAST && fn < CHGPU_FN_CAST + 16))
         return 1;
     return 2;
 }
@@ -380,6 +384,14 @@ int build_body(chgpu_expr * e)
                 rhs = "(u8)civil_(" + N(0) + ").d";
             else if (fn == CHGPU_FN_TO_YYYYMM)
                 rhs = "(u32)(civil_(" + N(0) + ").y * 100u + civil_(" + N(0) + ").m)";
+            else if (fn == CHGPU_FN_TO_YYYYMMDD)
+                rhs = "(u32)(civil_(" + N(0) + ").y * 10000u + civil_(" + N(0) + ").m * 100u + civil_(" + N(0) + ").d)";
+            else if (fn == CHGPU_FN_TO_DAY_OF_WEEK) // ToDayOfWeekImpl, mode 0: Monday = 1 ... Sunday = 7; 1970-01-01 was a Thursday
+                rhs = "(u8)(((u32)" + N(0) + " + 3u) % 7u + 1u)";
+            else if (fn == CHGPU_FN_TO_QUARTER)
+                rhs = "(u8)((civil_(" + N(0) + ").m - 1u) / 3u + 1u)";
+            else if (fn == CHGPU_FN_TO_START_OF_MONTH)
+                rhs = "(u16)((u32)" + N(0) + " - (civil_(" + N(0) + ").d - 1u))";
             else // cast
                 rhs = std::string("(") + ct + ")" + N(0);
         }

@@ -21,7 +21,8 @@ FUNCTIONS = {
     "and": 20, "or": 21, "xor": 22, "not": 23,
     "if": 30,
     "bitAnd": 40, "bitOr": 41, "bitXor": 42,
-    "toYear": 50, "toMonth": 51, "toDayOfMonth": 52, "toYYYYMM": 53,
+    "toYear": 50, "toMonth": 51, "toDayOfMonth": 52, "toYYYYMM": 53, "toYYYYMMDD": 54, "toDayOfWeek": 55, "toQuarter": 56,
+    "toStartOfMonth": 57,
 }
 FN_CAST = 64
 CASTS = {"toInt64": K.I64, "toUInt32": K.U32, "toUInt64": K.U64, "toFloat64": K.F64, "toUInt8": K.U8, "toInt32": K.I32,

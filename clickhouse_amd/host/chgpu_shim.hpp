@@ -354,6 +354,8 @@ public:
             {"and", CHGPU_FN_AND}, {"or", CHGPU_FN_OR}, {"xor", CHGPU_FN_XOR}, {"not", CHGPU_FN_NOT}, {"if", CHGPU_FN_IF},
             {"bitAnd", CHGPU_FN_BIT_AND}, {"bitOr", CHGPU_FN_BIT_OR}, {"bitXor", CHGPU_FN_BIT_XOR}, {"toYear", CHGPU_FN_TO_YEAR},
             {"toMonth", CHGPU_FN_TO_MONTH}, {"toDayOfMonth", CHGPU_FN_TO_DAY_OF_MONTH}, {"toYYYYMM", CHGPU_FN_TO_YYYYMM},
+            {"toYYYYMMDD", CHGPU_FN_TO_YYYYMMDD}, {"toDayOfWeek", CHGPU_FN_TO_DAY_OF_WEEK}, {"toQuarter", CHGPU_FN_TO_QUARTER},
+            {"toStartOfMonth", CHGPU_FN_TO_START_OF_MONTH},
             {"toInt64", CHGPU_FN_CAST + CHGPU_I64}, {"toUInt64", CHGPU_FN_CAST + CHGPU_U64}, {"toInt32", CHGPU_FN_CAST + CHGPU_I32},
             {"toUInt32", CHGPU_FN_CAST + CHGPU_U32}, {"toInt16", CHGPU_FN_CAST + CHGPU_I16}, {"toUInt16", CHGPU_FN_CAST + CHGPU_U16},
             {"toInt8", CHGPU_FN_CAST + CHGPU_I8}, {"toUInt8", CHGPU_FN_CAST + CHGPU_U8}, {"toFloat64", CHGPU_FN_CAST + CHGPU_F64},

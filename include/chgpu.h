@@ -223,6 +223,7 @@ enum
     CHGPU_FN_IF = 30,                                                 /* if(cond, then, else): ResultOfIf */
     CHGPU_FN_BIT_AND = 40, CHGPU_FN_BIT_OR = 41, CHGPU_FN_BIT_XOR = 42, /* integers: ResultOfBit */
     CHGPU_FN_TO_YEAR = 50, CHGPU_FN_TO_MONTH = 51, CHGPU_FN_TO_DAY_OF_MONTH = 52, CHGPU_FN_TO_YYYYMM = 53, /* Date -> UInt16/UInt8/UInt8/UInt32 */
+    CHGPU_FN_TO_YYYYMMDD = 54, CHGPU_FN_TO_DAY_OF_WEEK = 55, CHGPU_FN_TO_QUARTER = 56, CHGPU_FN_TO_START_OF_MONTH = 57, /* -> UInt32/UInt8/UInt8/Date */
     CHGPU_FN_CAST = 64                                                /* CHGPU_FN_CAST + CHGPU_<type>: toInt64(x) ... (static_cast) */
 };
 typedef struct chgpu_expr_node

@@ -33,7 +33,8 @@ TAG_OF = {np.dtype(v): k for k, v in NP_OF.items()}
 EX_INPUT, EX_CONST, EX_FUNC = 0, 1, 2
 FN = {"equals": 0, "notEquals": 1, "less": 2, "greater": 3, "lessOrEquals": 4, "greaterOrEquals": 5, "plus": 10, "minus": 11,
       "multiply": 12, "divide": 13, "negate": 14, "intDiv": 15, "modulo": 16, "and": 20, "or": 21, "xor": 22, "not": 23, "if": 30, "bitAnd": 40,
-      "bitOr": 41, "bitXor": 42, "toYear": 50, "toMonth": 51, "toDayOfMonth": 52, "toYYYYMM": 53}
+      "bitOr": 41, "bitXor": 42, "toYear": 50, "toMonth": 51, "toDayOfMonth": 52, "toYYYYMM": 53, "toYYYYMMDD": 54, "toDayOfWeek": 55,
+      "toQuarter": 56, "toStartOfMonth": 57}
 FN_CAST = 64
 
 assert np.finfo(np.longdouble).nmant >= 63, "this oracle needs the x87 80-bit long double"
@@ -108,8 +109,12 @@ def result_type(fn, a=None, b=None, c=None):
         return U16 if a == U16 else None
     if fn in (51, 52):
         return U8 if a == U16 else None
-    if fn == 53:
+    if fn in (53, 54):
         return U32 if a == U16 else None
+    if fn in (55, 56):
+        return U8 if a == U16 else None
+    if fn == 57:
+        return U16 if a == U16 else None
     if FN_CAST <= fn < FN_CAST + 16:
         to = fn - FN_CAST
         if to not in NP_OF or (_is_float(a) and not _is_float(to)):
@@ -195,9 +200,16 @@ def apply_function(fn, args, types):
         return r.astype(u).view(out)
     if fn == 30:
         return np.where(x != 0, _cast(args[1], rt), _cast(args[2], rt))
-    if fn in (50, 51, 52, 53):
+    if fn in (50, 51, 52, 53, 54, 56):
         y, m, d = _civil(x)
-        return (y if fn == 50 else m if fn == 51 else d if fn == 52 else y * 100 + m).astype(out)
+        return (y if fn == 50 else m if fn == 51 else d if fn == 52 else y * 100 + m if fn == 53 else y * 10000 + m * 100 + d if fn == 54
+                else (m - 1) // 3 + 1).astype(out)
+    if fn == 55:  # ToDayOfWeekImpl mode 0 (DateTimeTransforms.h): Monday = 1 ... Sunday = 7
+        dd = x.astype("int64").astype("datetime64[D]")
+        return ((dd.astype("datetime64[D]").view("int64") - np.datetime64("1969-12-29", "D").astype("int64")) % 7 + 1).astype(out)  # 1969-12-29 was a Monday
+    if fn == 57:  # ToStartOfMonthImpl
+        dd = x.astype("int64").astype("datetime64[D]")
+        return dd.astype("datetime64[M]").astype("datetime64[D]").astype("int64").astype(out)
     return _cast(x, rt)
 
 
@@ -282,7 +294,7 @@ def evaluate(nodes, cols):
             vals.append(np.repeat(one, n))  # ColumnConst materialised
             types.append(typ)
         else:
-            ar = 3 if code == 30 else 1 if (code in (14, 23) or 50 <= code <= 53 or code >= FN_CAST) else 2
+            ar = 3 if code == 30 else 1 if (code in (14, 23) or 50 <= code <= 57 or code >= FN_CAST) else 2
             a = [vals[args[j]] for j in range(ar)]
             t = [types[args[j]] for j in range(ar)]
             vals.append(apply_function(code, a, t))

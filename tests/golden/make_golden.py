@@ -130,9 +130,9 @@ def make_mod_kat(ref_root):
            # 00977_int_div: four intDiv forms over numbers(1, 10), ten result lines each (lines 4-13, 24-33, 44-53, 64-73 of the .reference)
            "00977_int_div": dict(source="tests/queries/0_stateless/00977_int_div.reference",
                                  rows=[rows_of(ref_root, "00977_int_div", lo, lo + 10) for lo in (3, 23, 43, 63)]),
-           # 00479_date_and_datetime_to_number: toYYYYMM(toDate('2017-07-21')) -- the first line
+           # 00479_date_and_datetime_to_number: toYYYYMM / toYYYYMMDD of toDate('2017-07-21') -- the first two lines
            "00479_toYYYYMM_of_date_2017_07_21": dict(source="tests/queries/0_stateless/00479_date_and_datetime_to_number.reference",
-                                                    rows=rows_of(ref_root, "00479_date_and_datetime_to_number", 0, 1))}
+                                                    rows=rows_of(ref_root, "00479_date_and_datetime_to_number", 0, 2))}
     with open(os.path.join(HERE, "expr_mod_kat.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote expr_mod_kat.json")

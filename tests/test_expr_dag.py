@@ -71,17 +71,23 @@ def test_oracle_accurate_comparison_known_answers():
 
 def test_oracle_calendar_against_python_datetime():
     days = np.array([0, 1, 58, 59, 60, 365, 366, 789, 8400, 8401, 8765, 8766, 11016, 11017, 19782, 47540, 47541, 65535], dtype=np.uint16)
-    nodes = [(OE.EX_INPUT, 0, OE.U16, (-1, -1, -1), 0)] + [(OE.EX_FUNC, OE.FN[f], 0, (0, -1, -1), 0) for f in ("toYear", "toMonth", "toDayOfMonth", "toYYYYMM")]
+    nodes = [(OE.EX_INPUT, 0, OE.U16, (-1, -1, -1), 0)] + [(OE.EX_FUNC, OE.FN[f], 0, (0, -1, -1), 0) for f in
+             ("toYear", "toMonth", "toDayOfMonth", "toYYYYMM", "toYYYYMMDD", "toDayOfWeek", "toQuarter", "toStartOfMonth")]
     vals, types = OE.evaluate(nodes, [days])
-    assert types[1:] == [OE.U16, OE.U8, OE.U8, OE.U32]
+    assert types[1:] == [OE.U16, OE.U8, OE.U8, OE.U32, OE.U32, OE.U8, OE.U8, OE.U16]
+    for i, d in enumerate(days.tolist()):
+        c = datetime.date(1970, 1, 1) + datetime.timedelta(days=d)
+        assert int(vals[5][i]) == c.year * 10000 + c.month * 100 + c.day and int(vals[6][i]) == c.isoweekday()
+        assert int(vals[7][i]) == (c.month - 1) // 3 + 1 and int(vals[8][i]) == (c.replace(day=1) - datetime.date(1970, 1, 1)).days
     for i, d in enumerate(days.tolist()):
         c = datetime.date(1970, 1, 1) + datetime.timedelta(days=d)
         assert (int(vals[1][i]), int(vals[2][i]), int(vals[3][i]), int(vals[4][i])) == (c.year, c.month, c.day, c.year * 100 + c.month)
     # the reference's own answer: 00479_date_and_datetime_to_number, toYYYYMM(toDate('2017-07-21')) = 201707
     with open(os.path.join(HERE, "golden", "expr_mod_kat.json")) as f:
-        want = int(json.load(f)["00479_toYYYYMM_of_date_2017_07_21"]["rows"][0][0])
+        r479 = json.load(f)["00479_toYYYYMM_of_date_2017_07_21"]["rows"]
     d0 = np.array([(datetime.date(2017, 7, 21) - datetime.date(1970, 1, 1)).days], dtype=np.uint16)
-    assert int(OE.evaluate(nodes, [d0])[0][4][0]) == want == 201707
+    v0 = OE.evaluate(nodes, [d0])[0]
+    assert int(v0[4][0]) == int(r479[0][0]) == 201707 and int(v0[5][0]) == int(r479[1][0]) == 20170721
 
 
 def test_oracle_result_types_documented_examples():
@@ -104,7 +110,7 @@ def test_oracle_result_types_documented_examples():
 def _all_function_cases():
     tags = list(range(10))
     for name, fn in OE.FN.items():
-        ar = 3 if name == "if" else 1 if name in ("negate", "not", "toYear", "toMonth", "toDayOfMonth", "toYYYYMM") else 2
+        ar = 3 if name == "if" else 1 if name in ("negate", "not") or name.startswith("to") else 2
         if ar == 1:
             for a in tags:
                 yield fn, (a,)
@@ -236,7 +242,7 @@ def _random_dag(ch, rng, col_dtypes, n_funcs):
     while made < n_funcs:
         name = names[rng.integers(0, len(names))]
         fn = OE.FN_CAST + int(rng.integers(0, 10)) if name == "cast" else OE.FN[name]
-        ar = 3 if name == "if" else 1 if name in ("negate", "not", "toYear", "toMonth", "toDayOfMonth", "toYYYYMM", "cast") else 2
+        ar = 3 if name == "if" else 1 if name in ("negate", "not", "cast") or name.startswith("to") else 2
         args = [int(rng.integers(0, len(types))) for _ in range(ar)]
         if name in ("intDiv", "modulo"):  # only constant divisors that cannot throw are compiled
             ok = [c for c, v in consts.items() if types[c] not in (OE.F64, OE.F32) and v not in (0, -1) and v != np.iinfo(OE.NP_OF[types[c]]).max]
