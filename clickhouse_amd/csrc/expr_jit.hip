@@ -49,7 +49,7 @@ int rtc_load()
         if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
             break;
     if (!h)
-        return chgpu_set_error(CHGPU_ERR_DEVICE, "cannot load libhiprtc: %s", dlerror());
+        return chgpu_set_error(CHGPU_ERR_NOT_IMPLEMENTED, "cannot load libhiprtc (%s): expressions stay on the CPU", dlerror());
 #define SYM(field, name)                                              \
     *(void **)&g_rtc.field = dlsym(h, name);                          \
     if (!g_rtc.field)                                                 \
