@@ -424,7 +424,13 @@ struct KernelSpec
     u32 vec = 1;
 };
 
-constexpr int JIT_UNROLL = 4;
+static int jit_env(const char * name, int dflt)
+{
+    const char * v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+// vectors in flight per lane and column / workgroups per CU: developer overrides for A/B runs (CHGPU_TUNE_JIT_UNROLL, _WG_MAP, _WG_SUM)
+static const int JIT_UNROLL = jit_env("CHGPU_TUNE_JIT_UNROLL", 4);
 constexpr u32 JIT_MAX_COLS = 8;
 
 struct JitArgs
@@ -886,7 +892,8 @@ extern "C" int chgpu_expr_execute(chgpu_ctx * ctx, const chgpu_expr * e, uint32_
     a.n = rows;
     if (rows)
     {
-        const u32 grid = chgpu_grid_for(ctx, (rows + ks.vec * JIT_UNROLL - 1) / (ks.vec * JIT_UNROLL), 256, 4);
+        static const int wg_map = jit_env("CHGPU_TUNE_JIT_WG_MAP", 4);
+        const u32 grid = chgpu_grid_for(ctx, (rows + ks.vec * JIT_UNROLL - 1) / (ks.vec * JIT_UNROLL), 256, wg_map);
         void * params[] = {&a};
         CHGPU_HIP(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
         ctx->counters[6] += 1;
@@ -914,7 +921,8 @@ extern "C" int chgpu_expr_filter_sum_node(chgpu_ctx * ctx, const chgpu_expr * e,
         hipFunction_t fn = nullptr, fin = nullptr;
         CHGPU_HIP(hipModuleGetFunction(&fn, mod, "k_run"));
         CHGPU_HIP(hipModuleGetFunction(&fin, mod, "k_fin"));
-        const u32 grid = chgpu_grid_for(ctx, (rows + ks.vec * JIT_UNROLL - 1) / (ks.vec * JIT_UNROLL), 256, 2);
+        static const int wg_sum = jit_env("CHGPU_TUNE_JIT_WG_SUM", 2);
+        const u32 grid = chgpu_grid_for(ctx, (rows + ks.vec * JIT_UNROLL - 1) / (ks.vec * JIT_UNROLL), 256, wg_sum);
         void * scratch = nullptr;
         CHGPU_TRY(chgpu_scratch(ctx, ((size_t)grid + 1) * 2 * sizeof(u64), &scratch));
         JitArgs a;
