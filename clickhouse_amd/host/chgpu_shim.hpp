@@ -15,6 +15,8 @@
 //   ExpressionTransform         src/Processors/Transforms/ExpressionTransform.cpp:22-30      chgpu::GpuExpressionTransform, GpuExpressionFilterTransform
 //   ColumnLowCardinality + low_cardinality_key* methods   src/Columns/ColumnLowCardinality.h:27-69, ColumnsHashing.h:82-260   chgpu::ColumnLowCardinality, LowCardinalityDictionary
 //   ColumnString as a key       src/Columns/ColumnString.h:40-49, ColumnUnique.h:520-620     chgpu::ColumnString::dictionaryEncode
+//   sortBlock / SortDescription src/Interpreters/sortBlock.cpp:240-330, Core/SortDescription.h   chgpu::sortBlock
+//   CompressedReadBuffer        src/Compression/CompressedReadBufferBase.cpp:175-222         chgpu::readCompressedColumn
 //   IAggregateFunction          src/AggregateFunctions/IAggregateFunction.h:55-399      chgpu::AggregateDescription (closed POD set)
 //   Aggregator                  src/Interpreters/Aggregator.h:179-265          chgpu::GpuAggregator
 //   AggregatingTransform        src/Processors/Transforms/AggregatingTransform.cpp:640-840   chgpu::GpuAggregatingTransform
@@ -808,5 +810,108 @@ private:
     size_t left_key_position;
     uint64_t max_joined_block_rows;
 };
+
+/// SortColumnDescription (src/Core/SortDescription.h:26-60): column position, direction (+1 ASC / -1 DESC), nulls_direction (NaN counts
+/// as greater than every number when +1: ASC NULLS LAST, DESC NULLS FIRST).
+struct SortColumnDescription
+{
+    size_t column_number;
+    int direction = 1;
+    int nulls_direction = 1;
+};
+using SortDescription = std::vector<SortColumnDescription>;
+
+/// sortBlock (src/Interpreters/sortBlock.cpp:240-330): the permutation of the whole description (stable radix sorts from the least
+/// significant column to the most; one column + limit takes the sampled-threshold path), applied to every column (IColumn::permute).
+inline void sortBlock(Chunk & block, const SortDescription & description, uint64_t limit = 0)
+{
+    if (description.empty() || block.num_rows == 0)
+        return;
+    ContextPtr ctx = block.columns.at(description[0].column_number)->context();
+    chgpu_col * perm = nullptr;
+    if (description.size() == 1 && limit)
+    {
+        const auto & d = description[0];
+        check(chgpu_sort_permutation_limit(ctx->get(), block.columns.at(d.column_number)->handle(), d.direction < 0, d.nulls_direction, limit, &perm));
+    }
+    else
+    {
+        for (size_t k = description.size(); k-- > 0;)
+        {
+            const auto & d = description[k];
+            chgpu_col * next = nullptr;
+            const int rc = chgpu_sort_permutation(ctx->get(), block.columns.at(d.column_number)->handle(), perm, d.direction < 0, d.nulls_direction, &next);
+            if (perm)
+                chgpu_col_free(perm);
+            check(rc);
+            perm = next;
+        }
+    }
+    ColumnVector permutation(ctx, perm);
+    const uint64_t take = limit && limit < block.num_rows ? limit : 0;
+    for (auto & col : block.columns)
+    {
+        chgpu_col * out = nullptr;
+        check(chgpu_index(ctx->get(), col->handle(), permutation.handle(), take, 0, &out));
+        col = std::make_shared<ColumnVector>(ctx, out);
+    }
+    if (take)
+        block.num_rows = take;
+}
+
+/// CompressedReadBuffer + SerializationNumber::deserializeBinaryBulk for one numeric column file (MergeTree `<column>.bin`): the
+/// host walks the frame headers (CompressedReadBufferBase.cpp:175-222), the compressed bytes cross PCIe once, the frames are decoded
+/// in HBM.  LZ4, NONE and CODEC(Delta, LZ4); any other codec throws NOT_IMPLEMENTED (the caller decompresses on the CPU as before).
+inline ColumnPtr readCompressedColumn(const ContextPtr & ctx, const unsigned char * file, size_t size, int type)
+{
+    constexpr size_t CHECKSUM = 16, HEADER = 9;
+    std::vector<uint64_t> offs;
+    std::vector<uint32_t> sizes, dsizes, stages;
+    std::vector<uint8_t> methods, posts;
+    auto u32_at = [&](size_t p) { uint32_t v; std::memcpy(&v, file + p, 4); return v; };
+    uint64_t total = 0;
+    for (size_t pos = 0; pos < size;)
+    {
+        if (size - pos < CHECKSUM + HEADER)
+            throw Exception(CHGPU_ERR_BAD_ARGUMENTS, "Cannot read all data: truncated frame header");
+        uint8_t method = file[pos + CHECKSUM];
+        const uint32_t csize = u32_at(pos + CHECKSUM + 1), dsize = u32_at(pos + CHECKSUM + 5);
+        if (csize < HEADER || pos + CHECKSUM + csize > size)
+            throw Exception(CHGPU_ERR_BAD_ARGUMENTS, "Cannot decompress: frame size out of range");
+        size_t off = pos + CHECKSUM + HEADER, sz = csize - HEADER;
+        uint8_t post = 0;
+        uint32_t stage = dsize;
+        if (method == 0x91 && sz >= 3 + HEADER && file[off] == 2 && file[off + 1] == 0x92 && file[off + 2] == 0x82) // Multiple{Delta, LZ4}
+        {
+            const uint32_t c2 = u32_at(off + 3 + 1), d2 = u32_at(off + 3 + 5);
+            if (file[off + 3] != 0x82 || c2 < HEADER || 3 + c2 > sz)
+                throw Exception(CHGPU_ERR_BAD_ARGUMENTS, "Cannot decompress: bad stage header in codec Multiple");
+            method = 0x82, post = 0x92, stage = d2;
+            off += 3 + HEADER, sz = c2 - HEADER;
+        }
+        offs.push_back(off), sizes.push_back(static_cast<uint32_t>(sz)), dsizes.push_back(dsize), stages.push_back(stage);
+        methods.push_back(method), posts.push_back(post);
+        total += dsize;
+        pos += CHECKSUM + csize;
+    }
+    auto compressed = ColumnVector::fromHost<uint8_t>(ctx, file, size);
+    chgpu_col * raw = nullptr;
+    check(chgpu_decompress_frames(ctx->get(), compressed->handle(), static_cast<uint32_t>(offs.size()), offs.data(), sizes.data(), dsizes.data(), methods.data(),
+                                  posts.data(), stages.data(), &raw));
+    ColumnVector bytes(ctx, raw);
+    size_t es = 8;
+    switch (type)
+    {
+        case CHGPU_U32: case CHGPU_I32: case CHGPU_F32: es = 4; break;
+        case CHGPU_U16: case CHGPU_I16: es = 2; break;
+        case CHGPU_U8: case CHGPU_I8: es = 1; break;
+        default: break;
+    }
+    if (total % es)
+        throw Exception(CHGPU_ERR_SIZES_MISMATCH, "Cannot read all data: size is not a multiple of the element size");
+    chgpu_col * out = nullptr;
+    check(chgpu_col_from_bytes(ctx->get(), bytes.handle(), 0, type, total / es, &out));
+    return std::make_shared<ColumnVector>(ctx, out);
+}
 
 } // namespace chgpu

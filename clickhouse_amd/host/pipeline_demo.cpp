@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <algorithm>
 #include <map>
 #include <thread>
 #include <unordered_map>
@@ -328,6 +329,34 @@ int main(int argc, char ** argv)
             REQUIRE(nj.num_rows == 3);
             REQUIRE((nj.columns[0]->getData<uint64_t>() == std::vector<uint64_t>{1, 3, 9}));
             REQUIRE((nj.columns[1]->getData<int64_t>() == std::vector<int64_t>{10, 30, 90}));
+        }
+
+        // ---- ORDER BY k DESC, a ASC LIMIT 5 over the first stripe rows; and a NONE-compressed column file read back ------------
+        {
+            const size_t m = std::min<size_t>(n, 50000);
+            Chunk blk;
+            blk.columns = {ColumnVector::fromHost<int64_t>(ctx, a.data(), m), ColumnVector::fromHost<uint32_t>(ctx, k.data(), m)};
+            blk.num_rows = m;
+            sortBlock(blk, {{1, -1, 1}, {0, 1, 1}}, 5);
+            std::vector<size_t> order(m);
+            for (size_t i = 0; i < m; ++i)
+                order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return k[x] != k[y] ? k[x] > k[y] : a[x] < a[y]; });
+            auto sa2 = blk.columns[0]->getData<int64_t>();
+            auto sk2 = blk.columns[1]->getData<uint32_t>();
+            REQUIRE(blk.num_rows == std::min<size_t>(5, m));
+            for (size_t i = 0; i < blk.num_rows; ++i)
+                REQUIRE(sa2[i] == a[order[i]] && sk2[i] == k[order[i]]);
+            // a column file of one uncompressed (method NONE) frame: checksum(16) | 0x02 | compressed size | decompressed size | payload
+            std::vector<unsigned char> file(16 + 9 + m * 8, 0);
+            file[16] = 0x02;
+            const uint32_t csz = static_cast<uint32_t>(9 + m * 8), dsz = static_cast<uint32_t>(m * 8);
+            std::memcpy(&file[17], &csz, 4);
+            std::memcpy(&file[21], &dsz, 4);
+            std::memcpy(&file[25], a.data(), m * 8);
+            auto col = readCompressedColumn(ctx, file.data(), file.size(), CHGPU_I64);
+            auto back = col->getData<int64_t>();
+            REQUIRE(back.size() == m && std::equal(back.begin(), back.end(), a.begin()));
         }
 
         // unsupported surface -> NOT_IMPLEMENTED (CPU fallback signal), not a crash
