@@ -328,7 +328,8 @@ int chgpu_lc_remap(chgpu_ctx * ctx, const chgpu_col * indexes, const chgpu_col *
    first appearance (ColumnUnique::uniqueInsertRangeFrom, src/Columns/ColumnUnique.h:520-620); first_rows_u64[id] = the row where
    the value first appears (the caller reads the dictionary's strings from its own Block there).  Exact: values are compared
    byte by byte; a 64-bit tag shared by two different values answers CHGPU_ERR_NOT_IMPLEMENTED (CPU path).  ids + dictionary
-   are a ColumnLowCardinality: chgpu_lc_remap / GROUP BY / join as above. */
+   are a ColumnLowCardinality: chgpu_lc_remap / GROUP BY / join as above.  The kernels read values 8 bytes at a time: a wrapped chars
+   buffer (chgpu_col_wrap) must keep 8 readable bytes after its end, as PaddedPODArray's right pad does (columns made by this library do). */
 int chgpu_string_dictionary_encode(chgpu_ctx * ctx, const chgpu_col * offsets_u64, const chgpu_col * chars_u8, chgpu_col ** ids_u32,
                                    chgpu_col ** first_rows_u64, uint64_t * n_distinct);
 /* ColumnString::filter (src/Columns/ColumnString.cpp:270-290 -> filterArraysImpl, src/Columns/ColumnsCommon.cpp:191-286): the values
