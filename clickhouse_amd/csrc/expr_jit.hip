@@ -895,7 +895,13 @@ extern "C" int chgpu_expr_execute(chgpu_ctx * ctx, const chgpu_expr * e, uint32_
         static const int wg_map = jit_env("CHGPU_TUNE_JIT_WG_MAP", 4);
         const u32 grid = chgpu_grid_for(ctx, (rows + ks.vec * JIT_UNROLL - 1) / (ks.vec * JIT_UNROLL), 256, wg_map);
         void * params[] = {&a};
-        CHGPU_HIP(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
+        const hipError_t le = hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr);
+        if (le != hipSuccess)
+        {
+            for (chgpu_col * c : res)
+                chgpu_col_free(c);
+            return chgpu_set_error(CHGPU_ERR_DEVICE, "expression kernel launch: %s", hipGetErrorString(le));
+        }
         ctx->counters[6] += 1;
     }
     for (uint32_t o = 0; o < n_outputs; ++o)

@@ -22,7 +22,9 @@ class ColumnLowCardinality:
     """dictionary: sequence of values (str / bytes / numbers), position -> value; indexes: UInt8/16/32/64 Column in HBM"""
 
     def __init__(self, dictionary, indexes: Column):
-        self.dictionary = list(dictionary)
+        # the list object itself identifies the dictionary: Blocks cut / filtered from one column share it, and LowCardinalityDictionary
+        # resolves a shared dictionary once (the reference keys its cache by the dictionary's hash, ColumnsHashing.h:155-183)
+        self.dictionary = dictionary if isinstance(dictionary, list) else list(dictionary)
         self.indexes = indexes
 
     def size(self) -> int:
