@@ -67,6 +67,7 @@ SIGNATURES = {
     "chgpu_expr_execute": (_i, [_vp, _vp, _u32, _pp, _u32, C.POINTER(_u32), _pp]),
     "chgpu_expr_filter_sum_node": (_i, [_vp, _vp, _u32, _pp, _i, _i, C.POINTER(_i), _vp, _pu64]),
     "chgpu_expr_filter_execute": (_i, [_vp, _vp, _u32, _pp, _u32, _u32, C.POINTER(_u32), _pp, _pu64]),
+    "chgpu_expr_filter_minmax_node": (_i, [_vp, _vp, _u32, _pp, _i, _u32, C.POINTER(_i), _vp, _vp, _pu64]),
     "chgpu_expr_free": (_i, [_vp]),
     "chgpu_index": (_i, [_vp, _vp, _vp, _u64, _i, _pp]),
     "chgpu_replicate": (_i, [_vp, _vp, _vp, _pp]),

@@ -631,6 +631,75 @@ std::string gen_filter_source(const chgpu_expr * e, const KernelSpec & ks)
     return s;
 }
 
+// min(value), max(value), count() over the rows that pass the filter (executeWithoutKeyImpl with AggregateFunctionMin / Max,
+// src/AggregateFunctions/AggregateFunctionMinMax.h; SingleValueDataFixed::setIfSmaller / setIfGreater) for INTEGER values: the value is
+// widened to 64 bits and mapped to an order-preserving unsigned key, lanes keep a running (lowest, highest), waves reduce by shuffles.
+// Float values are not carried: the reference keeps a NaN that arrives first (setIfSmaller compares with <), an order-dependent result.
+std::string gen_minmax_source(const chgpu_expr * e, int filter_node, int value_node)
+{
+    std::string s = PRELUDE;
+    s += "struct Args { const void * in[8]; void * out[8]; u64 n; u64 * part; u32 n_parts; u32 pad; };\n";
+    s += "struct Row {";
+    for (size_t j = 0; j < e->input_types.size(); ++j)
+        if (e->input_types[j] >= 0)
+            s += std::string(" ") + ctype(e->input_types[j]) + " c" + std::to_string(j) + ";";
+    s += " };\nstruct Res { bool keep; u64 key; };\nDEV void eval(const Row & r, Res & o)\n{\n" + e->body;
+    s += filter_node >= 0 ? "    o.keep = n" + std::to_string(filter_node) + " != 0;\n" : std::string("    o.keep = true;\n");
+    const bool sg = chgpu_type_is_signed(e->types[value_node]);
+    s += std::string("    o.key = ") + (sg ? "(u64)(i64)n" + std::to_string(value_node) + " ^ 0x8000000000000000ull" : "(u64)n" + std::to_string(value_node)) + ";\n}\n";
+    std::string load;
+    for (size_t j = 0; j < e->input_types.size(); ++j)
+        if (e->input_types[j] >= 0)
+            load += "            r.c" + std::to_string(j) + " = ((const " + ctype(e->input_types[j]) + " *)a.in[" + std::to_string(j) + "])[in ? i : 0];\n";
+    s += R"SRC(
+DEV u64 shfl_u64(u64 v, int d) { return ((u64)__shfl_down((u32)(v >> 32), d, 64) << 32) | __shfl_down((u32)v, d, 64); }
+extern "C" __global__ __launch_bounds__(256) void k_mm(Args a)
+{
+    u64 lo = ~0ull, hi = 0ull, cnt = 0;
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 i0 = (u64)blockIdx.x * 256 + threadIdx.x; i0 < a.n; i0 += stride * 4)
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+            const u64 i = i0 + (u64)q * stride;
+            const bool in = i < a.n;
+            Row r; Res o;
+)SRC" + load + R"SRC(
+            eval(r, o);
+            if (in && o.keep) { lo = o.key < lo ? o.key : lo; hi = o.key > hi ? o.key : hi; ++cnt; }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+    {
+        const u64 l2 = shfl_u64(lo, d), h2 = shfl_u64(hi, d), c2 = shfl_u64(cnt, d);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; cnt += c2;
+    }
+    __shared__ u64 sl[4], sh[4], sc[4];
+    if ((threadIdx.x & 63) == 0) { sl[threadIdx.x >> 6] = lo; sh[threadIdx.x >> 6] = hi; sc[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        for (int w = 1; w < 4; ++w) { lo = sl[w] < lo ? sl[w] : lo; hi = sh[w] > hi ? sh[w] : hi; cnt += sc[w]; }
+        a.part[3 * blockIdx.x] = lo; a.part[3 * blockIdx.x + 1] = hi; a.part[3 * blockIdx.x + 2] = cnt;
+    }
+}
+extern "C" __global__ __launch_bounds__(64) void k_mm_fin(Args a)
+{
+    if (threadIdx.x != 0) return;
+    u64 lo = ~0ull, hi = 0ull, cnt = 0;
+    for (u32 p = 0; p < a.n_parts; ++p)
+    {
+        const u64 l2 = a.part[3 * p], h2 = a.part[3 * p + 1];
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; cnt += a.part[3 * p + 2];
+    }
+    a.part[3 * a.n_parts] = lo; a.part[3 * a.n_parts + 1] = hi; a.part[3 * a.n_parts + 2] = cnt;
+}
+)SRC";
+    return s;
+}
+
 int jit_compile(const std::string & src, const std::vector<char> ** code_out)
 {
     std::lock_guard<std::mutex> g(g_jit_mutex);
@@ -1028,5 +1097,56 @@ extern "C" int chgpu_expr_filter_execute(chgpu_ctx * ctx, const chgpu_expr * e, 
     for (uint32_t o = 0; o < n_outputs; ++o)
         outs[o] = res[o];
     *rows_out = total;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_expr_filter_minmax_node(chgpu_ctx * ctx, const chgpu_expr * e, uint32_t n_cols, const chgpu_col * const * cols, int filter_node,
+                                             uint32_t value_node, int * value_type_out, void * min_out, void * max_out, uint64_t * count_out)
+{
+    CHGPU_REQUIRE(ctx && e && cols, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(value_node < e->types.size() && filter_node < (int)e->types.size(), CHGPU_ERR_BAD_ARGUMENTS, "bad node");
+    CHGPU_REQUIRE(filter_node < 0 || chgpu_type_is_int(e->types[filter_node]), CHGPU_ERR_BAD_ARGUMENTS,
+                  "Illegal type for filter: the WHERE node must be an integer (FilterDescription.cpp:86-92)");
+    const int vt = e->types[value_node];
+    CHGPU_REQUIRE(chgpu_type_is_int(vt), CHGPU_ERR_NOT_IMPLEMENTED,
+                  "min / max of a Float column keep a NaN that arrives first (SingleValueDataFixed::setIfSmaller): order-dependent, CPU path");
+    u64 rows = 0;
+    CHGPU_TRY(check_spec(e, n_cols, cols, &rows));
+    if (value_type_out)
+        *value_type_out = vt;
+    u64 res[3] = {~0ull, 0, 0};
+    if (rows)
+    {
+        hipModule_t mod = nullptr;
+        CHGPU_TRY(jit_module(ctx, gen_minmax_source(e, filter_node, (int)value_node), &mod));
+        hipFunction_t fn = nullptr, fin = nullptr;
+        CHGPU_HIP(hipModuleGetFunction(&fn, mod, "k_mm"));
+        CHGPU_HIP(hipModuleGetFunction(&fin, mod, "k_mm_fin"));
+        const u32 grid = chgpu_grid_for(ctx, (rows + 3) / 4, 256, 8);
+        void * scratch = nullptr;
+        CHGPU_TRY(chgpu_scratch(ctx, ((size_t)grid + 1) * 3 * sizeof(u64), &scratch));
+        JitArgs a;
+        memset(&a, 0, sizeof(a));
+        for (size_t j = 0; j < e->input_types.size(); ++j)
+            a.in[j] = e->input_types[j] >= 0 ? cols[j]->data : nullptr;
+        a.n = rows;
+        a.part = (u64 *)scratch;
+        a.n_parts = grid;
+        void * params[] = {&a};
+        CHGPU_HIP(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
+        CHGPU_HIP(hipModuleLaunchKernel(fin, 1, 1, 1, 64, 1, 1, 0, ctx->stream, params, nullptr));
+        ctx->counters[6] += 2;
+        CHGPU_TRY(chgpu_read_back(ctx, a.part + 3 * (size_t)grid, res, sizeof(res)));
+    }
+    // no row passed: the aggregate of an empty set is the type's default (AggregateFunctionMin on non-Nullable arguments: 0)
+    const u64 sign = chgpu_type_is_signed(vt) ? 0x8000000000000000ull : 0;
+    const u64 vmin = res[2] ? (res[0] ^ sign) : 0, vmax = res[2] ? (res[1] ^ sign) : 0;
+    const size_t es = chgpu_type_size(vt);
+    if (min_out)
+        memcpy(min_out, &vmin, es); // little endian: the low bytes are the value in its own width
+    if (max_out)
+        memcpy(max_out, &vmax, es);
+    if (count_out)
+        *count_out = res[2];
     return CHGPU_OK;
 }

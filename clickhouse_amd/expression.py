@@ -118,6 +118,17 @@ class ExpressionActions:
         K.check(K.lib().chgpu_expr_filter_execute(ctx._h, self._h, len(cols), arr, filter_node, len(out_nodes), outs_n, outs, C.byref(rows)))
         return [Column(ctx, C.c_void_p(h)) for h in outs], int(rows.value)
 
+    def filter_minmax(self, ctx: Context, cols, filter_node: int, value_node: int):
+        """(min(value_node), max(value_node), count()) over the rows where filter_node != 0 (-1: every row); integer values only"""
+        arr = (C.c_void_p * len(cols))(*[c._h if c is not None else None for c in cols])
+        vt = C.c_int(0)
+        lo, hi = np.zeros(1, dtype=np.uint64), np.zeros(1, dtype=np.uint64)
+        cnt = C.c_uint64(0)
+        K.check(K.lib().chgpu_expr_filter_minmax_node(ctx._h, self._h, len(cols), arr, filter_node, value_node, C.byref(vt),
+                                                      lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), C.byref(cnt)))
+        dt = np.dtype(NP_OF[vt.value])
+        return lo.view(dt)[0], hi.view(dt)[0], int(cnt.value)
+
     def filter_sum(self, ctx: Context, cols, filter_node: int = -1, value_node: int = -1):
         """(sum(value_node), count()) over the rows where filter_node != 0, one pass"""
         arr = (C.c_void_p * len(cols))(*[c._h if c is not None else None for c in cols])

@@ -255,6 +255,13 @@ int chgpu_expr_filter_sum_node(chgpu_ctx * ctx, const chgpu_expr * expr, uint32_
 int chgpu_expr_filter_execute(chgpu_ctx * ctx, const chgpu_expr * expr, uint32_t n_cols, const chgpu_col * const * cols,
                               uint32_t filter_node, uint32_t n_outputs, const uint32_t * out_nodes, chgpu_col ** outs,
                               uint64_t * rows_out);
+/* SELECT min(value_node), max(value_node), count() WHERE filter_node in one pass (AggregateFunctionMin / Max without key,
+   src/AggregateFunctions/AggregateFunctionMinMax.h) for INTEGER value nodes; min_out / max_out receive the value in the node's own
+   width (*value_type_out), 0 when no row passes.  Float values -> CHGPU_ERR_NOT_IMPLEMENTED (the reference keeps a NaN that arrives
+   first: an order-dependent result). */
+int chgpu_expr_filter_minmax_node(chgpu_ctx * ctx, const chgpu_expr * expr, uint32_t n_cols, const chgpu_col * const * cols,
+                                  int filter_node, uint32_t value_node, int * value_type_out, void * min_out, void * max_out,
+                                  uint64_t * count_out);
 int chgpu_expr_free(chgpu_expr * expr);
 
 /* ================================================================================================

@@ -324,6 +324,18 @@ def test_gpu_random_dags_match_oracle_bit_exact(seed):
         assert nrows == int(keep.sum())
         for k, o in zip(outs_k, got):
             assert _same(o.numpy(), vals[k][keep]), (seed, "filter_execute", fn0, k)
+    # fused WHERE + min / max / count over integer nodes
+    if ints0:
+        vn = ints0[int(rng.integers(0, len(ints0)))]
+        fn1 = ints0[int(rng.integers(0, len(ints0)))]
+        lo, hi, cnt = ex.filter_minmax(ctx, cols_d, fn1, vn)
+        keep1 = vals[fn1] != 0
+        sel = vals[vn][keep1]
+        assert cnt == int(keep1.sum())
+        if cnt:
+            assert lo.dtype == sel.dtype and int(lo) == int(sel.min()) and int(hi) == int(sel.max()), (seed, "minmax", fn1, vn)
+        else:
+            assert int(lo) == 0 and int(hi) == 0
     # fused WHERE + sum + count over a random (filter, value) pair
     ints = [k for k in fnodes if types[k] not in (OE.F64, OE.F32)]
     if ints:
