@@ -213,3 +213,25 @@ def test_gpu_sort_nan_order_reference_blocks():
         assert _same_floats(col.index(perm).numpy().tolist(), want), (a.shape, desc, hint)
         f32 = ctx.upload(a.astype(np.float32))
         assert _same_floats(f32.index(ch.sort_permutation(f32, None, desc, hint)).numpy().astype(np.float64).tolist(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key_dtype,val_dtype,groups", [(np.uint32, np.int64, 1000), (np.int64, np.int32, 50_000), (np.uint16, np.uint8, 7), (np.uint64, np.uint64, 1)])
+def test_gpu_group_by_min_max_through_ordered_output(key_dtype, val_dtype, groups):
+    """GROUP BY key -> min(value), max(value) composed from ORDER BY key, value + run boundaries; numpy minimum.at / maximum.at beside it"""
+    import clickhouse_amd as ch
+    ctx = ch.Context()
+    rng = np.random.Generator(np.random.PCG64(groups))
+    n = 300_007
+    ki = np.iinfo(key_dtype)
+    k = (rng.integers(0, groups, size=n).astype(np.int64) + (ki.min if ki.min < 0 else 0) // 2).astype(key_dtype)
+    v = _column(rng, val_dtype, n, few_values=False)
+    gk, gmin, gmax = ch.group_by_min_max(ctx, ctx.upload(k), ctx.upload(v))
+    uk, inv = np.unique(k, return_inverse=True)
+    wmin = np.full(uk.shape[0], np.iinfo(val_dtype).max, dtype=val_dtype)
+    wmax = np.full(uk.shape[0], np.iinfo(val_dtype).min, dtype=val_dtype)
+    np.minimum.at(wmin, inv, v)
+    np.maximum.at(wmax, inv, v)
+    assert np.array_equal(gk.numpy(), uk) and np.array_equal(gmin.numpy(), wmin) and np.array_equal(gmax.numpy(), wmax)
+    with pytest.raises(ch.ChgpuError):
+        ch.group_by_min_max(ctx, ctx.upload(k), ctx.upload(v.astype(np.float64)))
