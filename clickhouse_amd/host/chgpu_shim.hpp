@@ -417,6 +417,23 @@ public:
         return {bits, count};
     }
 
+    /// SELECT min(value), max(value), count() WHERE filter over one chunk (integer value nodes); the bits are the value in its own width
+    struct MinMax { uint64_t min_bits = 0, max_bits = 0, count = 0; int type = 0; };
+    MinMax filterMinMax(const Columns & columns, int filter_node, ActionsDAG::Node value_node) const
+    {
+        std::vector<const chgpu_col *> in;
+        ContextPtr ctx;
+        for (auto & c : columns)
+        {
+            in.push_back(c ? c->handle() : nullptr);
+            if (c && !ctx)
+                ctx = c->context();
+        }
+        MinMax r;
+        check(chgpu_expr_filter_minmax_node(ctx->get(), h, static_cast<uint32_t>(in.size()), in.data(), filter_node, value_node, &r.type, &r.min_bits, &r.max_bits, &r.count));
+        return r;
+    }
+
 private:
     chgpu_expr * h = nullptr;
 };

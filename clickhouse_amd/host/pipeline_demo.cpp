@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <atomic>
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <map>
 #include <thread>
 #include <unordered_map>
@@ -184,6 +186,16 @@ int main(int argc, char ** argv)
             int rt = -1;
             auto fused = actions->filterSum(stripe.columns, static_cast<int>(p), static_cast<int>(v), &rt); // one pass, nothing materialised
             REQUIRE(rt == CHGPU_I64 && fused.first == ws && fused.second == wc);
+            auto mm = actions->filterMinMax(stripe.columns, static_cast<int>(p), v);
+            int64_t wmin = INT64_MAX, wmax = INT64_MIN;
+            for (size_t i = 0; i < n; ++i)
+                if (a[i] < thr && k[i] >= 500)
+                {
+                    const int64_t x = static_cast<int64_t>(static_cast<uint64_t>(a[i]) * k[i] - 7);
+                    wmin = std::min(wmin, x), wmax = std::max(wmax, x);
+                }
+            REQUIRE(mm.count == wc && mm.type == CHGPU_I64);
+            REQUIRE(wc == 0 || (static_cast<int64_t>(mm.min_bits) == wmin && static_cast<int64_t>(mm.max_bits) == wmax));
             // the same through the processors: ExpressionTransform appends v, FilterTransform on the DAG's filter node, sum
             GpuExpressionTransform project(actions, {v});
             GpuExpressionFilterTransform where(actions, p);
