@@ -486,13 +486,26 @@ std::string gen_source(const chgpu_expr * e, const KernelSpec & ks)
     if (ks.fsum)
         s += facc ? "    f64 acc = 0; u64 cnt = 0;\n" : "    u64 acc = 0; u64 cnt = 0;\n";
     s += "    const u64 nvec = a.n / " + VS + ";\n    constexpr u64 CH = 256ull * " + U + ";\n    const u64 nch = nvec / CH;\n";
-    s += "    for (u64 ch = blockIdx.x; ch < nch; ch += gridDim.x)\n    {\n        const u64 vb = ch * CH + threadIdx.x;\n";
+    // every wave owns a contiguous strip of U * 64 vectors of the chunk.  One-byte outputs (masks) whose V * U bytes per lane make 16
+    // are transposed through a wave-private LDS strip so that each lane stores 16 CONTIGUOUS bytes once per chunk instead of U
+    // narrow vectors (k_cmp_mask's scheme: the 4-byte stores cost the generated mask kernel 0.57 of peak against 0.72).
+    const bool tr_ok = !ks.fsum && V * (u32)JIT_UNROLL == 16;
+    std::vector<int> tr_slot(ks.out_nodes.size(), -1);
+    int n_tr = 0;
+    if (tr_ok)
+        for (size_t o = 0; o < ks.out_nodes.size(); ++o)
+            if (chgpu_type_size(e->types[ks.out_nodes[o]]) == 1)
+                tr_slot[o] = n_tr++;
+    if (n_tr)
+        s += "    typedef u8 v16b_t __attribute__((ext_vector_type(16)));\n    __shared__ __attribute__((aligned(16))) u8 tr[" + std::to_string(n_tr) + "][4][1024];\n";
+    s += "    for (u64 ch = blockIdx.x; ch < nch; ch += gridDim.x)\n    {\n        const u64 sb = ch * CH + (u64)(threadIdx.x >> 6) * (64 * " + U +
+         ");\n        const u64 vb = sb + (threadIdx.x & 63);\n";
     for (size_t j = 0; j < e->input_types.size(); ++j)
         if (e->input_types[j] >= 0)
         {
             const std::string vt = vtype(e->input_types[j]), J = std::to_string(j);
             s += "        " + vt + " x" + J + "[" + U + "];\n";
-            s += "#pragma unroll\n        for (int k = 0; k < " + U + "; ++k) x" + J + "[k] = __builtin_nontemporal_load((const " + vt + " *)a.in[" + J + "] + vb + (u64)k * 256);\n";
+            s += "#pragma unroll\n        for (int k = 0; k < " + U + "; ++k) x" + J + "[k] = __builtin_nontemporal_load((const " + vt + " *)a.in[" + J + "] + vb + (u64)k * 64);\n";
         }
     s += "#pragma unroll\n        for (int k = 0; k < " + U + "; ++k)\n        {\n";
     if (!ks.fsum)
@@ -515,8 +528,24 @@ std::string gen_source(const chgpu_expr * e, const KernelSpec & ks)
     s += "            }\n";
     if (!ks.fsum)
         for (size_t o = 0; o < ks.out_nodes.size(); ++o)
-            s += "            ((" + vtype(e->types[ks.out_nodes[o]]) + " *)a.out[" + std::to_string(o) + "])[vb + (u64)k * 256] = y" + std::to_string(o) + ";\n";
-    s += "        }\n    }\n";
+        {
+            if (tr_slot[o] >= 0)
+                s += "            *(" + vtype(e->types[ks.out_nodes[o]]) + " *)&tr[" + std::to_string(tr_slot[o]) + "][threadIdx.x >> 6][(k * 64 + (threadIdx.x & 63)) * " + VS +
+                     "] = y" + std::to_string(o) + ";\n";
+            else
+                s += "            ((" + vtype(e->types[ks.out_nodes[o]]) + " *)a.out[" + std::to_string(o) + "])[vb + (u64)k * 64] = y" + std::to_string(o) + ";\n";
+        }
+    s += "        }\n";
+    if (n_tr)
+    {
+        s += "        __builtin_amdgcn_wave_barrier();\n"; // LDS operations of one wave complete in order
+        for (size_t o = 0; o < ks.out_nodes.size(); ++o)
+            if (tr_slot[o] >= 0)
+                s += "        *((v16b_t *)((u8 *)a.out[" + std::to_string(o) + "] + sb * " + VS + ") + (threadIdx.x & 63)) = *(const v16b_t *)&tr[" +
+                     std::to_string(tr_slot[o]) + "][threadIdx.x >> 6][(threadIdx.x & 63) * 16];\n";
+        s += "        __builtin_amdgcn_wave_barrier();\n";
+    }
+    s += "    }\n";
     // ragged tail, one row per lane
     s += "    for (u64 i = nch * CH * " + VS + " + (u64)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (u64)gridDim.x * 256)\n    {\n        Row r; Res o;\n";
     for (size_t j = 0; j < e->input_types.size(); ++j)
