@@ -32,6 +32,10 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU (default: the 1 B rows of configs[1])")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C3 (GROUP BY) and C4 (hash join) sections of the line (N=1 only)")
+    ap.add_argument("--c3-rows", type=int, default=1_000_000_000)
+    ap.add_argument("--c4-probe-rows", type=int, default=100_000_000)
+    ap.add_argument("--c4-build-rows", type=int, default=10_000_000)
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL code path on one GPU)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (rehearsal of the N>1 code path on one GPU)")
     args = ap.parse_args()
@@ -154,15 +158,18 @@ def main():
     algo_bytes = 8.0 * n  # 8 B/row, one launch scans the rank's whole column
     achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9
 
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "traffic.json")  # PMC-derived bytes/launch recorded by profiles/collect.sh
+    # HBM bytes per launch from the PMC passes of THIS command (profiles/collect.sh writes the file; counters cannot be read
+    # from inside the process, so the number is the last committed collection and traffic_source says which one)
+    traffic, traffic_source, tj = None, None, {}
+    tpath = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if tj.get("rows") == n:
                 traffic = tj.get("k_filter_sum_hbm_bytes_per_launch")
+                traffic_source = tj.get("source", "profiles/traffic.json")
         except Exception:
-            traffic = None
+            traffic, tj = None, {}
 
     out = {
         "metric": json.load(open(os.path.join(REPO, "BASELINE.json")))["metric"],
@@ -191,6 +198,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "kernel": "k_filter_sum<long,2,true,false,IntRangePred>",
             "kernel_avg_ms": kern_avg_ms,
             "algorithmic_bytes_per_launch": algo_bytes,
@@ -199,6 +207,15 @@ def main():
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, args.cpu_sample_rows, ctx, ch)
+    if world == 1 and not args.no_configs:
+        # BASELINE.json configs[2] and configs[3] (its one-GPU half) on the same clock; `value` above stays configs[1]
+        del a, col, slots, results
+        ctx.trim()
+        torch.cuda.empty_cache()
+        out["configs"] = {
+            "C3": config_c3(args, ctx, ch, torch, np, dev, stream, tj, not args.no_cpu_baseline),
+            "C4_one_gpu": config_c4(args, ctx, ch, torch, np, dev, stream, tj, not args.no_cpu_baseline),
+        }
 
     if _saved_stdout_fd is not None:
         sys.stdout.flush()
@@ -208,6 +225,162 @@ def main():
     if dist is not None:
         os.dup2(2, 1)  # anything RCCL says while shutting down goes to stderr again
         dist.destroy_process_group()
+
+
+def _timed(fn, torch, stream, reps, warmup=1):
+    """fn() launches on `stream`; -> (mean device ms between HIP events on that stream, mean wall ms incl. the host synchronisation, last result)"""
+    r = None
+    for _ in range(warmup):
+        r = fn()
+    stream.synchronize()
+    dev_ms, wall_ms = [], []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        r = fn()
+        e1.record(stream)
+        e1.synchronize()
+        wall_ms.append((time.perf_counter() - t0) * 1e3)
+        dev_ms.append(e0.elapsed_time(e1))
+    return sum(dev_ms) / len(dev_ms), sum(wall_ms) / len(wall_ms), r
+
+
+def _kernels_from_profile(prefixes):
+    """per-kernel average ms of the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/): the live number in
+    the line is the HIP-event bracket around the whole operator; this list says how it splits"""
+    import csv
+    import glob
+    paths = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_bench_kernel_stats.csv")))
+    if not paths:
+        return None, None
+    rows = []
+    with open(paths[-1]) as f:
+        for r in csv.DictReader(f):
+            name = r.get("Name", "")
+            if any(name.startswith(p) or (" " + p) in name or ("void " + p) in name for p in prefixes):
+                rows.append({"kernel": name[:96], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6})
+    return rows, os.path.relpath(paths[-1], REPO)
+
+
+def config_c3(args, ctx, ch, torch, np, dev, stream, tj, with_cpu):
+    """BASELINE.json configs[2]: SELECT k, sum(v), count() GROUP BY k -- UInt32 key uniform in [0, 1e6), Int64 values, 1e9 rows resident
+    in HBM, size hint given (the reference passes statistics-based hints too: Aggregator.cpp:107-128).  One operator call =
+    chgpu_agg_create + chgpu_agg_add_block over the whole stripe (table creation and the control-block read-back included)."""
+    rows = args.c3_rows
+    g = torch.Generator(device=dev).manual_seed(2)
+    k = torch.randint(0, 1_000_000, (rows,), dtype=torch.int32, device=dev, generator=g)
+    v = torch.randint(-2**31, 2**31, (rows,), dtype=torch.int64, device=dev, generator=g)
+    kc = ctx.wrap(k.data_ptr(), np.uint32, rows, keepalive=k)
+    vc = ctx.wrap(v.data_ptr(), np.int64, rows, keepalive=v)
+    aggs = [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)]
+
+    def run(n=rows):
+        A = ch.Aggregator(np.uint32, aggs, size_hint=1_000_000, ctx=ctx)
+        A.execute_on_block(kc, [vc, None], 0, n)
+        return A
+
+    dev_ms, wall_ms, A = _timed(run, torch, stream, reps=5, warmup=2)
+    groups = len(A)
+    # size-independent check at full size: every key once, counts partition the rows, sum of sums == sum of the column (mod 2^64)
+    gk, (gs, gc) = A.convert_to_block()
+    assert np.unique(gk).shape[0] == gk.shape[0] == groups and int(gc.sum()) == rows
+    assert int(gs.astype(np.uint64).sum()) == int(v.sum().item()) % 2**64
+    algo = 12.0 * rows  # SURVEY 8(d): 4 B key + 8 B value per row
+    kernels, ksrc = _kernels_from_profile(["k_gb_", "k_agg_", "k_scan", "k_part"])
+    res = {"workload": "GROUP BY UInt32 key (1 M groups), sum(Int64) + count(), HBM-resident, size_hint=1e6",
+           "rows": rows, "groups": groups, "calls": 7, "ms": dev_ms, "wall_ms": wall_ms, "rows_per_s": rows / (dev_ms * 1e-3),
+           "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": algo / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tj.get("C3_hbm_bytes_per_call"),
+                        "traffic_source": tj.get("source") if tj.get("C3_hbm_bytes_per_call") else None,
+                        "kernels": kernels, "kernels_source": ksrc}}
+    if with_cpu:
+        import oracle
+        oracle.build()
+        cores = max(1, len(os.sched_getaffinity(0)))
+        sample = min(rows, 200_000_000)
+        ks = k[:sample].cpu().numpy().view(np.uint32)
+        vs = v[:sample].cpu().numpy()
+        t0 = time.perf_counter()
+        ref, secs = oracle.groupby_pipeline(ks, aggs, [vs, None], threads=cores)
+        tN = time.perf_counter() - t0
+        s1 = min(sample, 40_000_000)
+        t0 = time.perf_counter()
+        oracle.groupby_pipeline(ks[:s1], aggs, [vs[:s1], None], threads=1)
+        t1 = time.perf_counter() - t0
+        # parity on the sample: keys, sums and counts bit for bit
+        ok, (os_, oc) = ref.convert_to_block()
+        sk, (ss, sc) = run(sample).convert_to_block()
+        i, j = np.argsort(sk), np.argsort(ok)
+        assert np.array_equal(sk[i], ok[j]) and np.array_equal(ss[i], os_[j]) and np.array_equal(sc[i], oc[j]), "C3: GPU differs from the CPU restatement"
+        res["cpu_baseline"] = {"value": sample / tN, "unit": "rows/s", "cores": cores, "kind": "port",
+                               "sample": f"first {sample} rows, Blocks of 65409 rows, {cores} streams each with its own table and the reference's "
+                                         f"hash-cell prefetch, two-level bucket-parallel merge ({secs[0]:.2f} s consume + {secs[1]:.2f} s merge); "
+                                         f"single stream over {s1} rows: {s1 / t1:.4g} rows/s",
+                               "single_thread_value": s1 / t1}
+        res["parity"] = "bit-exact on the sample (keys, sums, counts) + full-size partition properties"
+    return res
+
+
+def config_c4(args, ctx, ch, torch, np, dev, stream, tj, with_cpu):
+    """BASELINE.json configs[3], the share of ONE GPU: 1e8-row probe INNER JOIN 1e7-row build on a UInt64 key (unique build keys, ~50 %
+    hits), checksum form SELECT count(), sum(bv).  build = chgpu_join_create + add_block + finish_build; probe = the join with the
+    aggregation fused behind it."""
+    nb, npb = args.c4_build_rows, args.c4_probe_rows
+    g = torch.Generator(device=dev).manual_seed(5)
+    bk = (torch.randperm(nb, device=dev, generator=g).to(torch.int64) + 1) * 2654435761
+    pk = torch.where(torch.rand(npb, device=dev, generator=g) < 0.5, bk[torch.randint(0, nb, (npb,), device=dev, generator=g)],
+                     torch.randint(0, 2**62, (npb,), dtype=torch.int64, device=dev, generator=g))
+    bv = torch.randint(-2**40, 2**40, (nb,), dtype=torch.int64, device=dev, generator=g)
+    bkc = ctx.wrap(bk.data_ptr(), np.uint64, nb, keepalive=bk)
+    pkc = ctx.wrap(pk.data_ptr(), np.uint64, npb, keepalive=pk)
+    bvc = ctx.wrap(bv.data_ptr(), np.int64, nb, keepalive=bv)
+
+    def build():
+        j = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, ctx=ctx)
+        j.add_block(bkc)
+        j.finish_build()
+        return j
+
+    def probe(j, pcol):
+        return j.probe_count_sum(pcol, bvc)  # (count, sum bits)
+
+    b_ms, b_wall, j = _timed(build, torch, stream, reps=3, warmup=1)
+    p_ms, p_wall, (cnt, sm) = _timed(lambda: probe(j, pkc), torch, stream, reps=5, warmup=1)
+    # independent check at full size: membership by a sorted-array search, payload through the same permutation
+    sbk, order = torch.sort(bk)
+    pos = torch.searchsorted(sbk, pk).clamp_(max=nb - 1)
+    hit = sbk[pos] == pk
+    want_cnt = int(hit.sum().item())
+    want_sum = int(bv[order[pos[hit]]].sum().item()) % 2**64
+    assert (cnt, sm % 2**64) == (want_cnt, want_sum), ("C4", cnt, sm, want_cnt, want_sum)
+    del sbk, order, pos, hit
+    algo = 8.0 * npb + 16.0 * nb + 8.0 * cnt  # SURVEY 8(d): probe keys + build keys and payload + payload per matched row
+    kernels, ksrc = _kernels_from_profile(["k_join_", "k_index", "k_jp_"])
+    tot = b_ms + p_ms
+    res = {"workload": "100 M-row probe INNER JOIN 10 M-row build on UInt64 (ALL, unique build keys, ~50 % hits), SELECT count(), sum(bv); one GPU",
+           "build_rows": nb, "probe_rows": npb, "matches": cnt, "build_calls": 4, "probe_calls": 6, "build_ms": b_ms, "probe_ms": p_ms, "ms": tot, "wall_ms": b_wall + p_wall,
+           "rows_per_s": (nb + npb) / (tot * 1e-3), "probe_rows_per_s": npb / (p_ms * 1e-3),
+           "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": algo / (tot * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tj.get("C4_hbm_bytes_per_call"),
+                        "traffic_source": tj.get("source") if tj.get("C4_hbm_bytes_per_call") else None,
+                        "kernels": kernels, "kernels_source": ksrc}}
+    if with_cpu:
+        import oracle
+        oracle.build()
+        cores = max(1, len(os.sched_getaffinity(0)))
+        bk_h, bv_h = bk.cpu().numpy().view(np.uint64), bv.cpu().numpy()
+        pk_h = pk.cpu().numpy().view(np.uint64)
+        c_cnt, c_sum, t_b, t_p = oracle.join_count_sum_pipeline(bk_h, bv_h, pk_h, threads=cores)
+        assert (c_cnt, c_sum) == (cnt, sm % 2**64), "C4: GPU differs from the CPU restatement"
+        s1 = min(npb, 20_000_000)
+        _, _, _, t_p1 = oracle.join_count_sum_pipeline(bk_h, bv_h, pk_h[:s1], threads=1)
+        res["cpu_baseline"] = {"value": (nb + npb) / (t_b + t_p), "unit": "rows/s", "cores": cores, "kind": "port",
+                               "sample": f"the whole config: build by one stream ({nb / t_b:.4g} rows/s), probe + payload gather + sum by {cores} streams over "
+                                         f"Blocks of 65409 rows ({npb / t_p:.4g} rows/s); single probe stream over {s1} rows: {s1 / t_p1:.4g} rows/s",
+                               "build_rows_per_s": nb / t_b, "probe_rows_per_s": npb / t_p, "single_thread_probe_value": s1 / t_p1}
+        res["parity"] = "count and sum(payload) bit-exact against the CPU restatement and an independent sorted-search join, full size"
+    return res
 
 
 def cpu_baseline(a, sample_rows, ctx, ch):
@@ -221,7 +394,7 @@ def cpu_baseline(a, sample_rows, ctx, ch):
     oracle.build()
     m = min(sample_rows, a.shape[0])
     host = a[:m].cpu().numpy()
-    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    cores = max(1, len(os.sched_getaffinity(0)))  # every core this process may run on
     best1, bestN = None, None
     r1 = rN = None
     for _ in range(5):

@@ -98,6 +98,18 @@ SIGNATURES = {
     "chgpu_join_finish_build": (_i, [_vp]),
     "chgpu_join_total_rows": (_i, [_vp, _pu64, _pu64]),
     "chgpu_join_probe": (_i, [_vp, _vp, _vp, _u64, _pp, _pp, _pp, _pu64, _pu64]),
+    "chgpu_join_probe_agg": (_i, [_vp, _vp, _vp, _vp, _pu64, _vp]),
+    "chgpu_comm_unique_id": (_i, [_vp]),
+    "chgpu_comm_init": (_i, [_vp, _i, _i, _vp, _pp]),
+    "chgpu_comm_destroy": (_i, [_vp]),
+    "chgpu_comm_rank": (_i, [_vp]),
+    "chgpu_comm_world": (_i, [_vp]),
+    "chgpu_comm_stats": (_i, [_vp, _pu64]),
+    "chgpu_all_to_all_counts": (_i, [_vp, _pu64, _pu64]),
+    "chgpu_all_to_all": (_i, [_vp, _vp, _pu64, _pu64, _pp]),
+    "chgpu_all_reduce_u64": (_i, [_vp, _vp]),
+    "chgpu_all_reduce_u64_host": (_i, [_vp, _pu64, _u32]),
+    "chgpu_comm_barrier": (_i, [_vp]),
     "chgpu_join_flatten_rowids": (_i, [_vp, _vp, _pp]),
     "chgpu_join_non_joined_rows": (_i, [_vp, _pp, _pu64]),
     "chgpu_join_free": (_i, [_vp]),

@@ -91,6 +91,26 @@ struct chgpu_col
     int * shared_refs = nullptr; // several owning columns carved out of one allocation (scatter outputs)
 };
 
+// Every entry point runs on its context's device whatever device the calling thread had current (pipeline threads migrate; a new
+// thread starts on device 0): allocations, module loads and launches below must all land on ctx->device.  Restores on scope exit.
+struct ChgpuDeviceGuard
+{
+    int prev = -1;
+    bool switched = false;
+    explicit ChgpuDeviceGuard(const chgpu_ctx * ctx)
+    {
+        if (ctx && hipGetDevice(&prev) == hipSuccess && prev != ctx->device)
+            switched = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    ~ChgpuDeviceGuard()
+    {
+        if (switched)
+            (void)hipSetDevice(prev);
+    }
+    ChgpuDeviceGuard(const ChgpuDeviceGuard &) = delete;
+    ChgpuDeviceGuard & operator=(const ChgpuDeviceGuard &) = delete;
+};
+
 static inline size_t chgpu_type_size(int type)
 {
     switch (type)

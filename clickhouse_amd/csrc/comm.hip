@@ -1,0 +1,298 @@
+// comm.hip — the exchange step of the sharded operators, over RCCL (xGMI inside a node).
+//
+// Reference steps replaced (file:line in the reference checkout):
+//   chgpu_all_to_all      ConcurrentHashJoin::dispatchBlock: the scattered sub-blocks handed to the per-slot HashJoins
+//                         (src/Interpreters/ConcurrentHashJoin.cpp:538-565), and the two-level bucket hand-over of a parallel
+//                         merge (ConcurrentHashJoin.cpp:600-653; AggregatingTransform.cpp:120-136) -- threads sharing one address space
+//                         there, one process per GPU exchanging hash partitions here
+//   chgpu_all_reduce_u64  mergeWithoutKeyDataImpl across streams (src/Interpreters/Aggregator.cpp:2584-2628)
+//
+// One communicator = one rank = one chgpu_ctx (device + stream).  librccl is loaded with dlopen (like libhiprtc) so the library has
+// no link-time dependency on it and a process that already carries an RCCL (PyTorch bundles one) keeps a single copy.
+// An all-to-all is ONE grouped send/recv: every peer's partition leaves at once, so all xGMI links of the GPU carry data together
+// (xGMI is point-to-point: a ring would be bound by one link).  The local partition is a device-to-device copy.
+#include "chgpu_internal.h"
+
+#include <dlfcn.h>
+
+#include <mutex>
+#include <vector>
+
+namespace
+{
+typedef struct ncclComm * ncclComm_t;
+struct ncclUniqueId_ { char internal[128]; };
+enum { nccl_Success = 0 };
+enum { nccl_Int8 = 0, nccl_Uint8 = 1, nccl_Uint64 = 5 };
+enum { nccl_Sum = 0 };
+
+struct Rccl
+{
+    void * h = nullptr;
+    int (*GetUniqueId)(ncclUniqueId_ *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId_, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    const char * (*GetErrorString)(int) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+
+int rccl_load()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.h)
+        return CHGPU_OK;
+    void * h = nullptr;
+    // an RCCL this process already carries wins (one copy per process), then the system one
+    if (const char * env = getenv("CHGPU_RCCL_LIB"))
+        h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    if (!h)
+        h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    const char * names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char * n : names)
+        if (!h)
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!h)
+        return chgpu_set_error(CHGPU_ERR_DEVICE, "cannot load librccl (%s): the sharded operators need RCCL", dlerror());
+#define SYM(field, name)                                          \
+    *(void **)&g_rccl.field = dlsym(h, name);                     \
+    if (!g_rccl.field)                                            \
+        return chgpu_set_error(CHGPU_ERR_DEVICE, "librccl lacks %s", name);
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(GetErrorString, "ncclGetErrorString")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
+    SYM(Send, "ncclSend")
+    SYM(Recv, "ncclRecv")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(AllGather, "ncclAllGather")
+#undef SYM
+    g_rccl.h = h;
+    return CHGPU_OK;
+}
+} // namespace
+
+#define CHGPU_NCCL(expr)                                                                                                  \
+    do                                                                                                                    \
+    {                                                                                                                     \
+        int _r = (expr);                                                                                                  \
+        if (_r != nccl_Success)                                                                                           \
+            return chgpu_set_error(CHGPU_ERR_DEVICE, "%s: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+struct chgpu_comm
+{
+    chgpu_ctx * ctx = nullptr;
+    int rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    u64 * dev_buf = nullptr; // small device staging for counts / reductions: [2 * world + 64] u64
+    u64 bytes_sent = 0, bytes_received = 0, collectives = 0;
+};
+
+extern "C" int chgpu_comm_unique_id(uint8_t id_out[CHGPU_UNIQUE_ID_BYTES])
+{
+    CHGPU_REQUIRE(id_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_TRY(rccl_load());
+    ncclUniqueId_ id;
+    CHGPU_NCCL(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == CHGPU_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    memcpy(id_out, &id, sizeof(id));
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_comm_init(chgpu_ctx * ctx, int rank, int world, const uint8_t unique_id[CHGPU_UNIQUE_ID_BYTES], chgpu_comm ** out)
+{
+    CHGPU_REQUIRE(ctx && out && unique_id, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(world >= 1 && rank >= 0 && rank < world, CHGPU_ERR_BAD_ARGUMENTS, "rank %d of %d", rank, world);
+    // shard = two-level bucket & (slots - 1): the slot count must be a power of two (ConcurrentHashJoin.cpp:158) and <= 256 buckets
+    CHGPU_REQUIRE((world & (world - 1)) == 0 && world <= 256, CHGPU_ERR_BAD_ARGUMENTS, "world size %d: must be a power of two <= 256", world);
+    ChgpuDeviceGuard guard(ctx);
+    CHGPU_TRY(rccl_load());
+    chgpu_comm * c = new chgpu_comm();
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    ncclUniqueId_ id;
+    memcpy(&id, unique_id, sizeof(id));
+    int r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != nccl_Success)
+    {
+        delete c;
+        return chgpu_set_error(CHGPU_ERR_DEVICE, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(r));
+    }
+    hipError_t e = hipMalloc((void **)&c->dev_buf, ((size_t)2 * world + 64) * sizeof(u64));
+    if (e != hipSuccess)
+    {
+        g_rccl.CommDestroy(c->comm);
+        delete c;
+        return chgpu_set_error(CHGPU_ERR_OOM, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_comm_destroy(chgpu_comm * c)
+{
+    if (!c)
+        return CHGPU_OK;
+    ChgpuDeviceGuard guard(c->ctx);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->comm)
+        g_rccl.CommDestroy(c->comm);
+    if (c->dev_buf)
+        (void)hipFree(c->dev_buf);
+    delete c;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_comm_rank(const chgpu_comm * c) { return c ? c->rank : -1; }
+extern "C" int chgpu_comm_world(const chgpu_comm * c) { return c ? c->world : 0; }
+
+extern "C" int chgpu_comm_stats(const chgpu_comm * c, uint64_t out[3])
+{
+    CHGPU_REQUIRE(c && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    out[0] = c->bytes_sent;
+    out[1] = c->bytes_received;
+    out[2] = c->collectives;
+    return CHGPU_OK;
+}
+
+// recv_counts[p] = send_counts[rank] of peer p: the row counts that size the receive side of an all-to-all
+extern "C" int chgpu_all_to_all_counts(chgpu_comm * c, const uint64_t * send_counts, uint64_t * recv_counts)
+{
+    CHGPU_REQUIRE(c && send_counts && recv_counts, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    chgpu_ctx * ctx = c->ctx;
+    ChgpuDeviceGuard guard(ctx);
+    const int W = c->world;
+    if (W == 1)
+    {
+        recv_counts[0] = send_counts[0];
+        return CHGPU_OK;
+    }
+    u64 * snd = c->dev_buf, * rcv = c->dev_buf + W;
+    CHGPU_HIP(hipMemcpyAsync(snd, send_counts, (size_t)W * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    CHGPU_HIP(hipMemcpyAsync(rcv + c->rank, snd + c->rank, sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+    CHGPU_NCCL(g_rccl.GroupStart());
+    for (int p = 0; p < W; ++p)
+    {
+        if (p == c->rank)
+            continue;
+        CHGPU_NCCL(g_rccl.Send(snd + p, 1, nccl_Uint64, p, c->comm, ctx->stream));
+        CHGPU_NCCL(g_rccl.Recv(rcv + p, 1, nccl_Uint64, p, c->comm, ctx->stream));
+    }
+    CHGPU_NCCL(g_rccl.GroupEnd());
+    c->collectives += 1;
+    return chgpu_read_back(ctx, rcv, recv_counts, (size_t)W * sizeof(u64));
+}
+
+// send: shards back to back (chgpu_partition_by_hash's output), shard p = rows [sum(send_counts[:p]), +send_counts[p]) goes to rank p;
+// *recv_out: a new column holding what ranks 0..W-1 sent here, back to back in rank order (rows = sum(recv_counts)).
+extern "C" int chgpu_all_to_all(chgpu_comm * c, const chgpu_col * send, const uint64_t * send_counts, const uint64_t * recv_counts, chgpu_col ** recv_out)
+{
+    CHGPU_REQUIRE(c && send && send_counts && recv_counts && recv_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    chgpu_ctx * ctx = c->ctx;
+    ChgpuDeviceGuard guard(ctx);
+    const int W = c->world;
+    const size_t es = chgpu_type_size(send->type);
+    u64 stot = 0, rtot = 0;
+    for (int p = 0; p < W; ++p)
+    {
+        stot += send_counts[p];
+        rtot += recv_counts[p];
+    }
+    CHGPU_REQUIRE(stot == send->rows, CHGPU_ERR_SIZES_MISMATCH, "send counts add up to %llu rows, the column has %llu", (unsigned long long)stot,
+                  (unsigned long long)send->rows);
+    CHGPU_REQUIRE(recv_counts[c->rank] == send_counts[c->rank], CHGPU_ERR_SIZES_MISMATCH, "own partition: send %llu != recv %llu",
+                  (unsigned long long)send_counts[c->rank], (unsigned long long)recv_counts[c->rank]);
+    chgpu_col * out = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, send->type, rtot, &out));
+    auto fail = [&](int code) {
+        chgpu_col_free(out);
+        return code;
+    };
+    std::vector<u64> soff((size_t)W + 1, 0), roff((size_t)W + 1, 0);
+    for (int p = 0; p < W; ++p)
+    {
+        soff[p + 1] = soff[p] + send_counts[p];
+        roff[p + 1] = roff[p] + recv_counts[p];
+    }
+    // own partition: device-to-device, no transport
+    if (send_counts[c->rank])
+    {
+        hipError_t e = hipMemcpyAsync((char *)out->data + roff[c->rank] * es, (const char *)send->data + soff[c->rank] * es, send_counts[c->rank] * es,
+                                      hipMemcpyDeviceToDevice, ctx->stream);
+        if (e != hipSuccess)
+            return fail(chgpu_set_error(CHGPU_ERR_DEVICE, "all_to_all local copy: %s", hipGetErrorString(e)));
+    }
+    if (W > 1)
+    {
+        int r = g_rccl.GroupStart();
+        for (int p = 0; p < W && r == nccl_Success; ++p)
+        {
+            if (p == c->rank)
+                continue;
+            if (send_counts[p])
+                r = g_rccl.Send((const char *)send->data + soff[p] * es, send_counts[p] * es, nccl_Uint8, p, c->comm, ctx->stream);
+            if (r == nccl_Success && recv_counts[p])
+                r = g_rccl.Recv((char *)out->data + roff[p] * es, recv_counts[p] * es, nccl_Uint8, p, c->comm, ctx->stream);
+        }
+        const int r2 = g_rccl.GroupEnd();
+        if (r != nccl_Success || r2 != nccl_Success)
+            return fail(chgpu_set_error(CHGPU_ERR_DEVICE, "all_to_all: %s", g_rccl.GetErrorString(r != nccl_Success ? r : r2)));
+        c->bytes_sent += (stot - send_counts[c->rank]) * es;
+        c->bytes_received += (rtot - recv_counts[c->rank]) * es;
+    }
+    c->collectives += 1;
+    *recv_out = out;
+    return CHGPU_OK;
+}
+
+// element-wise wrap-around sum over all ranks, in place, of a UInt64 / Int64 device column (integer states and counters)
+extern "C" int chgpu_all_reduce_u64(chgpu_comm * c, chgpu_col * inout)
+{
+    CHGPU_REQUIRE(c && inout, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(inout->type == CHGPU_U64 || inout->type == CHGPU_I64, CHGPU_ERR_BAD_ARGUMENTS, "all_reduce_u64 takes a UInt64 / Int64 column");
+    ChgpuDeviceGuard guard(c->ctx);
+    if (c->world > 1 && inout->rows)
+    {
+        CHGPU_NCCL(g_rccl.AllReduce(inout->data, inout->data, inout->rows, nccl_Uint64, nccl_Sum, c->comm, c->ctx->stream));
+        c->bytes_sent += inout->rows * 8;
+        c->bytes_received += inout->rows * 8;
+    }
+    c->collectives += 1;
+    return CHGPU_OK;
+}
+
+// the same for n <= 64 host values (sums and counts of a keyless aggregation, row totals): staged through the device, synchronises
+extern "C" int chgpu_all_reduce_u64_host(chgpu_comm * c, uint64_t * values, uint32_t n)
+{
+    CHGPU_REQUIRE(c && values, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(n <= 64, CHGPU_ERR_BAD_ARGUMENTS, "at most 64 values");
+    chgpu_ctx * ctx = c->ctx;
+    ChgpuDeviceGuard guard(ctx);
+    if (c->world == 1 || n == 0)
+        return CHGPU_OK;
+    u64 * buf = c->dev_buf + 2 * c->world;
+    CHGPU_HIP(hipMemcpyAsync(buf, values, (size_t)n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    CHGPU_NCCL(g_rccl.AllReduce(buf, buf, n, nccl_Uint64, nccl_Sum, c->comm, ctx->stream));
+    c->collectives += 1;
+    return chgpu_read_back(ctx, buf, values, (size_t)n * sizeof(u64));
+}
+
+// every rank's queued work on its stream has finished when this returns on all ranks
+extern "C" int chgpu_comm_barrier(chgpu_comm * c)
+{
+    CHGPU_REQUIRE(c, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    uint64_t one = 1;
+    CHGPU_TRY(chgpu_all_reduce_u64_host(c, &one, 1));
+    CHGPU_HIP(hipStreamSynchronize(c->ctx->stream));
+    return CHGPU_OK;
+}

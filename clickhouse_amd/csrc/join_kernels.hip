@@ -733,18 +733,21 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
     JoinCtrl c;
     CHGPU_TRY(chgpu_read_back(ctx, t.ctrl, &c, sizeof(c)));
     j->n_keys = c.n_keys;
-    if (jf_track_used(j))
     {
+        // first flat row of every right block: row ids (block << 32 | row) -> position in payload columns glued over all blocks
         const u64 nb = j->blocks.size();
         std::vector<u64> bases(nb ? nb : 1, 0);
         for (u64 b = 0; b < nb; ++b)
             bases[b] = j->blocks[b].base;
         void * um = nullptr, * bm = nullptr;
-        CHGPU_TRY(chgpu_pool_alloc(ctx, j->total_rows + 64, &um, &j->used_class));
-        j->used = (u8 *)um;
+        if (jf_track_used(j))
+        {
+            CHGPU_TRY(chgpu_pool_alloc(ctx, j->total_rows + 64, &um, &j->used_class));
+            j->used = (u8 *)um;
+            CHGPU_HIP(hipMemsetAsync(j->used, 0, j->total_rows + 64, ctx->stream));
+        }
         CHGPU_TRY(chgpu_pool_alloc(ctx, bases.size() * sizeof(u64), &bm, &j->base_class));
         j->block_base_dev = (u64 *)bm;
-        CHGPU_HIP(hipMemsetAsync(j->used, 0, j->total_rows + 64, ctx->stream));
         CHGPU_HIP(hipMemcpyAsync(j->block_base_dev, bases.data(), bases.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
         CHGPU_HIP(hipStreamSynchronize(ctx->stream)); // `bases` is a host temporary
     }
@@ -1005,5 +1008,250 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
     *n_left_consumed = c.consumed;
     ctx->counters[3] += c.consumed;
     ctx->counters[4] += c.n_out;
+    return CHGPU_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Fused probe -> payload gather -> aggregate without key: joinBlock (HashJoinMethodsImpl.h:402-549) followed by
+// AddedColumns' lazy gather (AddedColumns.cpp:39-131) and executeWithoutKeyImpl (Aggregator.cpp:1276-1321) in ONE pass over the
+// left keys.  Nothing per left row is written: no counts, no packed values, no offsets_to_replicate, no row ids, no gathered column --
+// the plan `SELECT count(), sum(right.v) FROM left JOIN right USING k` only ever needed two numbers.
+// Every lane keeps R rows in flight (the table and payload reads are dependent random accesses); the {key, value} cell is fetched
+// with one 16-byte load.
+// ---------------------------------------------------------------------------------------------
+typedef u64 jv2 __attribute__((ext_vector_type(2)));
+
+template <bool PF>
+__device__ __forceinline__ bool jt_find_value(const JoinTable & t, const PfView & pf, u64 key, u64 & value, u32 & slot_out)
+{
+    if (key == 0)
+    {
+        if (!t.ctrl->has_zero)
+            return false;
+        slot_out = (u32)t.capacity;
+        value = t.kv[2 * t.capacity + 1];
+        return true;
+    }
+    if constexpr (PF)
+        if (!jt_pf_maybe(pf, key))
+            return false;
+    const u64 mask = t.capacity - 1;
+    u64 slot = dev_intHash64(key) & mask;
+    for (u64 step = 0; step < t.capacity; ++step)
+    {
+        const jv2 c = *(const jv2 *)(t.kv + 2 * slot);
+        if (c.x == key)
+        {
+            value = c.y;
+            slot_out = (u32)slot;
+            return true;
+        }
+        if (c.x == 0)
+            return false;
+        slot = (slot + 1) & mask;
+    }
+    return false;
+}
+
+// payload value at flat row f, widened to the 8-byte sum operand (integers sign/zero-extended, floats as Float64 bits)
+__device__ __forceinline__ u64 jload_payload(const void * p, int type, u64 f)
+{
+    switch (type)
+    {
+        case CHGPU_I64: case CHGPU_U64: case CHGPU_F64: return ((const u64 *)p)[f];
+        case CHGPU_U32: return ((const u32 *)p)[f];
+        case CHGPU_I32: return (u64)(i64)((const i32 *)p)[f];
+        case CHGPU_U16: return ((const u16 *)p)[f];
+        case CHGPU_I16: return (u64)(i64)((const i16 *)p)[f];
+        case CHGPU_U8: return ((const u8 *)p)[f];
+        case CHGPU_I8: return (u64)(i64)((const i8 *)p)[f];
+        default: return (u64)__double_as_longlong((double)((const float *)p)[f]); // CHGPU_F32
+    }
+}
+
+template <bool PF, bool FLOAT>
+__global__ __launch_bounds__(JT) void k_join_probe_agg(JoinTable t, int variant, const void * __restrict__ keys, int key_type, const u8 * __restrict__ null_map, u64 n,
+                                                       const void * __restrict__ payload, int payload_type, const u64 * __restrict__ block_base, u64 n_blocks,
+                                                       u64 * __restrict__ partials /* [grid][2] */)
+{
+    PfView pf{};
+    if constexpr (PF)
+        pf = jt_pf_view(t);
+    constexpr int R = 4;
+    u64 cnt = 0, isum = 0;
+    double fsum = 0.0;
+    auto flat_of = [&](u64 rowid) -> u64 { return n_blocks == 1 ? (rowid & 0xFFFFFFFFull) : block_base[rowid >> 32] + (rowid & 0xFFFFFFFFull); };
+    auto add_row = [&](u64 rowid) {
+        if (!payload)
+            return;
+        const u64 b = jload_payload(payload, payload_type, flat_of(rowid));
+        if constexpr (FLOAT)
+            fsum += __longlong_as_double((long long)b);
+        else
+            isum += b;
+    };
+    const u64 stride = (u64)gridDim.x * JT;
+    for (u64 i0 = (u64)blockIdx.x * JT + threadIdx.x; i0 < n; i0 += stride * R)
+    {
+        u64 key[R];
+        bool ok[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+        {
+            const u64 i = i0 + (u64)q * stride;
+            ok[q] = i < n;
+            key[q] = ok[q] ? jload_key(keys, key_type, i) : 0;
+            ok[q] = ok[q] && !(null_map && null_map[i]);
+        }
+        u64 val[R];
+        u32 slot[R];
+        bool found[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+            found[q] = ok[q] && jt_find_value<PF>(t, pf, key[q], val[q], slot[q]);
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+        {
+            if (i0 + (u64)q * stride >= n)
+                continue;
+            // a row with a NULL key finds nothing (HashJoinMethodsImpl.h:451-452) but is still a left row of LEFT / ANTI joins
+            if (!found[q])
+            {
+                // addNotFoundRow<add_missing>: a default right row (payload 0) for LEFT ALL / LEFT ANY, the kept row of ANTI
+                cnt += (variant == PV_ALL_LEFT || variant == PV_ANY_LEFT || variant == PV_ANTI_LEFT) ? 1 : 0;
+                continue;
+            }
+            if (variant == PV_ANTI_LEFT)
+                continue;
+            const u64 v = val[q];
+            if (!(v & JV_MULTI))
+            {
+                cnt += 1;
+                add_row(v);
+                continue;
+            }
+            const u64 c0 = (v >> 40) & JV_CNT_SAT;
+            const u32 c = c0 < JV_CNT_SAT ? (u32)c0 : t.cnt[slot[q]];
+            const u64 * run = t.rowids + (v & JV_START_MASK);
+            cnt += c;
+            for (u32 k = 0; k < c; ++k)
+                add_row(run[k]);
+        }
+    }
+    // fixed-order reduction: lane partials -> wave (shuffle tree) -> workgroup (LDS, wave order) -> one partial per workgroup
+    __shared__ u64 sh_c[JT / 64], sh_s[JT / 64];
+    cnt = wave_reduce_add_u64(cnt);
+    u64 sbits;
+    if constexpr (FLOAT)
+        sbits = (u64)__double_as_longlong(wave_reduce_add_f64(fsum));
+    else
+        sbits = wave_reduce_add_u64(isum);
+    if ((threadIdx.x & 63) == 0)
+    {
+        sh_c[threadIdx.x >> 6] = cnt;
+        sh_s[threadIdx.x >> 6] = sbits;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        u64 c = 0, si = 0;
+        double sf = 0.0;
+        for (u32 w = 0; w < JT / 64; ++w)
+        {
+            c += sh_c[w];
+            if constexpr (FLOAT)
+                sf += __longlong_as_double((long long)sh_s[w]);
+            else
+                si += sh_s[w];
+        }
+        partials[2 * (u64)blockIdx.x] = c;
+        partials[2 * (u64)blockIdx.x + 1] = FLOAT ? (u64)__double_as_longlong(sf) : si;
+    }
+}
+
+template <bool FLOAT>
+__global__ __launch_bounds__(64) void k_join_probe_agg_finish(const u64 * __restrict__ partials, u32 n_parts, u64 * __restrict__ out2)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    u64 c = 0, si = 0;
+    double sf = 0.0;
+    for (u32 p = 0; p < n_parts; ++p) // workgroup order: run-to-run reproducible Float64 sums
+    {
+        c += partials[2 * (u64)p];
+        if constexpr (FLOAT)
+            sf += __longlong_as_double((long long)partials[2 * (u64)p + 1]);
+        else
+            si += partials[2 * (u64)p + 1];
+    }
+    out2[0] = c;
+    out2[1] = FLOAT ? (u64)__double_as_longlong(sf) : si;
+}
+
+extern "C" int chgpu_join_probe_agg(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map, const chgpu_col * right_payload,
+                                    uint64_t * count_out, void * sum_out)
+{
+    CHGPU_REQUIRE(j && key_col && count_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(!right_payload || sum_out, CHGPU_ERR_BAD_ARGUMENTS, "sum_out must not be NULL when a payload column is given");
+    CHGPU_REQUIRE(key_col->type == j->key_type, CHGPU_ERR_BAD_ARGUMENTS, "left key column has type %d, expected %d", key_col->type, j->key_type);
+    if (null_map)
+        CHGPU_REQUIRE(null_map->type == CHGPU_U8 && null_map->rows == key_col->rows, CHGPU_ERR_SIZES_MISMATCH, "null map size mismatch");
+    CHGPU_REQUIRE(!(j->kind == CHGPU_JOIN_INNER && j->strictness == CHGPU_STRICT_ANY), CHGPU_ERR_NOT_IMPLEMENTED,
+                  "INNER ANY consumes right rows across joinBlock calls (setUsedOnce): use chgpu_join_probe");
+    CHGPU_REQUIRE(!jf_track_used(j), CHGPU_ERR_NOT_IMPLEMENTED, "RIGHT / FULL joins emit non-joined rows afterwards: use chgpu_join_probe");
+    if (!j->finished)
+        CHGPU_TRY(chgpu_join_finish_build(j));
+    if (right_payload)
+    {
+        CHGPU_REQUIRE(chgpu_type_size(right_payload->type) != 0, CHGPU_ERR_BAD_ARGUMENTS, "payload type %d", right_payload->type);
+        CHGPU_REQUIRE(right_payload->rows == j->total_rows, CHGPU_ERR_SIZES_MISMATCH,
+                      "payload column has %llu rows, the right side has %llu (it must be the right blocks' column glued in insertion order)",
+                      (unsigned long long)right_payload->rows, (unsigned long long)j->total_rows);
+    }
+    chgpu_ctx * ctx = j->ctx;
+    const u64 n = key_col->rows;
+    int variant;
+    if (j->strictness == CHGPU_STRICT_ALL) variant = jf_left_kind(j) == CHGPU_JOIN_LEFT ? PV_ALL_LEFT : PV_ALL_INNER;
+    else if (j->strictness == CHGPU_STRICT_SEMI) variant = PV_SEMI_LEFT;
+    else if (j->strictness == CHGPU_STRICT_ANTI) variant = PV_ANTI_LEFT;
+    else variant = PV_ANY_LEFT;
+    const bool is_float = right_payload && chgpu_type_is_float(right_payload->type);
+    u64 res[2] = {0, 0};
+    if (n)
+    {
+        const u32 grid = chgpu_grid_for(ctx, (n + 3) / 4, JT, 8);
+        void * scratch = nullptr;
+        CHGPU_TRY(chgpu_scratch(ctx, ((size_t)grid + 1) * 16, &scratch));
+        u64 * partials = (u64 *)scratch;
+        u64 * out2 = partials + 2 * (size_t)grid;
+        const void * pp = right_payload ? right_payload->data : nullptr;
+        const int pt = right_payload ? right_payload->type : CHGPU_U64;
+        const u8 * nm = null_map ? (const u8 *)null_map->data : nullptr;
+#define CHGPU_JPA(PFV, FL)                                                                                                                              \
+    hipLaunchKernelGGL((k_join_probe_agg<PFV, FL>), dim3(grid), dim3(JT), 0, ctx->stream, j->t, variant, (const void *)key_col->data, j->key_type, nm, n, pp, pt, \
+                       (const u64 *)j->block_base_dev, (u64)j->blocks.size(), partials)
+        if (j->t.pf)
+        {
+            if (is_float) CHGPU_JPA(true, true); else CHGPU_JPA(true, false);
+        }
+        else
+        {
+            if (is_float) CHGPU_JPA(false, true); else CHGPU_JPA(false, false);
+        }
+#undef CHGPU_JPA
+        if (is_float)
+            hipLaunchKernelGGL(k_join_probe_agg_finish<true>, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)partials, grid, out2);
+        else
+            hipLaunchKernelGGL(k_join_probe_agg_finish<false>, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)partials, grid, out2);
+        ctx->counters[6] += 2;
+        CHGPU_HIP(hipGetLastError());
+        CHGPU_TRY(chgpu_read_back(ctx, out2, res, sizeof(res)));
+    }
+    *count_out = res[0];
+    if (sum_out)
+        memcpy(sum_out, &res[1], 8);
+    ctx->counters[3] += n;
+    ctx->counters[4] += res[0];
     return CHGPU_OK;
 }

@@ -86,6 +86,25 @@ class HashJoin:
                     offsets=Column(self.ctx, oh) if oh.value else None,
                     right_rowid=Column(self.ctx, rh) if need_right_rows else None)
 
+    def probe_count_sum(self, keys, payload=None, null_map=None):
+        """joinBlock + `SELECT count(), sum(payload)` behind it, fused (chgpu_join_probe_agg): -> (count, sum).  payload: the right
+        side's column over all right blocks in insertion order (None: count only, sum is None).  The sum has SumSimple's type:
+        a Python int for integer payloads (signed for signed types), a float for Float32/64."""
+        k = self._col(keys, self.key_dtype)
+        nm = self._col(null_map, np.uint8) if null_map is not None else None
+        p = self._col(payload) if payload is not None else None
+        cnt = C.c_uint64(0)
+        bits = C.c_uint64(0)
+        K.check(K.lib().chgpu_join_probe_agg(self._h, k._h, nm._h if nm else None, p._h if p else None, C.byref(cnt),
+                                             C.byref(bits) if p else None))
+        if p is None:
+            return int(cnt.value), None
+        kind = np.dtype(p.dtype).kind
+        raw = np.array([bits.value], dtype=np.uint64)
+        if kind == "f":
+            return int(cnt.value), float(raw.view(np.float64)[0])
+        return int(cnt.value), int(raw.view(np.int64)[0]) if kind == "i" else int(bits.value)
+
     def non_joined_rows(self):
         """IJoin::getNonJoinedBlocks for RIGHT / FULL joins: (right_block, right_row) of the build rows no left row matched,
         in insertion order (call after the last probe)"""

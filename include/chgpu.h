@@ -401,6 +401,16 @@ int chgpu_join_total_rows(chgpu_join * j, uint64_t * rows, uint64_t * keys);
 int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map_u8,
                      uint64_t max_joined_block_rows, chgpu_col ** filter_u8, chgpu_col ** offsets_u64,
                      chgpu_col ** right_rowid_u64, uint64_t * n_out, uint64_t * n_left_consumed);
+/* joinBlock with the aggregation that consumes its output fused behind it: `SELECT count(), sum(right.payload) FROM left JOIN right`
+   (HashJoinMethodsImpl.h:402-549 -> AddedColumns' lazy gather, AddedColumns.cpp:39-131 -> Aggregator::executeWithoutKeyImpl,
+   Aggregator.cpp:1276-1321).  One pass over the left keys; nothing per left row is written (no offsets_to_replicate, no row ids, no
+   gathered column).  *count_out = rows the join would emit; sum_out = 8 bytes typed like SumSimple(payload type): the sum of the
+   payload over those rows (default rows of LEFT joins add 0; LEFT ANTI emits no right row).  right_payload is the right Blocks'
+   column glued in insertion order (chgpu_col_concat), may be NULL for count only.  Variants: INNER ALL, LEFT ALL, LEFT ANY,
+   LEFT SEMI, LEFT ANTI; INNER ANY / RIGHT / FULL -> CHGPU_ERR_NOT_IMPLEMENTED (stateful across calls: use chgpu_join_probe).
+   Float sums are reduced in a fixed order: run-to-run reproducible. */
+int chgpu_join_probe_agg(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map_u8, const chgpu_col * right_payload,
+                         uint64_t * count_out, void * sum_out);
 /* (block_index << 32 | row) ids -> running ordinal of the row over all right blocks in insertion order (all-ones stays
    all-ones): the index into payload columns concatenated with chgpu_col_concat, i.e. fillFromBlocksAndRowNumbers
    (src/Columns/IColumn.cpp:515-526) for many right Blocks */
@@ -411,6 +421,40 @@ int chgpu_join_flatten_rowids(chgpu_join * j, const chgpu_col * right_rowid_u64,
    FULL like LEFT. */
 int chgpu_join_non_joined_rows(chgpu_join * j, chgpu_col ** right_rowid_u64, uint64_t * rows_out);
 int chgpu_join_free(chgpu_join * j);
+
+/* ================================================================================================
+ * (e) multi-GPU  —  the exchange step of the sharded operators over RCCL (xGMI inside a node); one process per GPU.
+ * ConcurrentHashJoin::dispatchBlock hands the sub-blocks of a scattered Block to the per-slot HashJoins
+ * (src/Interpreters/ConcurrentHashJoin.cpp:538-565), a parallel merge hands two-level buckets to their owners
+ * (ConcurrentHashJoin.cpp:600-653; src/Processors/Transforms/AggregatingTransform.cpp:120-136): threads of one address space there,
+ * ranks exchanging hash partitions here.  Shard of a key = ((crc32c(key) >> 24) & 0xFF) & (world - 1) (chgpu_hash_to_selector),
+ * so world is a power of two <= 256 (ConcurrentHashJoin.cpp:158).  A communicator binds one rank to one chgpu_ctx; all its
+ * traffic runs on that context's stream.  librccl is loaded on first use; without it these calls fail with CHGPU_ERR_DEVICE.
+ * Sequence: rank 0 calls chgpu_comm_unique_id and hands the 128 bytes to every rank out of band (the host pipeline's own control
+ * plane), every rank calls chgpu_comm_init (collective).  Then per exchange: chgpu_partition_by_hash -> chgpu_all_to_all_counts
+ * -> chgpu_all_to_all per column.
+ * ============================================================================================== */
+#define CHGPU_UNIQUE_ID_BYTES 128
+typedef struct chgpu_comm chgpu_comm;
+int chgpu_comm_unique_id(uint8_t id_out[CHGPU_UNIQUE_ID_BYTES]);
+int chgpu_comm_init(chgpu_ctx * ctx, int rank, int world, const uint8_t unique_id[CHGPU_UNIQUE_ID_BYTES], chgpu_comm ** out);
+int chgpu_comm_destroy(chgpu_comm * comm);
+int chgpu_comm_rank(const chgpu_comm * comm);
+int chgpu_comm_world(const chgpu_comm * comm);
+/* [0] bytes sent to other ranks [1] bytes received from other ranks [2] collectives issued */
+int chgpu_comm_stats(const chgpu_comm * comm, uint64_t out[3]);
+/* recv_counts[p] = the send_counts[my rank] of rank p: sizes the receive side of the all-to-all that follows (host arrays of `world`) */
+int chgpu_all_to_all_counts(chgpu_comm * comm, const uint64_t * send_counts, uint64_t * recv_counts);
+/* send: shards back to back as chgpu_partition_by_hash returns them (shard p = send_counts[p] rows for rank p); *recv_out: a new column of
+   sum(recv_counts) rows, what ranks 0..world-1 sent here in rank order.  One grouped send/recv: every xGMI link carries its peer's
+   partition at once; the own partition is a device copy.  Asynchronous on the context's stream. */
+int chgpu_all_to_all(chgpu_comm * comm, const chgpu_col * send, const uint64_t * send_counts, const uint64_t * recv_counts, chgpu_col ** recv_out);
+/* mergeWithoutKeyDataImpl across ranks (src/Interpreters/Aggregator.cpp:2584-2628): element-wise wrap-around sum of a UInt64 / Int64
+   device column over all ranks, in place (asynchronous); _host: the same for <= 64 host values (synchronises) */
+int chgpu_all_reduce_u64(chgpu_comm * comm, chgpu_col * inout_u64);
+int chgpu_all_reduce_u64_host(chgpu_comm * comm, uint64_t * values, uint32_t n);
+/* returns once every rank's queued work on its stream has finished */
+int chgpu_comm_barrier(chgpu_comm * comm);
 
 #ifdef __cplusplus
 }

@@ -121,6 +121,8 @@ def lib() -> C.CDLL:
             "cho_join_need_filter": (i32, [vp]),
             "cho_join_need_replication": (i32, [vp]),
             "cho_hash_to_selector": (None, [i32, vp, sz, sz, vp]),
+            "cho_groupby_pipeline": (vp, [i32, i32, vp, vp, vp, vp, sz, sz, i32, u64, vp]),
+            "cho_join_count_sum_pipeline": (i32, [vp, vp, sz, vp, sz, sz, i32, vp, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -514,6 +516,35 @@ class HashJoin:
             left = np.arange(c, dtype=np.int64)
         assert left.shape[0] == r["added_block"].shape[0], (left.shape, r["added_block"].shape)
         return left, r["added_block"], r["added_row"], c
+
+
+def groupby_pipeline(keys: np.ndarray, aggs, args, threads: int = 1, block_rows: int = DEFAULT_BLOCK_SIZE, two_level_threshold: int = 100000):
+    """N pipeline streams over Blocks -> merged Aggregator, (consume_s, merge_s).  The CPU baseline of config C3."""
+    A = Aggregator.__new__(Aggregator)
+    A.key_tag = TAG_OF[np.dtype(keys.dtype)]
+    A.aggs = [(k, (TAG_OF[np.dtype(d)] if d is not None else I64)) for k, d in aggs]
+    kinds = np.array([k for k, _ in A.aggs], dtype=np.int32)
+    types = np.array([t for _, t in A.aggs], dtype=np.int32)
+    keep = [np.ascontiguousarray(a) if a is not None else None for a in args]
+    ptrs = (C.c_void_p * max(1, len(keep)))(*[(a.ctypes.data if a is not None else None) for a in keep])
+    k = np.ascontiguousarray(keys)
+    secs = np.zeros(2, dtype=np.float64)
+    A._h = lib().cho_groupby_pipeline(A.key_tag, len(A.aggs), _p(kinds), _p(types), _p(k), ptrs, k.shape[0], block_rows, threads,
+                                      two_level_threshold, _p(secs))
+    assert A._h
+    return A, (float(secs[0]), float(secs[1]))
+
+
+def join_count_sum_pipeline(bk: np.ndarray, bv: np.ndarray, pk: np.ndarray, threads: int = 1, block_rows: int = DEFAULT_BLOCK_SIZE):
+    """SELECT count(), sum(bv) FROM probe INNER JOIN build ON pk = bk -> (count, sum as u64 bits, build_s, probe_s).  CPU baseline of C4."""
+    bk = np.ascontiguousarray(bk).view(np.uint64)
+    pk = np.ascontiguousarray(pk).view(np.uint64)
+    bv = np.ascontiguousarray(bv).view(np.int64)
+    cnt, sm = C.c_uint64(0), C.c_uint64(0)
+    secs = np.zeros(2, dtype=np.float64)
+    rc = lib().cho_join_count_sum_pipeline(_p(bk), _p(bv), bk.shape[0], _p(pk), pk.shape[0], block_rows, threads, C.byref(cnt), C.byref(sm), _p(secs))
+    assert rc == 0
+    return int(cnt.value), int(sm.value), float(secs[0]), float(secs[1])
 
 
 def hash_to_selector(keys: np.ndarray, num_shards: int) -> np.ndarray:

@@ -1089,7 +1089,7 @@ struct cho_agg
     aggmap_t single;              /* AggregatedDataWithUInt64Key (AggregatedData.h:38) */
     aggmap_t * impls;             /* AggregatedDataWithUInt64KeyTwoLevel: 256 sub-tables */
     char * without_key;           /* AggregatedDataWithoutKey */
-    arena_t arenas[64];           /* aggregates_pools: own + adopted on merge */
+    arena_t arenas[512];           /* aggregates_pools: own + adopted on merge */
     int n_arenas;
 };
 
@@ -1315,7 +1315,7 @@ int cho_agg_merge(cho_agg * dst, cho_agg * src)
     else
         agg_merge_table(dst, &dst->single, &src->single); /* mergeSingleLevelDataImpl (:2631-2683) */
     /* the destination keeps the source arenas alive (aggregates_pools adoption, :2500-2520) */
-    for (int i = 0; i < src->n_arenas && dst->n_arenas < 64; ++i)
+    for (int i = 0; i < src->n_arenas && dst->n_arenas < 512; ++i)
     {
         dst->arenas[dst->n_arenas++] = src->arenas[i];
         src->arenas[i].head = NULL;
@@ -1652,4 +1652,277 @@ void cho_hash_to_selector(int type, const void * keys, size_t n, size_t num_shar
        two-level (HasGetBucketFromHashMemberFunc) -> getBucketFromHash(hash) & (num_shards - 1) */
     for (size_t i = 0; i < n; ++i)
         selector[i] = cho_two_level_bucket(cho_intHashCRC32(load_key_zext(type, keys, i))) & (num_shards - 1);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CPU-baseline drivers for configs C3 / C4 (bench.py's cpu_baseline leg and the parity check on the sample).
+ * Same functions as above, driven natively per Block of block_rows rows by N streams like the reference's pipeline:
+ *   GROUP BY: one AggregatingTransform (own AggregatedDataVariants) per stream (AggregatingTransform.cpp:664-693), the hash
+ *     table cell of row i + look_ahead prefetched while row i is processed (Aggregator.cpp:1025-1054, HashTable.h:957-961,
+ *     Prefetching.h:27-52: look-ahead 4..32; 16 here), tables converted to two-level past the threshold, then the 256 buckets
+ *     merged by the streams in parallel, each bucket claimed atomically (AggregatingTransform.cpp:120-136 -> mergeBucketImpl,
+ *     Aggregator.cpp:2691-2725).
+ *   JOIN: HashJoin built by one stream Block by Block (addBlockToJoin), probed by N streams over their own Blocks (joinBlock is
+ *     concurrent on an immutable table, IJoin.h:92-93), payload gathered per appended row (fillFromBlocksAndRowNumbers,
+ *     IColumn.cpp:515-526) and summed -- the checksum form `SELECT count(), sum(bv)`.
+ * ---------------------------------------------------------------------------------------------- */
+#include <time.h>
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* executeImplBatch<prefetch = true> for the one-number methods: the same loop as cho_agg_execute_on_block with the look-ahead */
+static int agg_execute_on_block_prefetch(cho_agg * a, const void * keys, const void * const * args, size_t row_begin, size_t row_end, char ** places)
+{
+    const size_t look_ahead = 16;
+    for (size_t i = row_begin; i < row_end; ++i)
+    {
+        if (i + look_ahead < row_end)
+        {
+            uint64_t pk = load_key_zext(a->key_type, keys, i + look_ahead);
+            size_t ph = cho_intHashCRC32(pk);
+            aggmap_t * pt = agg_table_for_hash(a, ph);
+            __builtin_prefetch(&pt->buf[aggmap_place(pt, ph)]);
+        }
+        uint64_t key = load_key_zext(a->key_type, keys, i);
+        size_t h = cho_intHashCRC32(key);
+        int inserted;
+        aggmap_cell * c = aggmap_emplace_hashed(agg_table_for_hash(a, h), key, h, &inserted);
+        if (inserted)
+        {
+            c->mapped = NULL;
+            char * place = (char *)arena_aligned_alloc(&a->arenas[0], a->total_size_of_aggregate_states, 8);
+            memset(place, 0, a->total_size_of_aggregate_states);
+            c->mapped = place;
+        }
+        places[i - row_begin] = c->mapped;
+    }
+    for (int j = 0; j < a->n_aggs; ++j)
+        for (size_t i = row_begin; i < row_end; ++i)
+            agg_add_row(a, j, places[i - row_begin], args ? args[j] : NULL, i);
+    if (!a->is_two_level && a->two_level_threshold && a->single.m_size >= a->two_level_threshold)
+        agg_convert_to_two_level(a);
+    return 0;
+}
+
+typedef struct
+{
+    cho_agg * agg;
+    const void * keys;
+    const void * const * args;
+    size_t lo, hi, block_rows;
+} gb_stream;
+
+static void * gb_stream_run(void * p)
+{
+    gb_stream * s = (gb_stream *)p;
+    char ** places = (char **)malloc(sizeof(char *) * (s->block_rows ? s->block_rows : 1));
+    for (size_t b = s->lo; b < s->hi; b += s->block_rows)
+    {
+        size_t e = b + s->block_rows < s->hi ? b + s->block_rows : s->hi;
+        agg_execute_on_block_prefetch(s->agg, s->keys, s->args, b, e, places);
+    }
+    free(places);
+    return NULL;
+}
+
+typedef struct
+{
+    cho_agg ** aggs;
+    int n;
+    int * next_bucket; /* shared, claimed with an atomic increment */
+} gb_merge;
+
+static void * gb_merge_run(void * p)
+{
+    gb_merge * m = (gb_merge *)p;
+    for (;;)
+    {
+        int b = __atomic_fetch_add(m->next_bucket, 1, __ATOMIC_RELAXED);
+        if (b >= CHO_NUM_BUCKETS)
+            break;
+        for (int t = 1; t < m->n; ++t)
+            agg_merge_table(m->aggs[0], &m->aggs[0]->impls[b], &m->aggs[t]->impls[b]);
+    }
+    return NULL;
+}
+
+/* returns the merged aggregator (caller frees with cho_agg_free); seconds_out[0] = consume, [1] = merge */
+cho_agg * cho_groupby_pipeline(int key_type, int n_aggs, const int * kinds, const int * arg_types, const void * keys, const void * const * args,
+                               size_t n, size_t block_rows, int threads, uint64_t two_level_threshold, double * seconds_out)
+{
+    if (threads < 1)
+        threads = 1;
+    if (threads > 256)
+        threads = 256;
+    if (!block_rows)
+        block_rows = CHO_DEFAULT_BLOCK_SIZE;
+    cho_agg ** aggs = (cho_agg **)calloc((size_t)threads, sizeof(cho_agg *));
+    gb_stream * st = (gb_stream *)calloc((size_t)threads, sizeof(gb_stream));
+    pthread_t * th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    size_t n_blocks = (n + block_rows - 1) / block_rows;
+    double t0 = now_s();
+    for (int t = 0; t < threads; ++t)
+    {
+        aggs[t] = cho_agg_create(key_type, n_aggs, kinds, arg_types, two_level_threshold);
+        st[t].agg = aggs[t];
+        st[t].keys = keys;
+        st[t].args = args;
+        st[t].block_rows = block_rows;
+        size_t b0 = n_blocks * (size_t)t / (size_t)threads, b1 = n_blocks * (size_t)(t + 1) / (size_t)threads;
+        st[t].lo = b0 * block_rows;
+        st[t].hi = b1 * block_rows < n ? b1 * block_rows : n;
+        if (threads > 1)
+            pthread_create(&th[t], NULL, gb_stream_run, &st[t]);
+        else
+            gb_stream_run(&st[t]);
+    }
+    if (threads > 1)
+        for (int t = 0; t < threads; ++t)
+            pthread_join(th[t], NULL);
+    double t1 = now_s();
+    if (threads > 1 && key_type >= 0)
+    {
+        int any_two_level = 0;
+        for (int t = 0; t < threads; ++t)
+            any_two_level |= aggs[t]->is_two_level;
+        if (any_two_level)
+        {
+            /* prepareVariantsToMerge: all become two-level, then bucket-parallel merge */
+            for (int t = 0; t < threads; ++t)
+                agg_convert_to_two_level(aggs[t]);
+            int next = 0;
+            gb_merge m = {aggs, threads, &next};
+            for (int t = 0; t < threads; ++t)
+                pthread_create(&th[t], NULL, gb_merge_run, &m);
+            for (int t = 0; t < threads; ++t)
+                pthread_join(th[t], NULL);
+            for (int t = 1; t < threads; ++t)
+                for (int i = 0; i < aggs[t]->n_arenas && aggs[0]->n_arenas < 512; ++i)
+                {
+                    aggs[0]->arenas[aggs[0]->n_arenas++] = aggs[t]->arenas[i];
+                    aggs[t]->arenas[i].head = NULL;
+                    aggs[t]->arenas[i].total = 0;
+                }
+        }
+        else
+            for (int t = 1; t < threads; ++t)
+                cho_agg_merge(aggs[0], aggs[t]);
+    }
+    else
+        for (int t = 1; t < threads; ++t)
+            cho_agg_merge(aggs[0], aggs[t]);
+    double t2 = now_s();
+    if (seconds_out)
+    {
+        seconds_out[0] = t1 - t0;
+        seconds_out[1] = t2 - t1;
+    }
+    cho_agg * res = aggs[0];
+    for (int t = 1; t < threads; ++t)
+        cho_agg_free(aggs[t]);
+    free(aggs);
+    free(st);
+    free(th);
+    return res;
+}
+
+typedef struct
+{
+    cho_join * j;
+    const uint64_t * pk;
+    const int64_t * bv; /* payload of the build side, all right Blocks back to back */
+    size_t lo, hi, block_rows, build_block_rows;
+    uint64_t count, sum;
+} jp_stream;
+
+static void * jp_stream_run(void * p)
+{
+    jp_stream * s = (jp_stream *)p;
+    size_t cap = s->block_rows * 4 + 16;
+    uint64_t * offsets = (uint64_t *)malloc(8 * s->block_rows);
+    uint8_t * filter = (uint8_t *)malloc(s->block_rows);
+    int64_t * ab = (int64_t *)malloc(8 * cap);
+    int64_t * ar = (int64_t *)malloc(8 * cap);
+    uint64_t count = 0, sum = 0;
+    for (size_t b = s->lo; b < s->hi;)
+    {
+        size_t rows = b + s->block_rows < s->hi ? s->block_rows : s->hi - b;
+        size_t n_added = 0;
+        size_t consumed = cho_join_probe(s->j, s->pk + b, rows, NULL, cap / 2, filter, offsets, ab, ar, cap, &n_added);
+        if (n_added > cap)
+            n_added = cap; /* cannot happen with cap/2 as max_joined_block_rows unless one key has > cap/2 rows */
+        for (size_t k = 0; k < n_added; ++k)
+            if (ab[k] >= 0)
+                sum += (uint64_t)s->bv[(size_t)ab[k] * s->build_block_rows + (size_t)ar[k]];
+        count += n_added;
+        b += consumed ? consumed : rows;
+    }
+    s->count = count;
+    s->sum = sum;
+    free(offsets);
+    free(filter);
+    free(ab);
+    free(ar);
+    return NULL;
+}
+
+/* `SELECT count(), sum(bv) FROM probe INNER JOIN build ON pk = bk` (strictness ALL); seconds_out[0] = build, [1] = probe */
+int cho_join_count_sum_pipeline(const uint64_t * bk, const int64_t * bv, size_t nb, const uint64_t * pk, size_t np, size_t block_rows, int threads,
+                                uint64_t * count_out, uint64_t * sum_out, double * seconds_out)
+{
+    if (threads < 1)
+        threads = 1;
+    if (threads > 256)
+        threads = 256;
+    if (!block_rows)
+        block_rows = CHO_DEFAULT_BLOCK_SIZE;
+    double t0 = now_s();
+    cho_join * j = cho_join_create(CHO_JOIN_INNER, CHO_STRICT_ALL, 0);
+    if (!j)
+        return -1;
+    for (size_t b = 0; b < nb; b += block_rows)
+        cho_join_add_block(j, bk + b, b + block_rows < nb ? block_rows : nb - b, NULL, NULL);
+    double t1 = now_s();
+    jp_stream * st = (jp_stream *)calloc((size_t)threads, sizeof(jp_stream));
+    pthread_t * th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    size_t n_blocks = (np + block_rows - 1) / block_rows;
+    for (int t = 0; t < threads; ++t)
+    {
+        st[t].j = j;
+        st[t].pk = pk;
+        st[t].bv = bv;
+        st[t].block_rows = block_rows;
+        st[t].build_block_rows = block_rows;
+        size_t b0 = n_blocks * (size_t)t / (size_t)threads, b1 = n_blocks * (size_t)(t + 1) / (size_t)threads;
+        st[t].lo = b0 * block_rows;
+        st[t].hi = b1 * block_rows < np ? b1 * block_rows : np;
+        if (threads > 1)
+            pthread_create(&th[t], NULL, jp_stream_run, &st[t]);
+        else
+            jp_stream_run(&st[t]);
+    }
+    uint64_t count = 0, sum = 0;
+    for (int t = 0; t < threads; ++t)
+    {
+        if (threads > 1)
+            pthread_join(th[t], NULL);
+        count += st[t].count;
+        sum += st[t].sum;
+    }
+    double t2 = now_s();
+    *count_out = count;
+    *sum_out = sum;
+    if (seconds_out)
+    {
+        seconds_out[0] = t1 - t0;
+        seconds_out[1] = t2 - t1;
+    }
+    free(st);
+    free(th);
+    cho_join_free(j);
+    return 0;
 }

@@ -167,6 +167,15 @@ int cho_join_need_replication(const cho_join *);
 /* selector[i] = getBucketFromHash(hashCRC32(key)) & (num_shards-1) ; num_shards power of two <= 256 */
 void cho_hash_to_selector(int type, const void * keys, size_t n, size_t num_shards, uint64_t * selector);
 
+/* ---- CPU-baseline drivers (bench.py cpu_baseline leg; also the parity check on the sample): N pipeline streams over Blocks ---- */
+/* GROUP BY: one Aggregator per stream with the reference's hash-cell prefetch (Aggregator.cpp:1025-1054), two-level conversion,
+   bucket-parallel merge (AggregatingTransform.cpp:120-136).  Returns the merged aggregator; seconds_out[2] = {consume, merge}. */
+cho_agg * cho_groupby_pipeline(int key_type, int n_aggs, const int * kinds, const int * arg_types, const void * keys, const void * const * args,
+                               size_t n, size_t block_rows, int threads, uint64_t two_level_threshold, double * seconds_out);
+/* SELECT count(), sum(bv) FROM probe INNER JOIN build ON pk = bk (ALL): build by one stream, probe by N; seconds_out[2] = {build, probe} */
+int cho_join_count_sum_pipeline(const uint64_t * bk, const int64_t * bv, size_t nb, const uint64_t * pk, size_t np, size_t block_rows, int threads,
+                                uint64_t * count_out, uint64_t * sum_out, double * seconds_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,13 +5,15 @@
 #   pmc_write_<tag>/  rocprofv3 --pmc WRITE_SIZE   (own pass)
 # Counters are never combined with trace domains other than --kernel-trace (node-stability rule of this pool).
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 20 --warmup 3 --no-cpu-baseline"
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $ROOT/bench.py $ARGS > $OUT/prof_${TAG}_bench.json 2> $OUT/prof_${TAG}.err || exit 1
-timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$TAG -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch_${TAG}.err || exit 1
-timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$TAG -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_write_${TAG}.err || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $ROOT/bench.py $ARGS > $OUT/prof_${TAG}_bench.json 2> $OUT/prof_${TAG}.err || exit 1
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$TAG -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch_${TAG}.err || exit 1
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$TAG -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_write_${TAG}.err || exit 1
 python3 $ROOT/profiles/summarize_pmc.py $TAG
+# the per-kernel summary of the --stats pass, for profiles/${TAG}_bench_kernel_stats.csv
+cp $(ls -S $OUT/prof_$TAG/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_bench_kernel_stats.csv

@@ -49,11 +49,50 @@ if main:
     k = res["kernels"][main[0]]
     res["k_filter_sum_hbm_bytes_per_launch"] = k["hbm_read_bytes_per_launch_corrected"] + k["hbm_write_bytes_per_launch"]
 # the workload the counters were collected on (bench.py only quotes `traffic` for the same row count)
+bj = {}
 try:
     bj = json.loads(open(os.path.join(out, f"prof_{tag}_bench.json")).read().strip().splitlines()[-1])
     res["rows"] = bj["config"]["rows_per_gpu"]
 except Exception:
     res["rows"] = None
+
+
+def group_bytes(prefixes):
+    """HBM bytes moved by every launch of the kernels whose name starts with one of `prefixes`, read and write, and the per-kernel split"""
+    tot_r = tot_w = 0.0
+    split = {}
+    for name, k in res["kernels"].items():
+        short = name[5:] if name.startswith("void ") else name
+        if not any(short.startswith(p) for p in prefixes):
+            continue
+        r = k["hbm_read_bytes_per_launch_corrected"] * k["launches"]
+        w = k["hbm_write_bytes_per_launch"] * k["launches"]
+        tot_r += r
+        tot_w += w
+        split[short.split("(")[0][:80]] = {"launches": k["launches"], "read_bytes": r, "write_bytes": w}
+    return tot_r, tot_w, split
+
+
+# configs C3 / C4 of the same command: bytes of their kernel families divided by the number of operator calls the bench made
+cfg = bj.get("configs") or {}
+if "C3" in cfg and cfg["C3"].get("calls"):
+    r, w, split = group_bytes(["k_gb_", "k_agg_"])
+    calls = cfg["C3"]["calls"]
+    res["C3_hbm_bytes_per_call"] = (r + w) / calls
+    res["C3"] = {"calls": calls, "read_bytes_per_call": r / calls, "write_bytes_per_call": w / calls, "algorithmic_bytes": cfg["C3"]["roofline"]["algorithmic_bytes"],
+                 "kernels_total_over_all_calls": split}
+if "C4_one_gpu" in cfg and cfg["C4_one_gpu"].get("probe_calls"):
+    c4 = cfg["C4_one_gpu"]
+    r, w, split = group_bytes(["k_join_", "k_jp_"])
+    # build and probe run a different number of times: weigh each kernel by the calls of its phase
+    per_call = 0.0
+    for name, v in split.items():
+        is_build = any(t in name for t in ("k_join_insert", "k_join_fill", "k_join_root", "k_join_finalize", "k_join_stage"))
+        per_call += (v["read_bytes"] + v["write_bytes"]) / (c4["build_calls"] if is_build else c4["probe_calls"])
+    res["C4_hbm_bytes_per_call"] = per_call
+    res["C4"] = {"build_calls": c4["build_calls"], "probe_calls": c4["probe_calls"], "algorithmic_bytes": c4["roofline"]["algorithmic_bytes"],
+                 "kernels_total_over_all_calls": split}
+res["source"] = f"profiles/{tag}_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs) of `python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline`, profiles/collect.sh {tag}"
 with open(os.path.join(out, f"{tag}_traffic.json"), "w") as fo:
     json.dump(res, fo, indent=1)
-print(json.dumps(res, indent=1)[:3000])
+print(json.dumps({k: v for k, v in res.items() if k != "kernels"}, indent=1)[:6000])
