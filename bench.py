@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--c3-rows", type=int, default=1_000_000_000)
     ap.add_argument("--c4-probe-rows", type=int, default=100_000_000)
     ap.add_argument("--c4-build-rows", type=int, default=10_000_000)
+    ap.add_argument("--sharded-timeout", type=float, default=240.0, help="N>1: seconds the sharded GROUP BY / join section may take before the line is printed without it")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL code path on one GPU)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (rehearsal of the N>1 code path on one GPU)")
     args = ap.parse_args()
@@ -61,6 +62,7 @@ def main():
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")  # --force-dist without a launcher
         # stdout carries exactly one JSON line: RCCL prints its version banner to stdout when the communicator is created
         # (NCCL_DEBUG=VERSION is exported on the GPU boxes), so fd 1 points at stderr until the result is printed
         sys.stdout.flush()
@@ -148,11 +150,6 @@ def main():
         want_cnt = int((a < THRESHOLD).sum().item())
         assert (int(res[W][0]), int(res[W][1])) == (want_sum, want_cnt), (res[W], want_sum, want_cnt)
 
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
     total_rows = n * world * K
     value = total_rows / elapsed
     algo_bytes = 8.0 * n  # 8 B/row, one launch scans the rank's whole column
@@ -205,26 +202,186 @@ def main():
         },
     }
 
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a, args.cpu_sample_rows, ctx, ch)
-    if world == 1 and not args.no_configs:
-        # BASELINE.json configs[2] and configs[3] (its one-GPU half) on the same clock; `value` above stays configs[1]
+    def emit(line):
+        if rank == 0:
+            nonlocal _saved_stdout_fd
+            if _saved_stdout_fd is not None:
+                sys.stdout.flush()
+                os.dup2(_saved_stdout_fd, 1)  # the real stdout is back for the one JSON line
+                os.close(_saved_stdout_fd)
+                _saved_stdout_fd = None
+            print(json.dumps(line), flush=True)
+            if dist is not None:
+                os.dup2(2, 1)  # anything RCCL says while shutting down goes to stderr again
+
+    if world == 1 and dist is None:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a, args.cpu_sample_rows, ctx, ch)
+        if not args.no_configs:
+            # BASELINE.json configs[2] and configs[3] (its one-GPU half) on the same clock; `value` above stays configs[1]
+            del a, col, slots, results
+            ctx.trim()
+            torch.cuda.empty_cache()
+            out["configs"] = {
+                "C3": config_c3(args, ctx, ch, torch, np, dev, stream, tj, not args.no_cpu_baseline),
+                "C4_one_gpu": config_c4(args, ctx, ch, torch, np, dev, stream, tj, not args.no_cpu_baseline),
+            }
+        emit(out)
+        return
+
+    # ---- N > 1 (or --force-dist): the sharded GROUP BY and hash join, exchange over RCCL through the C ABI (chgpu_all_to_all) ----
+    if not args.no_configs:
         del a, col, slots, results
         ctx.trim()
         torch.cuda.empty_cache()
-        out["configs"] = {
-            "C3": config_c3(args, ctx, ch, torch, np, dev, stream, tj, not args.no_cpu_baseline),
-            "C4_one_gpu": config_c4(args, ctx, ch, torch, np, dev, stream, tj, not args.no_cpu_baseline),
-        }
+        # The headline line must survive whatever the exchange does on hardware this build has never seen: if the sharded section has
+        # not finished in time, every rank gives up on it, rank 0 prints the line without it and the process ends.
+        import threading
 
-    if _saved_stdout_fd is not None:
-        sys.stdout.flush()
-        os.dup2(_saved_stdout_fd, 1)  # the real stdout is back for the one JSON line
-        os.close(_saved_stdout_fd)
-    print(json.dumps(out), flush=True)
-    if dist is not None:
-        os.dup2(2, 1)  # anything RCCL says while shutting down goes to stderr again
-        dist.destroy_process_group()
+        def give_up():
+            out["configs"] = {"error": f"sharded section did not finish within {args.sharded_timeout} s"}
+            emit(out)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.sharded_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            out["configs"] = sharded_configs(args, ctx, ch, torch, np, dev, stream, rank, world, dist)
+        except Exception as e:  # noqa: BLE001 -- reported in the line, the headline stays
+            out["configs"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        watchdog.cancel()
+    emit(out)
+    dist.destroy_process_group()
+
+
+def sharded_configs(args, ctx, ch, torch, np, dev, stream, rank, world, dist):
+    """BASELINE.json configs[2] and [3] across `world` GPUs: every rank holds its share of the rows; partial GROUP BY states and join
+    rows are routed by key hash (owner = two-level bucket & (world - 1)) with chgpu_partition_by_hash + ONE chgpu_all_to_all per column
+    over RCCL / xGMI; owners merge / build / probe locally.  torch.distributed is only the control plane here (id broadcast, barriers,
+    the MAX over ranks of the timings)."""
+    from clickhouse_amd import distributed as D
+
+    def bcast(obj):
+        box = [obj]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def max_over_ranks(x):
+        backend_dev = dev if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([x], dtype=torch.float64, device=backend_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0].item())
+
+    torch.cuda.synchronize()
+    comm = D.Comm.from_env(ctx, rank, world, bcast)
+    eng = D.LocalEngine(ctx, comm)
+    res = {}
+
+    def timed(fn, reps=3, warmup=1):
+        out_ = None
+        for _ in range(warmup):
+            out_ = fn()
+        best = []
+        for _ in range(reps):
+            ctx.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out_ = fn()
+            ctx.synchronize()
+            best.append(max_over_ranks(time.perf_counter() - t0))
+        return sum(best) / len(best), out_
+
+    # ---- C3 sharded: every rank aggregates its own rows; partial states travel to their owners ------------------------------
+    rows = args.c3_rows
+    g = torch.Generator(device=dev).manual_seed(2 + 1000 * rank)
+    k = torch.randint(0, 1_000_000, (rows,), dtype=torch.int32, device=dev, generator=g)
+    v = torch.randint(-2**31, 2**31, (rows,), dtype=torch.int64, device=dev, generator=g)
+    kc = ctx.wrap(k.data_ptr(), np.uint32, rows, keepalive=k)
+    vc = ctx.wrap(v.data_ptr(), np.int64, rows, keepalive=v)
+    aggs = [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)]
+
+    def run_c3():
+        sg = D.ShardedGroupBy(eng, np.uint32, aggs, size_hint=1_000_000)
+        sg.add_block(kc, [vc, None])
+        return sg, sg.finish_columns()
+
+    before = comm.stats()
+    secs, (sg, owner) = timed(run_c3)
+    after = comm.stats()
+    gk, (gs, gc) = owner.convert_to_block()
+    # every group lives on exactly one rank, counts partition all rows, sums add up to the sum of all values (mod 2^64)
+    sel = ch.hash_to_selector(ctx.upload(gk), world).numpy() if gk.shape[0] else np.zeros(0, dtype=np.uint32)
+    assert (sel == rank).all(), "a rank holds groups it does not own"
+    tot = comm.all_reduce_u64([gk.shape[0], int(gc.sum()), int(gs.astype(np.uint64).sum(dtype=np.uint64)), int(v.sum().item()) % 2**64])
+    assert tot[1] == rows * world and tot[2] == tot[3], "sharded GROUP BY lost or duplicated rows"
+    res["C3_sharded"] = {"workload": "GROUP BY UInt32 key (1 M groups), sum(Int64) + count(): local pre-aggregation, partial states routed by "
+                                     "key hash with one all-to-all (RCCL), owner-side merge", "rows_per_gpu": rows, "global_rows": rows * world,
+                         "groups": tot[0], "ms": secs * 1e3, "rows_per_s": rows * world / secs, "scaling": "weak",
+                         "exchange_bytes_sent_per_rank": (after["bytes_sent"] - before["bytes_sent"]) // 4,
+                         "parity": "groups owned by exactly one rank; counts partition the rows; sum of sums == sum of values (mod 2^64)"}
+    if world == 1:
+        A = ch.Aggregator(np.uint32, aggs, size_hint=1_000_000, ctx=ctx)
+        A.execute_on_block(kc, [vc, None])
+        ok_, (os_, oc_) = A.convert_to_block()
+        i, j = np.argsort(gk), np.argsort(ok_)
+        assert np.array_equal(gk[i], ok_[j]) and np.array_equal(gs[i], os_[j]) and np.array_equal(gc[i], oc_[j])
+        res["C3_sharded"]["parity"] += "; world 1: equal to the single-GPU operator bit for bit"
+        del A
+    del k, v, kc, vc, sg, owner
+    ctx.trim()
+    torch.cuda.empty_cache()
+
+    # ---- C4 sharded: configs[3]'s per-GPU share (1/8 of 100 M probe rows and of 10 M build rows per rank) -----------------------
+    nb_all, np_all = args.c4_build_rows, args.c4_probe_rows
+    share = 8
+    nb_r, np_r = nb_all // share, np_all // share
+    nb_tot, np_tot = nb_r * world, np_r * world
+    g = torch.Generator(device=dev).manual_seed(5)   # the SAME table on every rank; a rank owns a slice of its rows
+    bk = (torch.randperm(nb_tot, device=dev, generator=g).to(torch.int64) + 1) * 2654435761
+    bv = torch.randint(-2**40, 2**40, (nb_tot,), dtype=torch.int64, device=dev, generator=g)
+    pk = torch.where(torch.rand(np_tot, device=dev, generator=g) < 0.5, bk[torch.randint(0, nb_tot, (np_tot,), device=dev, generator=g)],
+                     torch.randint(0, 2**62, (np_tot,), dtype=torch.int64, device=dev, generator=g))
+    my_bk, my_bv = bk[rank * nb_r:(rank + 1) * nb_r].contiguous(), bv[rank * nb_r:(rank + 1) * nb_r].contiguous()
+    my_pk = pk[rank * np_r:(rank + 1) * np_r].contiguous()
+    bkc = ctx.wrap(my_bk.data_ptr(), np.uint64, nb_r, keepalive=my_bk)
+    bvc = ctx.wrap(my_bv.data_ptr(), np.int64, nb_r, keepalive=my_bv)
+    pkc = ctx.wrap(my_pk.data_ptr(), np.uint64, np_r, keepalive=my_pk)
+
+    def build():
+        j = D.ShardedHashJoin(eng, ch.JOIN_INNER, ch.STRICT_ALL)
+        j.add_build_rows(bkc, [bvc])
+        j.finish_build()
+        return j
+
+    before = comm.stats()
+    b_secs, j = timed(build)
+    p_secs, (cnt, sm) = timed(lambda: j.probe_count_sum(pkc, 0))
+    after = comm.stats()
+    sbk, order = torch.sort(bk)
+    pos = torch.searchsorted(sbk, pk).clamp_(max=nb_tot - 1)
+    hit = sbk[pos] == pk
+    want = (int(hit.sum().item()), int(bv[order[pos[hit]]].sum().item()) % 2**64)
+    assert (cnt, sm) == want, ("C4 sharded", cnt, sm, want)
+    res["C4_sharded"] = {"workload": "probe INNER JOIN build on UInt64, SELECT count(), sum(bv): build and probe rows routed to the owner of "
+                                     "their key with one all-to-all each (RCCL), joined where they land, 16-byte all-reduce of the aggregate; "
+                                     "per-GPU share of configs[3] (1/8 of 100 M probe, 10 M build rows)",
+                         "build_rows_per_gpu": nb_r, "probe_rows_per_gpu": np_r, "global_build_rows": nb_tot, "global_probe_rows": np_tot,
+                         "matches": cnt, "build_ms": b_secs * 1e3, "probe_ms": p_secs * 1e3, "ms": (b_secs + p_secs) * 1e3,
+                         "rows_per_s": (nb_tot + np_tot) / (b_secs + p_secs), "scaling": "weak",
+                         "exchange_bytes_sent_per_rank": (after["bytes_sent"] - before["bytes_sent"]) // 4,
+                         "parity": "count and sum(payload) equal to an independent sorted-search join over the whole tables"}
+    if world == 1:
+        one = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, ctx=ctx)
+        one.add_block(bkc)
+        c1, s1 = one.probe_count_sum(pkc, bvc)
+        assert (c1, s1 % 2**64) == (cnt, sm)
+        res["C4_sharded"]["parity"] += "; world 1: equal to the single-GPU operator bit for bit"
+    res["transport"] = f"chgpu_all_to_all / chgpu_all_reduce_u64 over RCCL (C ABI), world {world}"
+    del j
+    comm.close()
+    return res
 
 
 def _timed(fn, torch, stream, reps, warmup=1):

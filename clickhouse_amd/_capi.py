@@ -39,6 +39,10 @@ SIGNATURES = {
     "chgpu_timer_stop_ms": (_i, [_vp, C.POINTER(C.c_double)]),
     "chgpu_col_upload": (_i, [_vp, _i, _vp, _u64, _pp]),
     "chgpu_col_alloc": (_i, [_vp, _i, _u64, _pp]),
+    "chgpu_host_alloc": (_i, [C.c_size_t, _pp]),
+    "chgpu_host_free": (_i, [_vp]),
+    "chgpu_col_upload_async": (_i, [_vp, _i, _vp, _u64, _pp, _pu64]),
+    "chgpu_upload_wait": (_i, [_vp, _u64]),
     "chgpu_col_wrap": (_i, [_vp, _i, _vp, _u64, _pp]),
     "chgpu_col_slice": (_i, [_vp, _vp, _u64, _u64, _pp]),
     "chgpu_col_concat": (_i, [_vp, _u32, _pp, _pp]),

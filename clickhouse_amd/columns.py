@@ -33,12 +33,21 @@ class Context:
         h = C.c_void_p()
         K.check(K.lib().chgpu_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
         self._h = h
+        self._closed = False
         self.device = device
 
     def close(self):
-        if getattr(self, "_h", None):
+        """chgpu_ctx_destroy: columns / aggregations / joins made on this context keep the C context alive until the last of them is
+        freed (they also keep this object alive), so closing first is safe in any garbage-collection order; making NEW objects on a
+        closed context is refused."""
+        if getattr(self, "_h", None) and not self._closed:
             K.lib().chgpu_ctx_destroy(self._h)
-            self._h = None
+            self._closed = True
+
+    def _live(self):
+        if self._closed:
+            raise K.ChgpuError(K.ERR_LOGICAL, "the context has been closed")
+        return self._h
 
     def __del__(self):
         try:
@@ -72,18 +81,18 @@ class Context:
     def upload(self, arr: np.ndarray) -> "Column":
         arr = np.ascontiguousarray(arr)
         h = C.c_void_p()
-        K.check(K.lib().chgpu_col_upload(self._h, TAG_OF[arr.dtype], arr.ctypes.data_as(C.c_void_p), arr.shape[0], C.byref(h)))
+        K.check(K.lib().chgpu_col_upload(self._live(), TAG_OF[arr.dtype], arr.ctypes.data_as(C.c_void_p), arr.shape[0], C.byref(h)))
         return Column(self, h)
 
     def alloc(self, dtype, rows: int) -> "Column":
         h = C.c_void_p()
-        K.check(K.lib().chgpu_col_alloc(self._h, TAG_OF[np.dtype(dtype)], rows, C.byref(h)))
+        K.check(K.lib().chgpu_col_alloc(self._live(), TAG_OF[np.dtype(dtype)], rows, C.byref(h)))
         return Column(self, h)
 
     def wrap(self, device_ptr: int, dtype, rows: int, keepalive=None) -> "Column":
         """Non-owning view of HBM the caller manages (e.g. a torch tensor's data_ptr())."""
         h = C.c_void_p()
-        K.check(K.lib().chgpu_col_wrap(self._h, TAG_OF[np.dtype(dtype)], C.c_void_p(device_ptr), rows, C.byref(h)))
+        K.check(K.lib().chgpu_col_wrap(self._live(), TAG_OF[np.dtype(dtype)], C.c_void_p(device_ptr), rows, C.byref(h)))
         c = Column(self, h)
         c._keepalive = keepalive
         return c

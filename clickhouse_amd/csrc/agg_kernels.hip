@@ -1245,6 +1245,7 @@ static int agg_ensure_table(chgpu_agg * a, u64 min_cells = 0)
 extern "C" int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, const int * agg_kinds, const int * arg_types,
                                 uint64_t size_hint, chgpu_agg ** out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && out && (agg_kinds || n_aggs == 0), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(n_aggs <= AGG_MAX_AGGS, CHGPU_ERR_NOT_IMPLEMENTED, "more than %u aggregate functions: CPU path", AGG_MAX_AGGS);
     CHGPU_REQUIRE(key_type < 0 || (chgpu_type_is_int(key_type)),
@@ -1278,17 +1279,21 @@ extern "C" int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, 
     }
     a->n_words = w;
     memset(a->host_words, 0, sizeof(a->host_words));
+    chgpu_ctx_retain(ctx);
     *out = a;
     return CHGPU_OK;
 }
 
 extern "C" int chgpu_agg_free(chgpu_agg * a)
 {
+    ChgpuDeviceGuard _dev_guard(a ? a->ctx : nullptr);
     if (!a)
         return CHGPU_OK;
     if (a->table_mem)
         chgpu_pool_free(a->ctx, a->table_mem, a->table_class);
+    chgpu_ctx * ctx = a->ctx;
     delete a;
+    chgpu_ctx_release(ctx);
     return CHGPU_OK;
 }
 
@@ -1622,12 +1627,14 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
 extern "C" int chgpu_agg_add_block(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols,
                                    uint64_t row_begin, uint64_t row_end)
 {
+    ChgpuDeviceGuard _dev_guard(a ? a->ctx : nullptr);
     return agg_add_block_impl(a, key_col, arg_cols, row_begin, row_end, nullptr);
 }
 
 extern "C" int chgpu_agg_add_block_filtered(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols,
                                             uint64_t row_begin, uint64_t row_end, const chgpu_col * filter_u8)
 {
+    ChgpuDeviceGuard _dev_guard(a ? a->ctx : nullptr);
     return agg_add_block_impl(a, key_col, arg_cols, row_begin, row_end, filter_u8);
 }
 
@@ -2065,6 +2072,7 @@ static bool agg_same_shape(const chgpu_agg * x, const chgpu_agg * y)
 
 extern "C" int chgpu_agg_merge(chgpu_agg * dst, const chgpu_agg * src)
 {
+    ChgpuDeviceGuard _dev_guard(dst ? dst->ctx : nullptr);
     CHGPU_REQUIRE(dst && src, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(agg_same_shape(dst, src), CHGPU_ERR_BAD_ARGUMENTS, "cannot merge aggregation states of different shape");
     if (dst->key_type < 0)
@@ -2096,6 +2104,7 @@ extern "C" int chgpu_agg_merge(chgpu_agg * dst, const chgpu_agg * src)
 
 extern "C" int chgpu_agg_merge_states(chgpu_agg * dst, const chgpu_col * key_col, const chgpu_col * const * state_cols, uint64_t rows)
 {
+    ChgpuDeviceGuard _dev_guard(dst ? dst->ctx : nullptr);
     CHGPU_REQUIRE(dst && state_cols, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     chgpu_ctx * ctx = dst->ctx;
     for (u32 w = 0; w < dst->n_words; ++w)
@@ -2167,6 +2176,7 @@ __global__ __launch_bounds__(256) void k_widen_keys(const void * keys, int type,
 
 extern "C" int chgpu_agg_size(chgpu_agg * a, uint64_t * groups)
 {
+    ChgpuDeviceGuard _dev_guard(a ? a->ctx : nullptr);
     CHGPU_REQUIRE(a && groups, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     if (a->key_type < 0)
     {
@@ -2276,6 +2286,7 @@ static int agg_export(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** word_co
 
 extern "C" int chgpu_agg_export_states(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** state_cols, uint64_t * groups)
 {
+    ChgpuDeviceGuard _dev_guard(a ? a->ctx : nullptr);
     CHGPU_REQUIRE(a && state_cols && groups, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     return agg_export(a, keys_out, state_cols, groups);
 }
@@ -2284,6 +2295,7 @@ extern "C" int chgpu_agg_export_states(chgpu_agg * a, chgpu_col ** keys_out, chg
 // MergingAggregatedMemoryEfficientTransform is a row range.  (The device table itself stays single-level)
 extern "C" int chgpu_agg_export_states_two_level(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** state_cols, uint64_t * groups, uint64_t * bucket_counts)
 {
+    ChgpuDeviceGuard _dev_guard(a ? a->ctx : nullptr);
     CHGPU_REQUIRE(a && keys_out && state_cols && groups && bucket_counts, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(a->key_type >= 0, CHGPU_ERR_BAD_ARGUMENTS, "an aggregation without key has no buckets");
     chgpu_col * keys = nullptr;
@@ -2324,6 +2336,7 @@ extern "C" int chgpu_agg_export_states_two_level(chgpu_agg * a, chgpu_col ** key
 
 extern "C" int chgpu_agg_finalize(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** res_cols, uint64_t * groups)
 {
+    ChgpuDeviceGuard _dev_guard(a ? a->ctx : nullptr);
     CHGPU_REQUIRE(a && res_cols && groups, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     chgpu_ctx * ctx = a->ctx;
     chgpu_col * words[AGG_MAX_WORDS] = {nullptr};

@@ -77,7 +77,21 @@ struct chgpu_ctx
     std::multimap<size_t, void *> pool_free;
     size_t pool_cached_bytes = 0;
     size_t pool_limit_bytes = (size_t)96 << 30;
+    // Objects made on this context (columns, aggregations, joins, communicators) hold a reference: chgpu_ctx_destroy with
+    // children still alive only marks the context; the last child to go tears it down.  Single-threaded like the rest of a ctx.
+    long refs = 0;
+    bool zombie = false;
+    // asynchronous uploads (chgpu_col_upload_async): their own stream, so a stripe's host-to-device copy overlaps the kernels of the
+    // previous stripe on `stream`; completion events in a ring, addressed by ticket
+    hipStream_t copy_stream = nullptr;
+    static constexpr int UPLOAD_RING = 32;
+    hipEvent_t upload_done[UPLOAD_RING] = {nullptr};
+    hipEvent_t upload_gate = nullptr; // recorded on `stream` when the destination buffer is handed out; the copy waits for it
+    u64 upload_next_ticket = 1;
 };
+
+void chgpu_ctx_retain(chgpu_ctx * ctx);
+void chgpu_ctx_release(chgpu_ctx * ctx); // tears a zombie context down when the last reference goes
 
 struct chgpu_col
 {

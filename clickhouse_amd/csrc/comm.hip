@@ -135,6 +135,7 @@ extern "C" int chgpu_comm_init(chgpu_ctx * ctx, int rank, int world, const uint8
         delete c;
         return chgpu_set_error(CHGPU_ERR_OOM, "hipMalloc: %s", hipGetErrorString(e));
     }
+    chgpu_ctx_retain(ctx);
     *out = c;
     return CHGPU_OK;
 }
@@ -149,7 +150,9 @@ extern "C" int chgpu_comm_destroy(chgpu_comm * c)
         g_rccl.CommDestroy(c->comm);
     if (c->dev_buf)
         (void)hipFree(c->dev_buf);
+    chgpu_ctx * ctx = c->ctx;
     delete c;
+    chgpu_ctx_release(ctx);
     return CHGPU_OK;
 }
 

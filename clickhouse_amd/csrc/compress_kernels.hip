@@ -397,6 +397,7 @@ extern "C" int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compre
                                        const uint32_t * payload_sizes, const uint32_t * decompressed_sizes, const uint8_t * methods,
                                        const uint8_t * post_methods, const uint32_t * stage_sizes, chgpu_col ** out_u8)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && compressed_u8 && out_u8, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(compressed_u8->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "compressed data is a UInt8 column");
     CHGPU_REQUIRE(n_frames == 0 || (payload_offsets && payload_sizes && decompressed_sizes && methods), CHGPU_ERR_BAD_ARGUMENTS, "NULL frame arrays");
@@ -505,6 +506,7 @@ __global__ __launch_bounds__(256) void k_bytes_copy(const u8 * __restrict__ src,
 
 extern "C" int chgpu_col_from_bytes(chgpu_ctx * ctx, const chgpu_col * bytes_u8, uint64_t byte_offset, int type, uint64_t rows, chgpu_col ** out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && bytes_u8 && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     const size_t es = chgpu_type_size(type);
     CHGPU_REQUIRE(es && bytes_u8->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "bad type");

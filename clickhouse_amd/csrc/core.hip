@@ -23,7 +23,9 @@ extern "C" int chgpu_ctx_create(int device_id, void * hip_stream, chgpu_ctx ** o
     int n_dev = 0;
     CHGPU_HIP(hipGetDeviceCount(&n_dev));
     CHGPU_REQUIRE(device_id >= 0 && device_id < n_dev, CHGPU_ERR_BAD_ARGUMENTS, "device %d out of range (%d devices)", device_id, n_dev);
-    CHGPU_HIP(hipSetDevice(device_id));
+    chgpu_ctx probe_dev;
+    probe_dev.device = device_id;
+    ChgpuDeviceGuard guard(&probe_dev); // the caller's current device is restored when this returns
     hipDeviceProp_t prop;
     CHGPU_HIP(hipGetDeviceProperties(&prop, device_id));
     chgpu_ctx * ctx = new chgpu_ctx();
@@ -50,12 +52,18 @@ extern "C" int chgpu_ctx_create(int device_id, void * hip_stream, chgpu_ctx ** o
     return CHGPU_OK;
 }
 
-extern "C" int chgpu_ctx_destroy(chgpu_ctx * ctx)
+static void ctx_teardown(chgpu_ctx * ctx)
 {
-    if (!ctx)
-        return CHGPU_OK;
-    (void)hipSetDevice(ctx->device);
+    ChgpuDeviceGuard guard(ctx);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream)
+    {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    for (auto & e : ctx->upload_done)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->upload_gate) (void)hipEventDestroy(ctx->upload_gate);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (auto & kv : ctx->pool_free)
         (void)hipFree(kv.second);
@@ -66,11 +74,38 @@ extern "C" int chgpu_ctx_destroy(chgpu_ctx * ctx)
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+void chgpu_ctx_retain(chgpu_ctx * ctx)
+{
+    if (ctx)
+        ++ctx->refs;
+}
+
+void chgpu_ctx_release(chgpu_ctx * ctx)
+{
+    if (ctx && --ctx->refs == 0 && ctx->zombie)
+        ctx_teardown(ctx);
+}
+
+extern "C" int chgpu_ctx_destroy(chgpu_ctx * ctx)
+{
+    if (!ctx)
+        return CHGPU_OK;
+    if (ctx->refs > 0)
+    {
+        // columns / aggregations / joins made on this context are still alive and will touch it when they are freed
+        // (pool_free, counters): keep it until the last of them is gone
+        ctx->zombie = true;
+        return CHGPU_OK;
+    }
+    ctx_teardown(ctx);
     return CHGPU_OK;
 }
 
 extern "C" int chgpu_ctx_synchronize(chgpu_ctx * ctx)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx, CHGPU_ERR_BAD_ARGUMENTS, "ctx is NULL");
     CHGPU_HIP(hipStreamSynchronize(ctx->stream));
     return CHGPU_OK;
@@ -78,6 +113,7 @@ extern "C" int chgpu_ctx_synchronize(chgpu_ctx * ctx)
 
 extern "C" int chgpu_ctx_trim(chgpu_ctx * ctx)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx, CHGPU_ERR_BAD_ARGUMENTS, "ctx is NULL");
     CHGPU_HIP(hipStreamSynchronize(ctx->stream));
     for (auto & kv : ctx->pool_free)
@@ -93,6 +129,7 @@ extern "C" int chgpu_ctx_trim(chgpu_ctx * ctx)
 
 extern "C" int chgpu_ctx_counters(chgpu_ctx * ctx, uint64_t out[CHGPU_N_COUNTERS])
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     memcpy(out, ctx->counters, sizeof(ctx->counters));
     return CHGPU_OK;
@@ -100,6 +137,7 @@ extern "C" int chgpu_ctx_counters(chgpu_ctx * ctx, uint64_t out[CHGPU_N_COUNTERS
 
 extern "C" int chgpu_timer_start(chgpu_ctx * ctx)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx, CHGPU_ERR_BAD_ARGUMENTS, "ctx is NULL");
     CHGPU_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
     return CHGPU_OK;
@@ -107,6 +145,7 @@ extern "C" int chgpu_timer_start(chgpu_ctx * ctx)
 
 extern "C" int chgpu_timer_stop_ms(chgpu_ctx * ctx, double * elapsed_ms)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && elapsed_ms, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
     CHGPU_HIP(hipEventSynchronize(ctx->ev_stop));
@@ -120,6 +159,7 @@ int chgpu_scratch(chgpu_ctx * ctx, size_t bytes, void ** out)
 {
     if (bytes > ctx->scratch_bytes)
     {
+        ChgpuDeviceGuard guard(ctx);
         // growing frees the old buffer: earlier kernels on this stream may still read it -> drain first
         CHGPU_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->scratch)
@@ -138,6 +178,7 @@ int chgpu_pinned(chgpu_ctx * ctx, size_t bytes, void ** out)
 {
     if (bytes > ctx->pinned_bytes)
     {
+        ChgpuDeviceGuard guard(ctx);
         CHGPU_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->pinned)
             CHGPU_HIP(hipHostFree(ctx->pinned));
@@ -178,6 +219,7 @@ static size_t pool_class(size_t bytes)
 int chgpu_pool_alloc(chgpu_ctx * ctx, size_t bytes, void ** out, size_t * class_bytes)
 {
     const size_t cls = pool_class(bytes);
+    ChgpuDeviceGuard guard(ctx);
     auto it = ctx->pool_free.lower_bound(cls);
     if (it != ctx->pool_free.end() && it->first <= cls + cls / 2)
     {
@@ -222,12 +264,13 @@ int chgpu_col_new(chgpu_ctx * ctx, int type, u64 rows, chgpu_col ** out)
 {
     size_t es = chgpu_type_size(type);
     CHGPU_REQUIRE(es, CHGPU_ERR_BAD_ARGUMENTS, "unknown column type %d", type);
-    CHGPU_HIP(hipSetDevice(ctx->device));
+    ChgpuDeviceGuard guard(ctx);
     size_t bytes = rows * es + 2 * CHGPU_PAD;
     void * base = nullptr;
     size_t cls = 0;
     CHGPU_TRY(chgpu_pool_alloc(ctx, bytes, &base, &cls));
     chgpu_col * c = new chgpu_col();
+    chgpu_ctx_retain(ctx);
     c->ctx = ctx;
     c->type = type;
     c->rows = rows;
@@ -241,12 +284,14 @@ int chgpu_col_new(chgpu_ctx * ctx, int type, u64 rows, chgpu_col ** out)
 
 extern "C" int chgpu_col_alloc(chgpu_ctx * ctx, int type, uint64_t rows, chgpu_col ** out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     return chgpu_col_new(ctx, type, rows, out);
 }
 
 extern "C" int chgpu_col_upload(chgpu_ctx * ctx, int type, const void * host_ptr, uint64_t rows, chgpu_col ** out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && out && (host_ptr || rows == 0), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     chgpu_col * c = nullptr;
     CHGPU_TRY(chgpu_col_new(ctx, type, rows, &c));
@@ -265,12 +310,82 @@ extern "C" int chgpu_col_upload(chgpu_ctx * ctx, int type, const void * host_ptr
     return CHGPU_OK;
 }
 
+extern "C" int chgpu_host_alloc(size_t bytes, void ** out)
+{
+    CHGPU_REQUIRE(out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_host_free(void * p)
+{
+    if (p)
+        CHGPU_HIP(hipHostFree(p));
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_col_upload_async(chgpu_ctx * ctx, int type, const void * pinned_host_ptr, uint64_t rows, chgpu_col ** out, uint64_t * ticket_out)
+{
+    CHGPU_REQUIRE(ctx && out && ticket_out && (pinned_host_ptr || rows == 0), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    ChgpuDeviceGuard guard(ctx);
+    if (!ctx->copy_stream)
+    {
+        CHGPU_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        CHGPU_HIP(hipEventCreateWithFlags(&ctx->upload_gate, hipEventDisableTiming));
+        for (auto & e : ctx->upload_done)
+            CHGPU_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    chgpu_col * c = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, type, rows, &c));
+    const u64 ticket = ctx->upload_next_ticket++;
+    hipEvent_t done = ctx->upload_done[ticket % chgpu_ctx::UPLOAD_RING];
+    hipError_t e = hipSuccess;
+    // the buffer may come from the pool: kernels queued on `stream` before now may still read its previous contents
+    if ((e = hipEventRecord(ctx->upload_gate, ctx->stream)) == hipSuccess && (e = hipStreamWaitEvent(ctx->copy_stream, ctx->upload_gate, 0)) == hipSuccess)
+    {
+        if (rows)
+            e = hipMemcpyAsync(c->data, pinned_host_ptr, rows * chgpu_type_size(type), hipMemcpyHostToDevice, ctx->copy_stream);
+        if (e == hipSuccess)
+            e = hipEventRecord(done, ctx->copy_stream);
+        // whatever the caller launches on `stream` next sees the uploaded column
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(ctx->stream, done, 0);
+    }
+    if (e != hipSuccess)
+    {
+        chgpu_col_free(c);
+        return chgpu_set_error(CHGPU_ERR_DEVICE, "upload_async: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    *ticket_out = ticket;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_upload_wait(chgpu_ctx * ctx, uint64_t ticket)
+{
+    ChgpuDeviceGuard _dev_guard(ctx);
+    CHGPU_REQUIRE(ctx, CHGPU_ERR_BAD_ARGUMENTS, "ctx is NULL");
+    if (ticket == 0 || ticket >= ctx->upload_next_ticket)
+        return ticket == 0 ? CHGPU_OK : chgpu_set_error(CHGPU_ERR_BAD_ARGUMENTS, "upload ticket %llu was never issued", (unsigned long long)ticket);
+    ChgpuDeviceGuard guard(ctx);
+    if (ticket + chgpu_ctx::UPLOAD_RING <= ctx->upload_next_ticket)
+    {
+        // its event slot has been reused by a later upload: copies on one stream complete in order, so waiting for the copy stream covers it
+        CHGPU_HIP(hipStreamSynchronize(ctx->copy_stream));
+        return CHGPU_OK;
+    }
+    CHGPU_HIP(hipEventSynchronize(ctx->upload_done[ticket % chgpu_ctx::UPLOAD_RING]));
+    return CHGPU_OK;
+}
+
 extern "C" int chgpu_col_wrap(chgpu_ctx * ctx, int type, void * device_ptr, uint64_t rows, chgpu_col ** out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && out && (device_ptr || rows == 0), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(chgpu_type_size(type), CHGPU_ERR_BAD_ARGUMENTS, "unknown column type %d", type);
     CHGPU_REQUIRE(((uintptr_t)device_ptr % chgpu_type_size(type)) == 0, CHGPU_ERR_BAD_ARGUMENTS, "device pointer not element-aligned");
     chgpu_col * c = new chgpu_col();
+    chgpu_ctx_retain(ctx);
     c->ctx = ctx;
     c->type = type;
     c->rows = rows;
@@ -282,6 +397,7 @@ extern "C" int chgpu_col_wrap(chgpu_ctx * ctx, int type, void * device_ptr, uint
 
 extern "C" int chgpu_col_slice(chgpu_ctx * ctx, const chgpu_col * col, uint64_t start, uint64_t rows, chgpu_col ** out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && col && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(start <= col->rows && rows <= col->rows - start, CHGPU_ERR_BAD_ARGUMENTS,
                   "cut(%llu,%llu) out of bounds of a column of %llu rows", (unsigned long long)start, (unsigned long long)rows, (unsigned long long)col->rows);
@@ -290,6 +406,7 @@ extern "C" int chgpu_col_slice(chgpu_ctx * ctx, const chgpu_col * col, uint64_t 
 
 extern "C" int chgpu_col_concat(chgpu_ctx * ctx, uint32_t n, const chgpu_col * const * cols, chgpu_col ** out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && cols && out && n >= 1, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     u64 total = 0;
     for (u32 k = 0; k < n; ++k)
@@ -321,6 +438,7 @@ extern "C" int chgpu_col_concat(chgpu_ctx * ctx, uint32_t n, const chgpu_col * c
 
 extern "C" int chgpu_col_download(chgpu_ctx * ctx, const chgpu_col * col, void * host_ptr, uint64_t rows)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && col && (host_ptr || rows == 0), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(rows <= col->rows, CHGPU_ERR_SIZES_MISMATCH, "download of %llu rows from a column of %llu", (unsigned long long)rows, (unsigned long long)col->rows);
     if (rows)
@@ -357,7 +475,9 @@ extern "C" int chgpu_col_free(chgpu_col * col)
                 (void)hipFree(col->base);
         }
     }
+    chgpu_ctx * ctx = col->ctx;
     delete col;
+    chgpu_ctx_release(ctx);
     return CHGPU_OK;
 }
 
@@ -367,6 +487,7 @@ int chgpu_crc_lut(chgpu_ctx * ctx, const u32 ** lut_dev)
 {
     if (!ctx->crc_lut_dev)
     {
+        ChgpuDeviceGuard guard(ctx);
         std::vector<u32> lut(8 * 256 + 1);
         auto soft = [](u64 x, u32 crc) {
             for (int i = 0; i < 8; ++i)

@@ -961,6 +961,7 @@ static bool cols_aligned(const chgpu_expr * e, const chgpu_col * const * cols)
 extern "C" int chgpu_expr_execute(chgpu_ctx * ctx, const chgpu_expr * e, uint32_t n_cols, const chgpu_col * const * cols, uint32_t n_outputs,
                                   const uint32_t * out_nodes, chgpu_col ** outs)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && e && cols && outs, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     u64 rows = 0;
     CHGPU_TRY(check_spec(e, n_cols, cols, &rows));
@@ -1010,6 +1011,7 @@ extern "C" int chgpu_expr_execute(chgpu_ctx * ctx, const chgpu_expr * e, uint32_
 extern "C" int chgpu_expr_filter_sum_node(chgpu_ctx * ctx, const chgpu_expr * e, uint32_t n_cols, const chgpu_col * const * cols, int filter_node,
                                           int value_node, int * result_type_out, void * sum_out, uint64_t * count_out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && e && cols, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     u64 rows = 0;
     CHGPU_TRY(check_spec(e, n_cols, cols, &rows));
@@ -1052,6 +1054,7 @@ extern "C" int chgpu_expr_filter_sum_node(chgpu_ctx * ctx, const chgpu_expr * e,
 extern "C" int chgpu_expr_filter_execute(chgpu_ctx * ctx, const chgpu_expr * e, uint32_t n_cols, const chgpu_col * const * cols, uint32_t filter_node,
                                          uint32_t n_outputs, const uint32_t * out_nodes, chgpu_col ** outs, uint64_t * rows_out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && e && cols && outs && rows_out && out_nodes, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(n_outputs >= 1 && n_outputs <= 7, CHGPU_ERR_BAD_ARGUMENTS, "1..7 outputs");
     CHGPU_REQUIRE(filter_node < e->types.size() && chgpu_type_is_int(e->types[filter_node]), CHGPU_ERR_BAD_ARGUMENTS,
@@ -1132,6 +1135,7 @@ extern "C" int chgpu_expr_filter_execute(chgpu_ctx * ctx, const chgpu_expr * e, 
 extern "C" int chgpu_expr_filter_minmax_node(chgpu_ctx * ctx, const chgpu_expr * e, uint32_t n_cols, const chgpu_col * const * cols, int filter_node,
                                              uint32_t value_node, int * value_type_out, void * min_out, void * max_out, uint64_t * count_out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && e && cols, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(value_node < e->types.size() && filter_node < (int)e->types.size(), CHGPU_ERR_BAD_ARGUMENTS, "bad node");
     CHGPU_REQUIRE(filter_node < 0 || chgpu_type_is_int(e->types[filter_node]), CHGPU_ERR_BAD_ARGUMENTS,

@@ -529,6 +529,7 @@ static int filter_sum_mixed(chgpu_ctx * ctx, const chgpu_col * pred, int op, int
 extern "C" int chgpu_filter_sum_async(chgpu_ctx * ctx, const chgpu_col * pred, int op, int scalar_type, const void * scalar,
                                       const chgpu_col * val, chgpu_col * result)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && pred && val && result, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(pred->rows == val->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of predicate column (%llu) doesn't match size of value column (%llu)",
                   (unsigned long long)pred->rows, (unsigned long long)val->rows);
@@ -544,6 +545,7 @@ extern "C" int chgpu_filter_sum_async(chgpu_ctx * ctx, const chgpu_col * pred, i
 extern "C" int chgpu_filter_sum(chgpu_ctx * ctx, const chgpu_col * pred, int op, int scalar_type, const void * scalar,
                                 const chgpu_col * val, void * sum_out, uint64_t * count_out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && pred && val && sum_out && count_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(pred->rows == val->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of predicate column (%llu) doesn't match size of value column (%llu)",
                   (unsigned long long)pred->rows, (unsigned long long)val->rows);
@@ -613,12 +615,14 @@ static int sum_add_many_impl(chgpu_ctx * ctx, const chgpu_col * col, const chgpu
 
 extern "C" int chgpu_sum_add_many(chgpu_ctx * ctx, const chgpu_col * col, uint64_t row_begin, uint64_t row_end, void * state8)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     return sum_add_many_impl(ctx, col, nullptr, row_begin, row_end, state8);
 }
 
 extern "C" int chgpu_sum_add_many_conditional(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * cond_u8,
                                               uint64_t row_begin, uint64_t row_end, void * state8)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(cond_u8, CHGPU_ERR_BAD_ARGUMENTS, "condition column is NULL");
     return sum_add_many_impl(ctx, col, cond_u8, row_begin, row_end, state8);
 }
@@ -718,6 +722,7 @@ static int launch_cmp_t(chgpu_ctx * ctx, const void * a, u64 n, Pred p, u8 * c)
 
 extern "C" int chgpu_cmp_const(chgpu_ctx * ctx, const chgpu_col * col, int op, int scalar_type, const void * scalar, chgpu_col ** mask_out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && col && mask_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CmpSpec spec;
     CHGPU_TRY(make_cmp_spec(col->type, op, scalar_type, scalar, &spec));
@@ -771,6 +776,7 @@ __global__ __launch_bounds__(256) void k_and_not(const u8 * __restrict__ d, cons
 
 extern "C" int chgpu_filter_description_nullable(chgpu_ctx * ctx, const chgpu_col * data, const chgpu_col * nul, chgpu_col ** out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && data && nul && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(data->type == CHGPU_U8 && nul->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "Nullable(UInt8) filter expected");
     CHGPU_REQUIRE(data->rows == nul->rows, CHGPU_ERR_SIZES_MISMATCH, "null map size mismatch");
@@ -942,6 +948,7 @@ __global__ __launch_bounds__(256) void k_count_nonzero(const u8 * __restrict__ m
 
 extern "C" int chgpu_count_bytes_in_filter(chgpu_ctx * ctx, const chgpu_col * mask, uint64_t * count)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && mask && count, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(mask->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "filter must be a UInt8 column");
     void * scratch = nullptr;
@@ -1047,6 +1054,7 @@ static int filter_apply(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col 
 extern "C" int chgpu_filter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * mask, int64_t result_size_hint,
                             chgpu_col ** out, uint64_t * out_rows)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     (void)result_size_hint; // the device path sizes the result exactly from the scan; the hint only matters for CPU reserve()
     CHGPU_REQUIRE(ctx && col && mask && out && out_rows, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(mask->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "filter must be a UInt8 column");
@@ -1089,6 +1097,7 @@ __global__ __launch_bounds__(256) void k_filter_emit_indices(const u8 * __restri
 
 extern "C" int chgpu_filter_to_indices(chgpu_ctx * ctx, const chgpu_col * mask, chgpu_col ** indexes_u64, uint64_t * rows_out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && mask && indexes_u64 && rows_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(mask->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "filter must be a UInt8 column");
     chgpu_col * res = nullptr;
@@ -1120,6 +1129,7 @@ extern "C" int chgpu_filter_to_indices(chgpu_ctx * ctx, const chgpu_col * mask, 
 extern "C" int chgpu_filter_columns(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, const chgpu_col * mask,
                                     int64_t result_size_hint, chgpu_col ** outs, uint64_t * out_rows)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     (void)result_size_hint;
     CHGPU_REQUIRE(ctx && mask && out_rows && (n_cols == 0 || (cols && outs)), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(mask->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "filter must be a UInt8 column");
@@ -1170,6 +1180,7 @@ __global__ __launch_bounds__(256) void k_index(const T * __restrict__ data, cons
 extern "C" int chgpu_index(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * indexes, uint64_t limit,
                            int default_for_missing, chgpu_col ** out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && col && indexes && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(indexes->type == CHGPU_U64 || indexes->type == CHGPU_U32, CHGPU_ERR_BAD_ARGUMENTS, "indexes must be UInt64 or UInt32");
     if (limit == 0)
@@ -1214,6 +1225,7 @@ __global__ __launch_bounds__(256) void k_replicate(const T * __restrict__ data, 
 
 extern "C" int chgpu_replicate(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * offsets, chgpu_col ** out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && col && offsets && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(offsets->type == CHGPU_U64, CHGPU_ERR_BAD_ARGUMENTS, "offsets must be UInt64");
     CHGPU_REQUIRE(offsets->rows == col->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of offsets doesn't match size of column."); // ColumnVector.cpp:881-883
@@ -1249,6 +1261,7 @@ __global__ __launch_bounds__(256) void k_and_u8(const u8 * __restrict__ a, const
 
 extern "C" int chgpu_and(chgpu_ctx * ctx, const chgpu_col * a, const chgpu_col * b, chgpu_col ** out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && a && b && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(a->type == CHGPU_U8 && b->type == CHGPU_U8, CHGPU_ERR_NOT_IMPLEMENTED, "and() over non-UInt8 arguments: CPU path");
     CHGPU_REQUIRE(a->rows == b->rows, CHGPU_ERR_SIZES_MISMATCH, "arguments of function and have different sizes");
@@ -1308,6 +1321,7 @@ __global__ __launch_bounds__(256) void k_arith(const TA * __restrict__ a, const 
 
 extern "C" int chgpu_arith(chgpu_ctx * ctx, int value_op, const chgpu_col * a, const chgpu_col * b, chgpu_col ** out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && a && b && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     const int rt = arith_result_type(value_op, a->type, b->type);
     CHGPU_REQUIRE(rt >= 0, CHGPU_ERR_NOT_IMPLEMENTED, "arithmetic on these types/operator: CPU path");
@@ -1797,6 +1811,7 @@ extern "C" int chgpu_expr_filter_sum(chgpu_ctx * ctx, uint32_t n_cols, const chg
                                      const uint64_t * pred_scalar_bits, int value_op, uint32_t val_a, uint32_t val_b,
                                      int * result_type_out, void * sum_out, uint64_t * count_out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && cols && sum_out && count_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(n_cols >= 1 && n_cols <= EX_MAX_COLS, CHGPU_ERR_NOT_IMPLEMENTED, "fused expression over more than %u columns: CPU path", EX_MAX_COLS);
     CHGPU_REQUIRE(n_preds <= EX_MAX_PREDS, CHGPU_ERR_NOT_IMPLEMENTED, "more than %u predicates: CPU path", EX_MAX_PREDS);

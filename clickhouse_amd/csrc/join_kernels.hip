@@ -563,6 +563,7 @@ static u64 jpow2_ceil(u64 x)
 extern "C" int chgpu_join_create(chgpu_ctx * ctx, int key_type, int kind, int strictness, int any_take_last_row,
                                  uint64_t size_hint, chgpu_join ** out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     (void)size_hint;
     CHGPU_REQUIRE(ctx && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(chgpu_type_is_int(key_type),
@@ -579,12 +580,14 @@ extern "C" int chgpu_join_create(chgpu_ctx * ctx, int key_type, int kind, int st
     j->kind = kind;
     j->strictness = strictness;
     j->any_take_last_row = any_take_last_row ? 1 : 0;
+    chgpu_ctx_retain(ctx);
     *out = j;
     return CHGPU_OK;
 }
 
 extern "C" int chgpu_join_free(chgpu_join * j)
 {
+    ChgpuDeviceGuard _dev_guard(j ? j->ctx : nullptr);
     if (!j)
         return CHGPU_OK;
     for (auto & b : j->blocks)
@@ -598,13 +601,16 @@ extern "C" int chgpu_join_free(chgpu_join * j)
         chgpu_pool_free(j->ctx, j->used, j->used_class);
     if (j->block_base_dev)
         chgpu_pool_free(j->ctx, j->block_base_dev, j->base_class);
+    chgpu_ctx * ctx = j->ctx;
     delete j;
+    chgpu_ctx_release(ctx);
     return CHGPU_OK;
 }
 
 extern "C" int chgpu_join_add_block(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map, const chgpu_col * join_mask,
                                     uint32_t * block_index_out)
 {
+    ChgpuDeviceGuard _dev_guard(j ? j->ctx : nullptr);
     CHGPU_REQUIRE(j && key_col, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(!j->finished, CHGPU_ERR_LOGICAL, "addBlockToJoin after onBuildPhaseFinish");
     CHGPU_REQUIRE(key_col->type == j->key_type, CHGPU_ERR_BAD_ARGUMENTS, "key column has type %d, expected %d", key_col->type, j->key_type);
@@ -647,6 +653,7 @@ extern "C" int chgpu_join_add_block(chgpu_join * j, const chgpu_col * key_col, c
 
 extern "C" int chgpu_join_finish_build(chgpu_join * j)
 {
+    ChgpuDeviceGuard _dev_guard(j ? j->ctx : nullptr);
     CHGPU_REQUIRE(j, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     if (j->finished)
         return CHGPU_OK;
@@ -760,6 +767,7 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
    columns there and pads the left columns with defaults. */
 extern "C" int chgpu_join_non_joined_rows(chgpu_join * j, chgpu_col ** right_rowid_u64, uint64_t * rows_out)
 {
+    ChgpuDeviceGuard _dev_guard(j ? j->ctx : nullptr);
     CHGPU_REQUIRE(j && right_rowid_u64 && rows_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(jf_track_used(j), CHGPU_ERR_LOGICAL, "non-joined rows exist for RIGHT / FULL joins only");
     if (!j->finished)
@@ -814,6 +822,7 @@ __global__ __launch_bounds__(JT) void k_join_flatten(const u64 * __restrict__ ro
 
 extern "C" int chgpu_join_flatten_rowids(chgpu_join * j, const chgpu_col * rowids, chgpu_col ** flat)
 {
+    ChgpuDeviceGuard _dev_guard(j ? j->ctx : nullptr);
     CHGPU_REQUIRE(j && rowids && flat, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(chgpu_type_size(rowids->type) == 8, CHGPU_ERR_BAD_ARGUMENTS, "row ids must be a 64-bit column");
     chgpu_ctx * ctx = j->ctx;
@@ -841,6 +850,7 @@ extern "C" int chgpu_join_flatten_rowids(chgpu_join * j, const chgpu_col * rowid
 
 extern "C" int chgpu_join_total_rows(chgpu_join * j, uint64_t * rows, uint64_t * keys)
 {
+    ChgpuDeviceGuard _dev_guard(j ? j->ctx : nullptr);
     CHGPU_REQUIRE(j, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     if (rows)
         *rows = j->total_rows; // IJoin::getTotalRowCount
@@ -857,6 +867,7 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
                                 chgpu_col ** filter_out, chgpu_col ** offsets_out, chgpu_col ** right_rowid_out, uint64_t * n_out,
                                 uint64_t * n_left_consumed)
 {
+    ChgpuDeviceGuard _dev_guard(j ? j->ctx : nullptr);
     CHGPU_REQUIRE(j && key_col && n_out && n_left_consumed, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(key_col->type == j->key_type, CHGPU_ERR_BAD_ARGUMENTS, "left key column has type %d, expected %d", key_col->type, j->key_type);
     if (null_map)
@@ -1192,6 +1203,7 @@ __global__ __launch_bounds__(64) void k_join_probe_agg_finish(const u64 * __rest
 extern "C" int chgpu_join_probe_agg(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map, const chgpu_col * right_payload,
                                     uint64_t * count_out, void * sum_out)
 {
+    ChgpuDeviceGuard _dev_guard(j ? j->ctx : nullptr);
     CHGPU_REQUIRE(j && key_col && count_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(!right_payload || sum_out, CHGPU_ERR_BAD_ARGUMENTS, "sum_out must not be NULL when a payload column is given");
     CHGPU_REQUIRE(key_col->type == j->key_type, CHGPU_ERR_BAD_ARGUMENTS, "left key column has type %d, expected %d", key_col->type, j->key_type);

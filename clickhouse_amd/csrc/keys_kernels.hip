@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void k_unpack_fixed(const u64 * __restrict__ p
 
 extern "C" int chgpu_pack_fixed_keys(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, chgpu_col ** packed_u64)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && cols && packed_u64, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(n_cols >= 1 && n_cols <= PK_MAX_COLS, CHGPU_ERR_BAD_ARGUMENTS, "1..%u key columns expected", PK_MAX_COLS);
     PackCols pc;
@@ -80,6 +81,7 @@ extern "C" int chgpu_pack_fixed_keys(chgpu_ctx * ctx, uint32_t n_cols, const chg
 
 extern "C" int chgpu_unpack_fixed_key(chgpu_ctx * ctx, const chgpu_col * packed_u64, uint32_t byte_offset, int type, chgpu_col ** out_col)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && packed_u64 && out_col, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(chgpu_type_size(packed_u64->type) == 8, CHGPU_ERR_BAD_ARGUMENTS, "packed keys must be a 64-bit column");
     const size_t es = chgpu_type_size(type);
@@ -191,6 +193,7 @@ static int lc_launch(chgpu_ctx * ctx, const chgpu_col * indexes, const u32 * rm,
 
 extern "C" int chgpu_lc_remap(chgpu_ctx * ctx, const chgpu_col * indexes, const chgpu_col * remap_u32, chgpu_col ** out_u32)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && indexes && remap_u32 && out_u32, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(remap_u32->type == CHGPU_U32, CHGPU_ERR_BAD_ARGUMENTS, "the remap table must be UInt32");
     CHGPU_REQUIRE(indexes->type == CHGPU_U8 || indexes->type == CHGPU_U16 || indexes->type == CHGPU_U32 || indexes->type == CHGPU_U64,

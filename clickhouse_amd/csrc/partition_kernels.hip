@@ -304,6 +304,7 @@ __global__ void k_part_shard_starts(const u64 * __restrict__ offsets, u64 n_tile
 // ---------------------------------------------------------------------------------------------
 extern "C" int chgpu_weak_hash32(chgpu_ctx * ctx, const chgpu_col * col, chgpu_col * hash)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && col && hash, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(hash->type == CHGPU_U32, CHGPU_ERR_BAD_ARGUMENTS, "WeakHash32 data must be UInt32");
     CHGPU_REQUIRE(hash->rows == col->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of WeakHash32 does not match size of column: column size is %llu, hash size is %llu",
@@ -328,6 +329,7 @@ static int check_shards(u32 num_shards)
 
 extern "C" int chgpu_hash_to_selector(chgpu_ctx * ctx, const chgpu_col * keys, uint32_t num_shards, chgpu_col ** selector)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && keys && selector, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_TRY(check_shards(num_shards));
     CHGPU_REQUIRE(!chgpu_type_is_float(keys->type), CHGPU_ERR_NOT_IMPLEMENTED, "Float64 shard keys: CPU path");
@@ -439,6 +441,7 @@ int chgpu_partition_by_key_byte(chgpu_ctx * ctx, const chgpu_col * keys, u32 shi
 extern "C" int chgpu_partition_by_hash(chgpu_ctx * ctx, const chgpu_col * keys, uint32_t num_shards, uint32_t n_cols,
                                        const chgpu_col * const * cols, chgpu_col ** outs, uint64_t * counts)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && keys && cols && outs && counts, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_TRY(check_shards(num_shards));
     chgpu_col * sel = nullptr;
@@ -450,6 +453,7 @@ extern "C" int chgpu_partition_by_hash(chgpu_ctx * ctx, const chgpu_col * keys, 
 
 extern "C" int chgpu_scatter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * selector, uint32_t num_columns, chgpu_col ** outs)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && col && selector && outs, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(num_columns >= 1 && num_columns <= MAX_SHARDS, CHGPU_ERR_NOT_IMPLEMENTED, "scatter into more than %u columns: CPU path", MAX_SHARDS);
     CHGPU_REQUIRE(selector->type == CHGPU_U32, CHGPU_ERR_BAD_ARGUMENTS, "selector must be a UInt32 column");
@@ -470,6 +474,7 @@ extern "C" int chgpu_scatter(chgpu_ctx * ctx, const chgpu_col * col, const chgpu
     for (u32 s = 0; s < num_columns; ++s)
     {
         chgpu_col * v = new chgpu_col();
+        chgpu_ctx_retain(ctx);
         v->ctx = ctx;
         v->type = col->type;
         v->rows = counts[s];

@@ -113,6 +113,7 @@ static int sort_impl(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * p
 extern "C" int chgpu_sort_permutation(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * perm_in_u64, int descending, int nan_direction_hint,
                                       chgpu_col ** perm_out_u64)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && col && perm_out_u64, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(!perm_in_u64 || perm_in_u64->type == CHGPU_U64, CHGPU_ERR_BAD_ARGUMENTS, "a permutation is a UInt64 column (IColumn::Permutation)");
     CHGPU_REQUIRE(!perm_in_u64 || perm_in_u64->rows <= col->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of permutation (%llu) is greater than the column (%llu)",
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256) void k_sample_strided(const T * __restrict__ d
 extern "C" int chgpu_sort_permutation_limit(chgpu_ctx * ctx, const chgpu_col * col, int descending, int nan_direction_hint, uint64_t limit,
                                             chgpu_col ** perm_out_u64)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && col && perm_out_u64, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     const u64 n = col->rows;
     const bool is_float = chgpu_type_is_float(col->type);

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void k_str_ids(const u64 * __restrict__ rep_ro
 extern "C" int chgpu_string_dictionary_encode(chgpu_ctx * ctx, const chgpu_col * offsets_u64, const chgpu_col * chars_u8, chgpu_col ** ids_u32,
                                               chgpu_col ** first_rows_u64, uint64_t * n_distinct)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && offsets_u64 && chars_u8 && ids_u32 && first_rows_u64 && n_distinct, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(offsets_u64->type == CHGPU_U64 && chars_u8->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "ColumnString = UInt64 offsets + UInt8 chars");
     const u64 n = offsets_u64->rows;
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(256) void k_str_filter_move(const u64 * __restrict_
 extern "C" int chgpu_string_filter(chgpu_ctx * ctx, const chgpu_col * offsets_u64, const chgpu_col * chars_u8, const chgpu_col * filter_u8,
                                    chgpu_col ** out_offsets_u64, chgpu_col ** out_chars_u8, uint64_t * rows_out)
 {
+    ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx && offsets_u64 && chars_u8 && filter_u8 && out_offsets_u64 && out_chars_u8 && rows_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(offsets_u64->type == CHGPU_U64 && chars_u8->type == CHGPU_U8 && filter_u8->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS,
                   "ColumnString = UInt64 offsets + UInt8 chars; the filter is a UInt8 column");

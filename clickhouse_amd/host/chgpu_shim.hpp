@@ -37,6 +37,8 @@
 #include <string>
 #include <type_traits>
 #include <unordered_map>
+#include <array>
+#include <exception>
 #include <utility>
 #include <vector>
 
@@ -185,23 +187,61 @@ struct Chunk
 };
 
 /// Batches host Blocks into one HBM stripe per column: a 65 409-row Block is ~0.5 MB, far below what fills 256 CUs.
+/// Two page-locked staging buffers: flush() queues the stripe's upload on the context's copy stream and returns at once, so the
+/// host fills the other buffer -- and the device runs the previous stripe's kernels -- while the copy is in flight
+/// (chgpu_col_upload_async).  A buffer is refilled only after the upload that read it has finished.
 template <typename T>
 class StripeBuilder
 {
 public:
-    explicit StripeBuilder(ContextPtr ctx_, size_t reserve_rows = 0) : ctx(std::move(ctx_)) { staging.reserve(reserve_rows); }
-    void appendBlock(const T * data, size_t rows) { staging.insert(staging.end(), data, data + rows); }
-    size_t rows() const { return staging.size(); }
+    explicit StripeBuilder(ContextPtr ctx_, size_t stripe_rows_ = size_t(16) << 20) : ctx(std::move(ctx_)), stripe_rows(stripe_rows_ ? stripe_rows_ : 1)
+    {
+        for (auto & b : buf)
+        {
+            void * p = nullptr;
+            check(chgpu_host_alloc(stripe_rows * sizeof(T), &p));
+            b = static_cast<T *>(p);
+        }
+    }
+    ~StripeBuilder()
+    {
+        for (int k = 0; k < 2; ++k)
+        {
+            chgpu_upload_wait(ctx->get(), ticket[k]);
+            chgpu_host_free(buf[k]);
+        }
+    }
+    StripeBuilder(const StripeBuilder &) = delete;
+    /// rows that still fit into the current stripe
+    size_t room() const { return stripe_rows - filled; }
+    size_t rows() const { return filled; }
+    /// appends at most room() rows of the Block and returns how many it took: the caller flushes and appends the rest
+    size_t appendBlock(const T * data, size_t n)
+    {
+        if (filled == 0)
+            check(chgpu_upload_wait(ctx->get(), ticket[cur])); // the upload that last read this buffer
+        const size_t take = n < room() ? n : room();
+        std::memcpy(buf[cur] + filled, data, take * sizeof(T));
+        filled += take;
+        return take;
+    }
+    /// the stripe as a device column; the copy runs asynchronously, ordered before anything launched on the context afterwards
     ColumnPtr flush()
     {
-        auto col = ColumnVector::fromHost<T>(ctx, staging.data(), staging.size());
-        staging.clear();
-        return col;
+        chgpu_col * col = nullptr;
+        check(chgpu_col_upload_async(ctx->get(), TypeTag<T>::value, buf[cur], filled, &col, &ticket[cur]));
+        filled = 0;
+        cur ^= 1;
+        return std::make_shared<ColumnVector>(ctx, col);
     }
 
 private:
     ContextPtr ctx;
-    std::vector<T> staging;
+    size_t stripe_rows;
+    T * buf[2] = {nullptr, nullptr};
+    uint64_t ticket[2] = {0, 0};
+    int cur = 0;
+    size_t filled = 0;
 };
 
 /// IFunction for `col <op> constant` (FunctionsComparison.h:204-245): executeImpl -> UInt8 column.
@@ -242,25 +282,50 @@ class ISimpleTransform : public IProcessor
 public:
     void setInput(Chunk c) { input = std::move(c); has_input = true; }
     bool hasOutput() const { return has_output; }
-    Chunk pullOutput() { has_output = false; return std::move(output); }
+    Chunk pullOutput()
+    {
+        has_output = false;
+        if (output_exception)
+        {
+            auto e = output_exception;
+            output_exception = nullptr;
+            std::rethrow_exception(e);
+        }
+        return std::move(output);
+    }
+    /// ISimpleTransform::work (ISimpleTransform.cpp:76-108): transform() runs inside try/catch; a thrown exception does NOT unwind the
+    /// executor thread -- it is parked in the output slot (output_data.exception, :88-99) and rethrown by whoever pulls the port.
     void work() override
     {
         if (!has_input)
             return;
         Chunk c = std::move(input);
         has_input = false;
-        transform(c);
+        try
+        {
+            transform(c);
+        }
+        catch (...)
+        {
+            output.clear();
+            output_exception = std::current_exception(); // ISimpleTransform.cpp:90-98
+            has_output = true;
+            return;
+        }
         if (c.num_rows != 0) // ISimpleTransform.cpp:101-107: empty chunks are skipped
         {
             output = std::move(c);
             has_output = true;
         }
     }
+    /// the consumer's side of the port: an exception travels in the data slot and surfaces on pull (Port.h: pullData rethrows)
+    bool outputHasException() const { return static_cast<bool>(output_exception); }
 
 protected:
     virtual void transform(Chunk & chunk) = 0;
     Chunk input, output;
     bool has_input = false, has_output = false;
+    std::exception_ptr output_exception;
 };
 
 /// FilterTransform::doTransform (FilterTransform.cpp:136-256): expression -> filter column -> filter every column.
@@ -737,6 +802,17 @@ public:
         return res;
     }
 
+    /// joinBlock + `SELECT count(), sum(right payload column)` fused (chgpu_join_probe_agg): nothing per left row is materialised.
+    /// -> {count, sum bits typed like SumSimple(payload type)}
+    std::pair<uint64_t, uint64_t> probeCountSum(const ColumnVector & left_keys, size_t right_payload_position)
+    {
+        if (right_payload.empty() && !right_blocks.empty())
+            onBuildPhaseFinish();
+        uint64_t count = 0, sum_bits = 0;
+        check(chgpu_join_probe_agg(h, left_keys.handle(), nullptr, right_payload.at(right_payload_position)->handle(), &count, &sum_bits));
+        return {count, sum_bits};
+    }
+
     /// joinBlock(block, not_processed): the left chunk is replaced by [left columns..., right payload columns...];
     /// the unprocessed tail (max_joined_block_rows) comes back in not_processed (HashJoin.cpp:1090-1093).
     /// Right payloads are gathered on the device (fillFromBlocksAndRowNumbers, IColumn.cpp:515-526) from the glued columns.
@@ -826,6 +902,197 @@ private:
     std::shared_ptr<GpuHashJoin> join;
     size_t left_key_position;
     uint64_t max_joined_block_rows;
+};
+
+/// One rank of the node's exchange: one process per GPU, RCCL over xGMI behind the C ABI (chgpu_comm_*).  The 128-byte id made by
+/// rank 0 (uniqueId) reaches the other ranks through the host pipeline's own control plane.
+class Communicator
+{
+public:
+    using UniqueId = std::array<uint8_t, CHGPU_UNIQUE_ID_BYTES>;
+    static UniqueId uniqueId()
+    {
+        UniqueId id;
+        check(chgpu_comm_unique_id(id.data()));
+        return id;
+    }
+    Communicator(ContextPtr ctx_, int rank, int world, const UniqueId & id) : ctx(std::move(ctx_)) { check(chgpu_comm_init(ctx->get(), rank, world, id.data(), &h)); }
+    ~Communicator() { chgpu_comm_destroy(h); }
+    Communicator(const Communicator &) = delete;
+    int rank() const { return chgpu_comm_rank(h); }
+    int world() const { return chgpu_comm_world(h); }
+    const ContextPtr & context() const { return ctx; }
+    std::vector<uint64_t> allToAllCounts(const std::vector<uint64_t> & send_counts) const
+    {
+        std::vector<uint64_t> recv(send_counts.size(), 0);
+        check(chgpu_all_to_all_counts(h, send_counts.data(), recv.data()));
+        return recv;
+    }
+    ColumnPtr allToAll(const ColumnVector & send, const std::vector<uint64_t> & send_counts, const std::vector<uint64_t> & recv_counts) const;
+    void allReduce(std::vector<uint64_t> & values) const { check(chgpu_all_reduce_u64_host(h, values.data(), static_cast<uint32_t>(values.size()))); }
+    void barrier() const { check(chgpu_comm_barrier(h)); }
+
+private:
+    ContextPtr ctx;
+    chgpu_comm * h = nullptr;
+};
+using CommunicatorPtr = std::shared_ptr<Communicator>;
+
+inline ColumnPtr Communicator::allToAll(const ColumnVector & send, const std::vector<uint64_t> & send_counts, const std::vector<uint64_t> & recv_counts) const
+{
+    chgpu_col * out = nullptr;
+    check(chgpu_all_to_all(h, send.handle(), send_counts.data(), recv_counts.data(), &out));
+    return std::make_shared<ColumnVector>(ctx, out);
+}
+
+/// ConcurrentHashJoin::dispatchBlock (ConcurrentHashJoin.cpp:538-565: hashToSelector :426-440 + scatterBlocksWithSelector :518-536) with
+/// the slots living on different GPUs: the rows of `block` are split by shard = bucket(key) & (world - 1) and every shard travels
+/// to its owner in ONE all-to-all per column; the result is the chunk of rows THIS rank owns (its own shard + what the peers sent).
+inline Chunk dispatchBlock(const Communicator & comm, const Chunk & block, size_t key_position)
+{
+    const uint32_t world = static_cast<uint32_t>(comm.world());
+    if (world == 1)
+        return block;
+    const auto & ctx = comm.context();
+    std::vector<const chgpu_col *> in;
+    for (auto & c : block.columns)
+        in.push_back(c->handle());
+    std::vector<chgpu_col *> parts(in.size(), nullptr);
+    std::vector<uint64_t> counts(world, 0);
+    check(chgpu_partition_by_hash(ctx->get(), block.columns.at(key_position)->handle(), world, static_cast<uint32_t>(in.size()), in.data(), parts.data(), counts.data()));
+    Columns sends;
+    for (auto * p : parts)
+        sends.push_back(std::make_shared<ColumnVector>(ctx, p));
+    const auto recv_counts = comm.allToAllCounts(counts);
+    Chunk mine;
+    for (auto & c : sends)
+        mine.columns.push_back(comm.allToAll(*c, counts, recv_counts));
+    for (auto r : recv_counts)
+        mine.num_rows += r;
+    return mine;
+}
+
+/// GROUP BY over the GPUs of a node.  Every rank aggregates its own rows (one AggregatedDataVariants per stream, as
+/// AggregatingTransform does per thread); the partial states are then handed to their owners by two-level bucket -- the parallel merge of
+/// AggregatingTransform.cpp:120-136 / Aggregator::mergeBucketImpl (Aggregator.cpp:2691-2725) with the buckets owned by ranks instead of
+/// claimed by threads -- with ONE all-to-all of (key, state words); owners merge and finalise their shard.
+class GpuShardedAggregator
+{
+public:
+    GpuShardedAggregator(ContextPtr ctx_, CommunicatorPtr comm_, int key_type_, std::vector<AggregateDescription> aggregates_, uint64_t size_hint_ = 0)
+        : ctx(std::move(ctx_)), comm(std::move(comm_)), key_type(key_type_), aggregates(std::move(aggregates_)), size_hint(size_hint_)
+    {
+        for (auto & a : aggregates)
+        {
+            kinds.push_back(a.kind);
+            types.push_back(a.argument_type);
+            n_words += a.kind == CHGPU_AGG_AVG ? 2 : 1;
+        }
+        check(chgpu_agg_create(ctx->get(), key_type, static_cast<uint32_t>(aggregates.size()), kinds.data(), types.data(), size_hint, &local));
+    }
+    ~GpuShardedAggregator()
+    {
+        chgpu_agg_free(local);
+        chgpu_agg_free(owner);
+    }
+    GpuShardedAggregator(const GpuShardedAggregator &) = delete;
+
+    bool executeOnBlock(const Columns & columns, size_t row_begin, size_t row_end, size_t key_position)
+    {
+        std::vector<const chgpu_col *> args;
+        for (auto & a : aggregates)
+            args.push_back(a.kind == CHGPU_AGG_COUNT ? nullptr : columns.at(a.argument)->handle());
+        check(chgpu_agg_add_block(local, columns.at(key_position)->handle(), args.data(), row_begin, row_end));
+        return true;
+    }
+
+    /// mergeAndConvertToBlocks: the final block of the groups THIS rank owns (the result stays sharded, like the reference's buckets)
+    Chunk convertToBlock()
+    {
+        chgpu_agg * final_agg = local;
+        if (comm->world() > 1)
+        {
+            chgpu_col * keys = nullptr;
+            std::vector<chgpu_col *> words(n_words, nullptr);
+            uint64_t groups = 0;
+            check(chgpu_agg_export_states(local, &keys, words.data(), &groups)); // convertToBlockImplNotFinal
+            Chunk states;
+            states.num_rows = groups;
+            states.columns.push_back(std::make_shared<ColumnVector>(ctx, keys));
+            for (auto * w : words)
+                states.columns.push_back(std::make_shared<ColumnVector>(ctx, w));
+            Chunk mine = dispatchBlock(*comm, states, 0);
+            if (!owner)
+                check(chgpu_agg_create(ctx->get(), key_type, static_cast<uint32_t>(aggregates.size()), kinds.data(), types.data(), mine.num_rows, &owner));
+            std::vector<const chgpu_col *> sc;
+            for (size_t w = 0; w < n_words; ++w)
+                sc.push_back(mine.columns[1 + w]->handle());
+            check(chgpu_agg_merge_states(owner, mine.columns[0]->handle(), sc.data(), mine.num_rows)); // mergeBucketImpl on the owner
+            final_agg = owner;
+        }
+        chgpu_col * keys = nullptr;
+        std::vector<chgpu_col *> res(aggregates.size(), nullptr);
+        uint64_t groups = 0;
+        check(chgpu_agg_finalize(final_agg, &keys, res.data(), &groups));
+        Chunk out;
+        out.num_rows = groups;
+        out.columns.push_back(std::make_shared<ColumnVector>(ctx, keys));
+        for (auto * r : res)
+            out.columns.push_back(std::make_shared<ColumnVector>(ctx, r));
+        return out;
+    }
+
+private:
+    ContextPtr ctx;
+    CommunicatorPtr comm;
+    int key_type;
+    std::vector<AggregateDescription> aggregates;
+    uint64_t size_hint;
+    std::vector<int> kinds, types;
+    size_t n_words = 0;
+    chgpu_agg * local = nullptr;
+    chgpu_agg * owner = nullptr;
+};
+
+/// ConcurrentHashJoin (`parallel_hash`, src/Interpreters/ConcurrentHashJoin.h:25-39, .cpp) with one slot per GPU: build rows are
+/// dispatched to the slot that owns their key (addBlockToJoin -> dispatchBlock, ConcurrentHashJoin.cpp:214-263), every slot builds
+/// its HashJoin; probe rows are dispatched by the same rule and joined where they land (joinBlock, :265-310).  The joined rows stay on
+/// the owner rank -- the next operator (a sharded GROUP BY) consumes them there.
+class GpuConcurrentHashJoin
+{
+public:
+    GpuConcurrentHashJoin(ContextPtr ctx_, CommunicatorPtr comm_, int key_type, int kind, int strictness)
+        : ctx(ctx_), comm(std::move(comm_)), local(std::make_shared<GpuHashJoin>(ctx_, key_type, kind, strictness)) {}
+
+    bool addBlockToJoin(const Chunk & block, size_t key_position) { return local->addBlockToJoin(dispatchBlock(*comm, block, key_position), key_position); }
+    void onBuildPhaseFinish() { local->onBuildPhaseFinish(); }
+    size_t getTotalRowCount() const { return local->getTotalRowCount(); } // rows of THIS slot
+    /// joinBlock: `block` (this rank's left rows) is replaced by the joined rows this rank OWNS
+    void joinBlock(Chunk & block, size_t key_position, std::shared_ptr<Chunk> & not_processed, uint64_t max_joined_block_rows = 0)
+    {
+        Chunk mine = dispatchBlock(*comm, block, key_position);
+        local->joinBlock(mine, key_position, not_processed, max_joined_block_rows);
+        block = std::move(mine);
+    }
+    /// the join with a keyless aggregation fused behind it: SELECT count(), sum(right column) over the WHOLE join (all ranks):
+    /// dispatch the left keys, chgpu_join_probe_agg on the owner, one 16-byte all-reduce (mergeWithoutKeyDataImpl).
+    /// Integer payloads only across ranks (a Float64 sum would depend on the rank order of the reduction).
+    std::pair<uint64_t, uint64_t> joinCountSum(const Chunk & block, size_t key_position, size_t right_payload_position)
+    {
+        Chunk keys_only;
+        keys_only.columns.push_back(block.columns.at(key_position));
+        keys_only.num_rows = block.num_rows;
+        Chunk mine = dispatchBlock(*comm, keys_only, 0);
+        auto r = local->probeCountSum(*mine.columns[0], right_payload_position);
+        std::vector<uint64_t> v{r.first, r.second};
+        comm->allReduce(v);
+        return {v[0], v[1]};
+    }
+
+private:
+    ContextPtr ctx;
+    CommunicatorPtr comm;
+    std::shared_ptr<GpuHashJoin> local;
 };
 
 /// SortColumnDescription (src/Core/SortDescription.h:26-60): column position, direction (+1 ASC / -1 DESC), nulls_direction (NaN counts

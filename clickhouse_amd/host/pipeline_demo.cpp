@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <algorithm>
 #include <climits>
 #include <cstdint>
@@ -50,8 +51,8 @@ int main(int argc, char ** argv)
         for (size_t b = 0; b < n; b += DEFAULT_BLOCK_SIZE)
         {
             size_t rows = std::min(DEFAULT_BLOCK_SIZE, n - b);
-            sa.appendBlock(a.data() + b, rows); // many Blocks -> one HBM stripe
-            sk.appendBlock(k.data() + b, rows);
+            REQUIRE(sa.appendBlock(a.data() + b, rows) == rows); // many Blocks -> one HBM stripe
+            REQUIRE(sk.appendBlock(k.data() + b, rows) == rows);
         }
         Chunk stripe;
         stripe.columns = {sa.flush(), sk.flush()};
@@ -369,6 +370,99 @@ int main(int argc, char ** argv)
             auto col = readCompressedColumn(ctx, file.data(), file.size(), CHGPU_I64);
             auto back = col->getData<int64_t>();
             REQUIRE(back.size() == m && std::equal(back.begin(), back.end(), a.begin()));
+        }
+
+        // ---- ISimpleTransform::work never unwinds the executor thread: a chunk whose columns disagree in length (a broken upstream)
+        //      makes IColumn::filter throw SIZES_OF_COLUMNS_DOESNT_MATCH inside transform(); the exception travels in the output slot
+        //      (ISimpleTransform.cpp:88-99) and surfaces where the port is pulled ---------------------------------------------
+        if (want_cnt != 0 && want_cnt != n) // (a chunk in which every or no row passes never reaches IColumn::filter)
+        {
+            Chunk broken;
+            broken.columns = {stripe.columns[0], stripe.columns[1]->cut(0, n / 2, stripe.columns[1])};
+            broken.num_rows = n;
+            GpuFilterTransform f(0, FunctionComparisonConst(CHGPU_LT, thr));
+            f.setInput(broken);
+            bool unwound = false;
+            try { f.work(); } catch (...) { unwound = true; }
+            REQUIRE(!unwound && f.hasOutput() && f.outputHasException());
+            int code = 0;
+            try { f.pullOutput(); } catch (const Exception & e) { code = e.code(); }
+            REQUIRE(code == CHGPU_ERR_SIZES_MISMATCH);
+            f.setInput(stripe); // the processor is still usable afterwards
+            f.work();
+            REQUIRE(f.hasOutput() && !f.outputHasException() && f.pullOutput().num_rows == want_cnt);
+        }
+
+        // ---- stripes streamed through pinned double buffers: the upload of stripe s+1 overlaps the kernels of stripe s; the
+        //      PCIe-inclusive rate of `SELECT sum(a), count() WHERE a < thr` fed from host Blocks ------------------------------
+        {
+            const size_t stripe_rows = std::min<size_t>(n, size_t(4) << 20), reps = n >= (size_t(1) << 22) ? 4 : 1;
+            StripeBuilder<int64_t> sb(ctx, stripe_rows);
+            auto agg = std::make_shared<GpuAggregator>(ctx, -1, std::vector<AggregateDescription>{{CHGPU_AGG_SUM, CHGPU_I64, 0}, {CHGPU_AGG_COUNT, CHGPU_U64, 0}});
+            GpuAggregatingTransform at(agg, std::nullopt);
+            GpuFilterTransform f(0, FunctionComparisonConst(CHGPU_LT, thr));
+            auto run_stripe = [&] {
+                Chunk c;
+                c.num_rows = sb.rows();
+                c.columns = {sb.flush()};
+                f.setInput(std::move(c));
+                f.work();
+                if (f.hasOutput())
+                    at.consume(f.pullOutput());
+            };
+            const auto t0 = std::chrono::steady_clock::now();
+            for (size_t rep = 0; rep < reps; ++rep)
+                for (size_t b = 0; b < n; b += DEFAULT_BLOCK_SIZE)
+                {
+                    size_t rows = std::min(DEFAULT_BLOCK_SIZE, n - b), done = 0;
+                    while (done < rows)
+                    {
+                        done += sb.appendBlock(a.data() + b + done, rows - done);
+                        if (sb.room() == 0)
+                            run_stripe();
+                    }
+                }
+            if (sb.rows())
+                run_stripe();
+            Chunk r = at.generate();
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            REQUIRE(static_cast<uint64_t>(r.columns[0]->getData<int64_t>()[0]) == reps * want_sum && r.columns[1]->getData<uint64_t>()[0] == reps * want_cnt);
+            std::printf("striped upload + filter + sum: %.3g rows/s PCIe-inclusive (%zu rows, stripes of %zu)\n", double(n * reps) / secs, n * reps, stripe_rows);
+        }
+
+        // ---- the sharded operators at world size 1: RCCL is loaded and initialised, dispatchBlock degenerates to "all rows are mine";
+        //      results must equal the single-GPU operators' (the exchange itself runs in the multi-rank tests) -------------------
+        {
+            auto comm = std::make_shared<Communicator>(ctx, 0, 1, Communicator::uniqueId());
+            REQUIRE(comm->rank() == 0 && comm->world() == 1);
+            GpuShardedAggregator sagg(ctx, comm, CHGPU_U32, {{CHGPU_AGG_SUM, CHGPU_I64, 0}, {CHGPU_AGG_COUNT, CHGPU_U64, 0}}, 1000);
+            sagg.executeOnBlock(stripe.columns, 0, n, 1);
+            Chunk rs = sagg.convertToBlock();
+            REQUIRE(rs.num_rows == want.size());
+            auto sk2 = rs.columns[0]->getData<uint32_t>();
+            auto ss2 = rs.columns[1]->getData<int64_t>();
+            auto sc2 = rs.columns[2]->getData<uint64_t>();
+            for (size_t i = 0; i < sk2.size(); ++i)
+                REQUIRE(static_cast<uint64_t>(ss2[i]) == want.at(sk2[i]).first && sc2[i] == want.at(sk2[i]).second);
+            GpuConcurrentHashJoin cj(ctx, comm, CHGPU_U64, CHGPU_JOIN_INNER, CHGPU_STRICT_ALL);
+            Chunk right;
+            right.columns = {ColumnVector::fromHost<uint64_t>(ctx, bk.data(), nb), ColumnVector::fromHost<int64_t>(ctx, bv.data(), nb)};
+            right.num_rows = nb;
+            cj.addBlockToJoin(right, 0);
+            cj.onBuildPhaseFinish();
+            auto cs = cj.joinCountSum(left, 0, 1);
+            int64_t want_bv = 0;
+            for (auto key : pk)
+            {
+                auto range = build.equal_range(key);
+                for (auto it = range.first; it != range.second; ++it)
+                    want_bv += it->second;
+            }
+            REQUIRE(cs.first == want_rows && static_cast<int64_t>(cs.second) == want_bv);
+            std::vector<uint64_t> v{7, 9};
+            comm->allReduce(v);
+            comm->barrier();
+            REQUIRE(v[0] == 7 && v[1] == 9);
         }
 
         // unsupported surface -> NOT_IMPLEMENTED (CPU fallback signal), not a crash

@@ -12,7 +12,9 @@
  *     chgpu_last_error() gives the message of the calling thread's last failure; nothing throws across the ABI;
  *   - the caller owns host buffers; the library owns device buffers behind handles;
  *   - a chgpu_ctx binds one device + one HIP stream; N host threads drive N contexts concurrently (the
- *     threading contract of IProcessor::work(), src/Processors/IProcessor.h:176-193); one ctx is single-threaded;
+ *     threading contract of IProcessor::work(), src/Processors/IProcessor.h:176-193); one ctx is single-threaded, but MAY be used
+ *     from different threads one after another: every entry point makes the context's device current for the duration of
+ *     the call and restores the caller's (a fresh pipeline thread starts on device 0);
  *   - CHGPU_ERR_NOT_IMPLEMENTED means "fall back to the CPU path" (mirror of isCompilable() gating,
  *     src/AggregateFunctions/AggregateFunctionSum.h:590-604).
  */
@@ -81,6 +83,8 @@ int chgpu_abi_version(void);
 const char * chgpu_last_error(void);
 /* hip_stream: an existing hipStream_t to launch on (e.g. the host framework's stream), or NULL for a private one */
 int chgpu_ctx_create(int device_id, void * hip_stream, chgpu_ctx ** out);
+/* Columns, aggregations, joins and communicators made on a context keep it alive: destroying a context that still has children only
+   marks it, and the last child to be freed tears it down (no use-after-free whatever order a garbage collector picks). */
 int chgpu_ctx_destroy(chgpu_ctx * ctx);
 int chgpu_ctx_synchronize(chgpu_ctx * ctx);
 /* give the context's cached device memory (column pool + scratch arena) back to the driver; synchronizes */
@@ -101,6 +105,14 @@ int chgpu_timer_stop_ms(chgpu_ctx * ctx, double * elapsed_ms); /* synchronizes o
  * ============================================================================================== */
 int chgpu_col_upload(chgpu_ctx * ctx, int type, const void * host_ptr, uint64_t rows, chgpu_col ** out);
 int chgpu_col_alloc(chgpu_ctx * ctx, int type, uint64_t rows, chgpu_col ** out);
+/* Pinned, double-buffered staging (the StripeBuilder of the host shim): chgpu_host_alloc gives page-locked host memory; an upload from it
+   is queued on the context's COPY stream and returns at once -- the copy overlaps whatever kernels are already queued on the
+   context's stream, and everything the caller launches on that stream afterwards sees the column (an event orders them).  The host
+   buffer may be refilled once chgpu_upload_wait(ticket) has returned. */
+int chgpu_host_alloc(size_t bytes, void ** out);
+int chgpu_host_free(void * p);
+int chgpu_col_upload_async(chgpu_ctx * ctx, int type, const void * pinned_host_ptr, uint64_t rows, chgpu_col ** out, uint64_t * ticket_out);
+int chgpu_upload_wait(chgpu_ctx * ctx, uint64_t ticket);
 /* non-owning view of caller-managed HBM (columns already resident on the device) */
 int chgpu_col_wrap(chgpu_ctx * ctx, int type, void * device_ptr, uint64_t rows, chgpu_col ** out);
 /* IColumn::cut(start, length) as a non-owning view (src/Columns/IColumn.h:118-121) */

@@ -32,16 +32,15 @@ def _worker(rank, world, init_file, out_dir):
 
         # 1. no-key states: mergeWithoutKeyDataImpl == one all-reduce (integer sum wraps modulo 2^64)
         local = vals_all[lo:hi]
-        st = torch.from_numpy(np.array([local[local < 0].sum(), (local < 0).sum()], dtype=np.int64))
-        D.merge_without_key(st)
-        want = np.array([vals_all[vals_all < 0].sum(), (vals_all < 0).sum()], dtype=np.int64)
-        assert np.array_equal(st.numpy(), want)
+        got = eng.all_reduce_u64([int(local[local < 0].sum()), int((local < 0).sum())])
+        want = [int(vals_all[vals_all < 0].sum()) % 2**64, int((vals_all < 0).sum())]
+        assert got == want
 
         # 2. sharded GROUP BY: rows split by range, partial states routed to owner = bucket & (world-1)
         g = D.ShardedGroupBy(eng, np.uint64, [(O.AGG_SUM, np.int64), (O.AGG_COUNT, None)])
         for b in range(lo, hi, 7001):
             e = min(hi, b + 7001)
-            g.add_block(torch.from_numpy(keys_all[b:e].view(np.int64)), [torch.from_numpy(vals_all[b:e]), None])
+            g.add_block(keys_all[b:e], [vals_all[b:e], None])
         k, (s, c) = g.finish()
         owners = O.hash_to_selector(np.ascontiguousarray(k), world)
         assert (owners == rank).all(), "a rank holds groups it does not own"
@@ -59,30 +58,35 @@ def _worker(rank, world, init_file, out_dir):
             assert np.array_equal(kk[order], uk) and np.array_equal(ss[order].view(np.int64), ws)
             assert np.array_equal(cc[order], np.bincount(inv).astype(np.uint64))
 
-        # 3. sharded hash join (parallel_hash routing): union of per-rank results == the single-node join
+        # 3. sharded hash join (parallel_hash routing): build rows travel with their payload (here: the global build row number and a
+        #    value), probe rows with their global row number; the union of the per-rank results == the single-node join
         bk_all = rng.integers(0, 3000, size=9000, dtype=np.uint64)
+        bv_all = rng.integers(-2**50, 2**50, size=9000, dtype=np.int64)
         pk_all = rng.integers(0, 4000, size=20_000, dtype=np.uint64)
         j = D.ShardedHashJoin(eng, O.JOIN_INNER, O.STRICT_ALL)
         blo, bhi = rank * 9000 // world, (rank + 1) * 9000 // world
         plo, phi = rank * 20_000 // world, (rank + 1) * 20_000 // world
-        j.add_build_rows(torch.from_numpy(bk_all[blo:bhi].view(np.int64)))
-        left, right = j.probe(torch.from_numpy(pk_all[plo:phi].view(np.int64)))
-        # ids travel as (origin rank << 40 | origin row); rank 0 maps them back to global row numbers
+        for b in range(blo, bhi, 2000):  # the build side arrives Block by Block
+            e = min(bhi, b + 2000)
+            j.add_build_rows(bk_all[b:e], [np.arange(b, e, dtype=np.int64), bv_all[b:e]])
+        j.finish_build()
+        n_out, left, right = j.probe(pk_all[plo:phi], [np.arange(plo, phi, dtype=np.int64)])
+        assert left[0].shape[0] == n_out == right[0].shape[0]
+        assert (O.hash_to_selector(np.ascontiguousarray(left[0]), world) == rank).all(), "joined rows must stay on the rank that owns their key"
+        cnt, sm = j.probe_count_sum(pk_all[plo:phi], payload_index=1)   # the fused form: global count(), sum(bv)
         gathered = [None] * world
-        dist.all_gather_object(gathered, (left, right))
+        dist.all_gather_object(gathered, (left[1], right[0], right[1]))
         if rank == 0:
-            def glob(ids, split_total):
-                r = ids >> 40
-                row = ids & ((1 << 40) - 1)
-                return np.array([int(rr) * split_total // world for rr in r]) + row
             pairs = set()
-            for l, r_ in gathered:
-                pairs |= set(zip(glob(l, 20_000).tolist(), glob(r_, 9000).tolist()))
+            for l, r_, v in gathered:
+                pairs |= set(zip(l.tolist(), r_.tolist()))
+                assert np.array_equal(v, bv_all[r_])
             one = O.HashJoin(O.JOIN_INNER, O.STRICT_ALL)
             one.add_block(bk_all)
             ol, ob, orow, _ = one.joined_pairs(pk_all)
             assert pairs == set(zip(ol.tolist(), orow.tolist()))
             assert sum(x[0].shape[0] for x in gathered) == ol.shape[0]
+            assert cnt == ol.shape[0] and sm == int(bv_all[orow].astype(np.uint64).sum(dtype=np.uint64))
         dist.barrier()
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:

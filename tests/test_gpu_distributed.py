@@ -7,7 +7,6 @@ import tempfile
 
 import numpy as np
 import pytest
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -16,24 +15,37 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _worker(rank, world, init_file, out_dir):
     sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
     import clickhouse_amd as ch
     from clickhouse_amd import distributed as D
+    from cpu_engine import GlooExchange
 
-    torch.cuda.set_device(0)
+    class Engine(GlooExchange, D.LocalEngine):
+        """the real per-GPU operators; only the transport is swapped: partitions are staged through the host and moved by gloo"""
+
+        def __init__(self, ctx):
+            D.LocalEngine.__init__(self, ctx, None)
+
+        world = property(lambda self: dist.get_world_size(), lambda self, v: None)
+        rank = property(lambda self: dist.get_rank(), lambda self, v: None)
+
+        def all_to_all(self, col, counts, recv_counts):
+            return self.ctx.upload(self._a2a_host(col.numpy(), counts, recv_counts))
+
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     try:
-        eng = D.LocalEngine(device_index=0)
+        ctx = ch.Context(0)
+        eng = Engine(ctx)
         rng = np.random.Generator(np.random.PCG64(321))
         n = 400_000
         keys_all = rng.integers(0, 50_000, size=n, dtype=np.uint64)
         vals_all = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
         lo, hi = rank * n // world, (rank + 1) * n // world
-        dev = torch.device("cuda", 0)
 
         g = D.ShardedGroupBy(eng, np.uint64, [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)])
-        g.add_block(torch.from_numpy(keys_all[lo:hi].view(np.int64)).to(dev), [torch.from_numpy(vals_all[lo:hi]).to(dev), None])
+        g.add_block(ctx.upload(keys_all[lo:hi]), [ctx.upload(vals_all[lo:hi]), None])
         k, (s, c) = g.finish()
-        sel = ch.hash_to_selector(eng.ctx.upload(k), world).numpy()
+        sel = ch.hash_to_selector(ctx.upload(k), world).numpy()
         assert (sel == rank).all()
         gathered = [None] * world
         dist.all_gather_object(gathered, (k, s, c))
@@ -47,19 +59,28 @@ def _worker(rank, world, init_file, out_dir):
             order = np.argsort(kk)
             assert np.array_equal(kk[order], uk) and np.array_equal(ss[order], ws) and np.array_equal(cc[order], np.bincount(inv).astype(np.uint64))
 
-        bk_all = rng.integers(0, 30_000, size=90_000, dtype=np.uint64)
-        pk_all = rng.integers(0, 40_000, size=200_000, dtype=np.uint64)
+        nb, npb = 90_000, 200_000
+        bk_all = rng.integers(0, 30_000, size=nb, dtype=np.uint64)
+        bv_all = rng.integers(-2**50, 2**50, size=nb, dtype=np.int64)
+        pk_all = rng.integers(0, 40_000, size=npb, dtype=np.uint64)
         j = D.ShardedHashJoin(eng, ch.JOIN_INNER, ch.STRICT_ALL)
-        blo, bhi = rank * 90_000 // world, (rank + 1) * 90_000 // world
-        plo, phi = rank * 200_000 // world, (rank + 1) * 200_000 // world
-        j.add_build_rows(torch.from_numpy(bk_all[blo:bhi].view(np.int64)).to(dev))
-        left, right = j.probe(torch.from_numpy(pk_all[plo:phi].view(np.int64)).to(dev))
+        blo, bhi = rank * nb // world, (rank + 1) * nb // world
+        plo, phi = rank * npb // world, (rank + 1) * npb // world
+        for b in range(blo, bhi, 20_000):  # several right Blocks per rank: flat row ordinals over the routed blocks
+            e = min(bhi, b + 20_000)
+            j.add_build_rows(ctx.upload(bk_all[b:e]), [ctx.upload(np.arange(b, e, dtype=np.int64)), ctx.upload(bv_all[b:e])])
+        j.finish_build()
+        n_out, left, right = j.probe(ctx.upload(pk_all[plo:phi]), [ctx.upload(np.arange(plo, phi, dtype=np.int64))])
+        lk, lid, rid, rv = left[0].numpy(), left[1].numpy(), right[0].numpy(), right[1].numpy()   # results are device columns
+        assert lk.shape[0] == n_out == rid.shape[0]
+        assert (ch.hash_to_selector(ctx.upload(lk), world).numpy() == rank).all() if n_out else True
+        cnt, sm = j.probe_count_sum(ctx.upload(pk_all[plo:phi]), payload_index=1)
         gathered = [None] * world
-        dist.all_gather_object(gathered, (left, right))
+        dist.all_gather_object(gathered, (lid, rid, rv))
         if rank == 0:
-            def glob(ids, total):
-                return (ids >> 40) * (total // world) + (ids & ((1 << 40) - 1))
-            got = np.concatenate([np.stack([glob(l, 200_000), glob(r, 90_000)], axis=1) for l, r in gathered])
+            got = np.concatenate([np.stack([l, r], axis=1) for l, r, _ in gathered])
+            for _, r, v in gathered:
+                assert np.array_equal(v, bv_all[r])              # the payload travelled with its row and was gathered on the device
             order = np.argsort(bk_all, kind="stable")
             sk = bk_all[order]
             lo_i = np.searchsorted(sk, pk_all, "left")
@@ -68,6 +89,7 @@ def _worker(rank, world, init_file, out_dir):
             assert got.shape[0] == want_rows
             assert (pk_all[got[:, 0]] == bk_all[got[:, 1]]).all()
             assert len({(int(a), int(b)) for a, b in got}) == want_rows
+            assert cnt == want_rows and sm == int(bv_all[got[:, 1]].astype(np.uint64).sum(dtype=np.uint64))
         dist.barrier()
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:

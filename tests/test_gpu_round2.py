@@ -87,3 +87,89 @@ def test_join_probe_agg_refuses_stateful_variants(ch, ctx):
         j.probe_count_sum(np.arange(5, dtype=np.uint64), np.arange(9, dtype=np.int64))  # payload shorter than the right side
     assert e.value.code == ch._capi.ERR_SIZES_MISMATCH
     assert j.probe_count_sum(np.zeros(0, dtype=np.uint64), np.arange(10, dtype=np.int64)) == (0, 0)
+
+
+# ---- the RCCL exchange through the C ABI at world size 1 (one GPU per rank is all a test box has; world 2 runs the same orchestration over
+#      gloo in tests/test_gpu_distributed.py and tests/test_distributed_gloo.py) -----------------------------------------------------------
+def test_rccl_comm_world1_and_sharded_operators_match_single_gpu(ch, ctx):
+    from clickhouse_amd import distributed as D
+    comm = D.Comm(ctx, 0, 1, D.Comm.unique_id())
+    try:
+        assert comm.all_to_all_counts([12345]) == [12345]
+        src = ctx.upload(np.arange(1000, dtype=np.int64) * 3)
+        got = comm.all_to_all(src, [1000], [1000])
+        assert np.array_equal(got.numpy(), np.arange(1000, dtype=np.int64) * 3)
+        assert comm.all_reduce_u64([5, 2**64 - 1]) == [5, 2**64 - 1]
+        col = ctx.upload(np.array([1, 2, 3], dtype=np.uint64))
+        comm.all_reduce_column(col)
+        assert col.numpy().tolist() == [1, 2, 3]
+        comm.barrier()
+        with pytest.raises(ch.ChgpuError) as e:
+            comm.all_to_all(src, [999], [999])                      # counts must add up to the column
+        assert e.value.code == ch._capi.ERR_SIZES_MISMATCH
+        eng = D.LocalEngine(ctx, comm)
+        rng = np.random.Generator(np.random.PCG64(9))
+        k = rng.integers(0, 70_000, size=500_000, dtype=np.uint32)
+        v = rng.integers(-2**62, 2**62, size=500_000, dtype=np.int64)
+        aggs = [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)]
+        sg = D.ShardedGroupBy(eng, np.uint32, aggs)
+        sg.add_block(ctx.upload(k), [ctx.upload(v), None])
+        gk, (gs, gc) = sg.finish()
+        one = ch.Aggregator(np.uint32, aggs, ctx=ctx)
+        one.execute_on_block(k, [v, None])
+        ok, (os_, oc) = one.convert_to_block()
+        i, j = np.argsort(gk), np.argsort(ok)
+        assert np.array_equal(gk[i], ok[j]) and np.array_equal(gs[i], os_[j]) and np.array_equal(gc[i], oc[j])
+        bk = rng.permutation(100_000).astype(np.uint64) * np.uint64(7) + np.uint64(1)
+        bv = rng.integers(-2**40, 2**40, size=100_000, dtype=np.int64)
+        pk = rng.integers(0, 800_000, size=300_000, dtype=np.uint64)
+        sj = D.ShardedHashJoin(eng, ch.JOIN_INNER, ch.STRICT_ALL)
+        sj.add_build_rows(ctx.upload(bk), [ctx.upload(bv)])
+        cnt, sm = sj.probe_count_sum(ctx.upload(pk), 0)
+        hit = np.isin(pk, bk)
+        lut = dict(zip(bk.tolist(), bv.tolist()))
+        assert cnt == int(hit.sum()) and sm == sum(lut[x] for x in pk[hit].tolist()) % 2**64
+        n_out, left, right = sj.probe(ctx.upload(pk), [])
+        assert n_out == cnt and np.array_equal(right[0].numpy(), np.array([lut[x] for x in left[0].numpy().tolist()], dtype=np.int64))
+    finally:
+        comm.close()
+
+
+def test_context_outlives_nothing_children_keep_it_alive(ch):
+    """chgpu_ctx_destroy with live children only marks the context; the last child tears it down (no use-after-free in any order)"""
+    c = ch.Context(0)
+    col = c.upload(np.arange(10, dtype=np.int64))
+    agg = ch.Aggregator(np.uint32, [(ch.AGG_COUNT, None)], ctx=c)
+    agg.execute_on_block(np.arange(5, dtype=np.uint32), [None])
+    c.close()                                   # children still alive
+    assert col.numpy().tolist() == list(range(10))
+    assert len(agg) == 5
+    agg.close()
+    col.free()                                  # last reference: the context goes now
+
+
+def test_pinned_async_upload_overlaps_and_orders(ch, ctx):
+    import ctypes as C
+    K = ch._capi
+    n = 1 << 20
+    host = C.c_void_p()
+    K.check(K.lib().chgpu_host_alloc(n * 8, C.byref(host)))
+    try:
+        arr = np.ctypeslib.as_array(C.cast(host, C.POINTER(C.c_int64)), shape=(n,))
+        total = 0
+        tickets = []
+        for rep in range(4):
+            if tickets:
+                K.check(K.lib().chgpu_upload_wait(ctx._h, tickets[-1]))   # the buffer is refilled only after its upload finished
+            arr[:] = np.arange(n, dtype=np.int64) + rep
+            h, t = C.c_void_p(), C.c_uint64(0)
+            K.check(K.lib().chgpu_col_upload_async(ctx._h, K.I64, host, n, C.byref(h), C.byref(t)))
+            col = ch.Column(ctx, h)
+            s, c = ch.filter_sum(col, ch.GE, 0)                            # launched right behind the copy: must see the uploaded rows
+            assert (int(s), c) == (int(arr.sum()), n)
+            tickets.append(t.value)
+            total += 1
+        assert tickets == sorted(tickets) and len(set(tickets)) == 4
+        assert K.lib().chgpu_upload_wait(ctx._h, 10**9) == K.ERR_BAD_ARGUMENTS
+    finally:
+        K.check(K.lib().chgpu_host_free(host))
