@@ -25,6 +25,7 @@
 // re-runs only those rows, which is the reference's resize-on-overflow (HashTable.h:921-944) restructured for a device
 // that cannot realloc inside a kernel.
 #include "chgpu_internal.h"
+#include "radix_partition.h"
 
 #include <cmath>
 #include <cstdio>
@@ -452,6 +453,7 @@ __global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, co
 #define GBP_WG_PER_CU 1
 #endif
 static constexpr u32 GBP_THREADS = GBP_THREADS_V;
+static_assert(GBP_THREADS_V == 1024, "the shared partition kernels (radix_partition.h) run 1024 threads");
 static constexpr u32 GBP_MAX_P = 1024;
 static constexpr u32 GBP_MAX_K = 2;
 
@@ -461,6 +463,34 @@ static constexpr u64 GBP_MULT = 0x9E3779B97F4A7C15ull;  // partitions of the (se
 static constexpr u64 GBP_MULT1 = 0xC2B2AE3D27D4EB4Full; // first level of a two-level partitioning: an independent multiplier
 __device__ __forceinline__ u64 gbp_mix(u64 key) { return key * GBP_MULT; }
 __device__ __forceinline__ u32 gbp_part_of(u64 key, u32 pmask, u64 mult) { return (u32)((key * mult) >> 52) & pmask; }
+// Keys of <= 4 bytes (the partition buffers hold them as u32) hash in 32 bits: one v_mul_lo_u32 instead of a 64-bit multiply
+// (~5 VALU ops) in each of the three passes, which are issue-bound.  The TOP bits of key * odd pick the partition
+// (mul_hi(h, P) = top log2 P bits) and the bits right below them the LDS cell: bit b of the product depends on key bits 0..b only,
+// so low product bits must not be used (keys that differ in high bits only would share them).
+template <typename KT>
+__device__ __forceinline__ u32 gbp_part(KT key, u32 P, u64 mult)
+{
+    if constexpr (sizeof(KT) == 4)
+        return __umulhi((u32)key * ((u32)(mult >> 32) | 1u), P);
+    else
+        return gbp_part_of((u64)key, P - 1, mult);
+}
+template <typename KT>
+__device__ __forceinline__ u32 gbp_cell(KT key, u32 P, u32 S)
+{
+    if constexpr (sizeof(KT) == 4)
+        return __umulhi((u32)key * ((u32)(GBP_MULT >> 32) | 1u) * P, S); // the partition's bits shifted out, the next log2 S bits
+    else
+        return (u32)(gbp_mix((u64)key) >> 20) & (S - 1); // bits disjoint from the partition id (>> 52)
+}
+
+template <typename KT>
+struct GbpPartFn
+{
+    u32 P;
+    u64 mult;
+    __device__ __forceinline__ u32 operator()(KT key) const { return gbp_part<KT>(key, P, mult); }
+};
 
 struct GbpCols
 {
@@ -471,8 +501,9 @@ struct GbpCols
 };
 
 __global__ __launch_bounds__(GBP_THREADS) void k_gb_hist(const void * __restrict__ keys, int key_type, u64 row_begin, u64 n, u64 rows_per_wg,
-                                                         u32 P, u32 * __restrict__ counts, u64 mult)
+                                                         u32 P, u32 * __restrict__ counts, u64 mult, int key32)
 {
+    auto part_of = [&](u64 k) -> u32 { return key32 ? gbp_part<u32>((u32)k, P, mult) : gbp_part<u64>(k, P, mult); };
     __shared__ u32 cnt[GBP_MAX_P];
     for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
         cnt[p] = 0;
@@ -489,58 +520,10 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_hist(const void * __restrict
             k[q] = load_key_zext(keys, key_type, row_begin + i + (u64)q * GBP_THREADS);
 #pragma unroll
         for (int q = 0; q < HU; ++q)
-            atomicAdd(&cnt[gbp_part_of(k[q], P - 1, mult)], 1u);
+            atomicAdd(&cnt[part_of(k[q])], 1u);
     }
     for (; i < r1; i += GBP_THREADS)
-        atomicAdd(&cnt[gbp_part_of(load_key_zext(keys, key_type, row_begin + i), P - 1, mult)], 1u);
-    __syncthreads();
-    for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
-        counts[(u64)p * gridDim.x + blockIdx.x] = cnt[p];
-}
-
-// Same histogram with 16-byte nontemporal key loads (4- and 8-byte keys whose first row is 16-byte aligned): four loads
-// per lane are issued before the first LDS atomic.
-template <typename KT>
-__global__ __launch_bounds__(GBP_THREADS) void k_gb_hist_wide(const KT * __restrict__ keys, u64 n, u64 rows_per_wg, u32 P, u32 * __restrict__ counts, u64 mult)
-{
-    typedef u32 v4u __attribute__((ext_vector_type(4)));
-    constexpr u32 VEC = 16 / sizeof(KT);
-    constexpr int HU = 4;
-    __shared__ u32 cnt[GBP_MAX_P];
-    for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
-        cnt[p] = 0;
-    __syncthreads();
-    const u64 r0 = (u64)blockIdx.x * rows_per_wg;
-    const u64 r1 = r0 + rows_per_wg < n ? r0 + rows_per_wg : n;
-    const u32 pmask = P - 1;
-    u64 i = r0;
-    constexpr u64 STEP = (u64)HU * GBP_THREADS * VEC;
-    for (; i + STEP <= r1; i += STEP)
-    {
-        v4u v[HU];
-#pragma unroll
-        for (int q = 0; q < HU; ++q)
-            v[q] = __builtin_nontemporal_load((const v4u *)(keys + i + ((u64)q * GBP_THREADS + threadIdx.x) * VEC));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < HU; ++q)
-        {
-            if constexpr (sizeof(KT) == 4)
-            {
-                atomicAdd(&cnt[gbp_part_of(v[q].x, pmask, mult)], 1u);
-                atomicAdd(&cnt[gbp_part_of(v[q].y, pmask, mult)], 1u);
-                atomicAdd(&cnt[gbp_part_of(v[q].z, pmask, mult)], 1u);
-                atomicAdd(&cnt[gbp_part_of(v[q].w, pmask, mult)], 1u);
-            }
-            else
-            {
-                atomicAdd(&cnt[gbp_part_of((u64)v[q].x | ((u64)v[q].y << 32), pmask, mult)], 1u);
-                atomicAdd(&cnt[gbp_part_of((u64)v[q].z | ((u64)v[q].w << 32), pmask, mult)], 1u);
-            }
-        }
-    }
-    for (i += threadIdx.x; i < r1; i += GBP_THREADS)
-        atomicAdd(&cnt[gbp_part_of((u64)keys[i], pmask, mult)], 1u);
+        atomicAdd(&cnt[part_of(load_key_zext(keys, key_type, row_begin + i))], 1u);
     __syncthreads();
     for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
         counts[(u64)p * gridDim.x + blockIdx.x] = cnt[p];
@@ -663,7 +646,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
             part[j] = ~0u;
             if (i < r1)
             {
-                part[j] = gbp_part_of((u64)key[j], P - 1, mult);
+                part[j] = gbp_part<KT>(key[j], P, mult);
                 rank[j] = atomicAdd(&tile_cnt[part[j]], 1u);
             }
         }
@@ -729,7 +712,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
         const u32 tile_rows = (u32)(r1 - tbase < GBP_TILE ? r1 - tbase : GBP_TILE);
         for (u32 pos = threadIdx.x; pos < tile_rows; pos += GBP_THREADS)
         {
-            const u32 p = gbp_part_of((u64)stage_key[pos], P - 1, mult);
+            const u32 p = gbp_part<KT>(stage_key[pos], P, mult);
             const u64 dst = delta[p] + pos;
             // plain stores: runs are 64-128 B, L2 write-combining completes the lines (nontemporal stores: 4.7 -> 8.1 ms)
             out_keys[dst] = stage_key[pos];
@@ -794,6 +777,18 @@ __device__ __forceinline__ u64 part_extend(u64 raw, int ex)
     }
 }
 
+// does any state word of the compile-time update code use operation a or b?
+__host__ __device__ constexpr bool gbp_ops_use(u32 ops, u32 a, u32 b)
+{
+    for (u32 w = 0; w < 8; ++w)
+    {
+        const u32 op = (ops >> (4 * w)) & 15u;
+        if (op == a || op == b)
+            return true;
+    }
+    return false;
+}
+
 struct PartLds
 {
     u32 S1, cnt32, n8, keys_bytes;
@@ -811,7 +806,10 @@ struct PartLds
 // KS: element type of the key column as stored (UInt8 keys are read as they are and held as KT = UInt32 in LDS)
 // EXT: some argument word of this launch needs more than the zero extension its typed load gives (Int8/16/32 sign extension,
 // Float32 -> Float64); compiled out otherwise -- the pass is issue-bound and the extension logic cost it 4-14 % when present
-template <typename KT, int AW, typename KS = KT, bool EXT = false>
+// OPS != 0: the state update is fixed at compile time -- 4 bits per state word, word 0 in the low nibble: 1 / 2 = integer sum of
+// argument word 0 / 1, 3 / 4 = Float64 sum of argument word 0 / 1, 5 = row count kept in 32 bits, 6 = row count in 64 bits.  The
+// run-time descriptor walk costs ~25 scalar + ~10 vector instructions per 64 rows of a pass that is bound by instruction issue.
+template <typename KT, int AW, typename KS = KT, bool EXT = false, u32 OPS = 0>
 __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, const KS * __restrict__ keys, const void * __restrict__ words0, const void * __restrict__ words1,
                                                        const u64 * __restrict__ offsets, u32 G, u32 P, u64 n, u64 * __restrict__ pending, u32 S, u32 K, u32 cnt32,
                                                        u64 rows_per_chunk, const u32 * __restrict__ unit_start, u32 * __restrict__ unit_ctr,
@@ -844,7 +842,7 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
     {
         a_off[j] = a_off2[j] = 0;
         a_op[j] = a_op2[j] = a_src[j] = 0;
-        if (j < d.n_aggs)
+        if (OPS == 0 && j < d.n_aggs)
         {
             const u32 w = d.a[j].word;
             a_off[j] = L.off(w);
@@ -864,6 +862,10 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
             }
         }
     }
+    u32 w_off[4];
+#pragma unroll
+    for (u32 w = 0; w < 4; ++w)
+        w_off[w] = L.off(w);
     // PARTITION mode: work units (partition, chunk) are drawn from a device-wide counter until it passes the unit count
     // (every workgroup reaches that exit).  RANGE mode (offsets == nullptr): chunk blockIdx.x, +gridDim.x, ... of the
     // source columns themselves (keys/words0/words1 point at the block's first row) -- the low-cardinality GROUP BY runs this way.
@@ -927,8 +929,17 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                 cv[q] = cond ? (u32)__builtin_nontemporal_load(&cond[i]) : 1u;
                 kv[q] = (u64)__builtin_nontemporal_load(&keys[i]);
                 typedef typename std::conditional<AW == 8, u64, typename std::conditional<AW == 4, u32, typename std::conditional<AW == 2, u16, u8>::type>::type>::type AT;
-                av[q][0] = K > 0 ? (u64)__builtin_nontemporal_load((const AT *)words0 + i) : 0;
-                av[q][1] = K > 1 ? (u64)__builtin_nontemporal_load((const AT *)words1 + i) : 0;
+                // (with a compile-time OPS the loads are unconditional or absent: a run-time `K > 0` puts a branch around each load)
+                if constexpr (OPS != 0)
+                {
+                    av[q][0] = gbp_ops_use(OPS, 1, 3) ? (u64)__builtin_nontemporal_load((const AT *)words0 + i) : 0;
+                    av[q][1] = gbp_ops_use(OPS, 2, 4) ? (u64)__builtin_nontemporal_load((const AT *)words1 + i) : 0;
+                }
+                else
+                {
+                    av[q][0] = K > 0 ? (u64)__builtin_nontemporal_load((const AT *)words0 + i) : 0;
+                    av[q][1] = K > 1 ? (u64)__builtin_nontemporal_load((const AT *)words1 + i) : 0;
+                }
             }
         };
         // (Combining the rows of a hot key in registers before the LDS atomic was tried for Zipf inputs: once partitions are
@@ -961,7 +972,7 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                     }
                     else
                     {
-                        u32 s = (u32)(gbp_mix(key) >> 20) & (S - 1); // bits disjoint from the partition id (>> 52)
+                        u32 s = gbp_cell<KT>((KT)key, offsets ? P : 1u, S); // bits disjoint from the partition id
 #pragma unroll 1
                         for (int probe = 0; probe < 64; ++probe)
                         {
@@ -978,6 +989,26 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                     }
                     if (ls != ~0u)
                     {
+                        if constexpr (OPS != 0)
+                        {
+#pragma unroll
+                            for (u32 w = 0; w < 4; ++w)
+                            {
+                                const u32 op = (OPS >> (4 * w)) & 15u;
+                                if (op == 0)
+                                    break;
+                                unsigned char * wp = lds_raw + w_off[w];
+                                if (op == 1 || op == 2)
+                                    atomicAdd((unsigned long long *)wp + ls, (unsigned long long)(op == 1 ? b0 : b1));
+                                else if (op == 3 || op == 4)
+                                    atomicAdd((double *)wp + ls, __longlong_as_double((long long)(op == 3 ? b0 : b1)));
+                                else if (op == 5)
+                                    atomicAdd((unsigned int *)wp + ls, 1u);
+                                else
+                                    atomicAdd((unsigned long long *)wp + ls, 1ull);
+                            }
+                        }
+                        else
 #pragma unroll
                         for (u32 j = 0; j < AGG_MAX_AGGS; ++j)
                         {
@@ -1504,11 +1535,11 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     static const bool no_wide = getenv("CHGPU_TUNE_GB_NOWIDE") != nullptr;
     wide = wide && !no_wide;
     if (wide && key_w == 4)
-        hipLaunchKernelGGL(k_gb_hist_wide<u32>, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const u32 *)key_col->data + row_begin, n, rows_per_wg, P, counts, mult);
+        hipLaunchKernelGGL((k_rp_hist_wide<u32, GbpPartFn<u32>>), dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const u32 *)key_col->data + row_begin, n, rows_per_wg, P, counts, GbpPartFn<u32>{P, mult});
     else if (wide)
-        hipLaunchKernelGGL(k_gb_hist_wide<u64>, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const u64 *)key_col->data + row_begin, n, rows_per_wg, P, counts, mult);
+        hipLaunchKernelGGL((k_rp_hist_wide<u64, GbpPartFn<u64>>), dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const u64 *)key_col->data + row_begin, n, rows_per_wg, P, counts, GbpPartFn<u64>{P, mult});
     else
-        hipLaunchKernelGGL(k_gb_hist, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P, counts, mult);
+        hipLaunchKernelGGL(k_gb_hist, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P, counts, mult, key32 ? 1 : 0);
     int rc = chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, m, total_dev, tmp, tmp_b);
     if (rc == CHGPU_OK)
     {
@@ -1523,7 +1554,29 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
             hipLaunchKernelGGL(kern, dim3(G), dim3(GBP_THREADS), lds_sc, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P, \
                                (const u64 *)offsets, gc, (KT_ *)pkeys, mult);                                                                        \
     } while (0)
-        if (tile == 12288)     { if (key32) GB_SCATTER(12288, u32); else GB_SCATTER(12288, u64); }
+        static const bool no_carry = getenv("CHGPU_TUNE_GB_NOCARRY") != nullptr;
+        // carried-tail scatter: one 8-byte word, wide loads, P <= 256 (its 16-row carries take P * 16 * row bytes of LDS)
+        const size_t lds_cy = (size_t)8192 * row_lds + (size_t)P * 16 * row_lds + (size_t)P * 40 + 64;
+        if (wide && K == 1 && P <= 256 && !no_carry && lds_cy <= 159 * 1024)
+        {
+            if (key32)
+            {
+                auto kern = k_rp_scatter_carry<8192, u32, true, GbpPartFn<u32>>;
+                rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cy) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
+                if (rc == CHGPU_OK)
+                    hipLaunchKernelGGL(kern, dim3(G), dim3(GBP_THREADS), lds_cy, ctx->stream, (const u32 *)key_col->data + row_begin, (const u64 *)gc.src[0] + row_begin, n, rows_per_wg, P,
+                                       (const u64 *)offsets, (u32 *)pkeys, gc.dst[0], GbpPartFn<u32>{P, mult});
+            }
+            else
+            {
+                auto kern = k_rp_scatter_carry<8192, u64, true, GbpPartFn<u64>>;
+                rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cy) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
+                if (rc == CHGPU_OK)
+                    hipLaunchKernelGGL(kern, dim3(G), dim3(GBP_THREADS), lds_cy, ctx->stream, (const u64 *)key_col->data + row_begin, (const u64 *)gc.src[0] + row_begin, n, rows_per_wg, P,
+                                       (const u64 *)offsets, (u64 *)pkeys, gc.dst[0], GbpPartFn<u64>{P, mult});
+            }
+        }
+        else if (tile == 12288) { if (key32) GB_SCATTER(12288, u32); else GB_SCATTER(12288, u64); }
         else if (tile == 8192) { if (key32) GB_SCATTER(8192, u32); else GB_SCATTER(8192, u64); }
         else                   { if (key32) GB_SCATTER(4096, u32); else GB_SCATTER(4096, u64); }
 #undef GB_SCATTER
@@ -1594,18 +1647,67 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         hipLaunchKernelGGL(k_gb_units, dim3(1), dim3(1024), 0, ctx->stream, (const u64 *)offsets, G, P, n, chunk_rows, unit_start, unit_ctr);
         const u64 rows_per_chunk = chunk_rows;
         u32 grid = (u32)ctx->num_cus;
+        // the update of the state words as a compile-time code where the common shapes allow it (see k_agg_part_lds, OPS)
+        u32 ops = 0;
+        static const bool no_ops = getenv("CHGPU_TUNE_GB_NOOPS") != nullptr;
+        {
+            u32 word_op[AGG_MAX_WORDS] = {0};
+            bool ok = !no_ops && a->n_words <= 4;
+            for (u32 j = 0; j < d.n_aggs && ok; ++j)
+            {
+                const u32 w = d.a[j].word;
+                const bool c32 = (cnt32 >> w) & 1;
+                if (d.a[j].kind == CHGPU_AGG_COUNT)
+                    word_op[w] = c32 ? 5 : 6;
+                else
+                {
+                    const bool f = d.a[j].arg_type == CHGPU_F64;
+                    ok = ok && d.a[j].pre < 2;
+                    word_op[w] = (f ? 3 : 1) + d.a[j].pre;
+                    if (d.a[j].kind == CHGPU_AGG_AVG)
+                        word_op[w + 1] = ((cnt32 >> (w + 1)) & 1) ? 5 : 6;
+                }
+            }
+            for (u32 w = 0; w < a->n_words && ok; ++w)
+            {
+                ok = ok && word_op[w] != 0; // (a pass over a subset of the functions leaves words untouched: generic kernel)
+                ops |= word_op[w] << (4 * w);
+            }
+            if (!ok)
+                ops = 0;
+        }
+#define GB_AGG(KT_, OPS_)                                                                                                                              \
+    do                                                                                                                                                \
+    {                                                                                                                                                 \
+        auto kern = k_agg_part_lds<KT_, 8, KT_, false, OPS_>;                                                                                          \
+        rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
+        if (rc == CHGPU_OK)                                                                                                                           \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const KT_ *)pkeys, (const void *)pwords, (const void *)(pwords + n), \
+                               (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr, (const u8 *)nullptr); \
+    } while (0)
+#define GB_AGG_OPS(KT_)                                      \
+    switch (ops)                                             \
+    {                                                        \
+        case 0x51: GB_AGG(KT_, 0x51); break; /* sum, count */     \
+        case 0x15: GB_AGG(KT_, 0x15); break; /* count, sum */     \
+        case 0x1: GB_AGG(KT_, 0x1); break;   /* sum */            \
+        case 0x5: GB_AGG(KT_, 0x5); break;   /* count */          \
+        case 0x53: GB_AGG(KT_, 0x53); break; /* sum(Float64), count = avg(Float64) */ \
+        case 0x3: GB_AGG(KT_, 0x3); break;   /* sum(Float64) */   \
+        case 0x21: GB_AGG(KT_, 0x21); break; /* sum, sum */       \
+        case 0x521: GB_AGG(KT_, 0x521); break; /* sum, sum, count */ \
+        default: GB_AGG(KT_, 0); break;                      \
+    }
         if (key32)
         {
-            rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
-            if (rc == CHGPU_OK)
-                hipLaunchKernelGGL((k_agg_part_lds<u32, 8>), dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u32 *)pkeys, (const void *)pwords, (const void *)(pwords + n), (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr, (const u8 *)nullptr);
+            GB_AGG_OPS(u32)
         }
         else
         {
-            rc = hipFuncSetAttribute((const void *)k_agg_part_lds<u64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
-            if (rc == CHGPU_OK)
-                hipLaunchKernelGGL((k_agg_part_lds<u64, 8>), dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const u64 *)pkeys, (const void *)pwords, (const void *)(pwords + n), (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr, (const u8 *)nullptr);
+            GB_AGG_OPS(u64)
         }
+#undef GB_AGG_OPS
+#undef GB_AGG
     }
     ctx->counters[6] += 3;
     ctx->counters[5] += n;

@@ -16,6 +16,7 @@
 // sequence number.  The table is built once in chgpu_join_finish_build (IJoin::onBuildPhaseFinish), sized from the
 // number of build rows, so no kernel ever has to grow it.
 #include "chgpu_internal.h"
+#include "radix_partition.h"
 
 #include <cstdlib>
 
@@ -1200,6 +1201,219 @@ __global__ __launch_bounds__(64) void k_join_probe_agg_finish(const u64 * __rest
     out2[1] = FLOAT ? (u64)__double_as_longlong(sf) : si;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same fused probe for build sides far beyond a cache: the probe keys are first radix-partitioned by TABLE REGION (the top bits
+// of their home slot) with the carried-tail partition of radix_partition.h, then every region's keys are probed by the workgroups of
+// ONE XCD at a time, so the region's slice of the table (~1 MB) is fetched from HBM once and every further lookup is an L2 hit:
+// the unpartitioned probe pays one random 64-byte HBM / Infinity-Cache transaction per key (3.8e10/s chip-wide over a 256 MB table)
+// whatever the bandwidth.  Workgroup -> XCD placement is read from HW_REG_XCC_ID and only steers which queue a workgroup drains
+// first; every workgroup ends up draining all eight queues, so the result never depends on it.
+// ---------------------------------------------------------------------------------------------
+struct JoinRegionFn
+{
+    u64 mask;
+    u32 shift;
+    __device__ __forceinline__ u32 operator()(u64 key) const { return (u32)((dev_intHash64(key) & mask) >> shift); }
+};
+
+static constexpr u32 JPR_CHUNK = 4096; // keys per work item
+static constexpr u32 JPR_XCDS = 8;
+
+// per XCD x: the chunks of regions x, x + 8, ... as one queue; qstart[x * (R/8 + 1) + i] = first chunk of its i-th region
+__global__ void k_jp_queues(const u64 * __restrict__ offsets, u32 G, u32 R, u64 n, u32 * __restrict__ qstart, u32 * __restrict__ qctr)
+{
+    const u32 x = threadIdx.x;
+    if (x >= JPR_XCDS)
+        return;
+    const u32 per = R / JPR_XCDS;
+    u32 acc = 0;
+    for (u32 i = 0; i < per; ++i)
+    {
+        const u32 r = x + i * JPR_XCDS;
+        const u64 b = offsets[(u64)r * G], e = r + 1 < R ? offsets[(u64)(r + 1) * G] : n;
+        qstart[x * (per + 1) + i] = acc;
+        acc += (u32)((e - b + JPR_CHUNK - 1) / JPR_CHUNK);
+    }
+    qstart[x * (per + 1) + per] = acc;
+    qctr[x] = 0;
+}
+
+template <bool PF>
+__global__ __launch_bounds__(JT) void k_join_probe_agg_regions(JoinTable t, int variant, const u64 * __restrict__ keys, u64 n, const u64 * __restrict__ offsets, u32 G, u32 R,
+                                                               const u32 * __restrict__ qstart, u32 * __restrict__ qctr, const void * __restrict__ payload, int payload_type,
+                                                               const u64 * __restrict__ block_base, u64 n_blocks, unsigned long long * __restrict__ result2)
+{
+    PfView pf{};
+    if constexpr (PF)
+        pf = jt_pf_view(t);
+    __shared__ u64 sh_begin, sh_end;
+    __shared__ u32 sh_more;
+    __shared__ u64 sh_c[JT / 64], sh_s[JT / 64];
+    const u32 per = R / JPR_XCDS;
+    const u32 xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & (JPR_XCDS - 1); // HW_REG_XCC_ID[3:0]
+    u64 cnt = 0, isum = 0;
+    auto flat_of = [&](u64 rowid) -> u64 { return n_blocks == 1 ? (rowid & 0xFFFFFFFFull) : block_base[rowid >> 32] + (rowid & 0xFFFFFFFFull); };
+    for (u32 dx = 0; dx < JPR_XCDS; ++dx)
+    {
+        const u32 x = (xcc + dx) & (JPR_XCDS - 1);
+        const u32 * qs = qstart + x * (per + 1);
+        for (;;)
+        {
+            __syncthreads(); // the previous item's sh_* have been read by everyone
+            if (threadIdx.x == 0)
+            {
+                const u32 c = atomicAdd(&qctr[x], 1u);
+                u32 more = c < qs[per];
+                if (more)
+                {
+                    u32 i = 0;
+                    while (i + 1 < per && qs[i + 1] <= c)
+                        ++i;
+                    const u32 r = x + i * JPR_XCDS;
+                    const u64 rb = offsets[(u64)r * G], re = r + 1 < R ? offsets[(u64)(r + 1) * G] : n;
+                    const u64 b = rb + (u64)(c - qs[i]) * JPR_CHUNK;
+                    sh_begin = b;
+                    sh_end = b + JPR_CHUNK < re ? b + JPR_CHUNK : re;
+                }
+                sh_more = more;
+            }
+            __syncthreads();
+            if (!sh_more)
+                break; // every thread of the workgroup leaves this queue together; the counter only ever grows
+            const u64 begin = sh_begin, end = sh_end;
+            constexpr int RR = JPR_CHUNK / JT / 4; // 4 batches of RR = 4 keys per lane
+            static_assert(RR == 4, "chunk = 256 threads x 16 keys");
+#pragma unroll 1
+            for (u32 batch = 0; batch < 4; ++batch)
+            {
+                u64 key[RR], val[RR];
+                u32 slot[RR];
+                bool in[RR], found[RR];
+#pragma unroll
+                for (int q = 0; q < RR; ++q)
+                {
+                    const u64 i = begin + (u64)(batch * RR + q) * JT + threadIdx.x;
+                    in[q] = i < end;
+                    key[q] = in[q] ? __builtin_nontemporal_load(&keys[i]) : 0;
+                }
+#pragma unroll
+                for (int q = 0; q < RR; ++q)
+                    found[q] = in[q] && jt_find_value<PF>(t, pf, key[q], val[q], slot[q]);
+#pragma unroll
+                for (int q = 0; q < RR; ++q)
+                {
+                    if (!in[q])
+                        continue;
+                    if (!found[q])
+                    {
+                        cnt += (variant == PV_ALL_LEFT || variant == PV_ANY_LEFT || variant == PV_ANTI_LEFT) ? 1 : 0;
+                        continue;
+                    }
+                    if (variant == PV_ANTI_LEFT)
+                        continue;
+                    const u64 v = val[q];
+                    if (!(v & JV_MULTI))
+                    {
+                        cnt += 1;
+                        if (payload)
+                            isum += jload_payload(payload, payload_type, flat_of(v));
+                        continue;
+                    }
+                    const u64 c0 = (v >> 40) & JV_CNT_SAT;
+                    const u32 c = c0 < JV_CNT_SAT ? (u32)c0 : t.cnt[slot[q]];
+                    const u64 * run = t.rowids + (v & JV_START_MASK);
+                    cnt += c;
+                    if (payload)
+                        for (u32 k = 0; k < c; ++k)
+                            isum += jload_payload(payload, payload_type, flat_of(run[k]));
+                }
+            }
+        }
+    }
+    // integer count and wrap-around sum: the order of the additions does not matter
+    cnt = wave_reduce_add_u64(cnt);
+    isum = wave_reduce_add_u64(isum);
+    if ((threadIdx.x & 63) == 0)
+    {
+        sh_c[threadIdx.x >> 6] = cnt;
+        sh_s[threadIdx.x >> 6] = isum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        u64 c = 0, si = 0;
+        for (u32 w = 0; w < JT / 64; ++w)
+        {
+            c += sh_c[w];
+            si += sh_s[w];
+        }
+        atomicAdd(&result2[0], (unsigned long long)c);
+        atomicAdd(&result2[1], (unsigned long long)si);
+    }
+}
+
+// -> CHGPU_OK with res[] filled, or CHGPU_ERR_NOT_IMPLEMENTED when this plan does not apply (the caller then runs the one-pass probe)
+static int join_probe_agg_regions(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * right_payload, int variant, u64 res[2])
+{
+    chgpu_ctx * ctx = j->ctx;
+    const u64 n = key_col->rows, cap = j->t.capacity;
+    static const bool off = getenv("CHGPU_TUNE_JOIN_NO_REGIONS") != nullptr;
+    static const u64 min_rows = getenv("CHGPU_TUNE_JOIN_REGION_MIN_ROWS") ? strtoull(getenv("CHGPU_TUNE_JOIN_REGION_MIN_ROWS"), nullptr, 10) : (4ull << 20);
+    // worth it when the table is far larger than the XCDs' L2s together (32 MB) and there are enough keys to pay two extra passes
+    if (off || chgpu_type_size(j->key_type) != 8 || n < min_rows || cap * 16 < (64ull << 20) || ((uintptr_t)key_col->data % 16) != 0)
+        return CHGPU_ERR_NOT_IMPLEMENTED;
+    if (right_payload && chgpu_type_is_float(right_payload->type))
+        return CHGPU_ERR_NOT_IMPLEMENTED; // a Float64 sum keeps the one-pass probe's fixed reduction order
+    static const u32 region_kib = getenv("CHGPU_TUNE_JOIN_REGION_KIB") ? (u32)atoi(getenv("CHGPU_TUNE_JOIN_REGION_KIB")) : 1024;
+    u32 lg_cap = 0;
+    while ((1ull << lg_cap) < cap)
+        ++lg_cap;
+    u32 R = 8;
+    while (R < 256 && (cap * 16) / R > (u64)region_kib * 1024)
+        R <<= 1;
+    u32 lg_r = 0;
+    while ((1u << lg_r) < R)
+        ++lg_r;
+    const JoinRegionFn fn{cap - 1, lg_cap - lg_r};
+    const u32 G = (u32)ctx->num_cus;
+    constexpr u32 TILE = 12288;
+    u64 rows_per_wg = ((n + G - 1) / G + 63) / 64 * 64;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const u64 m = (u64)R * G;
+    const size_t cnt_b = al(m * 4), off_b = al(m * 8 + 8), tmp_b = chgpu_scan_tmp_bytes(m), q_b = al((size_t)JPR_XCDS * (R / JPR_XCDS + 1) * 4 + JPR_XCDS * 4 + 64);
+    void * scratch = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, cnt_b + off_b + 256 + tmp_b + q_b + al(n * 8) + 256, &scratch));
+    u32 * counts = (u32 *)scratch;
+    u64 * offsets = (u64 *)((char *)scratch + cnt_b);
+    u64 * total_dev = (u64 *)((char *)scratch + cnt_b + off_b); // [0] scan total, [2..3] the result
+    void * tmp = (char *)scratch + cnt_b + off_b + 256;
+    u32 * qstart = (u32 *)((char *)tmp + tmp_b);
+    u32 * qctr = qstart + JPR_XCDS * (R / JPR_XCDS + 1);
+    u64 * pkeys = (u64 *)((char *)qstart + q_b);
+    unsigned long long * result2 = (unsigned long long *)(total_dev + 2);
+    CHGPU_HIP(hipMemsetAsync(total_dev, 0, 64, ctx->stream));
+    hipLaunchKernelGGL((k_rp_hist_wide<u64, JoinRegionFn>), dim3(G), dim3(RP_THREADS), 0, ctx->stream, (const u64 *)key_col->data, n, rows_per_wg, R, counts, fn);
+    CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, m, total_dev, tmp, tmp_b));
+    const size_t lds = (size_t)TILE * 8 + (size_t)R * 16 * 8 + (size_t)R * 40 + 64;
+    auto scat = k_rp_scatter_carry<TILE, u64, false, JoinRegionFn>;
+    CHGPU_HIP(hipFuncSetAttribute((const void *)scat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(scat, dim3(G), dim3(RP_THREADS), lds, ctx->stream, (const u64 *)key_col->data, (const u64 *)nullptr, n, rows_per_wg, R, (const u64 *)offsets, pkeys,
+                       (u64 *)nullptr, fn);
+    hipLaunchKernelGGL(k_jp_queues, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)offsets, G, R, n, qstart, qctr);
+    const void * pp = right_payload ? right_payload->data : nullptr;
+    const int pt = right_payload ? right_payload->type : CHGPU_U64;
+    const u32 grid = (u32)ctx->num_cus * 4;
+    if (j->t.pf)
+        hipLaunchKernelGGL(k_join_probe_agg_regions<true>, dim3(grid), dim3(JT), 0, ctx->stream, j->t, variant, (const u64 *)pkeys, n, (const u64 *)offsets, G, R,
+                           (const u32 *)qstart, qctr, pp, pt, (const u64 *)j->block_base_dev, (u64)j->blocks.size(), result2);
+    else
+        hipLaunchKernelGGL(k_join_probe_agg_regions<false>, dim3(grid), dim3(JT), 0, ctx->stream, j->t, variant, (const u64 *)pkeys, n, (const u64 *)offsets, G, R,
+                           (const u32 *)qstart, qctr, pp, pt, (const u64 *)j->block_base_dev, (u64)j->blocks.size(), result2);
+    ctx->counters[6] += 4;
+    CHGPU_HIP(hipGetLastError());
+    return chgpu_read_back(ctx, result2, res, 16);
+}
+
 extern "C" int chgpu_join_probe_agg(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map, const chgpu_col * right_payload,
                                     uint64_t * count_out, void * sum_out)
 {
@@ -1230,7 +1444,10 @@ extern "C" int chgpu_join_probe_agg(chgpu_join * j, const chgpu_col * key_col, c
     else variant = PV_ANY_LEFT;
     const bool is_float = right_payload && chgpu_type_is_float(right_payload->type);
     u64 res[2] = {0, 0};
-    if (n)
+    int plan = n && !null_map ? join_probe_agg_regions(j, key_col, right_payload, variant, res) : CHGPU_ERR_NOT_IMPLEMENTED;
+    if (plan != CHGPU_OK && plan != CHGPU_ERR_NOT_IMPLEMENTED)
+        return plan;
+    if (n && plan != CHGPU_OK)
     {
         const u32 grid = chgpu_grid_for(ctx, (n + 3) / 4, JT, 8);
         void * scratch = nullptr;

@@ -173,3 +173,68 @@ def test_pinned_async_upload_overlaps_and_orders(ch, ctx):
         assert K.lib().chgpu_upload_wait(ctx._h, 10**9) == K.ERR_BAD_ARGUMENTS
     finally:
         K.check(K.lib().chgpu_host_free(host))
+
+
+# ---- GROUP BY partitioned path: carried-tail scatter, 32-bit partition hash, compile-time state updates -----------------------------
+@pytest.mark.parametrize("key_dtype,pattern", [(np.uint32, "uniform"), (np.uint32, "stride"), (np.int32, "zipf"), (np.uint64, "uniform"), (np.uint16, "uniform")])
+@pytest.mark.parametrize("aggs_name", ["sum_count", "count_sum", "sum", "avg_f64", "sum_sum_count"])
+def test_groupby_partitioned_shapes_match_numpy(ch, ctx, key_dtype, pattern, aggs_name):
+    rng = np.random.Generator(np.random.PCG64(2024))
+    n = 6_000_011   # ragged: not a multiple of any tile; >= 4 Mi rows so the partitioned strategy is taken
+    groups = 300_000
+    if pattern == "uniform":
+        k = rng.integers(0, min(groups, np.iinfo(key_dtype).max), size=n).astype(key_dtype)
+    elif pattern == "stride":
+        k = (rng.integers(0, groups, size=n).astype(np.uint64) * np.uint64(4096)).astype(key_dtype)  # keys differ in high bits only (+ key 0)
+    else:
+        k = np.minimum(rng.zipf(1.2, size=n), groups).astype(key_dtype)                                 # a few very hot keys
+    v = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
+    w = rng.integers(-2**31, 2**31, size=n, dtype=np.int64)
+    f = rng.random(n)
+    spec = {"sum_count": [(ch.AGG_SUM, np.int64, v), (ch.AGG_COUNT, None, None)],
+            "count_sum": [(ch.AGG_COUNT, None, None), (ch.AGG_SUM, np.int64, v)],
+            "sum": [(ch.AGG_SUM, np.int64, v)],
+            "avg_f64": [(ch.AGG_AVG, np.float64, f)],
+            "sum_sum_count": [(ch.AGG_SUM, np.int64, v), (ch.AGG_SUM, np.int64, w), (ch.AGG_COUNT, None, None)]}[aggs_name]
+    A = ch.Aggregator(key_dtype, [(kind, dt) for kind, dt, _ in spec], size_hint=groups, ctx=ctx)
+    cols = {id(a): ctx.upload(a) for _, _, a in spec if a is not None}
+    A.execute_on_block(ctx.upload(k), [cols[id(a)] if a is not None else None for _, _, a in spec])
+    gk, res = A.convert_to_block()
+    uk, inv = np.unique(k, return_inverse=True)
+    order = np.argsort(gk)
+    assert np.array_equal(gk[order], uk)
+    cnt = np.bincount(inv, minlength=uk.shape[0])
+    for (kind, dt, a), r in zip(spec, res):
+        if kind == ch.AGG_COUNT:
+            assert np.array_equal(r[order], cnt.astype(np.uint64))
+        elif kind == ch.AGG_SUM:
+            want = np.zeros(uk.shape[0], dtype=np.uint64)
+            np.add.at(want, inv, a.astype(np.uint64))               # wraps modulo 2^64 like AggregateFunctionSum
+            assert np.array_equal(r[order].view(np.uint64), want)
+        else:
+            want = np.bincount(inv, weights=a, minlength=uk.shape[0]) / cnt
+            assert np.allclose(r[order], want, rtol=1e-6, atol=0)    # BASELINE: 1e-6 relative for avg(Float64)
+
+
+# ---- fused join -> aggregate over a build side far beyond L2: probe keys partitioned by table region --------------------------------
+@pytest.mark.parametrize("kind", ["INNER", "LEFT"])
+def test_join_probe_agg_region_partitioned_matches_numpy(ch, ctx, kind):
+    rng = np.random.Generator(np.random.PCG64(99))
+    nb, npb, space = 3_200_000, 6_000_003, 6_000_000      # table 2^23 cells x 16 B = 128 MB: the region plan applies
+    bk = rng.integers(0, space // 2, size=nb, dtype=np.uint64)          # duplicates (MULTI cells) and the zero key
+    bv = rng.integers(-2**50, 2**50, size=nb, dtype=np.int64)
+    pk = rng.integers(0, space, size=npb, dtype=np.uint64)
+    j = ch.HashJoin(ch.JOIN_INNER if kind == "INNER" else ch.JOIN_LEFT, ch.STRICT_ALL, ctx=ctx)
+    j.add_block(bk[:1_000_000])
+    j.add_block(bk[1_000_000:])                                         # two right blocks: flat row ordinals
+    c, s = j.probe_count_sum(ctx.upload(pk), ctx.upload(bv))
+    mult = np.bincount(bk.astype(np.int64), minlength=space)
+    sums = np.zeros(space, dtype=np.uint64)
+    np.add.at(sums, bk.astype(np.int64), bv.astype(np.uint64))
+    m = mult[pk.astype(np.int64)]
+    want_c = int(m.sum()) + (int((m == 0).sum()) if kind == "LEFT" else 0)
+    want_s = int(sums[pk.astype(np.int64)].sum(dtype=np.uint64))
+    assert c == want_c and s % 2**64 == want_s
+    c2, s2 = j.probe_count_sum(ctx.upload(pk[:1000]), ctx.upload(bv))   # a small probe takes the one-pass kernel: same answers
+    m2 = mult[pk[:1000].astype(np.int64)]
+    assert c2 == int(m2.sum()) + (int((m2 == 0).sum()) if kind == "LEFT" else 0)
