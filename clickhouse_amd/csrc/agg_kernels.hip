@@ -453,7 +453,6 @@ __global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, co
 #define GBP_WG_PER_CU 1
 #endif
 static constexpr u32 GBP_THREADS = GBP_THREADS_V;
-static_assert(GBP_THREADS_V == 1024, "the shared partition kernels (radix_partition.h) run 1024 threads");
 static constexpr u32 GBP_MAX_P = 1024;
 static constexpr u32 GBP_MAX_K = 2;
 
@@ -538,7 +537,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_hist(const void * __restrict
 // nontemporal load; otherwise rows are strided by the workgroup size and loaded one by one through the type switches.
 template <u32 GBP_TILE, typename KT, bool WIDE>
 __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restrict__ keys, int key_type, u64 row_begin, u64 n, u64 rows_per_wg,
-                                                            u32 P, const u64 * __restrict__ offsets, GbpCols cols, KT * __restrict__ out_keys, u64 mult)
+                                                            u32 P, const u64 * __restrict__ offsets, GbpCols cols, KT * __restrict__ out_keys, u64 mult, int gmajor = 0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
     u64 * stage_word = (u64 *)gb_lds;
@@ -551,7 +550,7 @@ __global__ __launch_bounds__(GBP_THREADS) void k_gb_scatter(const void * __restr
 
     for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
     {
-        cursor[p] = offsets[(u64)p * gridDim.x + blockIdx.x];
+        cursor[p] = offsets[gmajor ? (u64)blockIdx.x * P + p : (u64)p * gridDim.x + blockIdx.x];
         tile_cnt[p] = 0;
     }
     __syncthreads();
@@ -1459,7 +1458,13 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         CHGPU_TRY(agg_read_ctrl(a, &c0));
         CHGPU_TRY(agg_grow(a, c0.n_groups, c0.has_zero != 0));
     }
-    const u32 G = (u32)ctx->num_cus * GBP_WG_PER_CU;
+    static const int gmajor_x = getenv("CHGPU_EXPERIMENT_GMAJOR") ? 1 : 0; // timing experiment only: the aggregate pass still reads p-major
+    // (carried tails measured SLOWER than plain runs -- 8.5 / 7.3 vs 6.4 ms at C3 -- and wrote more, not fewer, bytes (PMC WRITE_SIZE 21 GB
+    //  vs 13 GB): a partition's line is then written by two instructions a barrier apart; kept selectable for A/B runs)
+    static const int carry_mode = getenv("CHGPU_TUNE_GB_CARRY") ? atoi(getenv("CHGPU_TUNE_GB_CARRY")) : 0;
+    // (two scatter workgroups per CU in carry mode 2: the histogram is cut into the same row ranges)
+    const bool carry_shape = carry_mode && K == 1 && P <= 256 && n < (1ull << 32);
+    const u32 G = (u32)ctx->num_cus * (carry_shape && carry_mode == 2 ? 2 : GBP_WG_PER_CU);
     u64 rows_per_wg = (n + G - 1) / G;
     // the scatter's LDS image is tile*(8*K + key bytes) + 24*P bytes and must stay under ~159 KiB (160 KiB per workgroup, 64 B static)
     const size_t row_lds = 8 * K + (key32 ? 4 : 8);
@@ -1479,8 +1484,9 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     const size_t cnt_b = al(m * 4), off_b = al(m * 8 + 8), tmp_b = chgpu_scan_tmp_bytes(m), pend_b = al(((n + 63) / 64) * 8 + 8) + al((GBP_MAX_P + 2) * 4);
     // The partition buffers live in the context's scratch arena, which is kept between calls: a fresh hipMalloc of
     // 16 GB costs ~0.4 s, fifteen times the kernels it would serve.
-    const size_t keys_b = al((size_t)n * (key32 ? 4 : 8));
-    const size_t part_b = keys_b + al((size_t)n * 8 * K);
+    const u64 wstride = n + RP_SCATTER_SLACK; // rows per argument-word array (k_rp_scatter parks out-of-range rows in the slack)
+    const size_t keys_b = al((size_t)wstride * (key32 ? 4 : 8));
+    const size_t part_b = keys_b + al((size_t)wstride * 8 * K);
     const size_t own_b = al(cnt_b + off_b + 256 + tmp_b + pend_b + part_b);
     // a level-1 call reserves the region of its level-2 calls up front (growing the arena later would move it): the same
     // row count at most, bookkeeping for the largest partition count
@@ -1510,7 +1516,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
             continue;
         gc.src[kk] = arg_cols[j]->data;
         gc.type[kk] = a->arg_types[j];
-        gc.dst[kk] = pwords + (u64)kk * n;
+        gc.dst[kk] = pwords + (u64)kk * wstride;
         // the aggregate pass reads widened 8-byte words: integers were sign/zero-extended, Float64 kept its bits
         d.a[j].ptr = gc.dst[kk];
         d.a[j].arg_type = chgpu_type_is_float(a->arg_types[j]) ? CHGPU_F64 : CHGPU_U64;
@@ -1535,9 +1541,9 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     static const bool no_wide = getenv("CHGPU_TUNE_GB_NOWIDE") != nullptr;
     wide = wide && !no_wide;
     if (wide && key_w == 4)
-        hipLaunchKernelGGL((k_rp_hist_wide<u32, GbpPartFn<u32>>), dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const u32 *)key_col->data + row_begin, n, rows_per_wg, P, counts, GbpPartFn<u32>{P, mult});
+        hipLaunchKernelGGL((k_rp_hist_wide<u32, GbpPartFn<u32>>), dim3(G), dim3(RP_THREADS), 0, ctx->stream, (const u32 *)key_col->data + row_begin, n, rows_per_wg, P, counts, GbpPartFn<u32>{P, mult}, gmajor_x);
     else if (wide)
-        hipLaunchKernelGGL((k_rp_hist_wide<u64, GbpPartFn<u64>>), dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const u64 *)key_col->data + row_begin, n, rows_per_wg, P, counts, GbpPartFn<u64>{P, mult});
+        hipLaunchKernelGGL((k_rp_hist_wide<u64, GbpPartFn<u64>>), dim3(G), dim3(RP_THREADS), 0, ctx->stream, (const u64 *)key_col->data + row_begin, n, rows_per_wg, P, counts, GbpPartFn<u64>{P, mult});
     else
         hipLaunchKernelGGL(k_gb_hist, dim3(G), dim3(GBP_THREADS), 0, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P, counts, mult, key32 ? 1 : 0);
     int rc = chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, m, total_dev, tmp, tmp_b);
@@ -1552,29 +1558,57 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
         if (rc == CHGPU_OK)                                                                                                                     \
             hipLaunchKernelGGL(kern, dim3(G), dim3(GBP_THREADS), lds_sc, ctx->stream, (const void *)key_col->data, a->key_type, row_begin, n, rows_per_wg, P, \
-                               (const u64 *)offsets, gc, (KT_ *)pkeys, mult);                                                                        \
+                               (const u64 *)offsets, gc, (KT_ *)pkeys, mult, gmajor_x);                                                              \
     } while (0)
-        static const bool no_carry = getenv("CHGPU_TUNE_GB_NOCARRY") != nullptr;
-        // carried-tail scatter: one 8-byte word, wide loads, P <= 256 (its 16-row carries take P * 16 * row bytes of LDS)
-        const size_t lds_cy = (size_t)8192 * row_lds + (size_t)P * 16 * row_lds + (size_t)P * 40 + 64;
-        if (wide && K == 1 && P <= 256 && !no_carry && lds_cy <= 159 * 1024)
+        // carried-tail scatter (radix_partition.h): one 8-byte word, wide loads, P <= 256, < 2^32 rows.  carry_mode 2 = 512 threads x
+        // 4096-row tiles x 8-row pieces, two workgroups per CU; 1 = 1024 x 8192 x 16-row pieces, one per CU
+        static const bool old_scatter = getenv("CHGPU_TUNE_GB_OLD_SCATTER") != nullptr;
+        if (!carry_mode && !old_scatter && wide && K == 1 && n + RP_SCATTER_SLACK < (1ull << 32) && P + 1 <= 2 * RP_THREADS)
         {
-            if (key32)
+            // the branch-free scatter (radix_partition.h): one 8-byte word, wide loads
+            if (key32 && rp_scatter_lds_bytes(12288, P, 4, true) <= 159 * 1024)
             {
-                auto kern = k_rp_scatter_carry<8192, u32, true, GbpPartFn<u32>>;
-                rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cy) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
+                auto kern = k_rp_scatter<12288, u32, true, GbpPartFn<u32>>;
+                const size_t lds_b = rp_scatter_lds_bytes(12288, P, 4, true);
+                rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
                 if (rc == CHGPU_OK)
-                    hipLaunchKernelGGL(kern, dim3(G), dim3(GBP_THREADS), lds_cy, ctx->stream, (const u32 *)key_col->data + row_begin, (const u64 *)gc.src[0] + row_begin, n, rows_per_wg, P,
+                    hipLaunchKernelGGL(kern, dim3(G), dim3(RP_THREADS), lds_b, ctx->stream, (const u32 *)key_col->data + row_begin, (const u64 *)gc.src[0] + row_begin, n, rows_per_wg, P,
+                                       (const u64 *)offsets, (u32 *)pkeys, gc.dst[0], GbpPartFn<u32>{P, mult});
+            }
+            else if (key32)
+            {
+                auto kern = k_rp_scatter<8192, u32, true, GbpPartFn<u32>>;
+                const size_t lds_b = rp_scatter_lds_bytes(8192, P, 4, true);
+                rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
+                if (rc == CHGPU_OK)
+                    hipLaunchKernelGGL(kern, dim3(G), dim3(RP_THREADS), lds_b, ctx->stream, (const u32 *)key_col->data + row_begin, (const u64 *)gc.src[0] + row_begin, n, rows_per_wg, P,
                                        (const u64 *)offsets, (u32 *)pkeys, gc.dst[0], GbpPartFn<u32>{P, mult});
             }
             else
             {
-                auto kern = k_rp_scatter_carry<8192, u64, true, GbpPartFn<u64>>;
-                rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cy) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
+                auto kern = k_rp_scatter<8192, u64, true, GbpPartFn<u64>>;
+                const size_t lds_b = rp_scatter_lds_bytes(8192, P, 8, true);
+                rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
                 if (rc == CHGPU_OK)
-                    hipLaunchKernelGGL(kern, dim3(G), dim3(GBP_THREADS), lds_cy, ctx->stream, (const u64 *)key_col->data + row_begin, (const u64 *)gc.src[0] + row_begin, n, rows_per_wg, P,
+                    hipLaunchKernelGGL(kern, dim3(G), dim3(RP_THREADS), lds_b, ctx->stream, (const u64 *)key_col->data + row_begin, (const u64 *)gc.src[0] + row_begin, n, rows_per_wg, P,
                                        (const u64 *)offsets, (u64 *)pkeys, gc.dst[0], GbpPartFn<u64>{P, mult});
             }
+        }
+        else if (carry_mode && wide && K == 1 && P <= 256 && n < (1ull << 32))
+        {
+#define GB_CARRY(KT_, TILE_, THR_, CG_)                                                                                                          \
+    do                                                                                                                                          \
+    {                                                                                                                                           \
+        auto kern = k_rp_scatter_carry<TILE_, KT_, true, GbpPartFn<KT_>, THR_, CG_>;                                                             \
+        const size_t lds_cy = rp_scatter_carry_lds_bytes(TILE_, P, CG_, sizeof(KT_), true);                                                      \
+        rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cy) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
+        if (rc == CHGPU_OK)                                                                                                                     \
+            hipLaunchKernelGGL(kern, dim3(G), dim3(THR_), lds_cy, ctx->stream, (const KT_ *)key_col->data + row_begin, (const u64 *)gc.src[0] + row_begin, n, rows_per_wg, P, \
+                               (const u64 *)offsets, (KT_ *)pkeys, gc.dst[0], GbpPartFn<KT_>{P, mult});                                          \
+    } while (0)
+            if (carry_mode == 2) { if (key32) GB_CARRY(u32, 4096, 512, 8); else GB_CARRY(u64, 2048, 512, 8); }
+            else                 { if (key32) GB_CARRY(u32, 8192, 1024, 16); else GB_CARRY(u64, 4096, 1024, 16); }
+#undef GB_CARRY
         }
         else if (tile == 12288) { if (key32) GB_SCATTER(12288, u32); else GB_SCATTER(12288, u64); }
         else if (tile == 8192) { if (key32) GB_SCATTER(8192, u32); else GB_SCATTER(8192, u64); }
@@ -1622,7 +1656,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
             ac[c].ctx = ctx;
             ac[c].type = chgpu_type_is_float(a->arg_types[j]) ? CHGPU_F64 : CHGPU_U64; // two's complement sums: width is what matters
             ac[c].rows = n;
-            ac[c].data = pwords + (u64)c * n;
+            ac[c].data = pwords + (u64)c * wstride;
             a->arg_types[j] = ac[c].type;
             sub_args[j] = &ac[c];
             ++c;
@@ -1682,7 +1716,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         auto kern = k_agg_part_lds<KT_, 8, KT_, false, OPS_>;                                                                                          \
         rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
         if (rc == CHGPU_OK)                                                                                                                           \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const KT_ *)pkeys, (const void *)pwords, (const void *)(pwords + n), \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds_ag, ctx->stream, a->t, d, (const KT_ *)pkeys, (const void *)pwords, (const void *)(pwords + wstride), \
                                (const u64 *)offsets, G, P, n, pending, S, K, cnt32, rows_per_chunk, (const u32 *)unit_start, unit_ctr, (const u8 *)nullptr); \
     } while (0)
 #define GB_AGG_OPS(KT_)                                      \

@@ -108,6 +108,7 @@ struct chgpu_join
     size_t table_class = 0;
     u64 n_keys = 0;
     u64 inserted = 0;
+    bool unique_keys = false; // no key has more than one build row (the CSR arrays are then untouched)
     u64 left_seq = 0; // running left-row sequence across joinBlock calls (INNER ANY)
     // RIGHT / FULL: JoinUsedFlags (src/Interpreters/HashJoin/JoinUsedFlags.h) -- one byte per build row in insertion order
     u8 * used = nullptr;
@@ -209,11 +210,17 @@ __device__ __forceinline__ u32 jt_find(const JoinTable & t, const PfView & pf, u
     return NO_SLOT;
 }
 
-// build pass 1: claim cells, count rows per key, record the owning row
+// build pass 1: claim cells, count rows per key, record the owning row.
+// The row that CLAIMS a cell (wins the compare-and-swap on its key) stores its row id with a plain store into the cell's value word --
+// the same 16 bytes it has just touched -- and issues no further atomic.  Only later rows of the same key pay atomics (rows-per-key
+// count, min / max row id).  A primary-key build side (every row claims) thus costs ONE device-scope atomic per row instead of
+// three: the pass is bound by the ~2e10/s rate of scattered memory-side atomics, not by bandwidth.  ctrl->pad is set when any row found
+// its key already present: without duplicates the CSR passes below (scan, fill, root-first) are skipped altogether.
 __global__ __launch_bounds__(JT) void k_join_insert(JoinTable t, const u64 * __restrict__ keys, const u8 * __restrict__ valid, u64 n,
                                                     u64 block_index, int maps_all, int take_last, u32 * __restrict__ slot_of_row)
 {
     u32 my_claims = 0; // nobody reads n_keys before the kernel ends: count in registers, one atomic per wave at the end
+    u32 my_dups = 0;
     u64 my_max = 0;
     for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
     {
@@ -226,27 +233,38 @@ __global__ __launch_bounds__(JT) void k_join_insert(JoinTable t, const u64 * __r
             if (slot != NO_SLOT)
             {
                 const u64 rowid = (block_index << 32) | i;
-                if (maps_all)
-                {
-                    atomicAdd(&t.cnt[slot], 1u);                                              // RowRefList::rows
-                    atomicMin((unsigned long long *)&t.first_row[slot], (unsigned long long)rowid); // the root RowRef = first inserted
-                }
-                else if (take_last)
-                    atomicMax((unsigned long long *)&t.first_row[slot], (unsigned long long)(rowid + 1)); // stored +1 so 0 == unset
+                if (claimed)
+                    t.kv[2 * (u64)slot + 1] = rowid; // nobody else writes this word before k_join_merge_claims / finalize read it
                 else
-                    atomicMin((unsigned long long *)&t.first_row[slot], (unsigned long long)rowid);       // insertOne: first row wins
+                {
+                    ++my_dups;
+                    if (maps_all)
+                    {
+                        atomicAdd(&t.cnt[slot], 1u);                                              // RowRefList::rows beyond the claimer's
+                        atomicMin((unsigned long long *)&t.first_row[slot], (unsigned long long)rowid); // the root RowRef = first inserted
+                    }
+                    else if (take_last)
+                        atomicMax((unsigned long long *)&t.first_row[slot], (unsigned long long)(rowid + 1)); // stored +1 so 0 == unset
+                    else
+                        atomicMin((unsigned long long *)&t.first_row[slot], (unsigned long long)rowid);       // insertOne: first row wins
+                }
             }
         }
         slot_of_row[i] = slot;
         my_claims += claimed;
     }
     // (a same-address atomic per wave and iteration costs ~10 ns each: 1.5 ms of a 1e7-row build)
-    u32 tot = my_claims;
+    u32 tot = my_claims, dups = my_dups;
 #pragma unroll
     for (int dlt = 32; dlt >= 1; dlt >>= 1)
+    {
         tot += __shfl_xor(tot, dlt, 64);
+        dups += __shfl_xor(dups, dlt, 64);
+    }
     if ((threadIdx.x & 63) == 0 && tot)
         atomicAdd(&t.ctrl->n_keys, (unsigned long long)tot);
+    if ((threadIdx.x & 63) == 0 && dups && t.ctrl->pad == 0)
+        atomicOr(&t.ctrl->pad, 1u);
 #pragma unroll
     for (int dlt = 32; dlt >= 1; dlt >>= 1)
     {
@@ -255,6 +273,28 @@ __global__ __launch_bounds__(JT) void k_join_insert(JoinTable t, const u64 * __r
     }
     if ((threadIdx.x & 63) == 0 && my_max)
         atomicMax(&t.ctrl->max_key, (unsigned long long)my_max);
+}
+
+// build pass 1b (only when some key has several rows): fold the claimers' row ids (value words) into first_row / cnt so the CSR passes
+// see what three atomics per row used to leave there
+__global__ __launch_bounds__(JT) void k_join_merge_claims(JoinTable t, int maps_all, int take_last)
+{
+    for (u64 s = (u64)blockIdx.x * JT + threadIdx.x; s <= t.capacity; s += (u64)gridDim.x * JT)
+    {
+        const bool occupied = s == t.capacity ? (t.ctrl->has_zero != 0) : (t.kv[2 * s] != 0);
+        if (!occupied)
+            continue;
+        const u64 claim = t.kv[2 * s + 1];
+        if (maps_all)
+        {
+            t.cnt[s] += 1;
+            t.first_row[s] = claim < t.first_row[s] ? claim : t.first_row[s];
+        }
+        else if (take_last)
+            t.first_row[s] = claim + 1 > t.first_row[s] ? claim + 1 : t.first_row[s];
+        else
+            t.first_row[s] = claim < t.first_row[s] ? claim : t.first_row[s];
+    }
 }
 
 // build pass 3: CSR fill
@@ -290,8 +330,9 @@ __global__ __launch_bounds__(JT) void k_join_root_first(JoinTable t)
     }
 }
 
-// build pass 5: one 8-byte word per cell that answers a probe without touching cnt/start/rowids for unique keys
-__global__ __launch_bounds__(JT) void k_join_finalize_values(JoinTable t, int maps_all, int take_last)
+// build pass 5: one 8-byte word per cell that answers a probe without touching cnt/start/rowids for unique keys.
+// unique != 0: no key had a second row -- the value words already hold the claimers' row ids; only the prefilter is filled.
+__global__ __launch_bounds__(JT) void k_join_finalize_values(JoinTable t, int maps_all, int take_last, int unique)
 {
     const PfView pf = jt_pf_view(t); // every insert kernel has finished: max_key is final
     for (u64 s = (u64)blockIdx.x * JT + threadIdx.x; s <= t.capacity; s += (u64)gridDim.x * JT)
@@ -302,6 +343,12 @@ __global__ __launch_bounds__(JT) void k_join_finalize_values(JoinTable t, int ma
         {
             const u64 pos = jt_pf_pos(pf, t.kv[2 * s]);
             atomicOr(&t.pf[pos >> 5], 1u << (pos & 31));
+        }
+        if (unique)
+        {
+            if (!occupied)
+                t.kv[2 * s + 1] = NO_ROW;
+            continue;
         }
         if (occupied)
         {
@@ -661,7 +708,10 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
     chgpu_ctx * ctx = j->ctx;
     const bool maps_all = j->strictness == CHGPU_STRICT_ALL;
     const bool flagged = j->kind == CHGPU_JOIN_INNER && j->strictness == CHGPU_STRICT_ANY;
-    static const u32 cap_shift = getenv("CHGPU_TUNE_JOIN_CAP_SHIFT") ? (u32)atoi(getenv("CHGPU_TUNE_JOIN_CAP_SHIFT")) : 0;
+    // load factor in (0.175, 0.35]: a probe then resolves at its home cell nearly always (1.1 cells per hit, 1.3 per miss, against 1.75 / 3.6
+    // at 0.6).  Measured at C4: build 1.00 -> 0.90 ms (fewer retried claims), probe 3.40 -> 2.26 ms region-partitioned, 4.83 -> 3.39 ms
+    // one-pass.  The table is immutable after the build and 288 GB of HBM make the doubled footprint (512 MB of cells for 1e7 rows) cheap.
+    static const u32 cap_shift = getenv("CHGPU_TUNE_JOIN_CAP_SHIFT") ? (u32)atoi(getenv("CHGPU_TUNE_JOIN_CAP_SHIFT")) : 1;
     const u64 cap = jpow2_ceil(j->total_rows + j->total_rows * 3 / 7 + 1) << cap_shift;
     CHGPU_REQUIRE(cap + 1 < 0xFFFFFFFFull, CHGPU_ERR_NOT_IMPLEMENTED, "build side of %llu rows exceeds the 32-bit cell index", (unsigned long long)j->total_rows);
     const u64 cells = cap + 1;
@@ -719,7 +769,17 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
                            (u64)bi, maps_all ? 1 : 0, take_last ? 1 : 0, slot_of_row + b.base);
         ctx->counters[6] += 1;
     }
-    if (maps_all)
+    // did any key get a second row?  (one small read-back; the common primary-key build then skips four passes over the table)
+    JoinCtrl after_insert;
+    CHGPU_TRY(chgpu_read_back(ctx, t.ctrl, &after_insert, sizeof(after_insert)));
+    const bool unique = after_insert.pad == 0;
+    j->unique_keys = unique;
+    if (!unique)
+    {
+        hipLaunchKernelGGL(k_join_merge_claims, dim3(chgpu_grid_for(ctx, cells, JT, 8)), dim3(JT), 0, ctx->stream, t, maps_all ? 1 : 0, take_last ? 1 : 0);
+        ctx->counters[6] += 1;
+    }
+    if (maps_all && !unique)
     {
         CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, t.cnt, t.start, cells, total_dev, tmp, tmp_b));
         CHGPU_HIP(hipMemsetAsync(cursor, 0, cells * 4, ctx->stream));
@@ -735,8 +795,14 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
         ctx->counters[6] += 1;
         CHGPU_TRY(chgpu_read_back(ctx, total_dev, &j->inserted, sizeof(u64)));
     }
-    hipLaunchKernelGGL(k_join_finalize_values, dim3(chgpu_grid_for(ctx, cells, JT, 8)), dim3(JT), 0, ctx->stream, t, maps_all ? 1 : 0, take_last ? 1 : 0);
-    ctx->counters[6] += 1;
+    else if (maps_all)
+        j->inserted = after_insert.n_keys;
+    // (without duplicates and without a prefilter there is nothing to finalise: the value word of an empty cell is never read)
+    if (!unique || t.pf)
+    {
+        hipLaunchKernelGGL(k_join_finalize_values, dim3(chgpu_grid_for(ctx, cells, JT, 8)), dim3(JT), 0, ctx->stream, t, maps_all ? 1 : 0, take_last ? 1 : 0, unique ? 1 : 0);
+        ctx->counters[6] += 1;
+    }
     CHGPU_HIP(hipGetLastError());
     JoinCtrl c;
     CHGPU_TRY(chgpu_read_back(ctx, t.ctrl, &c, sizeof(c)));
@@ -1250,13 +1316,20 @@ __global__ __launch_bounds__(JT) void k_join_probe_agg_regions(JoinTable t, int 
     __shared__ u32 sh_more;
     __shared__ u64 sh_c[JT / 64], sh_s[JT / 64];
     const u32 per = R / JPR_XCDS;
+    // the queue tables and the region boundaries live in LDS: the lane that fetches a work item then makes no dependent global read
+    __shared__ u32 s_qs[JPR_XCDS * (256 / JPR_XCDS + 1)];
+    __shared__ u64 s_roff[256 + 1];
+    for (u32 i = threadIdx.x; i < JPR_XCDS * (per + 1); i += JT)
+        s_qs[i] = qstart[i];
+    for (u32 r = threadIdx.x; r <= R; r += JT)
+        s_roff[r] = r < R ? offsets[(u64)r * G] : n;
     const u32 xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & (JPR_XCDS - 1); // HW_REG_XCC_ID[3:0]
     u64 cnt = 0, isum = 0;
     auto flat_of = [&](u64 rowid) -> u64 { return n_blocks == 1 ? (rowid & 0xFFFFFFFFull) : block_base[rowid >> 32] + (rowid & 0xFFFFFFFFull); };
     for (u32 dx = 0; dx < JPR_XCDS; ++dx)
     {
         const u32 x = (xcc + dx) & (JPR_XCDS - 1);
-        const u32 * qs = qstart + x * (per + 1);
+        const u32 * qs = s_qs + x * (per + 1);
         for (;;)
         {
             __syncthreads(); // the previous item's sh_* have been read by everyone
@@ -1270,7 +1343,7 @@ __global__ __launch_bounds__(JT) void k_join_probe_agg_regions(JoinTable t, int 
                     while (i + 1 < per && qs[i + 1] <= c)
                         ++i;
                     const u32 r = x + i * JPR_XCDS;
-                    const u64 rb = offsets[(u64)r * G], re = r + 1 < R ? offsets[(u64)(r + 1) * G] : n;
+                    const u64 rb = s_roff[r], re = s_roff[r + 1];
                     const u64 b = rb + (u64)(c - qs[i]) * JPR_CHUNK;
                     sh_begin = b;
                     sh_end = b + JPR_CHUNK < re ? b + JPR_CHUNK : re;
@@ -1281,14 +1354,17 @@ __global__ __launch_bounds__(JT) void k_join_probe_agg_regions(JoinTable t, int 
             if (!sh_more)
                 break; // every thread of the workgroup leaves this queue together; the counter only ever grows
             const u64 begin = sh_begin, end = sh_end;
-            constexpr int RR = JPR_CHUNK / JT / 4; // 4 batches of RR = 4 keys per lane
-            static_assert(RR == 4, "chunk = 256 threads x 16 keys");
+            constexpr int RR = 8; // keys per lane and batch: their first cell reads (and then their payload reads) are all in flight together --
+                                  // a lane that walks its keys one after the other has ONE random access outstanding
+            static_assert(JPR_CHUNK == JT * RR * 2, "chunk = 256 threads x 2 batches x 8 keys");
+            const u64 mask = t.capacity - 1;
 #pragma unroll 1
-            for (u32 batch = 0; batch < 4; ++batch)
+            for (u32 batch = 0; batch < 2; ++batch)
             {
-                u64 key[RR], val[RR];
-                u32 slot[RR];
-                bool in[RR], found[RR];
+                u64 key[RR];
+                jv2 cell[RR];
+                u64 slot0[RR];
+                bool in[RR];
 #pragma unroll
                 for (int q = 0; q < RR; ++q)
                 {
@@ -1298,35 +1374,82 @@ __global__ __launch_bounds__(JT) void k_join_probe_agg_regions(JoinTable t, int 
                 }
 #pragma unroll
                 for (int q = 0; q < RR; ++q)
-                    found[q] = in[q] && jt_find_value<PF>(t, pf, key[q], val[q], slot[q]);
+                {
+                    slot0[q] = dev_intHash64(key[q]) & mask;
+                    bool go = in[q] && key[q] != 0;
+                    if constexpr (PF)
+                        go = go && jt_pf_maybe(pf, key[q]);
+                    cell[q] = go ? *(const jv2 *)(t.kv + 2 * slot0[q]) : jv2{0, 0};
+                }
+                u64 pay_row[RR];
+                bool pay[RR];
 #pragma unroll
                 for (int q = 0; q < RR; ++q)
                 {
+                    pay[q] = false;
+                    pay_row[q] = 0;
                     if (!in[q])
                         continue;
-                    if (!found[q])
+                    bool found = false;
+                    u64 v = 0;
+                    u32 sl = 0;
+                    if (key[q] == 0)
+                    {
+                        found = t.ctrl->has_zero != 0;
+                        sl = (u32)t.capacity;
+                        v = found ? t.kv[2 * t.capacity + 1] : 0;
+                    }
+                    else if (cell[q].x == key[q])
+                    {
+                        found = true;
+                        v = cell[q].y;
+                        sl = (u32)slot0[q];
+                    }
+                    else if (cell[q].x != 0)
+                    {
+                        // the home cell belongs to another key: walk on (rare at the table's load factor; misses end at the first empty cell)
+                        u64 s2 = (slot0[q] + 1) & mask;
+                        for (u64 step = 1; step < t.capacity; ++step)
+                        {
+                            const jv2 c = *(const jv2 *)(t.kv + 2 * s2);
+                            if (c.x == key[q])
+                            {
+                                found = true;
+                                v = c.y;
+                                sl = (u32)s2;
+                                break;
+                            }
+                            if (c.x == 0)
+                                break;
+                            s2 = (s2 + 1) & mask;
+                        }
+                    }
+                    if (!found)
                     {
                         cnt += (variant == PV_ALL_LEFT || variant == PV_ANY_LEFT || variant == PV_ANTI_LEFT) ? 1 : 0;
                         continue;
                     }
                     if (variant == PV_ANTI_LEFT)
                         continue;
-                    const u64 v = val[q];
                     if (!(v & JV_MULTI))
                     {
                         cnt += 1;
-                        if (payload)
-                            isum += jload_payload(payload, payload_type, flat_of(v));
+                        pay[q] = payload != nullptr;
+                        pay_row[q] = flat_of(v);
                         continue;
                     }
                     const u64 c0 = (v >> 40) & JV_CNT_SAT;
-                    const u32 c = c0 < JV_CNT_SAT ? (u32)c0 : t.cnt[slot[q]];
+                    const u32 c = c0 < JV_CNT_SAT ? (u32)c0 : t.cnt[sl];
                     const u64 * run = t.rowids + (v & JV_START_MASK);
                     cnt += c;
                     if (payload)
                         for (u32 k = 0; k < c; ++k)
                             isum += jload_payload(payload, payload_type, flat_of(run[k]));
                 }
+                // the single-row matches' payload reads, issued back to back
+#pragma unroll
+                for (int q = 0; q < RR; ++q)
+                    isum += pay[q] ? jload_payload(payload, payload_type, pay_row[q]) : 0;
             }
         }
     }
@@ -1394,7 +1517,7 @@ static int join_probe_agg_regions(chgpu_join * j, const chgpu_col * key_col, con
     CHGPU_HIP(hipMemsetAsync(total_dev, 0, 64, ctx->stream));
     hipLaunchKernelGGL((k_rp_hist_wide<u64, JoinRegionFn>), dim3(G), dim3(RP_THREADS), 0, ctx->stream, (const u64 *)key_col->data, n, rows_per_wg, R, counts, fn);
     CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, m, total_dev, tmp, tmp_b));
-    const size_t lds = (size_t)TILE * 8 + (size_t)R * 16 * 8 + (size_t)R * 40 + 64;
+    const size_t lds = rp_scatter_carry_lds_bytes(TILE, R, 16, 8, false);
     auto scat = k_rp_scatter_carry<TILE, u64, false, JoinRegionFn>;
     CHGPU_HIP(hipFuncSetAttribute((const void *)scat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(scat, dim3(G), dim3(RP_THREADS), lds, ctx->stream, (const u64 *)key_col->data, (const u64 *)nullptr, n, rows_per_wg, R, (const u64 *)offsets, pkeys,

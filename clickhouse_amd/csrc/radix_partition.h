@@ -6,11 +6,12 @@
 
 static constexpr u32 RP_THREADS = 1024;
 static constexpr u32 RP_MAX_P = 1024;
+static constexpr u32 RP_SCATTER_SLACK = 12288; // rows of slack k_rp_scatter needs behind each of its output arrays
 
 // Same histogram with 16-byte nontemporal key loads (4- and 8-byte keys whose first row is 16-byte aligned): four loads
 // per lane are issued before the first LDS atomic.
 template <typename KT, typename PartFn>
-__global__ __launch_bounds__(RP_THREADS) void k_rp_hist_wide(const KT * __restrict__ keys, u64 n, u64 rows_per_wg, u32 P, u32 * __restrict__ counts, PartFn part_fn)
+__global__ __launch_bounds__(RP_THREADS) void k_rp_hist_wide(const KT * __restrict__ keys, u64 n, u64 rows_per_wg, u32 P, u32 * __restrict__ counts, PartFn part_fn, int gmajor = 0)
 {
     constexpr u32 GBP_THREADS = RP_THREADS;
     constexpr u32 GBP_MAX_P = RP_MAX_P;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_hist_wide(const KT * __restri
         atomicAdd(&cnt[part_fn(keys[i])], 1u);
     __syncthreads();
     for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
-        counts[(u64)p * gridDim.x + blockIdx.x] = cnt[p];
+        counts[gmajor ? (u64)blockIdx.x * P + p : (u64)p * gridDim.x + blockIdx.x] = cnt[p];
 }
 
 // The same pass with the partial lines of every partition run CARRIED from tile to tile in LDS, so that global memory only ever
@@ -65,24 +66,26 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_hist_wide(const KT * __restri
 // below the last 16-row boundary is written, the tail becomes the new carry.  Old carries are written by 16 consecutive lanes
 // per partition together with the stage rows that complete their line (same tile, microseconds apart: the L2 merges them).
 // One 8-byte argument word, WIDE loads only (the shape of config C3); P <= 256.
-// dynamic LDS: stage_word u64[TILE] | carry_word u64[P*16] (both only with HAS_WORD) | base u64[P] | delta u64[P] | obase u64[P] |
-//              stage_key KT[TILE] | carry_key KT[P*16] | ccnt u32[P] | tile_cnt u32[P] | tile_off u32[P] | ocnt u32[P]
+// dynamic LDS: stage_word u64[TILE] | carry_word u64[P*CG] (both only with HAS_WORD) | stage_key KT[TILE] | carry_key KT[P*CG] |
+//              base | delta | obase | ccnt | tile_cnt | tile_off | ocnt, each u32[P]      (rp_scatter_carry_lds_bytes)
 // PartFn: u32 operator()(KT key) const -> partition in [0, P).  HAS_WORD = false: keys only (words / out_words unused).
-template <u32 GBP_TILE, typename KT, bool HAS_WORD, typename PartFn>
-__global__ __launch_bounds__(RP_THREADS) void k_rp_scatter_carry(const KT * __restrict__ keys, const u64 * __restrict__ words, u64 n, u64 rows_per_wg, u32 P,
-                                                                 const u64 * __restrict__ offsets, KT * __restrict__ out_keys, u64 * __restrict__ out_words, PartFn part_fn)
+// THREADS x TILE: 1024 x 8192 runs one workgroup per CU; 512 x 4096 with CG = 8 fits two (<= 80 KiB of LDS each), whose memory and
+// LDS phases then overlap -- a single workgroup drains its stores (s_waitcnt vmcnt(0)) before every tile.  Output rows are 32-bit
+// (the callers bound a call below 2^32 rows).
+template <u32 GBP_TILE, typename KT, bool HAS_WORD, typename PartFn, u32 THREADS = RP_THREADS, u32 CG = 16>
+__global__ __launch_bounds__(THREADS) void k_rp_scatter_carry(const KT * __restrict__ keys, const u64 * __restrict__ words, u64 n, u64 rows_per_wg, u32 P,
+                                                              const u64 * __restrict__ offsets, KT * __restrict__ out_keys, u64 * __restrict__ out_words, PartFn part_fn)
 {
-    constexpr u32 GBP_THREADS = RP_THREADS;
-    constexpr u32 CG = 16; // carry granularity in rows
+    constexpr u32 GBP_THREADS = THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
     u64 * stage_word = (u64 *)gb_lds;
     u64 * carry_word = stage_word + (HAS_WORD ? GBP_TILE : 0);
-    u64 * base = carry_word + (HAS_WORD ? (size_t)P * CG : 0);
-    u64 * delta = base + P;
-    u64 * obase = delta + P;
-    KT * stage_key = (KT *)(obase + P);
+    KT * stage_key = (KT *)(carry_word + (HAS_WORD ? (size_t)P * CG : 0));
     KT * carry_key = stage_key + GBP_TILE;
-    u32 * ccnt = (u32 *)(carry_key + (size_t)P * CG);
+    u32 * base = (u32 *)(carry_key + (size_t)P * CG);
+    u32 * delta = base + P;
+    u32 * obase = delta + P;
+    u32 * ccnt = obase + P;
     u32 * tile_cnt = ccnt + P;
     u32 * tile_off = tile_cnt + P;
     u32 * ocnt = tile_off + P;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_scatter_carry(const KT * __re
 
     for (u32 p = threadIdx.x; p < P; p += GBP_THREADS)
     {
-        base[p] = offsets[(u64)p * gridDim.x + blockIdx.x];
+        base[p] = (u32)offsets[(u64)p * gridDim.x + blockIdx.x];
         ccnt[p] = 0;
         tile_cnt[p] = 0;
     }
@@ -178,23 +181,24 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_scatter_carry(const KT * __re
             for (u32 w = 0; w < wave; ++w)
                 off += wave_tot[w];
             auto plan = [&](u32 p, u32 toff, u32 nnew) {
-                const u64 b = base[p];
+                const u32 b = base[p];
                 const u32 c = ccnt[p];
-                const u64 end = b + c + nnew;
-                const u64 fe = end & ~(u64)(CG - 1);
+                const u32 end = b + c + nnew;
+                const u32 fe = end & ~(CG - 1);
                 const bool flush = fe > b;
                 tile_off[p] = toff;
-                delta[p] = b + c - toff;          // stage position -> output row
+                delta[p] = b + c - toff;          // stage position -> output row (modulo 2^32: the sum with a position is exact)
                 obase[p] = b;
                 ocnt[p] = flush ? c : 0;          // old carry rows that leave now (all of them: they sit below fe)
                 base[p] = flush ? fe : b;         // rows at or above it stay in LDS as carry slot (row - base)
-                ccnt[p] = (u32)(end - (flush ? fe : b));
+                ccnt[p] = end - (flush ? fe : b);
                 tile_cnt[p] = 0;
             };
             if (e0 < P)
                 plan(e0, off, c0);
             if (e1 < P)
                 plan(e1, off + c0, c1);
+            static_assert(2 * THREADS >= 256, "the scan covers two partitions per thread");
         }
         __syncthreads();
         // 3. counting sort into the LDS staging arrays; the carried rows that leave are written out by 16 lanes per partition
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_scatter_carry(const KT * __re
             const u32 p = slot / CG, i = slot % CG;
             if (i < ocnt[p])
             {
-                const u64 dst = obase[p] + i;
+                const u32 dst = obase[p] + i;
                 out_keys[dst] = carry_key[slot];
                 if constexpr (HAS_WORD)
                     out_words[dst] = carry_word[slot];
@@ -229,8 +233,8 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_scatter_carry(const KT * __re
         {
             const KT k = stage_key[pos];
             const u32 p = part_fn(k);
-            const u64 dst = delta[p] + pos;
-            const u64 nb = base[p];
+            const u32 dst = delta[p] + pos;
+            const u32 nb = base[p];
             if (dst < nb)
             {
                 out_keys[dst] = k;
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_scatter_carry(const KT * __re
             }
             else
             {
-                const u32 cs = p * CG + (u32)(dst - nb);
+                const u32 cs = p * CG + (dst - nb);
                 carry_key[cs] = k;
                 if constexpr (HAS_WORD)
                     carry_word[cs] = stage_word[pos];
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_scatter_carry(const KT * __re
         const u32 p = slot / CG, i = slot % CG;
         if (i < ccnt[p])
         {
-            const u64 dst = base[p] + i;
+            const u32 dst = base[p] + i;
             out_keys[dst] = carry_key[slot];
             if constexpr (HAS_WORD)
                 out_words[dst] = carry_word[slot];
@@ -264,3 +268,226 @@ __global__ __launch_bounds__(RP_THREADS) void k_rp_scatter_carry(const KT * __re
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_rp_scatter: the partition pass without carried tails, written so that NO branch surrounds an LDS or memory operation inside a
+// step.  The first version of this pass handled every row inside its own `if (row < end)` region; hipcc then waits for each LDS
+// round trip before it issues the next (s_waitcnt lgkmcnt(0) at every control-flow join), a wave spends its time parked
+// (SQ_WAIT_ANY = 72 % of its cycles, PMC) and with one 1024-thread workgroup per CU there is nobody else to run.  Here rows beyond
+// the end of the range go to a dummy partition P that sorts behind every real one and is never written, so each step is a straight
+// run of independent operations: RPT ranks, RPT offset reads, 2*RPT staging writes, and a write-out whose LDS reads are all issued
+// before the first global store.  Output rows are 32-bit (the callers bound a call below 2^32 rows).
+// dynamic LDS: stage_word u64[TILE] (HAS_WORD) | stage_key KT[TILE] | cursor u32[P] | delta u32[P + 1] | tile_cnt u32[P + 1] | tile_off u32[P + 1]
+// ---------------------------------------------------------------------------------------------
+template <u32 GBP_TILE, typename KT, bool HAS_WORD, typename PartFn, u32 THREADS = RP_THREADS>
+__global__ __launch_bounds__(THREADS) void k_rp_scatter(const KT * __restrict__ keys, const u64 * __restrict__ words, u64 n, u64 rows_per_wg, u32 P,
+                                                        const u64 * __restrict__ offsets, KT * __restrict__ out_keys, u64 * __restrict__ out_words, PartFn part_fn)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
+    u64 * stage_word = (u64 *)gb_lds;
+    KT * stage_key = (KT *)(stage_word + (HAS_WORD ? GBP_TILE : 0));
+    u32 * cursor = (u32 *)(stage_key + GBP_TILE);
+    u32 * delta = cursor + P;
+    u32 * tile_cnt = delta + (P + 1);
+    u32 * tile_off = tile_cnt + (P + 1);
+    __shared__ u32 wave_tot[THREADS / 64];
+
+    for (u32 p = threadIdx.x; p <= P; p += THREADS)
+    {
+        if (p < P)
+            cursor[p] = (u32)offsets[(u64)p * gridDim.x + blockIdx.x];
+        tile_cnt[p] = 0;
+    }
+    __syncthreads();
+    const u64 r0 = (u64)blockIdx.x * rows_per_wg;
+    const u64 r1 = r0 + rows_per_wg < n ? r0 + rows_per_wg : n;
+    constexpr u32 RPT = GBP_TILE / THREADS;
+    static_assert(RPT % 2 == 0, "row pairs");
+    KT key[RPT];
+    u64 argw[HAS_WORD ? RPT : 1];
+    typedef u64 v2q __attribute__((ext_vector_type(2)));
+    typedef u32 v2d __attribute__((ext_vector_type(2)));
+    auto row_of = [&](u64 tb, u32 j) -> u64 { return tb + (u64)(j >> 1) * (2 * THREADS) + 2 * threadIdx.x + (j & 1); };
+    // The loads are unconditional and all vector loads: a pair that would start beyond the range re-reads the range's last whole pair
+    // (its rows are invalid -- row_of() >= r1 -- and go to the dummy partition); the lone last row of an odd range is fetched as
+    // the second element of the pair that ENDS with it (one row to the left: the hardware takes the misaligned address).  No
+    // conditional load anywhere: a load that may or may not have been issued forces s_waitcnt vmcnt(0) on every later wait.
+    const bool odd_tail = ((r1 - r0) & 1) != 0;
+    const u64 last_pair = r1 >= r0 + 2 ? ((r1 - r0 - 2) & ~(u64)1) + r0 : r0;
+    auto load_tile = [&](u64 tb) {
+#pragma unroll
+        for (u32 j = 0; j < RPT; j += 2)
+        {
+            const u64 i = row_of(tb, j);
+            const bool tail = odd_tail && i + 1 == r1;
+            const u64 li = tail ? i - 1 : (i + 1 < r1 ? i : last_pair);
+            if constexpr (sizeof(KT) == 4)
+            {
+                const v2d kk = __builtin_nontemporal_load((const v2d *)(keys + li));
+                key[j] = tail ? kk.y : kk.x, key[j + 1] = kk.y;
+            }
+            else
+            {
+                const v2q kk = __builtin_nontemporal_load((const v2q *)(keys + li));
+                key[j] = tail ? kk.y : kk.x, key[j + 1] = kk.y;
+            }
+            if constexpr (HAS_WORD)
+            {
+                const v2q a = __builtin_nontemporal_load((const v2q *)(words + li));
+                argw[j] = tail ? a.y : a.x, argw[j + 1] = a.y;
+            }
+        }
+    };
+    if (r0 >= r1)
+        return; // (the whole workgroup: no barrier below is left waiting)
+    u32 part[RPT], rank[RPT];
+    // 1. a rank inside the tile's partition bucket (rows past the end: the dummy bucket P)
+    auto step_rank = [&](u64 tb) {
+#pragma unroll
+        for (u32 j = 0; j < RPT; ++j)
+            part[j] = row_of(tb, j) < r1 ? part_fn(key[j]) : P;
+#pragma unroll
+        for (u32 j = 0; j < RPT; ++j)
+            rank[j] = atomicAdd(&tile_cnt[part[j]], 1u);
+    };
+    // 2. exclusive scan of tile_cnt[P + 1] -> tile_off (P + 1 <= 2 * threads); between two barriers
+    auto step_scan = [&]() {
+        __syncthreads();
+        const u32 e0 = threadIdx.x * 2, e1 = e0 + 1;
+        const u32 c0 = e0 <= P ? tile_cnt[e0] : 0, c1 = e1 <= P ? tile_cnt[e1] : 0;
+        const u32 v = c0 + c1;
+        const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        u32 inc = v;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1)
+        {
+            const u32 o = __shfl_up(inc, dlt, 64);
+            if (lane >= (u32)dlt)
+                inc += o;
+        }
+        if (lane == 63)
+            wave_tot[wave] = inc;
+        __syncthreads();
+        u32 off = inc - v;
+        for (u32 w = 0; w < wave; ++w)
+            off += wave_tot[w];
+        if (e0 <= P)
+        {
+            tile_off[e0] = off;
+            tile_cnt[e0] = 0;
+            if (e0 < P)
+            {
+                const u32 c = cursor[e0];
+                delta[e0] = c - off; // stage position -> output row (modulo 2^32: the sum with a position is exact)
+                cursor[e0] = c + c0;
+            }
+            else
+                delta[e0] = (u32)n - off; // rows past the end land in the slack behind the n output rows (never read)
+        }
+        if (e1 <= P)
+        {
+            tile_off[e1] = off + c0;
+            tile_cnt[e1] = 0;
+            if (e1 < P)
+            {
+                const u32 c = cursor[e1];
+                delta[e1] = c - (off + c0);
+                cursor[e1] = c + c1;
+            }
+            else
+                delta[e1] = (u32)n - (off + c0);
+        }
+        __syncthreads();
+    };
+    // The pipeline: a tile's loads are issued BEFORE the previous tile's stores and first used AFTER them, all in one iteration, so
+    // hipcc waits for them with s_waitcnt vmcnt(<the stores behind them>) and the stores drain while the next tile is ranked, scanned
+    // and staged.  (With the loads' first use at the top of the next iteration the wait count is the minimum over the paths into the
+    // loop -- the entry path has no stores behind the loads -- and every tile waited for ALL its predecessor's stores to be
+    // acknowledged: 72 % of the wave cycles parked, PMC SQ_WAIT_ANY.)  The prologue issues as many harmless stores into the slack
+    // as a write-out does, so that the entry path looks like the back edge to that analysis too.
+    load_tile(r0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (u32 j = 0; j < RPT; ++j)
+    {
+        const u32 dst = (u32)n + j * THREADS + threadIdx.x;
+        out_keys[dst] = 0;
+        if constexpr (HAS_WORD)
+            out_words[dst] = 0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    step_rank(r0);
+    step_scan();
+    for (u64 tbase = r0; tbase < r1; tbase += GBP_TILE)
+    {
+        // 3. counting sort into the LDS staging arrays
+        u32 pos3[RPT];
+#pragma unroll
+        for (u32 j = 0; j < RPT; ++j)
+            pos3[j] = tile_off[part[j]];
+#pragma unroll
+        for (u32 j = 0; j < RPT; ++j)
+        {
+            stage_key[pos3[j] + rank[j]] = key[j];
+            if constexpr (HAS_WORD)
+                stage_word[pos3[j] + rank[j]] = argw[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(tbase + GBP_TILE); // the next tile, unconditional (beyond the range it re-reads the last pair)
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // 4. write the partition runs: consecutive lanes -> consecutive addresses inside a run; in halves to bound registers.
+        //    EVERY staged row is stored, unconditionally: the rows past the end of the range sort behind the real ones and their
+        //    delta points into RP_SCATTER_SLACK rows of slack behind the output, so no branch surrounds a store.
+        constexpr u32 HALF = RPT / 2;
+        const u32 real_rows = tile_off[P];
+#pragma unroll
+        for (u32 h = 0; h < 2; ++h)
+        {
+            KT k4[HALF];
+            u64 w4[HAS_WORD ? HALF : 1];
+            u32 d4[HALF];
+#pragma unroll
+            for (u32 j = 0; j < HALF; ++j)
+            {
+                const u32 pos = (h * HALF + j) * THREADS + threadIdx.x;
+                k4[j] = stage_key[pos];
+                if constexpr (HAS_WORD)
+                    w4[j] = stage_word[pos];
+            }
+#pragma unroll
+            for (u32 j = 0; j < HALF; ++j)
+            {
+                const u32 pos = (h * HALF + j) * THREADS + threadIdx.x;
+                const u32 p = pos < real_rows ? part_fn(k4[j]) : P;
+                d4[j] = delta[p];
+            }
+#pragma unroll
+            for (u32 j = 0; j < HALF; ++j)
+            {
+                const u32 pos = (h * HALF + j) * THREADS + threadIdx.x;
+                const u32 dst = d4[j] + pos;
+                out_keys[dst] = k4[j];
+                if constexpr (HAS_WORD)
+                    out_words[dst] = w4[j];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the next tile: ranks now (its keys have arrived; the stores above keep draining), then the scan.  The ranks only touch
+        // tile_cnt[] (cleared by the last scan); the scan -- the first writer of tile_off[] / delta[] -- sits behind its own barrier,
+        // which every wave reaches only after it has finished the write-out above.  One tile too many is ranked at the end (all its
+        // rows in the dummy bucket): harmless and branch-free.
+        step_rank(tbase + GBP_TILE);
+        step_scan();
+    }
+}
+
+static inline size_t rp_scatter_lds_bytes(u32 tile, u32 P, size_t key_bytes, bool has_word)
+{
+    return (size_t)tile * (key_bytes + (has_word ? 8 : 0)) + (size_t)P * 4 + (size_t)(P + 1) * 12 + 64;
+}
+
+static inline size_t rp_scatter_carry_lds_bytes(u32 tile, u32 P, u32 cg, size_t key_bytes, bool has_word)
+{
+    return (size_t)tile * (key_bytes + (has_word ? 8 : 0)) + (size_t)P * cg * (key_bytes + (has_word ? 8 : 0)) + (size_t)P * 28 + 64;
+}
