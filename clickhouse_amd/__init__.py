@@ -7,9 +7,10 @@ from ._capi import VAL_COL, VAL_MINUS, VAL_MUL, VAL_PLUS
 from .columns import (Column, Context, and_, arith, concat, expr_filter_sum, cmp_const, count_bytes_in_filter, filter_columns, filter_description_nullable, filter_sum,
                       filter_sum_async, hash_to_selector, pack_fixed_keys, partition_by_hash, sum_add_many,
                       sum_add_many_conditional, unpack_fixed_key, sort_permutation, sort_block, sort_permutation_limit, filter_to_indices)
-from .aggregator import Aggregator, NullableKeyAggregator, group_by_min_max
+from .aggregator import Aggregator, NullableKeyAggregator, group_by_min_max, serialize_states, deserialize_states
 from .expression import ActionsDAG, ExpressionActions
 from .lowcardinality import ColumnString, ColumnLowCardinality, LowCardinalityAggregator, LowCardinalityDictionary, PackedKeysAggregator
 from .hashjoin import HashJoin
+from .keysfixed import KeyDict, KeysFixedAggregator, KeysFixedHashJoin
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -103,6 +103,18 @@ SIGNATURES = {
     "chgpu_join_total_rows": (_i, [_vp, _pu64, _pu64]),
     "chgpu_join_probe": (_i, [_vp, _vp, _vp, _u64, _pp, _pp, _pp, _pu64, _pu64]),
     "chgpu_join_probe_agg": (_i, [_vp, _vp, _vp, _vp, _pu64, _vp]),
+    "chgpu_compressed_walk_frames": (_i, [_vp, _u64, _i, _u32, C.POINTER(_u32), _pu64, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(_u32)]),
+    "chgpu_read_compressed_column": (_i, [_vp, _vp, _u64, _i, _i, _pp]),
+    "chgpu_city_hash128": (_i, [_vp, _u64, _pu64]),
+    "chgpu_native_walk_block": (_i, [_vp, _u64, _u64, _u32, _vp, C.POINTER(_u32), _pu64, C.POINTER(C.c_int32), C.POINTER(_i), _pu64]),
+    "chgpu_agg_serialize_states": (_i, [_vp, _i, _vp, _vp, _pp, _pp]),
+    "chgpu_agg_deserialize_states": (_i, [_vp, _i, _vp, _u32, _pu64, _pu64, _pp, _pp]),
+    "chgpu_keydict_create": (_i, [_vp, _u32, _u64, _pp]),
+    "chgpu_keydict_encode": (_i, [_vp, _u32, _pp, _u64, _u64, _i, _pp]),
+    "chgpu_keydict_size": (_i, [_vp, _pu64]),
+    "chgpu_keydict_key_column": (_i, [_vp, _vp, _u32, _i, _pp]),
+    "chgpu_keydict_selector": (_i, [_vp, _vp, _u32, _pp]),
+    "chgpu_keydict_free": (_i, [_vp]),
     "chgpu_comm_unique_id": (_i, [_vp]),
     "chgpu_comm_init": (_i, [_vp, _i, _i, _vp, _pp]),
     "chgpu_comm_destroy": (_i, [_vp]),

@@ -105,6 +105,24 @@ class Aggregator:
         return (keys.numpy() if keys is not None else None), [r.numpy() for r in res]
 
 
+def serialize_states(ctx: Context, kind: int, word0: Column, word1: Column | None = None):
+    """the ColumnAggregateFunction wire bytes of one aggregate function's states (IAggregateFunction::serialize per row: sum = 8 bytes,
+    count = VarUInt, avg = 8 bytes + VarUInt) -> (bytes Column, row offsets Column[rows + 1])"""
+    bh, oh = C.c_void_p(), C.c_void_p()
+    K.check(K.lib().chgpu_agg_serialize_states(ctx._live(), kind, word0._h, word1._h if word1 is not None else None, C.byref(bh), C.byref(oh)))
+    return Column(ctx, bh), Column(ctx, oh)
+
+
+def deserialize_states(ctx: Context, kind: int, data: Column, stream_rows, stream_byte_begin=None):
+    """the inverse, for mergeOnBlock: `stream_rows[s]` states from byte `stream_byte_begin[s]` of every stream -> (word0, word1 or None)"""
+    n = len(stream_rows)
+    rows = (C.c_uint64 * n)(*[int(r) for r in stream_rows])
+    begin = (C.c_uint64 * n)(*[int(b) for b in stream_byte_begin]) if stream_byte_begin is not None else None
+    h0, h1 = C.c_void_p(), C.c_void_p()
+    K.check(K.lib().chgpu_agg_deserialize_states(ctx._live(), kind, data._h, n, begin, rows, C.byref(h0), C.byref(h1) if kind == K.AGG_AVG else None))
+    return Column(ctx, h0), (Column(ctx, h1) if kind == K.AGG_AVG else None)
+
+
 class NullableKeyAggregator:
     """GROUP BY a Nullable(T) key: AggregationDataWithNullKey (src/Interpreters/AggregatedData.h:71-95) keeps the NULL group's state
     out of the hash table (has_null_key_data / null_key_data), and the key extraction sends rows whose null-map byte is set there

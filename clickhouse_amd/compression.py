@@ -20,32 +20,21 @@ CHECKSUM_SIZE, HEADER_SIZE = 16, 9  # CompressionInfo.h:10
 METHOD_NONE, METHOD_LZ4, METHOD_MULTIPLE, METHOD_DELTA = 0x02, 0x82, 0x91, 0x92
 
 
-def parse_frames(buf) -> list:
+def parse_frames(buf, verify_checksums: bool = True) -> list:
     """frame headers of a compressed buffer -> [(method, payload_offset, payload_size, decompressed_size, post_method, stage_size)]:
     the general-purpose stage to run on the device and, for CODEC(Delta, LZ4), the Delta stage behind it (post_method 0x92;
-    stage_size = bytes the LZ4 stage yields).  Any other codec chain keeps its method byte: the device call answers NOT_IMPLEMENTED."""
-    mv = memoryview(buf)
-    frames, pos, n = [], 0, len(mv)
-    while pos < n:
-        if n - pos < CHECKSUM_SIZE + HEADER_SIZE:
-            raise K.ChgpuError(K.ERR_BAD_ARGUMENTS, "Cannot read all data: truncated frame header")
-        method, csize, dsize = struct.unpack_from("<BII", mv, pos + CHECKSUM_SIZE)
-        if csize < HEADER_SIZE or pos + CHECKSUM_SIZE + csize > n:
-            raise K.ChgpuError(K.ERR_BAD_ARGUMENTS, "Cannot decompress: frame size out of range")
-        off, size = pos + CHECKSUM_SIZE + HEADER_SIZE, csize - HEADER_SIZE
-        post, stage = 0, dsize
-        if method == METHOD_MULTIPLE and size >= 1:  # CompressionCodecMultiple.cpp:68-130: [n][methods...][last stage: header + payload]
-            k = mv[off]
-            methods = bytes(mv[off + 1:off + 1 + k])
-            if methods == bytes([METHOD_DELTA, METHOD_LZ4]) and size >= 1 + k + HEADER_SIZE:
-                m2, c2, d2 = struct.unpack_from("<BII", mv, off + 1 + k)
-                if m2 != METHOD_LZ4 or c2 < HEADER_SIZE or 1 + k + c2 > size:
-                    raise K.ChgpuError(K.ERR_BAD_ARGUMENTS, "Cannot decompress: bad stage header in codec Multiple")
-                method, post, stage = METHOD_LZ4, METHOD_DELTA, d2
-                off, size = off + 1 + k + HEADER_SIZE, c2 - HEADER_SIZE
-        frames.append((method, off, size, dsize, post, stage))
-        pos += CHECKSUM_SIZE + csize
-    return frames
+    stage_size = bytes the LZ4 stage yields).  Any other codec chain keeps its method byte: the device call answers NOT_IMPLEMENTED.
+    The walk is chgpu_compressed_walk_frames: every frame's CityHash128 checksum is verified (verify_checksums=False = the reference's
+    disable_checksum), sizes above 1 GiB are refused (CompressedReadBufferBase.cpp:49-127,163-172)."""
+    raw = bytes(buf) if not isinstance(buf, (bytes, bytearray)) else buf
+    arr = (C.c_uint8 * len(raw)).from_buffer_copy(raw) if len(raw) else None
+    n = C.c_uint32(0)
+    K.check(K.lib().chgpu_compressed_walk_frames(arr, len(raw), int(verify_checksums), 0, C.byref(n), None, None, None, None, None, None))
+    cap = max(1, n.value)
+    offs, sizes, dsizes = (C.c_uint64 * cap)(), (C.c_uint32 * cap)(), (C.c_uint32 * cap)()
+    methods, posts, stages = (C.c_uint8 * cap)(), (C.c_uint8 * cap)(), (C.c_uint32 * cap)()
+    K.check(K.lib().chgpu_compressed_walk_frames(arr, len(raw), 0, cap, C.byref(n), offs, sizes, dsizes, methods, posts, stages))
+    return [(methods[f], offs[f], sizes[f], dsizes[f], posts[f], stages[f]) for f in range(n.value)]
 
 
 def decompress_frames(ctx: Context, compressed: Column, frames) -> Column:
@@ -68,12 +57,47 @@ def column_from_bytes(data: Column, byte_offset: int, dtype, rows: int) -> Colum
     return Column(data.ctx, h)
 
 
-def read_column_file(ctx: Context, buf, dtype) -> Column:
-    """a MergeTree `<column>.bin` of a numeric column (compressed frames of a plain little-endian array) -> Column in HBM"""
-    frames = parse_frames(buf)
-    compressed = ctx.upload(np.frombuffer(buf, dtype=np.uint8))
-    raw = decompress_frames(ctx, compressed, frames)
-    es = np.dtype(dtype).itemsize
-    if raw.size() % es:
-        raise K.ChgpuError(K.ERR_SIZES_MISMATCH, "Cannot read all data: size is not a multiple of the element size")
-    return column_from_bytes(raw, 0, dtype, raw.size() // es)
+def read_column_file(ctx: Context, buf, dtype, verify_checksums: bool = True) -> Column:
+    """a MergeTree `<column>.bin` of a numeric column (compressed frames of a plain little-endian array) -> Column in HBM
+    (chgpu_read_compressed_column: frame walk + checksum verification on the host, decode on the device)"""
+    raw = bytes(buf) if not isinstance(buf, (bytes, bytearray)) else buf
+    arr = (C.c_uint8 * len(raw)).from_buffer_copy(raw) if len(raw) else None
+    h = C.c_void_p()
+    K.check(K.lib().chgpu_read_compressed_column(ctx._live(), arr, len(raw), TAG_OF[np.dtype(dtype)], int(verify_checksums), C.byref(h)))
+    return Column(ctx, h)
+
+
+def city_hash128(data: bytes):
+    """CityHash_v1_0_2::CityHash128 -> (low64, high64): the checksum a writer puts in front of a frame"""
+    out = (C.c_uint64 * 2)()
+    K.check(K.lib().chgpu_city_hash128(bytes(data), len(data), out))
+    return int(out[0]), int(out[1])
+
+
+class NativeColumn:
+    def __init__(self, name, type_name, dtype, offset, nbytes):
+        self.name, self.type_name, self.dtype, self.offset, self.nbytes = name, type_name, dtype, offset, nbytes
+
+
+class _NativeColumnStruct(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("type_name", C.c_char * 32), ("type", C.c_int32), ("data_offset", C.c_uint64), ("data_bytes", C.c_uint64)]
+
+
+def read_native_block(ctx: Context, buf, pos: int = 0, server_revision: int = 0):
+    """NativeReader::read for one block of plain numeric columns: -> (dict(rows, bucket_num, is_overflows, next_pos), [(name, Column)])
+    The header walk is chgpu_native_walk_block; every column's values go to HBM as they lie in the buffer."""
+    from .columns import NP_OF
+    raw = bytes(buf)
+    view = raw[pos:]
+    arr = (C.c_uint8 * len(view)).from_buffer_copy(view) if len(view) else None
+    ncols, nrows, used = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+    bucket, over = C.c_int32(-1), C.c_int(0)
+    K.check(K.lib().chgpu_native_walk_block(arr, len(view), server_revision, 0, None, C.byref(ncols), C.byref(nrows), C.byref(bucket), C.byref(over), C.byref(used)))
+    cols = (_NativeColumnStruct * max(1, ncols.value))()
+    K.check(K.lib().chgpu_native_walk_block(arr, len(view), server_revision, ncols.value, cols, C.byref(ncols), C.byref(nrows), C.byref(bucket), C.byref(over), C.byref(used)))
+    out = []
+    for c in range(ncols.value):
+        dt = np.dtype(NP_OF[cols[c].type])
+        data = np.frombuffer(view, dtype=dt, count=nrows.value, offset=cols[c].data_offset)
+        out.append((cols[c].name.decode(), ctx.upload(data)))
+    return dict(rows=int(nrows.value), bucket_num=int(bucket.value), is_overflows=bool(over.value), next_pos=pos + int(used.value)), out

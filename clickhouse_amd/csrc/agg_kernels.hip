@@ -2334,6 +2334,8 @@ extern "C" int chgpu_agg_size(chgpu_agg * a, uint64_t * groups)
 static int agg_export(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** word_cols /* [n_words] */, u64 * groups)
 {
     chgpu_ctx * ctx = a->ctx;
+    for (u32 w = 0; w < a->n_words; ++w)
+        word_cols[w] = nullptr;
     if (a->key_type < 0)
     {
         for (u32 w = 0; w < a->n_words; ++w)
@@ -2380,9 +2382,17 @@ static int agg_export(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** word_co
         rc = chgpu_filter(ctx, &view, mask, 0, &word_cols[w], &nw);
     }
     chgpu_col_free(mask);
+    auto drop_words = [&]() {
+        for (u32 w = 0; w < a->n_words; ++w)
+        {
+            chgpu_col_free(word_cols[w]); // the word columns already filtered when a later step failed
+            word_cols[w] = nullptr;
+        }
+    };
     if (rc != CHGPU_OK)
     {
         chgpu_col_free(k64);
+        drop_words();
         return rc;
     }
     if (keys_out)
@@ -2410,7 +2420,10 @@ static int agg_export(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** word_co
             }
             chgpu_col_free(k64); // pooled: any reuse is stream-ordered behind the narrow kernel
             if (rc != CHGPU_OK)
+            {
+                drop_words();
                 return rc;
+            }
             *keys_out = kn;
         }
     }

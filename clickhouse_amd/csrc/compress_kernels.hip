@@ -362,7 +362,9 @@ __global__ __launch_bounds__(256) void k_delta_decode(const u8 * __restrict__ st
             __builtin_memcpy(&csize, in + 1, 4);
             __builtin_memcpy(&dsize, in + 5, 4);
             w = in[9], skip = in[10];
-            bad = in[0] != 0x92 || csize != ssz || dsize != job.out_size || !(w == 1 || w == 2 || w == 4 || w == 8) || 11 + skip > ssz || skip > job.out_size;
+            bad = in[0] != 0x92 || csize != ssz || dsize != job.out_size || !(w == 1 || w == 2 || w == 4 || w == 8) || skip >= w || 11 + skip > ssz || skip > job.out_size;
+            // (bytes_to_skip = size % width, CompressionCodecDelta.cpp:109-133: a header that claims more is malformed -- and the copy
+            //  below moves one byte per lane, i.e. at most 63)
             if (!bad)
             {
                 n_bytes = ssz - 11 - skip;

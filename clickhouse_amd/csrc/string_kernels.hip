@@ -57,6 +57,37 @@ __device__ __forceinline__ bool str_equal(const u8 * a, const u8 * b, u64 len)
     return true;
 }
 
+// ColumnString invariant (ColumnString.h:40-52): offsets strictly increase (every value has at least its terminating zero) and end inside
+// chars.  The kernels below compute `offsets[i] - begin - 1` bytes per value and read that many: an offset column that breaks the
+// invariant (corrupted or hostile input) would turn into a 2^64-byte walk -- a hang or a fault, not an error code.
+__global__ __launch_bounds__(256) void k_str_check_offsets(const u64 * __restrict__ offsets, u64 n, u64 chars_size, u32 * __restrict__ bad)
+{
+    bool b = false;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        const u64 begin = i ? offsets[i - 1] : 0, end = offsets[i];
+        b = b || !(begin < end && end <= chars_size);
+    }
+    if (b)
+        *bad = 1;
+}
+
+static int str_validate_offsets(chgpu_ctx * ctx, const chgpu_col * offsets_u64, const chgpu_col * chars_u8)
+{
+    const u64 n = offsets_u64->rows;
+    if (!n)
+        return CHGPU_OK;
+    void * scratch = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, 256, &scratch));
+    CHGPU_HIP(hipMemsetAsync(scratch, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_str_check_offsets, dim3(chgpu_grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, (const u64 *)offsets_u64->data, n, (u64)chars_u8->rows, (u32 *)scratch);
+    ctx->counters[6] += 1;
+    u32 bad = 0;
+    CHGPU_TRY(chgpu_read_back(ctx, scratch, &bad, 4));
+    CHGPU_REQUIRE(!bad, CHGPU_ERR_BAD_ARGUMENTS, "ColumnString offsets must strictly increase and stay inside chars (%llu bytes)", (unsigned long long)chars_u8->rows);
+    return CHGPU_OK;
+}
+
 __global__ __launch_bounds__(256) void k_str_hash(const u64 * __restrict__ offsets, const u8 * __restrict__ chars, u64 n, u64 * __restrict__ hash)
 {
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
@@ -172,6 +203,7 @@ extern "C" int chgpu_string_dictionary_encode(chgpu_ctx * ctx, const chgpu_col *
     CHGPU_TRY(chgpu_read_back(ctx, (const u64 *)offsets_u64->data + (n - 1), &last, sizeof(last)));
     CHGPU_REQUIRE(last == chars_u8->rows, CHGPU_ERR_SIZES_MISMATCH, "offsets.back() (%llu) != chars.size() (%llu)", (unsigned long long)last,
                   (unsigned long long)chars_u8->rows);
+    CHGPU_TRY(str_validate_offsets(ctx, offsets_u64, chars_u8));
     u64 cap = 1024;
     while (cap < 2 * n)
         cap <<= 1;
@@ -303,6 +335,7 @@ extern "C" int chgpu_string_filter(chgpu_ctx * ctx, const chgpu_col * offsets_u6
                   (unsigned long long)filter_u8->rows, (unsigned long long)n); // ColumnsCommon.cpp:199-200
     chgpu_col * oo = nullptr, * oc = nullptr;
     u64 kept_rows = 0, kept_bytes = 0;
+    CHGPU_TRY(str_validate_offsets(ctx, offsets_u64, chars_u8));
     if (n)
     {
         auto al = [](size_t b) { return (b + 255) / 256 * 256; };

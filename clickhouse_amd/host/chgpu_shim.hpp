@@ -1146,55 +1146,11 @@ inline void sortBlock(Chunk & block, const SortDescription & description, uint64
 /// CompressedReadBuffer + SerializationNumber::deserializeBinaryBulk for one numeric column file (MergeTree `<column>.bin`): the
 /// host walks the frame headers (CompressedReadBufferBase.cpp:175-222), the compressed bytes cross PCIe once, the frames are decoded
 /// in HBM.  LZ4, NONE and CODEC(Delta, LZ4); any other codec throws NOT_IMPLEMENTED (the caller decompresses on the CPU as before).
-inline ColumnPtr readCompressedColumn(const ContextPtr & ctx, const unsigned char * file, size_t size, int type)
+inline ColumnPtr readCompressedColumn(const ContextPtr & ctx, const unsigned char * file, size_t size, int type, bool verify_checksums = true)
 {
-    constexpr size_t CHECKSUM = 16, HEADER = 9;
-    std::vector<uint64_t> offs;
-    std::vector<uint32_t> sizes, dsizes, stages;
-    std::vector<uint8_t> methods, posts;
-    auto u32_at = [&](size_t p) { uint32_t v; std::memcpy(&v, file + p, 4); return v; };
-    uint64_t total = 0;
-    for (size_t pos = 0; pos < size;)
-    {
-        if (size - pos < CHECKSUM + HEADER)
-            throw Exception(CHGPU_ERR_BAD_ARGUMENTS, "Cannot read all data: truncated frame header");
-        uint8_t method = file[pos + CHECKSUM];
-        const uint32_t csize = u32_at(pos + CHECKSUM + 1), dsize = u32_at(pos + CHECKSUM + 5);
-        if (csize < HEADER || pos + CHECKSUM + csize > size)
-            throw Exception(CHGPU_ERR_BAD_ARGUMENTS, "Cannot decompress: frame size out of range");
-        size_t off = pos + CHECKSUM + HEADER, sz = csize - HEADER;
-        uint8_t post = 0;
-        uint32_t stage = dsize;
-        if (method == 0x91 && sz >= 3 + HEADER && file[off] == 2 && file[off + 1] == 0x92 && file[off + 2] == 0x82) // Multiple{Delta, LZ4}
-        {
-            const uint32_t c2 = u32_at(off + 3 + 1), d2 = u32_at(off + 3 + 5);
-            if (file[off + 3] != 0x82 || c2 < HEADER || 3 + c2 > sz)
-                throw Exception(CHGPU_ERR_BAD_ARGUMENTS, "Cannot decompress: bad stage header in codec Multiple");
-            method = 0x82, post = 0x92, stage = d2;
-            off += 3 + HEADER, sz = c2 - HEADER;
-        }
-        offs.push_back(off), sizes.push_back(static_cast<uint32_t>(sz)), dsizes.push_back(dsize), stages.push_back(stage);
-        methods.push_back(method), posts.push_back(post);
-        total += dsize;
-        pos += CHECKSUM + csize;
-    }
-    auto compressed = ColumnVector::fromHost<uint8_t>(ctx, file, size);
-    chgpu_col * raw = nullptr;
-    check(chgpu_decompress_frames(ctx->get(), compressed->handle(), static_cast<uint32_t>(offs.size()), offs.data(), sizes.data(), dsizes.data(), methods.data(),
-                                  posts.data(), stages.data(), &raw));
-    ColumnVector bytes(ctx, raw);
-    size_t es = 8;
-    switch (type)
-    {
-        case CHGPU_U32: case CHGPU_I32: case CHGPU_F32: es = 4; break;
-        case CHGPU_U16: case CHGPU_I16: es = 2; break;
-        case CHGPU_U8: case CHGPU_I8: es = 1; break;
-        default: break;
-    }
-    if (total % es)
-        throw Exception(CHGPU_ERR_SIZES_MISMATCH, "Cannot read all data: size is not a multiple of the element size");
+    // frame walk + CityHash128 verification + size caps on the host (CompressedReadBufferBase.cpp:49-127,163-172), decode on the device
     chgpu_col * out = nullptr;
-    check(chgpu_col_from_bytes(ctx->get(), bytes.handle(), 0, type, total / es, &out));
+    check(chgpu_read_compressed_column(ctx->get(), file, size, type, verify_checksums ? 1 : 0, &out));
     return std::make_shared<ColumnVector>(ctx, out);
 }
 

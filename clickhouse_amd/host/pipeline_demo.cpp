@@ -367,9 +367,16 @@ int main(int argc, char ** argv)
             std::memcpy(&file[17], &csz, 4);
             std::memcpy(&file[21], &dsz, 4);
             std::memcpy(&file[25], a.data(), m * 8);
+            uint64_t cksum[2];
+            check(chgpu_city_hash128(&file[16], csz, cksum)); // CompressedWriteBuffer: CityHash128 over header + payload, {low64, high64}
+            std::memcpy(&file[0], cksum, 16);
             auto col = readCompressedColumn(ctx, file.data(), file.size(), CHGPU_I64);
             auto back = col->getData<int64_t>();
             REQUIRE(back.size() == m && std::equal(back.begin(), back.end(), a.begin()));
+            file[40] ^= 0x10; // one flipped payload bit: refused, not decoded into a wrong column
+            bool refused = false;
+            try { readCompressedColumn(ctx, file.data(), file.size(), CHGPU_I64); } catch (const Exception & e) { refused = std::string(e.what()).find("Checksum") != std::string::npos; }
+            REQUIRE(refused);
         }
 
         // ---- ISimpleTransform::work never unwinds the executor thread: a chunk whose columns disagree in length (a broken upstream)

@@ -129,8 +129,8 @@ int chgpu_col_free(chgpu_col * col);
 /* ================================================================================================
  * §8(f) rank 3 — the feed side: compressed frames decoded in HBM.  A MergeTree column file / compressed Native stream is a
  * sequence of frames: 16-byte checksum, method byte, compressed size (incl. the 9-byte header), decompressed size, payload
- * (src/Compression/CompressedReadBufferBase.cpp:175-222, CompressionInfo.h:10-51).  The host walks the frame headers (the caller
- * verifies checksums if it wants them verified: CityHash128 is not carried), uploads the compressed bytes once and names the
+ * (src/Compression/CompressedReadBufferBase.cpp:175-222, CompressionInfo.h:10-51).  The host walks the frame headers and verifies the
+ * checksums (chgpu_compressed_walk_frames / chgpu_read_compressed_column below), uploads the compressed bytes once and names the
  * frames; every frame is decoded by one wavefront straight into the output buffer (LZ4 block format as in
  * LZ4_decompress_faster.cpp:470-684; method 0x02 NONE copies).  CODEC(Delta, LZ4) -- a Multiple frame (0x91,
  * CompressionCodecMultiple.cpp:68-130) whose methods are {0x92, 0x82} -- is two stages: the host names the inner LZ4 stage's payload
@@ -139,6 +139,34 @@ int chgpu_col_free(chgpu_col * col);
  * CHGPU_ERR_BAD_ARGUMENTS (CANNOT_DECOMPRESS), never a fault.  chgpu_col_from_bytes turns a byte range of the result into a typed
  * column (SerializationNumber::deserializeBinaryBulk: plain little-endian arrays).
  * ============================================================================================== */
+/* The frame walk itself, with the reference's integrity checks (CompressedReadBufferBase.cpp:49-127,130-222): every frame's checksum --
+   CityHash128 (cityhash 1.0.2) over header + payload, stored in front of it as {low64, high64} -- is verified unless verify_checksums == 0
+   (the reference's disable_checksum), compressed / decompressed sizes above 1 GiB (DBMS_MAX_COMPRESSED_SIZE) are refused, a Multiple{Delta,
+   LZ4} frame is split into its stages.  `file` is host memory.  Fills up to `capacity` entries of the arrays chgpu_decompress_frames takes
+   and returns the number of frames (call with capacity 0 to validate and count).  A mismatch answers CHGPU_ERR_BAD_ARGUMENTS with the
+   reference's message ("Checksum doesn't match: corrupted data." ...). */
+int chgpu_compressed_walk_frames(const uint8_t * file, uint64_t size, int verify_checksums, uint32_t capacity, uint32_t * n_frames, uint64_t * payload_offsets,
+                                 uint32_t * payload_sizes, uint32_t * decompressed_sizes, uint8_t * methods, uint8_t * post_methods, uint32_t * stage_sizes);
+/* CompressedReadBuffer + SerializationNumber::deserializeBinaryBulk in one call: a MergeTree `<column>.bin` / compressed Native stream of a
+   numeric column in host memory -> a typed column in HBM (walk + verify on the host, the compressed bytes cross PCIe, decode on the device) */
+int chgpu_read_compressed_column(chgpu_ctx * ctx, const uint8_t * file, uint64_t size, int type, int verify_checksums, chgpu_col ** out);
+/* CityHash_v1_0_2::CityHash128 (the checksum of a frame a writer has to put in front of it): out = {low64, high64} */
+int chgpu_city_hash128(const void * data, uint64_t size, uint64_t out_low_high[2]);
+/* Native format (src/Formats/NativeReader.cpp:113-260): the header walk of ONE block in host memory.  [BlockInfo when server_revision > 0:
+   (field, value)* 0 with field 1 = is_overflows, 2 = bucket_num (src/Core/BlockInfo.cpp:38-62)] columns, rows (VarUInt), then per column
+   name, type name (strings), [a custom-serialization flag byte from revision 54454 on] and the values.  Plain numeric columns are described
+   (where their rows x sizeof(T) little-endian bytes lie: upload them with chgpu_col_upload / chgpu_col_upload_async); any other type
+   answers CHGPU_ERR_NOT_IMPLEMENTED.  *bytes_consumed = where the next block starts. */
+typedef struct chgpu_native_column
+{
+    char name[64];
+    char type_name[32];
+    int32_t type;         /* CHGPU_* element type */
+    uint64_t data_offset; /* byte offset of the column's values inside `data` */
+    uint64_t data_bytes;
+} chgpu_native_column;
+int chgpu_native_walk_block(const uint8_t * data, uint64_t size, uint64_t server_revision, uint32_t capacity, chgpu_native_column * columns, uint32_t * n_columns,
+                            uint64_t * n_rows, int32_t * bucket_num, int * is_overflows, uint64_t * bytes_consumed);
 int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compressed_u8, uint32_t n_frames, const uint64_t * payload_offsets,
                             const uint32_t * payload_sizes, const uint32_t * decompressed_sizes, const uint8_t * methods,
                             const uint8_t * post_methods, const uint32_t * stage_sizes, chgpu_col ** out_u8);
@@ -332,10 +360,28 @@ int chgpu_partition_by_hash(chgpu_ctx * ctx, const chgpu_col * keys, uint32_t nu
  * ============================================================================================== */
 /* a15 multi-column fixed-width keys: packFixed<UInt64> (src/Interpreters/AggregationCommon.h:91-158) — the keys16/32/64
    variants of chooseAggregationMethod (Aggregator.cpp:773-778).  Columns are laid out consecutively (little endian) in one
-   UInt64 per row; more than 8 key bytes -> CHGPU_ERR_NOT_IMPLEMENTED (keys128/256 stay on the CPU).  unpack is the
+   UInt64 per row; more than 8 key bytes -> CHGPU_ERR_NOT_IMPLEMENTED here: use a chgpu_keydict (keys128 / keys256, below).  unpack is the
    inverse used when the key column(s) of the result block are produced (insertKeyIntoColumns). */
 int chgpu_pack_fixed_keys(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, chgpu_col ** packed_u64);
 int chgpu_unpack_fixed_key(chgpu_ctx * ctx, const chgpu_col * packed_u64, uint32_t byte_offset, int type, chgpu_col ** out);
+/* a15 keys128 / keys256: several fixed-width key columns that pack into more than 8 bytes (AggregatedDataVariants.h:70-71,83-84:
+   HashMap<UInt128 / UInt256, ...>; HashMethodKeysFixed, src/Common/ColumnsHashing/HashMethod.h:236-410; packFixed,
+   AggregationCommon.h:91-158; the same maps under HashJoin, HashJoin.h:267-358).  A chgpu_keydict is a device-resident, exact dictionary
+   packed key -> dense UInt32 id (numbered as keys are first claimed; stable for the dictionary's lifetime, across blocks and growth).
+   chgpu_keydict_encode packs the columns of rows [row_begin, row_end) (packFixed order: consecutively, little endian, zero padded to
+   key_bytes = 16 or 32) and returns their ids: insert != 0 is emplaceKey (GROUP BY, join build), insert == 0 is findKey (join probe):
+   a key the dictionary does not hold gets 0xFFFFFFFF.  The ids are an ordinary UInt32 key column for chgpu_agg_* / chgpu_join_* /
+   chgpu_partition_*; chgpu_keydict_key_column gives back one original key column for a column of ids (insertKeyIntoColumns; bytes
+   [byte_offset, +sizeof(type)) of the packed key; 0xFFFFFFFF -> 0); chgpu_keydict_selector the shard of every id by the reference's own
+   hash of the packed key (UInt128HashCRC32 / UInt256HashCRC32, Hash.h:346-355,412-423 -> two-level bucket & (num_shards - 1)). */
+typedef struct chgpu_keydict chgpu_keydict;
+int chgpu_keydict_create(chgpu_ctx * ctx, uint32_t key_bytes, uint64_t size_hint, chgpu_keydict ** out);
+int chgpu_keydict_encode(chgpu_keydict * dict, uint32_t n_cols, const chgpu_col * const * cols, uint64_t row_begin, uint64_t row_end, int insert,
+                         chgpu_col ** ids_u32);
+int chgpu_keydict_size(chgpu_keydict * dict, uint64_t * n_keys);
+int chgpu_keydict_key_column(chgpu_keydict * dict, const chgpu_col * ids_u32, uint32_t byte_offset, int type, chgpu_col ** out);
+int chgpu_keydict_selector(chgpu_keydict * dict, const chgpu_col * ids_u32, uint32_t num_shards, chgpu_col ** selector_u32);
+int chgpu_keydict_free(chgpu_keydict * dict);
 /* §8(f) rank 2 — LowCardinality keys (src/Columns/ColumnLowCardinality.h:27-69; low_cardinality_key* variants,
    AggregatedDataVariants.h:119-127; HashMethodSingleLowCardinalityColumn's per-position cache, ColumnsHashing.h:82-260).
    Every Block brings its own dictionary; the host resolves it against the query-wide dictionary into remap_u32[local position]
@@ -385,6 +431,17 @@ int chgpu_agg_export_states(chgpu_agg * agg, chgpu_col ** keys_out, chgpu_col **
    BlockInfo::bucket_num (src/Core/BlockInfo.h:21-29) a CPU initiator's MergingAggregatedMemoryEfficientTransform expects. */
 int chgpu_agg_export_states_two_level(chgpu_agg * agg, chgpu_col ** keys_out, chgpu_col ** state_cols, uint64_t * groups,
                                       uint64_t * bucket_counts);
+/* §8(f) rank 4 — partial states on the wire: the bytes IAggregateFunction::serialize writes for every row of a ColumnAggregateFunction
+   (SerializationAggregateFunction: the rows' states one after the other, no lengths): sum = the 8-byte sum, little endian
+   (AggregateFunctionSum.h:288-291); count = VarUInt (AggregateFunctionCount.h:126-129); avg = the 8-byte numerator + VarUInt denominator
+   (AggregateFunctionAvg.h, AvgFraction).  word0 / word1 are the state columns chgpu_agg_export_states(_two_level) returns (word1: avg's
+   denominator).  offsets_u64 (may be NULL) receives rows + 1 byte offsets, so the 256 bucket blocks of a two-level export can be cut
+   out of one buffer.  deserialize is the inverse for mergeOnBlock: `n_streams` independent runs of states (stream s: stream_rows[s] states
+   from byte stream_byte_begin[s]; a single stream may pass NULL) -> word columns for chgpu_agg_merge_states.  A state's length is only
+   known after its VarUInt, so one lane walks one stream; bucket-wise exchanges give 256 streams per peer. */
+int chgpu_agg_serialize_states(chgpu_ctx * ctx, int kind, const chgpu_col * word0, const chgpu_col * word1, chgpu_col ** bytes_u8, chgpu_col ** offsets_u64);
+int chgpu_agg_deserialize_states(chgpu_ctx * ctx, int kind, const chgpu_col * bytes_u8, uint32_t n_streams, const uint64_t * stream_byte_begin,
+                                 const uint64_t * stream_rows, chgpu_col ** word0, chgpu_col ** word1);
 int chgpu_agg_free(chgpu_agg * agg);
 
 /* ================================================================================================

@@ -121,6 +121,13 @@ def lib() -> C.CDLL:
             "cho_join_need_filter": (i32, [vp]),
             "cho_join_need_replication": (i32, [vp]),
             "cho_hash_to_selector": (None, [i32, vp, sz, sz, vp]),
+            "cho_pack_fixed": (None, [sz, vp, vp, sz, sz, vp]),
+            "cho_hash_keys_fixed": (u64, [vp, sz]),
+            "cho_widemap_create": (vp, [sz]),
+            "cho_widemap_free": (None, [vp]),
+            "cho_widemap_size": (sz, [vp]),
+            "cho_widemap_batch": (None, [vp, vp, sz, i32, vp]),
+            "cho_widemap_keys": (None, [vp, vp]),
             "cho_groupby_pipeline": (vp, [i32, i32, vp, vp, vp, vp, sz, sz, i32, u64, vp]),
             "cho_join_count_sum_pipeline": (i32, [vp, vp, sz, vp, sz, sz, i32, vp, vp, vp]),
         }
@@ -154,6 +161,8 @@ def ref_hash():
             ("ref_hashCRC32_UInt32_seed", u64, [C.c_uint32, u64]),
             ("ref_intHashCRC32_batch", None, [C.c_void_p, u64, C.c_void_p]),
             ("ref_intHash64_batch", None, [C.c_void_p, u64, C.c_void_p]),
+            ("ref_UInt128HashCRC32", u64, [u64, u64]),
+            ("ref_UInt256HashCRC32", u64, [u64, u64, u64, u64]),
         ]:
             fn = getattr(R, name)
             fn.restype = res
@@ -516,6 +525,80 @@ class HashJoin:
             left = np.arange(c, dtype=np.int64)
         assert left.shape[0] == r["added_block"].shape[0], (left.shape, r["added_block"].shape)
         return left, r["added_block"], r["added_row"], c
+
+
+def pack_fixed(key_cols, key_bytes: int | None = None) -> np.ndarray:
+    """packFixed (AggregationCommon.h:91-158) -> uint8[n, key_bytes]; key_bytes None: 16 when the columns fit, else 32"""
+    cols = [np.ascontiguousarray(c) for c in key_cols]
+    total = sum(c.dtype.itemsize for c in cols)
+    key_bytes = key_bytes or (16 if total <= 16 else 32)
+    assert total <= key_bytes
+    n = cols[0].shape[0]
+    out = np.empty((n, key_bytes), dtype=np.uint8)
+    sizes = np.array([c.dtype.itemsize for c in cols], dtype=np.uint32)
+    ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+    lib().cho_pack_fixed(len(cols), _p(sizes), ptrs, n, key_bytes, _p(out))
+    return out
+
+
+def hash_keys_fixed(packed_row: np.ndarray) -> int:
+    """UInt128HashCRC32 / UInt256HashCRC32 of one packed key (uint8[16] or uint8[32])"""
+    w = np.ascontiguousarray(packed_row).view(np.uint64)
+    return int(lib().cho_hash_keys_fixed(_p(w), w.shape[0]))
+
+
+class WideKeyMap:
+    """HashMap<UInt128 / UInt256, id> restated (keys128 / keys256): emplace / find of packed keys -> ids by first appearance"""
+
+    def __init__(self, key_bytes: int):
+        self.key_bytes = key_bytes
+        self._h = lib().cho_widemap_create(key_bytes)
+        assert self._h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().cho_widemap_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def batch(self, packed: np.ndarray, insert: bool = True) -> np.ndarray:
+        packed = np.ascontiguousarray(packed)
+        ids = np.empty(packed.shape[0], dtype=np.uint64)
+        lib().cho_widemap_batch(self._h, _p(packed), packed.shape[0], int(insert), _p(ids))
+        return ids
+
+    def __len__(self):
+        return int(lib().cho_widemap_size(self._h))
+
+    def keys(self) -> np.ndarray:
+        out = np.empty((len(self), self.key_bytes), dtype=np.uint8)
+        lib().cho_widemap_keys(self._h, _p(out))
+        return out
+
+
+class KeysFixedAggregator:
+    """Aggregator with the keys128 / keys256 method: HashMethodKeysFixed over packFixed keys; states per key as in Aggregator"""
+
+    def __init__(self, key_dtypes, aggs):
+        self.key_dtypes = [np.dtype(d) for d in key_dtypes]
+        total = sum(d.itemsize for d in self.key_dtypes)
+        self.map = WideKeyMap(16 if total <= 16 else 32)
+        self.inner = Aggregator(np.uint64, aggs, two_level_threshold=0)
+
+    def execute_on_block(self, key_cols, args):
+        packed = pack_fixed([np.ascontiguousarray(c).astype(d, copy=False) for c, d in zip(key_cols, self.key_dtypes)], self.map.key_bytes)
+        self.inner.execute_on_block(self.map.batch(packed, True), args)
+
+    def convert_to_block(self):
+        ids, res = self.inner.convert_to_block()
+        keys = self.map.keys()[ids.astype(np.int64)]
+        cols, off = [], 0
+        for d in self.key_dtypes:
+            cols.append(np.ascontiguousarray(keys[:, off:off + d.itemsize]).view(d).reshape(-1))
+            off += d.itemsize
+        return cols, res
 
 
 def groupby_pipeline(keys: np.ndarray, aggs, args, threads: int = 1, block_rows: int = DEFAULT_BLOCK_SIZE, two_level_threshold: int = 100000):

@@ -1926,3 +1926,156 @@ int cho_join_count_sum_pipeline(const uint64_t * bk, const int64_t * bv, size_t 
     cho_join_free(j);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * a15 keys128 / keys256: HashMethodKeysFixed (src/Common/ColumnsHashing/HashMethod.h:236-410) over packFixed
+ * (src/Interpreters/AggregationCommon.h:91-158) with HashMap<UInt128 / UInt256, ..., UInt128HashCRC32 / UInt256HashCRC32>
+ * (AggregatedData.h:57-60; Hash.h:346-355, 412-423).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* packFixed: the key columns' raw element bytes laid consecutively into a zero-initialised key of key_bytes */
+void cho_pack_fixed(size_t n_cols, const uint32_t * sizes, const void * const * cols, size_t n, size_t key_bytes, uint8_t * out)
+{
+    memset(out, 0, n * key_bytes);
+    for (size_t i = 0; i < n; ++i)
+    {
+        size_t offset = 0;
+        for (size_t j = 0; j < n_cols; ++j)
+        {
+            memcpy(out + i * key_bytes + offset, (const char *)cols[j] + i * sizes[j], sizes[j]);
+            offset += sizes[j];
+        }
+    }
+}
+
+/* UInt128HashCRC32 / UInt256HashCRC32: crc32c chained over the 64-bit words from -1 */
+uint64_t cho_hash_keys_fixed(const uint64_t * words, size_t n_words)
+{
+    uint64_t crc = ~0ull;
+    for (size_t w = 0; w < n_words; ++w)
+        crc = _mm_crc32_u64(crc, words[w]);
+    return crc;
+}
+
+/* The map: open addressing, linear probing, power-of-two buffer (initial 256 cells), grows x4 below 2^23 cells then x2 when more
+   than half full (HashTableGrowerWithPrecalculation, HashTable.h:273-330); the all-zero key lives out of line (HashTable.h:358-391).
+   The mapped value is the dense number of the key by first appearance: what a test needs to express any GROUP BY / join over it. */
+struct cho_widemap
+{
+    size_t key_words, degree, size;
+    uint64_t * keys;   /* [cells][key_words]; all-zero = empty */
+    uint64_t * mapped; /* [cells] */
+    int has_zero;
+    uint64_t zero_mapped;
+    uint64_t * by_id;  /* [size][key_words] in id order */
+    size_t by_id_cap;
+};
+
+cho_widemap * cho_widemap_create(size_t key_bytes)
+{
+    if (key_bytes != 16 && key_bytes != 32)
+        return NULL;
+    cho_widemap * m = (cho_widemap *)calloc(1, sizeof(*m));
+    m->key_words = key_bytes / 8;
+    m->degree = 8;
+    m->keys = (uint64_t *)calloc((size_t)1 << m->degree, key_bytes);
+    m->mapped = (uint64_t *)calloc((size_t)1 << m->degree, 8);
+    return m;
+}
+
+void cho_widemap_free(cho_widemap * m)
+{
+    if (!m)
+        return;
+    free(m->keys);
+    free(m->mapped);
+    free(m->by_id);
+    free(m);
+}
+
+size_t cho_widemap_size(const cho_widemap * m) { return m->size; }
+
+static int wide_is_zero(const uint64_t * k, size_t w)
+{
+    for (size_t q = 0; q < w; ++q)
+        if (k[q])
+            return 0;
+    return 1;
+}
+
+static size_t wide_find_cell(const cho_widemap * m, const uint64_t * key, uint64_t hash)
+{
+    const size_t mask = ((size_t)1 << m->degree) - 1, w = m->key_words;
+    size_t place = hash & mask;
+    while (!wide_is_zero(m->keys + place * w, w) && memcmp(m->keys + place * w, key, w * 8) != 0)
+        place = (place + 1) & mask;
+    return place;
+}
+
+static void wide_grow(cho_widemap * m)
+{
+    const size_t old_cells = (size_t)1 << m->degree, w = m->key_words;
+    uint64_t * ok = m->keys, * om = m->mapped;
+    m->degree += m->degree >= 23 ? 1 : 2;
+    m->keys = (uint64_t *)calloc((size_t)1 << m->degree, w * 8);
+    m->mapped = (uint64_t *)calloc((size_t)1 << m->degree, 8);
+    for (size_t c = 0; c < old_cells; ++c)
+        if (!wide_is_zero(ok + c * w, w))
+        {
+            size_t place = wide_find_cell(m, ok + c * w, cho_hash_keys_fixed(ok + c * w, w));
+            memcpy(m->keys + place * w, ok + c * w, w * 8);
+            m->mapped[place] = om[c];
+        }
+    free(ok);
+    free(om);
+}
+
+/* emplaceKey (insert != 0) / findKey for n packed keys; ids_out[i] = dense id by first appearance, ~0 when absent (find) */
+void cho_widemap_batch(cho_widemap * m, const uint8_t * packed, size_t n, int insert, uint64_t * ids_out)
+{
+    const size_t w = m->key_words;
+    for (size_t i = 0; i < n; ++i)
+    {
+        uint64_t key[4];
+        memcpy(key, packed + i * w * 8, w * 8);
+        if (wide_is_zero(key, w))
+        {
+            if (!m->has_zero && insert)
+            {
+                m->has_zero = 1;
+                m->zero_mapped = m->size++;
+                goto record_new;
+            }
+            ids_out[i] = m->has_zero ? m->zero_mapped : ~0ull;
+            continue;
+        }
+        {
+            size_t place = wide_find_cell(m, key, cho_hash_keys_fixed(key, w));
+            if (!wide_is_zero(m->keys + place * w, w))
+            {
+                ids_out[i] = m->mapped[place];
+                continue;
+            }
+            if (!insert)
+            {
+                ids_out[i] = ~0ull;
+                continue;
+            }
+            memcpy(m->keys + place * w, key, w * 8);
+            m->mapped[place] = m->size++;
+        }
+    record_new:
+        if (m->size > m->by_id_cap)
+        {
+            m->by_id_cap = m->by_id_cap ? m->by_id_cap * 2 : 1024;
+            m->by_id = (uint64_t *)realloc(m->by_id, m->by_id_cap * w * 8);
+        }
+        memcpy(m->by_id + (m->size - 1) * w, key, w * 8);
+        ids_out[i] = m->size - 1;
+        if (m->size - (m->has_zero ? 1 : 0) > ((size_t)1 << (m->degree - 1)))
+            wide_grow(m);
+    }
+}
+
+/* the packed keys in id order: out[size][key_bytes] */
+void cho_widemap_keys(const cho_widemap * m, uint8_t * out) { memcpy(out, m->by_id, m->size * m->key_words * 8); }

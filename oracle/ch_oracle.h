@@ -167,6 +167,17 @@ int cho_join_need_replication(const cho_join *);
 /* selector[i] = getBucketFromHash(hashCRC32(key)) & (num_shards-1) ; num_shards power of two <= 256 */
 void cho_hash_to_selector(int type, const void * keys, size_t n, size_t num_shards, uint64_t * selector);
 
+/* ---- a15 keys128 / keys256: packFixed (AggregationCommon.h:91-158) + HashMap<UInt128 / UInt256> with UInt128HashCRC32 / UInt256HashCRC32 ---- */
+void cho_pack_fixed(size_t n_cols, const uint32_t * sizes, const void * const * cols, size_t n, size_t key_bytes, uint8_t * out);
+uint64_t cho_hash_keys_fixed(const uint64_t * words, size_t n_words); /* Hash.h:346-355, 412-423 */
+typedef struct cho_widemap cho_widemap;
+cho_widemap * cho_widemap_create(size_t key_bytes); /* 16 or 32 */
+void cho_widemap_free(cho_widemap *);
+size_t cho_widemap_size(const cho_widemap *);
+/* emplaceKey (insert != 0) / findKey: ids_out[i] = number of the key by first appearance, ~0 when absent */
+void cho_widemap_batch(cho_widemap *, const uint8_t * packed, size_t n, int insert, uint64_t * ids_out);
+void cho_widemap_keys(const cho_widemap *, uint8_t * out);
+
 /* ---- CPU-baseline drivers (bench.py cpu_baseline leg; also the parity check on the sample): N pipeline streams over Blocks ---- */
 /* GROUP BY: one Aggregator per stream with the reference's hash-cell prefetch (Aggregator.cpp:1025-1054), two-level conversion,
    bucket-parallel merge (AggregatingTransform.cpp:120-136).  Returns the merged aggregator; seconds_out[2] = {consume, merge}. */

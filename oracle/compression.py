@@ -2,7 +2,7 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 
 Frame (src/Compression/CompressedReadBufferBase.cpp:175-222, CompressionInfo.h:10-51, ICompressionCodec.cpp compress()):
-  16 bytes  CityHash128 of everything that follows (NOT verified here nor by the product: cityhash102 is not restated)
+  16 bytes  CityHash128 (cityhash 1.0.2) of everything that follows, as {low64, high64}: written by write_frames, verified by read_frames
   1 byte    method (0x82 LZ4, 0x02 NONE, 0x92 Delta, ...)
   4 bytes   compressed size, little endian, INCLUDING this 9-byte header
   4 bytes   decompressed size
@@ -38,6 +38,8 @@ def lib():
             fn = getattr(L, name)
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.cho_city_hash128.restype = None
+        L.cho_city_hash128.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
 
@@ -58,6 +60,19 @@ def delta_decode(payload: bytes, dst_size: int) -> bytes:
     return dst.tobytes()
 
 
+def city_hash128(data: bytes):
+    """CityHash_v1_0_2::CityHash128 -> (low64, high64)"""
+    out = (C.c_uint64 * 2)()
+    lib().cho_city_hash128(bytes(data), len(data), out)
+    return int(out[0]), int(out[1])
+
+
+def _framed(stage: bytes) -> bytes:
+    """a frame = the checksum of (header + payload) in front of them (CompressedWriteBuffer::nextImpl)"""
+    lo, hi = city_hash128(stage)
+    return struct.pack("<QQ", lo, hi) + stage
+
+
 def _stage(method: int, payload: bytes, decompressed_size: int) -> bytes:
     """one codec application as ICompressionCodec::compress lays it out: 9-byte header + payload"""
     return struct.pack("<BII", method, HEADER + len(payload), decompressed_size) + payload
@@ -72,7 +87,7 @@ def delta_encode(raw: bytes, width: int) -> bytes:
 
 
 def write_frames(raw: bytes, block_size: int = 65536, method=METHOD_LZ4, delta_width: int = 8) -> bytes:
-    """CompressedWriteBuffer: one frame per `block_size` bytes of input (checksum bytes are left zero: unverified).
+    """CompressedWriteBuffer: one frame per `block_size` bytes of input, each with its CityHash128 checksum.
     method DELTA_LZ4 = CODEC(Delta(delta_width), LZ4): a Multiple frame (CompressionCodecMultiple.cpp:40-66) -- the method list, then
     the stages applied in order, each with its own header."""
     import pyarrow as pa
@@ -82,14 +97,14 @@ def write_frames(raw: bytes, block_size: int = 65536, method=METHOD_LZ4, delta_w
         if method == DELTA_LZ4:
             st1 = _stage(METHOD_DELTA, delta_encode(chunk, delta_width), len(chunk))
             st2 = _stage(METHOD_LZ4, pa.compress(st1, codec="lz4_raw", asbytes=True), len(st1))
-            out += bytes(CHECKSUM) + _stage(METHOD_MULTIPLE, bytes([2, METHOD_DELTA, METHOD_LZ4]) + st2, len(chunk))
+            out += _framed(_stage(METHOD_MULTIPLE, bytes([2, METHOD_DELTA, METHOD_LZ4]) + st2, len(chunk)))
             continue
         payload = pa.compress(chunk, codec="lz4_raw", asbytes=True) if method == METHOD_LZ4 else chunk
-        out += bytes(CHECKSUM) + _stage(method, payload, len(chunk))
+        out += _framed(_stage(method, payload, len(chunk)))
     return bytes(out)
 
 
-def parse_frames(buf: bytes):
+def parse_frames(buf: bytes, verify_checksums: bool = True):
     """-> list of (method, payload_offset, payload_size, decompressed_size)"""
     frames, pos = [], 0
     while pos < len(buf):
@@ -98,6 +113,8 @@ def parse_frames(buf: bytes):
         method, csize, dsize = struct.unpack_from("<BII", buf, pos + CHECKSUM)
         if csize < HEADER or pos + CHECKSUM + csize > len(buf):
             raise ValueError("CANNOT_DECOMPRESS: bad frame size")
+        if verify_checksums and struct.unpack_from("<QQ", buf, pos) != city_hash128(buf[pos + CHECKSUM:pos + CHECKSUM + csize]):
+            raise ValueError("CHECKSUM_DOESNT_MATCH")
         frames.append((method, pos + CHECKSUM + HEADER, csize - HEADER, dsize))
         pos += CHECKSUM + csize
     return frames

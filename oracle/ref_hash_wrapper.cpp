@@ -29,3 +29,23 @@ void ref_intHash64_batch(const unsigned long long * keys, unsigned long long n, 
         out[i] = intHash64(keys[i]);
 }
 }
+
+/* keys128 / keys256: the hashes of the wide-key maps (Hash.h:346-355, 412-423) */
+extern "C" {
+unsigned long long ref_UInt128HashCRC32(unsigned long long w0, unsigned long long w1)
+{
+    UInt128 x;
+    x.items[0] = w0;
+    x.items[1] = w1;
+    return UInt128HashCRC32()(x);
+}
+unsigned long long ref_UInt256HashCRC32(unsigned long long w0, unsigned long long w1, unsigned long long w2, unsigned long long w3)
+{
+    UInt256 x;
+    x.items[0] = w0;
+    x.items[1] = w1;
+    x.items[2] = w2;
+    x.items[3] = w3;
+    return UInt256HashCRC32()(x);
+}
+}

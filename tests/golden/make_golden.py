@@ -88,6 +88,46 @@ def main():
     make_mod_kat(ref_root)
     make_sort_kat(ref_root)
     make_string_kat(ref_root)
+    make_round2_kat(ref_root)
+
+
+def make_round2_kat(ref_root):
+    """Round-2 fixtures: CityHash128 vectors from the reference's own contrib/cityhash102 compiled in place (oracle/ref_city_wrapper.cpp),
+    UInt128HashCRC32 / UInt256HashCRC32 vectors from its Hash.h (oracle/ref_hash_wrapper.cpp), and the serialized aggregate-state bytes the
+    reference's tests expect: hex(avgState(number)) over numbers(10) (01926_bin_unbin), hex(countState) over 10 rows
+    (00357_to_string_complex_types), hex(countState(if(even, number, null))) over numbers(5) (03210_...return_type_bug)."""
+    import ctypes as C
+    import oracle
+    oracle.build()
+    city = C.CDLL(os.path.join(REPO, "oracle", "_ref", "libchref_city.so"))
+    rng = np.random.Generator(np.random.PCG64(102))
+    vecs = []
+    for n in list(range(0, 40)) + [63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4096 + 25]:
+        data = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        out = (C.c_uint64 * 2)()
+        city.ref_CityHash128(data, n, out)
+        vecs.append(dict(hex=data.hex(), low64=str(out[0]), high64=str(out[1])))
+    R = oracle.ref_hash()
+    wide = []
+    for _ in range(32):
+        w = [int(x) for x in rng.integers(0, 2**64, size=4, dtype=np.uint64)]
+        if _ < 4:
+            w = [[0, 0, 0, 0], [1, 0, 0, 0], [0, 1, 0, 0], [2**64 - 1] * 4][_]
+        wide.append(dict(words=[str(x) for x in w], UInt128HashCRC32=str(R.ref_UInt128HashCRC32(w[0], w[1])),
+                         UInt256HashCRC32=str(R.ref_UInt256HashCRC32(*w))))
+    def last_line(name):
+        with open(os.path.join(ref_root, "tests/queries/0_stateless", name + ".reference")) as f:
+            return [l.rstrip("\n") for l in f]
+    bin_unbin = last_line("01926_bin_unbin")
+    states = dict(avgState_numbers10=dict(source="tests/queries/0_stateless/01926_bin_unbin.reference", hex=[l for l in bin_unbin if l == l.upper() and len(l) == 18][0]),
+                  countState_10rows=dict(source="tests/queries/0_stateless/00357_to_string_complex_types.reference", hex=[l for l in last_line("00357_to_string_complex_types") if l == "0A"][0]),
+                  countState_3rows=dict(source="tests/queries/0_stateless/03210_optimize_rewrite_aggregate_function_with_if_return_type_bug.reference",
+                                        hex=last_line("03210_optimize_rewrite_aggregate_function_with_if_return_type_bug")[0]))
+    with open(os.path.join(HERE, "round2_kat.json"), "w") as f:
+        json.dump(dict(city_hash128_source="contrib/cityhash102 (CityHash_v1_0_2::CityHash128) compiled in place", city_hash128=vecs,
+                       keys_fixed_source="src/Common/HashTable/Hash.h UInt128HashCRC32 / UInt256HashCRC32 compiled in place", keys_fixed=wide,
+                       agg_states=states), f, indent=1)
+    print("wrote round2_kat.json:", len(vecs), "city vectors,", len(wide), "wide-key vectors, states", {k: v["hex"] for k, v in states.items()})
 
 
 def make_string_kat(ref_root):

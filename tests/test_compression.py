@@ -88,7 +88,7 @@ def test_gpu_delta_lz4_frames_decode_to_original_bytes():
     st1[9] = 3  # element width 3
     import pyarrow as pa
     st2 = OC._stage(OC.METHOD_LZ4, pa.compress(bytes(st1), codec="lz4_raw", asbytes=True), len(st1))
-    buf = bytes(16) + OC._stage(OC.METHOD_MULTIPLE, bytes([2, 0x92, 0x82]) + st2, len(raw))
+    buf = OC._framed(OC._stage(OC.METHOD_MULTIPLE, bytes([2, 0x92, 0x82]) + st2, len(raw)))  # the checksum is right, the Delta header is not
     with pytest.raises(ch.ChgpuError) as ei:
         CC.decompress_frames(ctx, ctx.upload(np.frombuffer(buf, dtype=np.uint8)), CC.parse_frames(buf))
     assert ei.value.code == ch._capi.ERR_BAD_ARGUMENTS
@@ -134,3 +134,88 @@ def test_gpu_malformed_frames_are_errors_not_faults():
         CC.parse_frames(good[:-5])
     # the context still works after the rejected calls
     assert CC.decompress_frames(ctx, up, frames).numpy().tobytes() == np.arange(50_000, dtype=np.int64).tobytes()
+
+
+# ---- frame integrity: host-side, no GPU needed (the walk runs on the host in the product too) -------------------------------------------
+def test_city_hash128_product_and_oracle_match_reference_vectors():
+    """CityHash128 1.0.2: the product's implementation (feed.hip) and the oracle's (ch_compress.c) against vectors produced by the reference's
+    own contrib/cityhash102 compiled in place (tests/golden/round2_kat.json, generator tests/golden/make_golden.py)"""
+    import json
+    import os
+    from clickhouse_amd import compression as CC
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "round2_kat.json")))["city_hash128"]
+    assert len(kat) >= 40
+    for v in kat:
+        data = bytes.fromhex(v["hex"])
+        want = (int(v["low64"]), int(v["high64"]))
+        assert CC.city_hash128(data) == want and OC.city_hash128(data) == want, len(data)
+
+
+def test_frame_walk_verifies_checksums_and_caps_sizes():
+    import clickhouse_amd as ch
+    from clickhouse_amd import compression as CC
+    raw = np.arange(30_000, dtype=np.int64).tobytes()
+    good = OC.write_frames(raw, 65536)
+    frames = CC.parse_frames(good)
+    assert len(frames) == 4 and [f[:4] for f in frames] == OC.parse_frames(good)
+    for pos in (0, 15, 16, 20, 24, 25, 1000, len(good) - 1):                 # checksum bytes, header bytes, payload bytes
+        bad = bytearray(good)
+        bad[pos] ^= 0x04
+        with pytest.raises(ch.ChgpuError) as ei:
+            CC.parse_frames(bytes(bad))
+        assert ei.value.code == ch._capi.ERR_BAD_ARGUMENTS
+    bad = bytearray(good)
+    bad[1000] ^= 0x04
+    assert len(CC.parse_frames(bytes(bad), verify_checksums=False)) == 4      # disable_checksum: the walk alone
+    import struct
+    huge = bytearray(good[:16 + 9])
+    struct.pack_into("<I", huge, 16 + 5, 0x40000001)                          # decompressed size above DBMS_MAX_COMPRESSED_SIZE
+    with pytest.raises(ch.ChgpuError) as ei:
+        CC.parse_frames(bytes(huge), verify_checksums=False)
+    assert "TOO_LARGE_SIZE_COMPRESSED" in str(ei.value)
+
+
+def test_native_block_header_walk():
+    """NativeReader::read's header walk over a block written the way NativeWriter lays it out"""
+    import ctypes as C
+    import clickhouse_amd as ch
+    from clickhouse_amd import compression as CC
+    K = ch._capi
+
+    def varuint(x):
+        out = bytearray()
+        while x >= 0x80:
+            out.append((x & 0x7F) | 0x80)
+            x >>= 7
+        out.append(x)
+        return bytes(out)
+
+    def string(s):
+        return varuint(len(s)) + s.encode()
+
+    a = np.arange(1000, dtype=np.uint64) * 3
+    b = (np.arange(1000) % 7).astype(np.int32)
+    for rev in (0, 54453, 54454):
+        blk = bytearray()
+        if rev > 0:
+            blk += varuint(1) + bytes([0]) + varuint(2) + (17).to_bytes(4, "little", signed=True) + varuint(0)   # BlockInfo: is_overflows, bucket_num
+        blk += varuint(2) + varuint(1000)
+        for name, tname, arr in (("k", "UInt64", a), ("v", "Int32", b)):
+            blk += string(name) + string(tname)
+            if rev >= 54454:
+                blk += bytes([0])
+            blk += arr.tobytes()
+        raw = bytes(blk) + b"next block"
+        arr_t = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        cols = (CC._NativeColumnStruct * 2)()
+        ncols, nrows, used = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+        bucket, over = C.c_int32(-1), C.c_int(0)
+        K.check(K.lib().chgpu_native_walk_block(arr_t, len(raw), rev, 2, cols, C.byref(ncols), C.byref(nrows), C.byref(bucket), C.byref(over), C.byref(used)))
+        assert (ncols.value, nrows.value, used.value) == (2, 1000, len(blk)) and bucket.value == (17 if rev > 0 else -1)
+        assert (cols[0].name, cols[0].type_name, cols[0].type, cols[0].data_bytes) == (b"k", b"UInt64", K.U64, 8000)
+        assert raw[cols[1].data_offset:cols[1].data_offset + 4000] == b.tobytes()
+    rc = K.lib().chgpu_native_walk_block(arr_t, 30, 54454, 2, cols, C.byref(ncols), C.byref(nrows), C.byref(bucket), C.byref(over), C.byref(used))
+    assert rc == K.ERR_BAD_ARGUMENTS                                                                   # truncated
+    s = bytes(varuint(1) + varuint(3) + string("s") + string("String") + b"\x01a\x01b\x01c")
+    arr_s = (C.c_uint8 * len(s)).from_buffer_copy(s)
+    assert K.lib().chgpu_native_walk_block(arr_s, len(s), 0, 2, cols, C.byref(ncols), C.byref(nrows), None, None, C.byref(used)) == K.ERR_NOT_IMPLEMENTED

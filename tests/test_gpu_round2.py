@@ -238,3 +238,144 @@ def test_join_probe_agg_region_partitioned_matches_numpy(ch, ctx, kind):
     c2, s2 = j.probe_count_sum(ctx.upload(pk[:1000]), ctx.upload(bv))   # a small probe takes the one-pass kernel: same answers
     m2 = mult[pk[:1000].astype(np.int64)]
     assert c2 == int(m2.sum()) + (int((m2 == 0).sum()) if kind == "LEFT" else 0)
+
+
+# ---- keys128 / keys256: the device dictionary (chgpu_keydict) under GROUP BY and joins ----------------------------------------------
+@pytest.mark.parametrize("key_dtypes", [(np.uint64, np.uint64), (np.uint64, np.uint32, np.uint16), (np.uint64, np.uint64, np.uint64, np.uint32, np.uint8)])
+def test_keys_fixed_group_by_matches_oracle(ch, ctx, oracle_mod, key_dtypes):
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(11))
+    aggs = [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)]
+    G = ch.KeysFixedAggregator(key_dtypes, aggs, ctx=ctx)
+    R = O.KeysFixedAggregator(key_dtypes, aggs)
+    for n in (70_001, 1, 300_000):                                    # several blocks: ids persist, the table grows
+        cols = [rng.integers(0, 40, size=n).astype(d) for d in key_dtypes]
+        cols[0][: n // 50] = 0
+        for c in cols[1:]:
+            c[: n // 50] = 0                                          # the all-zero key
+        v = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
+        G.execute_on_block(cols, [v, None])
+        R.execute_on_block(cols, [v, None])
+    gk, (gs, gc) = G.convert_to_block()
+    rk, (rs, rc) = R.convert_to_block()
+    assert len(G) == len(rk[0])
+    go = np.lexsort([k.astype(np.uint64) for k in gk])
+    ro = np.lexsort([k.astype(np.uint64) for k in rk])
+    for a, b in zip(gk, rk):
+        assert a.dtype == b.dtype and np.array_equal(a[go], b[ro])
+    assert np.array_equal(gs[go], rs[ro]) and np.array_equal(gc[go], rc[ro])
+
+
+def test_keys_fixed_00120_two_key_group_by_on_gpu(ch, ctx, oracle_mod, golden):
+    """the reference's 00120_join_and_group_by as what it is: GROUP BY (UInt64, UInt32) -- 12 key bytes, the keys128 method"""
+    L = oracle_mod.lib()
+    n = np.arange(10, dtype=np.uint64)
+    v1 = np.array([L.cho_sql_intHash64(int(x)) for x in n], dtype=np.uint64)
+    v2 = np.array([L.cho_sql_intHash32(int(x)) for x in n], dtype=np.uint32)
+    A = ch.KeysFixedAggregator([np.uint64, np.uint32], [(ch.AGG_SUM, np.uint64)], ctx=ctx)
+    A.execute_on_block([v1, v2], [n])
+    (k1, k2), (s,) = A.convert_to_block()
+    rows = sorted([[str(int(x)), str(int(y)), str(int(z))] for x, y, z in zip(k1, k2, s)], key=lambda r: (int(r[0]), int(r[1])))
+    assert rows == golden["rows"]["00120_join_and_group_by"]["rows"]
+
+
+def test_keys_fixed_join_and_selector(ch, ctx, oracle_mod):
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(12))
+    bk = [rng.integers(0, 300, size=20_000, dtype=np.uint64), rng.integers(0, 5, size=20_000).astype(np.uint32), rng.integers(0, 3, size=20_000).astype(np.uint16)]
+    pk = [rng.integers(0, 400, size=50_000, dtype=np.uint64), rng.integers(0, 6, size=50_000).astype(np.uint32), rng.integers(0, 3, size=50_000).astype(np.uint16)]
+    bv = rng.integers(-2**40, 2**40, size=20_000, dtype=np.int64)
+    j = ch.KeysFixedHashJoin([np.uint64, np.uint32, np.uint16], ch.JOIN_INNER, ch.STRICT_ALL, ctx=ctx)
+    j.add_block(bk)
+    c, s = j.probe_count_sum(pk, ctx.upload(bv))
+    m = O.WideKeyMap(16)
+    bid = m.batch(O.pack_fixed(bk, 16), True).astype(np.int64)
+    pid = m.batch(O.pack_fixed(pk, 16), False)
+    mult = np.bincount(bid, minlength=len(m))
+    sums = np.zeros(len(m), dtype=np.uint64)
+    np.add.at(sums, bid, bv.astype(np.uint64))
+    hit = pid != np.uint64(2**64 - 1)
+    assert c == int(mult[pid[hit].astype(np.int64)].sum()) and s % 2**64 == int(sums[pid[hit].astype(np.int64)].sum(dtype=np.uint64))
+    # the shard of a wide key by the reference's own hash: UInt128HashCRC32 -> two-level bucket & (shards - 1)
+    ids = j.dict.encode(bk, insert=False)
+    sel = j.dict.selector(ids, 8).numpy()
+    packed = O.pack_fixed(bk, 16)
+    want = np.array([((O.hash_keys_fixed(r) >> 24) & 0xFF) & 7 for r in packed[:2000]], dtype=np.uint32)
+    assert np.array_equal(sel[:2000], want)
+
+
+def test_keys_fixed_tag_collisions_are_resolved_exactly(ch, oracle_mod):
+    """with 8-bit tags (test hook) nearly every key shares its tag with others: the verification rounds must still give exact ids"""
+    import os
+    import subprocess
+    import sys
+    code = '''
+import numpy as np, clickhouse_amd as ch
+ctx = ch.Context(0)
+rng = np.random.Generator(np.random.PCG64(5))
+a = rng.integers(0, 3000, size=200_000, dtype=np.uint64); b = rng.integers(0, 3, size=200_000, dtype=np.uint64)
+d = ch.KeyDict([np.uint64, np.uint64], ctx)
+ids = d.encode([a, b]).numpy()
+pairs = np.stack([a, b], axis=1)
+uniq = np.unique(pairs, axis=0)
+assert len(d) == uniq.shape[0], (len(d), uniq.shape[0])
+first = {}
+for i, (x, y) in enumerate(pairs.tolist()):
+    assert first.setdefault(int(ids[i]), (x, y)) == (x, y)
+assert len(first) == uniq.shape[0]
+k0, k1 = [c.numpy() for c in d.key_columns(ctx.upload(ids))]
+assert np.array_equal(k0, a) and np.array_equal(k1, b)
+print("ok")
+'''
+    env = dict(os.environ, CHGPU_TEST_KEYDICT_WEAK_TAGS="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+# ---- partial states on the wire ------------------------------------------------------------------------------------------------------
+def test_state_bytes_match_reference_vectors_and_round_trip(ch, ctx, golden):
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "round2_kat.json")))["agg_states"]
+    # avgState(number) over numbers(10): the reference prints 2D000000000000000A (01926_bin_unbin)
+    A = ch.Aggregator(None, [(ch.AGG_AVG, np.uint64), (ch.AGG_COUNT, None), (ch.AGG_SUM, np.uint64)], ctx=ctx)
+    A.execute_on_block(None, [np.arange(10, dtype=np.uint64), None, np.arange(10, dtype=np.uint64)])
+    _, words, rows = A.export_state_columns()
+    assert rows == 1 and len(words) == 4                                   # avg numerator, avg denominator, count, sum
+    b, off = ch.serialize_states(ctx, ch.AGG_AVG, words[0], words[1])
+    assert b.numpy().tobytes().hex().upper() == kat["avgState_numbers10"]["hex"] and off.numpy().tolist() == [0, 9]
+    b, _ = ch.serialize_states(ctx, ch.AGG_COUNT, words[2])
+    assert b.numpy().tobytes().hex().upper() == kat["countState_10rows"]["hex"]     # countState over 10 rows: 0A (00357)
+    b, _ = ch.serialize_states(ctx, ch.AGG_SUM, words[3])
+    assert b.numpy().tobytes() == (45).to_bytes(8, "little")                        # the numerator bytes of the avg vector
+    three = ctx.upload(np.array([3], dtype=np.uint64))
+    assert ch.serialize_states(ctx, ch.AGG_COUNT, three)[0].numpy().tobytes().hex().upper() == kat["countState_3rows"]["hex"]
+    # round trip over a two-level export: 256 bucket streams cut out of one buffer, counts across the VarUInt length boundaries
+    rng = np.random.Generator(np.random.PCG64(21))
+    keys = rng.integers(0, 50_000, size=400_000, dtype=np.uint64)
+    vals = rng.integers(-2**62, 2**62, size=400_000, dtype=np.int64)
+    G = ch.Aggregator(np.uint64, [(ch.AGG_AVG, np.int64), (ch.AGG_COUNT, None)], ctx=ctx)
+    G.execute_on_block(keys, [vals, None])
+    kcol, words, groups, bucket_counts = G.export_state_columns_two_level()
+    big = ctx.upload(np.array([0, 127, 128, 16383, 16384, 2**32, 2**63, 2**64 - 1], dtype=np.uint64))
+    bb, bo = ch.serialize_states(ctx, ch.AGG_COUNT, big)
+    assert bo.numpy().tolist() == [0, 1, 2, 4, 6, 9, 14, 23, 33]
+    back, _ = ch.deserialize_states(ctx, ch.AGG_COUNT, bb, [8])
+    assert np.array_equal(back.numpy(), big.numpy())
+    ab, ao = ch.serialize_states(ctx, ch.AGG_AVG, words[0], words[1])
+    ao_h = ao.numpy()
+    starts = np.concatenate([[0], np.cumsum(bucket_counts)[:-1]]).astype(np.int64)
+    num, den = ch.deserialize_states(ctx, ch.AGG_AVG, ab, bucket_counts, ao_h[starts].tolist())   # one stream per bucket block
+    assert np.array_equal(num.numpy(), words[0].numpy()) and np.array_equal(den.numpy(), words[1].numpy())
+    # a CPU-initiator style merge: the deserialised states folded into a fresh aggregator give the same final result
+    M = ch.Aggregator(np.uint64, [(ch.AGG_AVG, np.int64), (ch.AGG_COUNT, None)], ctx=ctx)
+    cb, _ = ch.serialize_states(ctx, ch.AGG_COUNT, words[2])
+    cnt, _ = ch.deserialize_states(ctx, ch.AGG_COUNT, cb, [groups])
+    M.merge_states(kcol, [num, den, cnt], groups)
+    k1, r1 = G.convert_to_block()
+    k2, r2 = M.convert_to_block()
+    i, j = np.argsort(k1), np.argsort(k2)
+    assert np.array_equal(k1[i], k2[j]) and np.array_equal(r1[0][i], r2[0][j]) and np.array_equal(r1[1][i], r2[1][j])
+    trunc = ctx.upload(ab.numpy()[:-1])
+    with pytest.raises(ch.ChgpuError):
+        ch.deserialize_states(ctx, ch.AGG_AVG, trunc, [groups])

@@ -86,3 +86,45 @@ def test_01300_avg_float64_group_by(oracle_mod, golden):
     want = sorted(float(r[0]) for r in golden["rows"]["01300_avg_group_by_mod5"]["rows"])
     got = S.q01300(oracle_mod)
     assert [round(g, 6) for g in got] == want
+
+
+# ---- round 2: keys128 / keys256 restatement pinned by the compiled reference's vectors and by 00120 as a true two-key GROUP BY ------------
+def test_keys_fixed_hashes_match_reference_vectors(oracle_mod):
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "round2_kat.json")))["keys_fixed"]
+    for v in kat:
+        w = np.array([int(x) for x in v["words"]], dtype=np.uint64)
+        assert oracle_mod.hash_keys_fixed(w[:2].view(np.uint8)) == int(v["UInt128HashCRC32"])
+        assert oracle_mod.hash_keys_fixed(w.view(np.uint8)) == int(v["UInt256HashCRC32"])
+
+
+def test_keys_fixed_pack_and_group_by_two_keys(oracle_mod, golden):
+    O = oracle_mod
+    L = O.lib()
+    a = np.array([1, 2, 3], dtype=np.uint64)
+    b = np.array([7, 8, 9], dtype=np.uint32)
+    c = np.array([0x1234, 0xFFFF, 0], dtype=np.uint16)
+    p = O.pack_fixed([a, b, c])
+    assert p.shape == (3, 16)
+    assert bytes(p[1]) == (2).to_bytes(8, "little") + (8).to_bytes(4, "little") + (0xFFFF).to_bytes(2, "little") + bytes(2)   # packFixed: consecutive, zero padded
+    # 00120_join_and_group_by: GROUP BY (intHash64(number), intHash32(number)) -> sum(number): 12 key bytes = keys128
+    n = np.arange(10, dtype=np.uint64)
+    v1 = np.array([L.cho_sql_intHash64(int(x)) for x in n], dtype=np.uint64)
+    v2 = np.array([L.cho_sql_intHash32(int(x)) for x in n], dtype=np.uint32)
+    A = O.KeysFixedAggregator([np.uint64, np.uint32], [(O.AGG_SUM, np.uint64)])
+    A.execute_on_block([v1, v2], [n])
+    (k1, k2), (s,) = A.convert_to_block()
+    rows = sorted([[str(int(x)), str(int(y)), str(int(z))] for x, y, z in zip(k1, k2, s)], key=lambda r: (int(r[0]), int(r[1])))
+    assert rows == golden["rows"]["00120_join_and_group_by"]["rows"]
+    # the zero key, growth, find-without-insert
+    m = O.WideKeyMap(32)
+    rng = np.random.Generator(np.random.PCG64(3))
+    keys = rng.integers(0, 3, size=(5000, 32), dtype=np.uint8)
+    keys[0] = 0
+    uniq, first = np.unique(keys, axis=0, return_index=True)
+    ids = m.batch(keys, True)
+    assert len(m) == uniq.shape[0] and ids[0] == 0 and np.array_equal(m.keys()[ids.astype(np.int64)], keys)
+    probe = np.concatenate([keys[:10], np.full((1, 32), 9, dtype=np.uint8)])
+    got = m.batch(probe, False)
+    assert np.array_equal(got[:10], ids[:10]) and got[10] == 2**64 - 1 and len(m) == uniq.shape[0]
