@@ -865,8 +865,8 @@ extern "C" int chgpu_expr_compile(uint32_t n_nodes, const chgpu_expr_node * node
                     // the most negative value of a signed divisor type: the reference's constant-divisor path (ModuloByConstantImpl::vectorConstant,
                     // src/Functions/modulo.cpp:56-80) throws ILLEGAL_DIVISION "Division by the most negative number" where ModuloImpl::apply would
                     // compute a % b -- e.g. Int64 % toInt64(-9223372036854775808), Int32 % toInt8(-128).  Refused for every operand pair (a superset).
-                    if (chgpu_type_is_signed(at[1]) && bits == (1ull << (8 * sb - 1)))
-                        ok = false;
+                    if (nd.code == CHGPU_FN_MODULO && chgpu_type_is_signed(at[1]) && bits == (1ull << (8 * sb - 1)))
+                        ok = false; // (intDiv by that constant does not throw: DivideIntegralByConstantImpl, src/Functions/intDiv.cpp:55-78)
                 }
                 if (!ok)
                     rc = chgpu_set_error(CHGPU_ERR_NOT_IMPLEMENTED, "node %u: intDiv / modulo need a constant integer divisor that cannot raise ILLEGAL_DIVISION", k);

@@ -1284,6 +1284,7 @@ struct JoinRegionFn
 
 static constexpr u32 JPR_CHUNK = 4096; // keys per work item
 static constexpr u32 JPR_XCDS = 8;
+static constexpr u32 JPR_MAX_REGIONS = 512;
 
 // per XCD x: the chunks of regions x, x + 8, ... as one queue; qstart[x * (R/8 + 1) + i] = first chunk of its i-th region
 __global__ void k_jp_queues(const u64 * __restrict__ offsets, u32 G, u32 R, u64 n, u32 * __restrict__ qstart, u32 * __restrict__ qctr)
@@ -1304,7 +1305,30 @@ __global__ void k_jp_queues(const u64 * __restrict__ offsets, u32 G, u32 R, u64 
     qctr[x] = 0;
 }
 
-template <bool PF>
+// A primary-key build side probed for sum(payload): the payload of every cell's row is gathered ONCE into the cell's value word
+// (a copy of the table: {key, widened payload}), so a hit needs no second random access -- and no access outside its table region:
+// the row-id indirection into an 80 MB payload column cost 3.2 GB of line fetches per 1e8 probes and evicted the region's slice
+// from the XCD's L2 while it was being probed (PMC FETCH_SIZE 9.6 GB per launch before, for 0.8 GB of keys and 0.5 GB of table).
+__global__ __launch_bounds__(JT) void k_join_fuse_payload(JoinTable t, const void * __restrict__ payload, int payload_type, const u64 * __restrict__ block_base, u64 n_blocks,
+                                                          u64 * __restrict__ kvp)
+{
+    for (u64 s = (u64)blockIdx.x * JT + threadIdx.x; s <= t.capacity; s += (u64)gridDim.x * JT)
+    {
+        const u64 k = t.kv[2 * s];
+        const bool occupied = s == t.capacity ? (t.ctrl->has_zero != 0) : (k != 0);
+        u64 v = 0;
+        if (occupied)
+        {
+            const u64 rowid = t.kv[2 * s + 1];
+            const u64 flat = n_blocks == 1 ? (rowid & 0xFFFFFFFFull) : block_base[rowid >> 32] + (rowid & 0xFFFFFFFFull);
+            v = jload_payload(payload, payload_type, flat);
+        }
+        *(jv2 *)(kvp + 2 * s) = jv2{k, v};
+    }
+}
+
+// FUSED: t.kv points at such a {key, payload} copy (unique build keys): a hit adds the cell's second word
+template <bool PF, bool FUSED = false>
 __global__ __launch_bounds__(JT) void k_join_probe_agg_regions(JoinTable t, int variant, const u64 * __restrict__ keys, u64 n, const u64 * __restrict__ offsets, u32 G, u32 R,
                                                                const u32 * __restrict__ qstart, u32 * __restrict__ qctr, const void * __restrict__ payload, int payload_type,
                                                                const u64 * __restrict__ block_base, u64 n_blocks, unsigned long long * __restrict__ result2)
@@ -1317,8 +1341,8 @@ __global__ __launch_bounds__(JT) void k_join_probe_agg_regions(JoinTable t, int 
     __shared__ u64 sh_c[JT / 64], sh_s[JT / 64];
     const u32 per = R / JPR_XCDS;
     // the queue tables and the region boundaries live in LDS: the lane that fetches a work item then makes no dependent global read
-    __shared__ u32 s_qs[JPR_XCDS * (256 / JPR_XCDS + 1)];
-    __shared__ u64 s_roff[256 + 1];
+    __shared__ u32 s_qs[JPR_XCDS * (JPR_MAX_REGIONS / JPR_XCDS + 1)];
+    __shared__ u64 s_roff[JPR_MAX_REGIONS + 1];
     for (u32 i = threadIdx.x; i < JPR_XCDS * (per + 1); i += JT)
         s_qs[i] = qstart[i];
     for (u32 r = threadIdx.x; r <= R; r += JT)
@@ -1431,6 +1455,12 @@ __global__ __launch_bounds__(JT) void k_join_probe_agg_regions(JoinTable t, int 
                     }
                     if (variant == PV_ANTI_LEFT)
                         continue;
+                    if constexpr (FUSED)
+                    {
+                        cnt += 1;
+                        isum += v; // the value word IS the payload
+                        continue;
+                    }
                     if (!(v & JV_MULTI))
                     {
                         cnt += 1;
@@ -1447,9 +1477,10 @@ __global__ __launch_bounds__(JT) void k_join_probe_agg_regions(JoinTable t, int 
                             isum += jload_payload(payload, payload_type, flat_of(run[k]));
                 }
                 // the single-row matches' payload reads, issued back to back
+                if constexpr (!FUSED)
 #pragma unroll
-                for (int q = 0; q < RR; ++q)
-                    isum += pay[q] ? jload_payload(payload, payload_type, pay_row[q]) : 0;
+                    for (int q = 0; q < RR; ++q)
+                        isum += pay[q] ? jload_payload(payload, payload_type, pay_row[q]) : 0;
             }
         }
     }
@@ -1483,7 +1514,7 @@ static int join_probe_agg_regions(chgpu_join * j, const chgpu_col * key_col, con
     static const bool off = getenv("CHGPU_TUNE_JOIN_NO_REGIONS") != nullptr;
     static const u64 min_rows = getenv("CHGPU_TUNE_JOIN_REGION_MIN_ROWS") ? strtoull(getenv("CHGPU_TUNE_JOIN_REGION_MIN_ROWS"), nullptr, 10) : (4ull << 20);
     // worth it when the table is far larger than the XCDs' L2s together (32 MB) and there are enough keys to pay two extra passes
-    if (off || chgpu_type_size(j->key_type) != 8 || n < min_rows || cap * 16 < (64ull << 20) || ((uintptr_t)key_col->data % 16) != 0)
+    if (off || chgpu_type_size(j->key_type) != 8 || n < min_rows || n + RP_SCATTER_SLACK >= (1ull << 32) || cap * 16 < (64ull << 20) || ((uintptr_t)key_col->data % 16) != 0)
         return CHGPU_ERR_NOT_IMPLEMENTED;
     if (right_payload && chgpu_type_is_float(right_payload->type))
         return CHGPU_ERR_NOT_IMPLEMENTED; // a Float64 sum keeps the one-pass probe's fixed reduction order
@@ -1492,20 +1523,19 @@ static int join_probe_agg_regions(chgpu_join * j, const chgpu_col * key_col, con
     while ((1ull << lg_cap) < cap)
         ++lg_cap;
     u32 R = 8;
-    while (R < 256 && (cap * 16) / R > (u64)region_kib * 1024)
+    while (R < JPR_MAX_REGIONS && (cap * 16) / R > (u64)region_kib * 1024)
         R <<= 1;
     u32 lg_r = 0;
     while ((1u << lg_r) < R)
         ++lg_r;
     const JoinRegionFn fn{cap - 1, lg_cap - lg_r};
     const u32 G = (u32)ctx->num_cus;
-    constexpr u32 TILE = 12288;
     u64 rows_per_wg = ((n + G - 1) / G + 63) / 64 * 64;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     const u64 m = (u64)R * G;
     const size_t cnt_b = al(m * 4), off_b = al(m * 8 + 8), tmp_b = chgpu_scan_tmp_bytes(m), q_b = al((size_t)JPR_XCDS * (R / JPR_XCDS + 1) * 4 + JPR_XCDS * 4 + 64);
     void * scratch = nullptr;
-    CHGPU_TRY(chgpu_scratch(ctx, cnt_b + off_b + 256 + tmp_b + q_b + al(n * 8) + 256, &scratch));
+    CHGPU_TRY(chgpu_scratch(ctx, cnt_b + off_b + 256 + tmp_b + q_b + al((n + RP_SCATTER_SLACK) * 8) + 256, &scratch));
     u32 * counts = (u32 *)scratch;
     u64 * offsets = (u64 *)((char *)scratch + cnt_b);
     u64 * total_dev = (u64 *)((char *)scratch + cnt_b + off_b); // [0] scan total, [2..3] the result
@@ -1517,15 +1547,38 @@ static int join_probe_agg_regions(chgpu_join * j, const chgpu_col * key_col, con
     CHGPU_HIP(hipMemsetAsync(total_dev, 0, 64, ctx->stream));
     hipLaunchKernelGGL((k_rp_hist_wide<u64, JoinRegionFn>), dim3(G), dim3(RP_THREADS), 0, ctx->stream, (const u64 *)key_col->data, n, rows_per_wg, R, counts, fn);
     CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, m, total_dev, tmp, tmp_b));
-    const size_t lds = rp_scatter_carry_lds_bytes(TILE, R, 16, 8, false);
-    auto scat = k_rp_scatter_carry<TILE, u64, false, JoinRegionFn>;
-    CHGPU_HIP(hipFuncSetAttribute((const void *)scat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(scat, dim3(G), dim3(RP_THREADS), lds, ctx->stream, (const u64 *)key_col->data, (const u64 *)nullptr, n, rows_per_wg, R, (const u64 *)offsets, pkeys,
-                       (u64 *)nullptr, fn);
+    {
+        // keys only, plain runs (radix_partition.h k_rp_scatter; carried tails measured slower and wrote 1.26 GB for 0.8 GB of keys)
+        const size_t lds = rp_scatter_lds_bytes(12288, R, 8, false);
+        auto scat = k_rp_scatter<12288, u64, false, JoinRegionFn>;
+        CHGPU_HIP(hipFuncSetAttribute((const void *)scat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(scat, dim3(G), dim3(RP_THREADS), lds, ctx->stream, (const u64 *)key_col->data, (const u64 *)nullptr, n, rows_per_wg, R, (const u64 *)offsets, pkeys,
+                           (u64 *)nullptr, fn);
+    }
     hipLaunchKernelGGL(k_jp_queues, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)offsets, G, R, n, qstart, qctr);
     const void * pp = right_payload ? right_payload->data : nullptr;
     const int pt = right_payload ? right_payload->type : CHGPU_U64;
     const u32 grid = (u32)ctx->num_cus * 4;
+    static const bool no_fuse = getenv("CHGPU_TUNE_JOIN_NO_FUSED_PAYLOAD") != nullptr;
+    if (j->unique_keys && right_payload && !j->t.pf && !no_fuse)
+    {
+        // {key, payload} cells: one 16-byte read answers a hit completely (k_join_fuse_payload); rebuilt per call -- the payload column
+        // is the caller's, and nothing ties its contents to its address between two calls
+        void * fm = nullptr;
+        size_t fcls = 0;
+        CHGPU_TRY(chgpu_pool_alloc(ctx, (size_t)(cap + 1) * 16, &fm, &fcls));
+        hipLaunchKernelGGL(k_join_fuse_payload, dim3(chgpu_grid_for(ctx, cap + 1, JT, 8)), dim3(JT), 0, ctx->stream, j->t, pp, pt, (const u64 *)j->block_base_dev, (u64)j->blocks.size(),
+                           (u64 *)fm);
+        JoinTable ft = j->t;
+        ft.kv = (u64 *)fm;
+        hipLaunchKernelGGL((k_join_probe_agg_regions<false, true>), dim3(grid), dim3(JT), 0, ctx->stream, ft, variant, (const u64 *)pkeys, n, (const u64 *)offsets, G, R,
+                           (const u32 *)qstart, qctr, pp, pt, (const u64 *)j->block_base_dev, (u64)j->blocks.size(), result2);
+        ctx->counters[6] += 5;
+        const hipError_t e = hipGetLastError();
+        chgpu_pool_free(ctx, fm, fcls); // reuse is stream-ordered behind the probe
+        CHGPU_REQUIRE(e == hipSuccess, CHGPU_ERR_DEVICE, "join probe launch: %s", hipGetErrorString(e));
+        return chgpu_read_back(ctx, result2, res, 16);
+    }
     if (j->t.pf)
         hipLaunchKernelGGL(k_join_probe_agg_regions<true>, dim3(grid), dim3(JT), 0, ctx->stream, j->t, variant, (const u64 *)pkeys, n, (const u64 *)offsets, G, R,
                            (const u32 *)qstart, qctr, pp, pt, (const u64 *)j->block_base_dev, (u64)j->blocks.size(), result2);

@@ -67,7 +67,7 @@ struct chgpu_keydict
     void * ctrl_mem = nullptr;
     size_t ctrl_class = 0;
     u64 n_ids = 0;
-    int weak_tags = 0; // test hook: 8-bit tags, so that the collision rounds run
+    int weak_tags = 0; // test hook: 20-bit tags, so that the collision rounds run
 };
 
 // packFixed (AggregationCommon.h:91-158): column j's element of row i copied to bytes [offset_j, offset_j + size_j) of the key
@@ -103,7 +103,7 @@ __device__ __forceinline__ u64 kd_tag(const u64 * w, u32 W, int weak)
     for (u32 q = 1; q < W; ++q)
         h = dev_intHash64(h ^ w[q]);
     if (weak)
-        h &= 0xFF; // test hook: force tag collisions between different keys
+        h &= 0xFFFFF; // test hook: 20-bit tags, so that different keys do share tags and the verification rounds run
     return h | 1ull;
 }
 

@@ -373,7 +373,7 @@ int main(int argc, char ** argv)
             auto col = readCompressedColumn(ctx, file.data(), file.size(), CHGPU_I64);
             auto back = col->getData<int64_t>();
             REQUIRE(back.size() == m && std::equal(back.begin(), back.end(), a.begin()));
-            file[40] ^= 0x10; // one flipped payload bit: refused, not decoded into a wrong column
+            file[file.size() - 1] ^= 0x10; // one flipped payload bit: refused, not decoded into a wrong column
             bool refused = false;
             try { readCompressedColumn(ctx, file.data(), file.size(), CHGPU_I64); } catch (const Exception & e) { refused = std::string(e.what()).find("Checksum") != std::string::npos; }
             REQUIRE(refused);

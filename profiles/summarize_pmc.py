@@ -58,32 +58,35 @@ except Exception:
 
 
 def group_bytes(prefixes):
-    """HBM bytes moved by every launch of the kernels whose name starts with one of `prefixes`, read and write, and the per-kernel split"""
+    """HBM bytes moved by every launch of the kernels of one operator, read and write, and the per-kernel split.  A prefix "k_x_" matches
+    kernel names that start with it; "k_rp_<Marker" matches the shared partition kernels instantiated with that functor type."""
     tot_r = tot_w = 0.0
     split = {}
     for name, k in res["kernels"].items():
         short = name[5:] if name.startswith("void ") else name
-        if not any(short.startswith(p) for p in prefixes):
+        hit = any(short.startswith(p) for p in prefixes if "<" not in p) or any(all(t in short for t in p.split("<")) for p in prefixes if "<" in p)
+        if not hit:
             continue
         r = k["hbm_read_bytes_per_launch_corrected"] * k["launches"]
         w = k["hbm_write_bytes_per_launch"] * k["launches"]
         tot_r += r
         tot_w += w
-        split[short.split("(")[0][:80]] = {"launches": k["launches"], "read_bytes": r, "write_bytes": w}
+        label = short.split("(")[0][:110]
+        split[label] = {"launches": k["launches"], "read_bytes": r, "write_bytes": w}
     return tot_r, tot_w, split
 
 
 # configs C3 / C4 of the same command: bytes of their kernel families divided by the number of operator calls the bench made
 cfg = bj.get("configs") or {}
 if "C3" in cfg and cfg["C3"].get("calls"):
-    r, w, split = group_bytes(["k_gb_", "k_agg_"])
+    r, w, split = group_bytes(["k_gb_", "k_agg_", "k_rp_<GbpPartFn"])
     calls = cfg["C3"]["calls"]
     res["C3_hbm_bytes_per_call"] = (r + w) / calls
     res["C3"] = {"calls": calls, "read_bytes_per_call": r / calls, "write_bytes_per_call": w / calls, "algorithmic_bytes": cfg["C3"]["roofline"]["algorithmic_bytes"],
                  "kernels_total_over_all_calls": split}
 if "C4_one_gpu" in cfg and cfg["C4_one_gpu"].get("probe_calls"):
     c4 = cfg["C4_one_gpu"]
-    r, w, split = group_bytes(["k_join_", "k_jp_"])
+    r, w, split = group_bytes(["k_join_", "k_jp_", "k_rp_<JoinRegionFn"])
     # build and probe run a different number of times: weigh each kernel by the calls of its phase
     per_call = 0.0
     for name, v in split.items():

@@ -11,6 +11,7 @@ run() { # label, what, env...
   env "$@" timeout -k 10 240 python3 tools/bench_r02.py $what 1000000000 "$label" >> $OUT/r02_ab.jsonl 2>> $OUT/r02_ab.err || echo "{\"label\": \"$label\", \"failed\": true}" >> $OUT/r02_ab.jsonl
   tail -1 $OUT/r02_ab.jsonl | cut -c1-420
 }
-run default both X=1
-run c3_old_scatter c3 CHGPU_TUNE_GB_OLD_SCATTER=1
-run c4_noregions c4 CHGPU_TUNE_JOIN_NO_REGIONS=1
+run c4_default c4 X=1
+run c4_nofuse c4 CHGPU_TUNE_JOIN_NO_FUSED_PAYLOAD=1
+run c4_region2048 c4 CHGPU_TUNE_JOIN_REGION_KIB=2048
+run c4_region512 c4 CHGPU_TUNE_JOIN_REGION_KIB=512
