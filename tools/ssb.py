@@ -103,8 +103,11 @@ def q41_gpu(ch, ctx, dims, lo):
     return {(int(y), int(n)): (int(a) - int(b), int(c)) for y, n, a, b, c in zip(yy, nn, s_rev, s_cost, cnt)}
 
 
-def q41_cpu(O, dims, lo, block_rows=65409):
-    """Same plan over the oracle, fact table in Blocks of `block_rows` (lo: dict of numpy arrays)."""
+def q41_cpu(O, dims, lo, block_rows=65409, threads=1):
+    """Same plan over the oracle, fact table in Blocks of `block_rows` (lo: dict of numpy arrays).  threads > 1: the reference's pipeline
+    shape -- the four right-side tables are built once and shared (joinBlock is concurrent on an immutable table, IJoin.h:92-93), every
+    stream pushes its own Blocks through the joins into its own AggregatedDataVariants, the variants are merged at the end."""
+    import threading
     cm = O.cmp_const(dims["c_region"], O.EQ, AMERICA)
     ck, cn = O.filter_column(dims["c_custkey"], cm), O.filter_column(dims["c_nation"], cm)
     j_c = O.HashJoin(O.JOIN_INNER, O.STRICT_ALL)
@@ -115,31 +118,46 @@ def q41_cpu(O, dims, lo, block_rows=65409):
     j_p.add_block(O.filter_column(dims["p_partkey"], O.cmp_const(dims["p_mfgr"], O.LE, 2)))
     j_d = O.HashJoin(O.JOIN_INNER, O.STRICT_ALL)
     j_d.add_block(dims["d_datekey"])
-    agg = O.Aggregator(np.uint64, [(O.AGG_SUM, np.uint32), (O.AGG_SUM, np.uint32), (O.AGG_COUNT, None)])
+    aggs_spec = [(O.AGG_SUM, np.uint32), (O.AGG_SUM, np.uint32), (O.AGG_COUNT, None)]
     n = lo["lo_custkey"].shape[0]
-    for b in range(0, n, block_rows):
-        e = min(n, b + block_rows)
-        blk = {k: v[b:e] for k, v in lo.items()}
-        f = j_s.probe(blk["lo_suppkey"])["filter"]
-        if not f.any():
-            continue
-        cust, part, date, rev, cost = (O.filter_column(blk[k], f) for k in ("lo_custkey", "lo_partkey", "lo_orderdate", "lo_revenue", "lo_supplycost"))
-        f = j_p.probe(part)["filter"]
-        if not f.any():
-            continue
-        cust, date, rev, cost = (O.filter_column(c, f) for c in (cust, date, rev, cost))
-        r = j_c.probe(cust)
-        off = r["offsets"]
-        if off.shape[0] == 0 or off[-1] == 0:
-            continue
-        date, rev, cost = (O.replicate(c, off) for c in (date, rev, cost))
-        nation = cn[r["added_row"]]
-        r = j_d.probe(date)
-        off = r["offsets"]
-        rev, cost, nation = (O.replicate(c, off) for c in (rev, cost, nation))
-        year = dims["d_year"][r["added_row"]]
-        key = year.astype(np.uint64) | (nation.astype(np.uint64) << np.uint64(32))   # packFixed<UInt64>: 4 bytes year, 1 byte nation
-        agg.execute_on_block(key, [rev, cost, None])
-    keys, (s_rev, s_cost, cnt) = agg.convert_to_block()
+    n_blocks = (n + block_rows - 1) // block_rows
+    threads = max(1, min(threads, n_blocks))
+    aggs = [O.Aggregator(np.uint64, aggs_spec) for _ in range(threads)]
+
+    def stream(t):
+        agg = aggs[t]
+        for bi in range(n_blocks * t // threads, n_blocks * (t + 1) // threads):
+            b, e = bi * block_rows, min(n, (bi + 1) * block_rows)
+            blk = {k: v[b:e] for k, v in lo.items()}
+            f = j_s.probe(blk["lo_suppkey"])["filter"]
+            if not f.any():
+                continue
+            cust, part, date, rev, cost = (O.filter_column(blk[k], f) for k in ("lo_custkey", "lo_partkey", "lo_orderdate", "lo_revenue", "lo_supplycost"))
+            f = j_p.probe(part)["filter"]
+            if not f.any():
+                continue
+            cust, date, rev, cost = (O.filter_column(c, f) for c in (cust, date, rev, cost))
+            r = j_c.probe(cust)
+            off = r["offsets"]
+            if off.shape[0] == 0 or off[-1] == 0:
+                continue
+            date, rev, cost = (O.replicate(c, off) for c in (date, rev, cost))
+            nation = cn[r["added_row"]]
+            r = j_d.probe(date)
+            off = r["offsets"]
+            rev, cost, nation = (O.replicate(c, off) for c in (rev, cost, nation))
+            year = dims["d_year"][r["added_row"]]
+            key = year.astype(np.uint64) | (nation.astype(np.uint64) << np.uint64(32))   # packFixed<UInt64>: 4 bytes year, 1 byte nation
+            agg.execute_on_block(key, [rev, cost, None])
+
+    if threads == 1:
+        stream(0)
+    else:
+        th = [threading.Thread(target=stream, args=(t,)) for t in range(threads)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        for a in aggs[1:]:
+            aggs[0].merge(a)
+    keys, (s_rev, s_cost, cnt) = aggs[0].convert_to_block()
     return {(int(k & np.uint64(0xFFFFFFFF)), int((k >> np.uint64(32)) & np.uint64(0xFF))): (int(a) - int(b), int(c))
             for k, a, b, c in zip(keys, s_rev, s_cost, cnt)}
