@@ -38,8 +38,6 @@ def main():
     ap.add_argument("--c4-build-rows", type=int, default=10_000_000)
     ap.add_argument("--no-c5", action="store_true", help="skip the SSB Q4.1-style section (configs[4], one GPU's share)")
     ap.add_argument("--c5-rows", type=int, default=750_000_000)
-    ap.add_argument("--no-c5", action="store_true", help="skip the SSB Q4.1-style section (configs[4], one GPU's share)")
-    ap.add_argument("--c5-rows", type=int, default=750_000_000)
     ap.add_argument("--sharded-timeout", type=float, default=240.0, help="N>1: seconds the sharded GROUP BY / join section may take before the line is printed without it")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL code path on one GPU)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (rehearsal of the N>1 code path on one GPU)")
