@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--c4-build-rows", type=int, default=10_000_000)
     ap.add_argument("--no-c5", action="store_true", help="skip the SSB Q4.1-style section (configs[4], one GPU's share)")
     ap.add_argument("--c5-rows", type=int, default=750_000_000)
+    ap.add_argument("--only-c5", action="store_true", help="of the configs, run only C5 (the profile of the SSB plan on its own: profiles/collect.sh)")
     ap.add_argument("--sharded-timeout", type=float, default=240.0, help="N>1: seconds the sharded GROUP BY / join section may take before the line is printed without it")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL code path on one GPU)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (rehearsal of the N>1 code path on one GPU)")
@@ -224,13 +225,14 @@ def main():
             del a, col, slots, results
             ctx.trim()
             torch.cuda.empty_cache()
-            c3 = config_c3(args, ctx, ch, torch, np, dev, stream, tj, not args.no_cpu_baseline)
-            ctx.trim()
-            torch.cuda.empty_cache()
-            c4 = config_c4(args, ctx, ch, torch, np, dev, stream, tj, not args.no_cpu_baseline)
-            ctx.trim()
-            torch.cuda.empty_cache()
-            out["configs"] = {"C3": c3, "C4_one_gpu": c4}
+            out["configs"] = {}
+            if not args.only_c5:
+                out["configs"]["C3"] = config_c3(args, ctx, ch, torch, np, dev, stream, tj, not args.no_cpu_baseline)
+                ctx.trim()
+                torch.cuda.empty_cache()
+                out["configs"]["C4_one_gpu"] = config_c4(args, ctx, ch, torch, np, dev, stream, tj, not args.no_cpu_baseline)
+                ctx.trim()
+                torch.cuda.empty_cache()
             if not args.no_c5:
                 try:
                     out["configs"]["C5_one_gpu_share"] = config_c5(args, ctx, ch, torch, np, dev, stream, not args.no_cpu_baseline)
@@ -565,43 +567,6 @@ def config_c4(args, ctx, ch, torch, np, dev, stream, tj, with_cpu):
                                "build_rows_per_s": nb / t_b, "probe_rows_per_s": npb / t_p, "single_thread_probe_value": s1 / t_p1}
         res["parity"] = "count and sum(payload) bit-exact against the CPU restatement and an independent sorted-search join, full size"
     return res
-
-
-def config_c5(args, ctx, ch, torch, np, dev, stream, with_cpu):
-    """BASELINE.json configs[4], the share of ONE GPU of the 6 B-row lineorder table (750 M rows at 8 GPUs; customer 30 M, supplier 2 M,
-    part 2 M rows replicated and HBM-resident): SSB Q4.1-style plan -- dimension filters, two semi joins, two inner joins with payload,
-    GROUP BY (year, nation) with packed keys, sum(revenue) - sum(supplycost) -- composed from the hot-path operators (tools/ssb.py)."""
-    sys.path.insert(0, os.path.join(REPO, "tools"))
-    import ssb
-    rows = args.c5_rows
-    C, S, P = 30_000_000, 2_000_000, 2_000_000
-    dims = ssb.gen_dims(C, S, P)
-    lo_t = ssb.gen_lineorder_torch(rows, C, S, P, dev)
-    lo = {k: ctx.wrap(v.data_ptr(), np.uint32, rows, keepalive=v) for k, v in lo_t.items()}
-    dims_dev = ssb.upload_dims(ctx, dims)
-    dev_ms, wall_ms, res = _timed(lambda: ssb.q41_gpu(ch, ctx, dims_dev, lo), torch, stream, reps=3, warmup=1)
-    algo = 24.0 * rows  # SURVEY 8(d): six 4-byte lineorder columns
-    out = {"workload": "SSB Q4.1-style: 2 semi joins + 2 inner joins with payload + GROUP BY (year, nation), sum(revenue) - sum(supplycost); one GPU's share "
-                       "of the 6 B-row lineorder table, dimension columns resident in HBM (their filters and the four hash-table builds inside the timed plan)",
-           "lineorder_rows": rows, "groups": len(res), "ms": wall_ms, "device_ms": dev_ms, "rows_per_s": rows / (wall_ms * 1e-3),
-           "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": algo / (wall_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": algo / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
-    if with_cpu:
-        import oracle
-        oracle.build()
-        threads = max(1, min(32, len(os.sched_getaffinity(0))))  # streams beyond this only contend for the interpreter lock of the per-Block driver
-        m = min(rows, 60_000_000)
-        lo_s = {k: v[:m].cpu().numpy().view(np.uint32) for k, v in lo_t.items()}
-        t0 = time.perf_counter()
-        want = ssb.q41_cpu(oracle, dims, lo_s, threads=threads)
-        t_cpu = time.perf_counter() - t0
-        got = ssb.q41_gpu(ch, ctx, dims_dev, {k: c.cut(0, m) for k, c in lo.items()})
-        assert got == want, "C5: the GPU plan differs from the CPU restatement on the sample"
-        out["cpu_baseline"] = {"value": m / t_cpu, "unit": "rows/s", "cores": threads, "kind": "port",
-                               "sample": f"first {m} lineorder rows through the same plan over the oracle, Blocks of 65409 rows, {threads} streams sharing the four "
-                                         "right-side tables, own aggregation states merged at the end (dimension filters and builds included)"}
-        out["parity"] = "every (year, nation) group: profit and row count bit-exact on the sample"
-    return out
 
 
 def config_c5(args, ctx, ch, torch, np, dev, stream, with_cpu):
