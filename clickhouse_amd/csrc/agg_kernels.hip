@@ -1087,6 +1087,235 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
     }
 }
 
+// ---- the TILE-SORTED plan (radix_partition.h, k_rp_tilesort): units and the aggregate pass that gathers one run per tile ----
+// unit_start[p] = first unit of partition p, a partition of r rows gets ceil(r / chunk_rows) units (each an equal share of the TILES:
+// a partition swollen by a hot key is long in every tile, so cutting by tiles cuts its rows evenly), unit_start[P] = number of units.
+__global__ __launch_bounds__(1024) void k_tile_units(const unsigned long long * __restrict__ part_total, u32 P, u64 chunk_rows, u32 n_tiles, u32 * __restrict__ unit_start, u32 * __restrict__ ctr)
+{
+    __shared__ u32 sc[1024];
+    const u32 p = threadIdx.x;
+    u32 c = 0;
+    if (p < P)
+    {
+        const u64 c64 = (part_total[p] + chunk_rows - 1) / chunk_rows;
+        c = (u32)(c64 < n_tiles ? c64 : n_tiles); // a unit is at least one tile
+    }
+    sc[p] = c;
+    __syncthreads();
+    for (u32 dlt = 1; dlt < 1024; dlt <<= 1)
+    {
+        const u32 o = p >= dlt ? sc[p - dlt] : 0;
+        __syncthreads();
+        sc[p] += o;
+        __syncthreads();
+    }
+    if (p < P)
+        unit_start[p] = sc[p] - c;
+    if (p == P - 1)
+        unit_start[P] = sc[p];
+    if (p == 0)
+        *ctr = 0;
+}
+
+// One workgroup aggregates a unit = (partition p, a range of tiles) in the same compact LDS table as k_agg_part_lds (PartLds), then
+// flushes it into the HBM table.  Every wave takes whole tiles: it reads the two index entries of (tile, p), then the run's rows
+// (lanes beyond the run's length idle: a uniform input gives runs of TILE / P = 48 rows); runs longer than 64 rows (skew) continue
+// in a plain loop.  Three stages are in flight per wave: index entries of set s+2, rows of set s+1, LDS updates of set s.
+// OPS: the compile-time state update code of k_agg_part_lds (one argument word: operations 1, 3, 5, 6).
+template <typename KT, u32 OPS, u32 TILE>
+__global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, const KT * __restrict__ keys, const u64 * __restrict__ words0,
+                                                        const unsigned short * __restrict__ tile_index, u32 n_tiles, u32 P, u64 * __restrict__ pending, u32 S, u32 cnt32,
+                                                        const u32 * __restrict__ unit_start, u32 * __restrict__ unit_ctr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    typedef typename std::conditional<sizeof(KT) == 4, unsigned int, unsigned long long>::type CasT;
+    KT * lkeys = (KT *)lds_raw;
+    PartLds L;
+    L.S1 = S + 1;
+    L.cnt32 = cnt32;
+    L.n8 = d.n_words - (u32)__popc(cnt32);
+    L.keys_bytes = ((u32)sizeof(KT) * L.S1 + 7) & ~7u;
+    const u32 lds_bytes = L.keys_bytes + 8 * L.S1 * L.n8 + 4 * L.S1 * (u32)__popc(cnt32);
+    __shared__ u32 lzero, sh_unit;
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const u64 gstride = t.capacity + 1;
+    const u64 last_row = (u64)n_tiles * TILE - 1;
+    u32 w_off[4];
+#pragma unroll
+    for (u32 w = 0; w < 4; ++w)
+        w_off[w] = L.off(w);
+    const u32 n_units = unit_start[P];
+    for (;;)
+    {
+        if (threadIdx.x == 0)
+            sh_unit = atomicAdd(unit_ctr, 1u);
+        __syncthreads();
+        const u32 unit = sh_unit;
+        if (unit >= n_units)
+            break; // (every workgroup reaches this exit)
+        u32 lo = 0, hi = P - 1; // largest p with unit_start[p] <= unit
+        while (lo < hi)
+        {
+            const u32 mid = (lo + hi + 1) >> 1;
+            if (unit_start[mid] <= unit)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        const u32 p = lo;
+        const u32 c_p = unit_start[p + 1] - unit_start[p], j = unit - unit_start[p];
+        const u32 t0 = (u32)((u64)n_tiles * j / c_p), t1 = (u32)((u64)n_tiles * (j + 1) / c_p);
+        for (u32 s = threadIdx.x; s < lds_bytes / 8 + 1; s += blockDim.x)
+            ((u64 *)lds_raw)[s] = 0; // the host rounds the allocation up to 8 bytes past lds_bytes
+        if (threadIdx.x == 0)
+            lzero = 0;
+        __syncthreads();
+        constexpr int PR = 4; // tiles per wave and set
+        const u32 step = n_waves * PR;
+        auto tile_of = [&](u32 set_base, int q) -> u32 { return set_base + (u32)q * n_waves + wave; };
+        auto load_idx = [&](u32 set_base, u32 (&st)[PR], u32 (&ln)[PR]) {
+#pragma unroll
+            for (int q = 0; q < PR; ++q)
+            {
+                const u32 tt = tile_of(set_base, q);
+                const bool valid = tt < t1;
+                const u64 e = (u64)(valid ? tt : t1 - 1) * (P + 1) + p;
+                const u32 a = tile_index[e], b = tile_index[e + 1];
+                st[q] = a;
+                ln[q] = valid ? b - a : 0;
+            }
+        };
+        auto load_rows = [&](u32 set_base, const u32 (&st)[PR], KT (&kv)[PR], u64 (&av)[PR]) {
+#pragma unroll
+            for (int q = 0; q < PR; ++q)
+            {
+                const u32 tt = tile_of(set_base, q);
+                u64 i = (u64)(tt < t1 ? tt : t1 - 1) * TILE + st[q] + lane;
+                i = i < last_row ? i : last_row;
+                kv[q] = __builtin_nontemporal_load(&keys[i]);
+                av[q] = gbp_ops_use(OPS, 1, 3) ? __builtin_nontemporal_load(&words0[i]) : 0;
+            }
+        };
+        auto update_row = [&](u64 i, KT key, u64 b0) {
+            u32 ls = ~0u;
+            if (key == 0)
+            {
+                ls = S;
+                lzero = 1;
+            }
+            else
+            {
+                u32 s = gbp_cell<KT>(key, P, S); // bits disjoint from the partition id
+#pragma unroll 1
+                for (int probe = 0; probe < 64; ++probe)
+                {
+                    KT k = lkeys[s];
+                    if (k == 0)
+                        k = (KT)atomicCAS((CasT *)&lkeys[s], (CasT)0, (CasT)key), k = (k == 0) ? key : k;
+                    if (k == key)
+                    {
+                        ls = s;
+                        break;
+                    }
+                    s = (s + 1) & (S - 1);
+                }
+            }
+            if (ls != ~0u)
+            {
+#pragma unroll
+                for (u32 w = 0; w < 4; ++w)
+                {
+                    const u32 op = (OPS >> (4 * w)) & 15u;
+                    if (op == 0)
+                        break;
+                    unsigned char * wp = lds_raw + w_off[w];
+                    if (op == 1)
+                        atomicAdd((unsigned long long *)wp + ls, (unsigned long long)b0);
+                    else if (op == 3)
+                        atomicAdd((double *)wp + ls, __longlong_as_double((long long)b0));
+                    else if (op == 5)
+                        atomicAdd((unsigned int *)wp + ls, 1u);
+                    else
+                        atomicAdd((unsigned long long *)wp + ls, 1ull);
+                }
+            }
+            else
+            {
+                // the LDS table is full around this key's cell: straight into the HBM table, or marked pending for the finish rounds
+                const u64 slot = table_emplace(t, (u64)key, true);
+                if (slot == ~0ull)
+                {
+                    atomicOr((unsigned long long *)&pending[i >> 6], 1ull << (i & 63));
+                    t.ctrl->overflow = 1;
+                }
+                else
+                    add_vals_global(t, d, slot, b0, 0, 1);
+            }
+        };
+        auto process = [&](u32 set_base, const u32 (&st)[PR], const u32 (&ln)[PR], const KT (&kv)[PR], const u64 (&av)[PR]) {
+#pragma unroll
+            for (int q = 0; q < PR; ++q)
+            {
+                const u32 tt = tile_of(set_base, q);
+                const u64 row0 = (u64)tt * TILE + st[q];
+                if (lane < ln[q])
+                    update_row(row0 + lane, kv[q], av[q]);
+                for (u32 off = 64; off < ln[q]; off += 64) // a run longer than one wave (skewed keys)
+                    if (off + lane < ln[q])
+                    {
+                        const u64 i = row0 + off + lane;
+                        update_row(i, keys[i], gbp_ops_use(OPS, 1, 3) ? words0[i] : 0);
+                    }
+            }
+        };
+        {
+            u32 stA[PR], lnA[PR], stB[PR], lnB[PR], stC[PR], lnC[PR], stD[PR], lnD[PR];
+            KT kA[PR], kB[PR];
+            u64 aA[PR], aB[PR];
+            u32 sb = t0;
+            load_idx(sb, stA, lnA);
+            load_idx(sb + step, stB, lnB);
+            load_rows(sb, stA, kA, aA);
+            for (; sb < t1; sb += 2 * step)
+            {
+                load_idx(sb + 2 * step, stC, lnC);
+                load_rows(sb + step, stB, kB, aB);
+                __builtin_amdgcn_sched_barrier(0);
+                process(sb, stA, lnA, kA, aA);
+                load_idx(sb + 3 * step, stD, lnD);
+                load_rows(sb + 2 * step, stC, kA, aA);
+                __builtin_amdgcn_sched_barrier(0);
+                process(sb + step, stB, lnB, kB, aB);
+#pragma unroll
+                for (int q = 0; q < PR; ++q)
+                    stA[q] = stC[q], lnA[q] = lnC[q], stB[q] = stD[q], lnB[q] = lnD[q];
+            }
+        }
+        __syncthreads();
+        for (u32 s = threadIdx.x; s <= S; s += blockDim.x)
+        {
+            const u64 key = (u64)lkeys[s];
+            const bool occupied = (s == S) ? (lzero != 0) : (key != 0);
+            if (!occupied)
+                continue;
+            const u64 slot = table_emplace(t, s == S ? 0 : key, false);
+            if (slot == ~0ull)
+            {
+                t.ctrl->fatal = 1;
+                continue;
+            }
+            for (u32 w = 0; w < d.n_words; ++w)
+            {
+                const unsigned char * wp = lds_raw + L.off(w);
+                const u64 bits = ((cnt32 >> w) & 1) ? (u64)((const u32 *)wp)[s] : ((const u64 *)wp)[s];
+                if (bits != 0)
+                    global_add_word(t.words + (u64)w * gstride + slot, bits, (d.word_is_f64 >> w) & 1);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Merge (key, state words) tuples into the table: mergeToViaEmplace, also the rehash of a grown table.
 // src_words[w] + i*1 ; src keys are u64; key==0 entries are skipped when skip_zero_keys (table arrays: empty cells),
 // zero_slot_index: index in the source arrays of the out-of-line zero key (or ~0).
@@ -1397,6 +1626,166 @@ static u64 agg_estimate_groups(u64 d, u64 m)
     return (u64)hi;
 }
 
+// The TILE-SORTED plan of a partitioned executeOnBlock (k_rp_tilesort + k_agg_tiles_lds): one level, one 8-byte argument column
+// (or none besides counts), 4- or 8-byte keys, a compile-time state update.  Two passes over the rows instead of three (no histogram),
+// and the partition pass writes whole lines in row order.  NOT_IMPLEMENTED = the shape does not fit (the caller runs the scatter plan).
+static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols, u64 row_begin, u64 n, u32 P, u32 S, u32 cnt32,
+                               u32 agg_mask, u64 chunk_rows)
+{
+    chgpu_ctx * ctx = a->ctx;
+    const size_t key_w = chgpu_type_size(a->key_type);
+    if ((key_w != 4 && key_w != 8) || P > 512 || ((uintptr_t)key_col->data + row_begin * key_w) % 16 != 0)
+        return CHGPU_ERR_NOT_IMPLEMENTED;
+    const bool key32 = key_w == 4;
+    const u32 TILE = key32 ? 12288u : 8192u;
+    if (n < (u64)TILE * ctx->num_cus || n / TILE >= (1ull << 31))
+        return CHGPU_ERR_NOT_IMPLEMENTED;
+    // the one argument column
+    int arg_j = -1;
+    for (u32 j = 0; j < a->n_aggs; ++j)
+        if (a->kinds[j] != CHGPU_AGG_COUNT && ((agg_mask >> j) & 1))
+        {
+            if (arg_j >= 0 && arg_cols[j]->data != arg_cols[arg_j]->data)
+                return CHGPU_ERR_NOT_IMPLEMENTED;
+            if (arg_j < 0)
+                arg_j = (int)j;
+        }
+    if (arg_j < 0 || chgpu_type_size(a->arg_types[arg_j]) != 8 || ((uintptr_t)arg_cols[arg_j]->data + row_begin * 8) % 16 != 0)
+        return CHGPU_ERR_NOT_IMPLEMENTED;
+    AggDesc d;
+    agg_fill_desc(a, arg_cols, &d);
+    const u32 n_tiles = (u32)((n + TILE - 1) / TILE);
+    const u64 n_pad = (u64)n_tiles * TILE;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t tot_b = al((size_t)P * 8), unit_b = al((size_t)(GBP_MAX_P + 2) * 4), pend_b = al((n_pad / 64 + 1) * 8),
+                 idx_b = al((size_t)n_tiles * (P + 1) * 2 + 16), keys_b = al((size_t)n_pad * key_w), words_b = al((size_t)n_pad * 8);
+    void * scratch = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, tot_b + unit_b + pend_b + idx_b + keys_b + words_b, &scratch));
+    unsigned long long * part_total = (unsigned long long *)scratch;
+    u32 * unit_start = (u32 *)((char *)scratch + tot_b);
+    u32 * unit_ctr = unit_start + GBP_MAX_P + 1;
+    u64 * pending = (u64 *)((char *)scratch + tot_b + unit_b);
+    unsigned short * tidx = (unsigned short *)((char *)pending + pend_b);
+    void * pkeys = (char *)tidx + idx_b;
+    u64 * pwords = (u64 *)((char *)pkeys + keys_b);
+    // the aggregate pass reads the widened words of the sorted copy
+    for (u32 j = 0; j < a->n_aggs; ++j)
+        if (a->kinds[j] != CHGPU_AGG_COUNT && ((agg_mask >> j) & 1))
+        {
+            d.a[j].ptr = pwords;
+            d.a[j].arg_type = chgpu_type_is_float(a->arg_types[j]) ? CHGPU_F64 : CHGPU_U64;
+            d.a[j].pre = 0;
+        }
+    if (agg_mask != ~0u)
+    {
+        u32 m = 0;
+        for (u32 j = 0; j < a->n_aggs; ++j)
+            if ((agg_mask >> j) & 1)
+                d.a[m++] = d.a[j];
+        d.n_aggs = m;
+    }
+    // the compile-time update code (see k_agg_part_lds, OPS)
+    u32 ops = 0;
+    {
+        u32 word_op[AGG_MAX_WORDS] = {0};
+        bool ok = a->n_words <= 4;
+        for (u32 j = 0; j < d.n_aggs && ok; ++j)
+        {
+            const u32 w = d.a[j].word;
+            if (d.a[j].kind == CHGPU_AGG_COUNT)
+                word_op[w] = ((cnt32 >> w) & 1) ? 5 : 6;
+            else
+            {
+                word_op[w] = d.a[j].arg_type == CHGPU_F64 ? 3 : 1;
+                if (d.a[j].kind == CHGPU_AGG_AVG)
+                    word_op[w + 1] = ((cnt32 >> (w + 1)) & 1) ? 5 : 6;
+            }
+        }
+        for (u32 w = 0; w < a->n_words && ok; ++w)
+        {
+            ok = ok && word_op[w] != 0;
+            ops |= word_op[w] << (4 * w);
+        }
+        if (!ok)
+            ops = 0;
+    }
+    if (ops != 0x51 && ops != 0x15 && ops != 0x1 && ops != 0x53 && ops != 0x3 && ops != 0x61 && ops != 0x16)
+        return CHGPU_ERR_NOT_IMPLEMENTED;
+    const u32 G = (u32)ctx->num_cus;
+    const u64 rows_per_wg = ((n + G - 1) / G + TILE - 1) / TILE * TILE;
+    static const bool debug = getenv("CHGPU_DEBUG") != nullptr;
+    if (debug)
+        fprintf(stderr, "chgpu: tile-sorted GROUP BY n=%llu hint=%llu S=%u P=%u tile=%u ops=0x%x\n", (unsigned long long)n, (unsigned long long)a->size_hint, S, P, TILE, ops);
+    CHGPU_HIP(hipMemsetAsync(scratch, 0, tot_b + unit_b + pend_b, ctx->stream));
+    int rc = CHGPU_OK;
+    const size_t lds_sort = rp_tilesort_lds_bytes(TILE, P, key_w);
+    if (key32)
+    {
+        auto kern = k_rp_tilesort<12288, u32, GbpPartFn<u32>>;
+        rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
+        if (rc == CHGPU_OK)
+            hipLaunchKernelGGL(kern, dim3(G), dim3(RP_THREADS), lds_sort, ctx->stream, (const u32 *)key_col->data + row_begin, (const u64 *)arg_cols[arg_j]->data + row_begin, n, rows_per_wg, P,
+                               (u32 *)pkeys, pwords, tidx, part_total, GbpPartFn<u32>{P, GBP_MULT});
+    }
+    else
+    {
+        auto kern = k_rp_tilesort<8192, u64, GbpPartFn<u64>>;
+        rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
+        if (rc == CHGPU_OK)
+            hipLaunchKernelGGL(kern, dim3(G), dim3(RP_THREADS), lds_sort, ctx->stream, (const u64 *)key_col->data + row_begin, (const u64 *)arg_cols[arg_j]->data + row_begin, n, rows_per_wg, P,
+                               (u64 *)pkeys, pwords, tidx, part_total, GbpPartFn<u64>{P, GBP_MULT});
+    }
+    if (rc == CHGPU_OK)
+    {
+        hipLaunchKernelGGL(k_tile_units, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)part_total, P, chunk_rows, n_tiles, unit_start, unit_ctr);
+        const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
+        const size_t keys_lds = ((size_t)key_w * (S + 1) + 7) & ~(size_t)7;
+        const size_t lds_ag = keys_lds + (size_t)(S + 1) * (8 * n8 + 4 * n4) + 16;
+#define GB_TILES(KT_, OPS_, TILE_)                                                                                                                    \
+    do                                                                                                                                                \
+    {                                                                                                                                                 \
+        auto kern = k_agg_tiles_lds<KT_, OPS_, TILE_>;                                                                                                 \
+        rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
+        if (rc == CHGPU_OK)                                                                                                                           \
+            hipLaunchKernelGGL(kern, dim3(G), dim3(1024), lds_ag, ctx->stream, a->t, d, (const KT_ *)pkeys, (const u64 *)pwords, (const unsigned short *)tidx, n_tiles, P, \
+                               pending, S, cnt32, (const u32 *)unit_start, unit_ctr);                                                                 \
+    } while (0)
+#define GB_TILES_OPS(KT_, TILE_)                              \
+    switch (ops)                                              \
+    {                                                         \
+        case 0x51: GB_TILES(KT_, 0x51, TILE_); break;         \
+        case 0x15: GB_TILES(KT_, 0x15, TILE_); break;         \
+        case 0x1: GB_TILES(KT_, 0x1, TILE_); break;           \
+        case 0x53: GB_TILES(KT_, 0x53, TILE_); break;         \
+        case 0x3: GB_TILES(KT_, 0x3, TILE_); break;           \
+        case 0x61: GB_TILES(KT_, 0x61, TILE_); break;         \
+        default: GB_TILES(KT_, 0x16, TILE_); break;           \
+    }
+        if (key32)
+        {
+            GB_TILES_OPS(u32, 12288)
+        }
+        else
+        {
+            GB_TILES_OPS(u64, 8192)
+        }
+#undef GB_TILES_OPS
+#undef GB_TILES
+    }
+    ctx->counters[6] += 3;
+    ctx->counters[5] += n;
+    if (rc == CHGPU_OK && hipGetLastError() != hipSuccess)
+        rc = CHGPU_ERR_DEVICE;
+    if (rc == CHGPU_OK)
+        rc = agg_finish_rounds(a, d, pkeys, key32 ? CHGPU_U32 : CHGPU_U64, 0, n_pad, pending);
+    else
+    {
+        (void)hipGetLastError();
+        chgpu_set_error(rc, "tile-sorted aggregation launch failed");
+    }
+    return rc;
+}
+
 // PARTITIONED executeOnBlock (see the kernel block comment).  Returns NOT_IMPLEMENTED when the shape does not fit
 // (the caller then uses the DIRECT kernel).
 // level 0: called by add_block; may turn itself into level 1 (the first of two partitioning levels: partitions the rows
@@ -1458,13 +1847,24 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         CHGPU_TRY(agg_read_ctrl(a, &c0));
         CHGPU_TRY(agg_grow(a, c0.n_groups, c0.has_zero != 0));
     }
+    // one level, one argument word: the tile-sorted plan (two passes, streaming writes) where its shape fits
+    static const bool no_tiled = getenv("CHGPU_TUNE_GB_NO_TILED") != nullptr;
+    if (level == 0 && K == 1 && !no_tiled)
+    {
+        const int rc_t = agg_add_block_tiled(a, key_col, arg_cols, row_begin, n, P, S, cnt32, agg_mask, chunk_rows);
+        if (rc_t != CHGPU_ERR_NOT_IMPLEMENTED)
+            return rc_t;
+    }
     static const int gmajor_x = getenv("CHGPU_EXPERIMENT_GMAJOR") ? 1 : 0; // timing experiment only: the aggregate pass still reads p-major
     // (carried tails measured SLOWER than plain runs -- 8.5 / 7.3 vs 6.4 ms at C3 -- and wrote more, not fewer, bytes (PMC WRITE_SIZE 21 GB
     //  vs 13 GB): a partition's line is then written by two instructions a barrier apart; kept selectable for A/B runs)
     static const int carry_mode = getenv("CHGPU_TUNE_GB_CARRY") ? atoi(getenv("CHGPU_TUNE_GB_CARRY")) : 0;
     // (two scatter workgroups per CU in carry mode 2: the histogram is cut into the same row ranges)
     const bool carry_shape = carry_mode && K == 1 && P <= 256 && n < (1ull << 32);
-    const u32 G = (u32)ctx->num_cus * (carry_shape && carry_mode == 2 ? 2 : GBP_WG_PER_CU);
+    // (experiment: several smaller scatter workgroups per CU so that one's rank / scan phases overlap another's loads and stores)
+    static const int wgs_per_cu_x = getenv("CHGPU_TUNE_GB_SCATTER_WGS") ? atoi(getenv("CHGPU_TUNE_GB_SCATTER_WGS")) : 1;
+    const bool multi_wg = !carry_mode && (wgs_per_cu_x == 2 || wgs_per_cu_x == 4) && K == 1 && key32 && P <= 256;
+    const u32 G = (u32)ctx->num_cus * (multi_wg ? (u32)wgs_per_cu_x : carry_shape && carry_mode == 2 ? 2 : GBP_WG_PER_CU);
     u64 rows_per_wg = (n + G - 1) / G;
     // the scatter's LDS image is tile*(8*K + key bytes) + 24*P bytes and must stay under ~159 KiB (160 KiB per workgroup, 64 B static)
     const size_t row_lds = 8 * K + (key32 ? 4 : 8);
@@ -1473,6 +1873,8 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     for (u32 cand : {8192u, 12288u})
         if (cand <= tile_cap && cand * row_lds + (size_t)P * 24 + 64 <= 159 * 1024)
             tile = cand;
+    if (multi_wg)
+        tile = 12288 / (u32)wgs_per_cu_x;
     rows_per_wg = (rows_per_wg + tile - 1) / tile * tile;
     static const bool debug = getenv("CHGPU_DEBUG") != nullptr;
     if (debug)
@@ -1566,7 +1968,22 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         if (!carry_mode && !old_scatter && wide && K == 1 && n + RP_SCATTER_SLACK < (1ull << 32) && P + 1 <= 2 * RP_THREADS)
         {
             // the branch-free scatter (radix_partition.h): one 8-byte word, wide loads
-            if (key32 && rp_scatter_lds_bytes(12288, P, 4, true) <= 159 * 1024)
+            if (multi_wg)
+            {
+#define GB_MULTI(TILE_, THR_)                                                                                                                   \
+    do                                                                                                                                          \
+    {                                                                                                                                           \
+        auto kern = k_rp_scatter<TILE_, u32, true, GbpPartFn<u32>, THR_>;                                                                        \
+        const size_t lds_b = rp_scatter_lds_bytes(TILE_, P, 4, true);                                                                            \
+        rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
+        if (rc == CHGPU_OK)                                                                                                                     \
+            hipLaunchKernelGGL(kern, dim3(G), dim3(THR_), lds_b, ctx->stream, (const u32 *)key_col->data + row_begin, (const u64 *)gc.src[0] + row_begin, n, rows_per_wg, P, \
+                               (const u64 *)offsets, (u32 *)pkeys, gc.dst[0], GbpPartFn<u32>{P, mult});                                          \
+    } while (0)
+                if (wgs_per_cu_x == 2) GB_MULTI(6144, 512); else GB_MULTI(3072, 256);
+#undef GB_MULTI
+            }
+            else if (key32 && rp_scatter_lds_bytes(12288, P, 4, true) <= 159 * 1024)
             {
                 auto kern = k_rp_scatter<12288, u32, true, GbpPartFn<u32>>;
                 const size_t lds_b = rp_scatter_lds_bytes(12288, P, 4, true);

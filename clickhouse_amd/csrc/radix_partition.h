@@ -482,6 +482,190 @@ __global__ __launch_bounds__(THREADS) void k_rp_scatter(const KT * __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_rp_tilesort: the partition pass WITHOUT a scatter.  Every TILE-row tile of the input is counting-sorted by partition in LDS and
+// written back to the SAME row range of the output arrays, so the pass writes whole lines in row order (a streaming copy: the
+// scatter of 48-row runs to P different places is what held k_rp_scatter at 3.3-3.9 TB/s where a copy moves 5.4 TB/s,
+// tools/mall_bench.hip); next to it goes tile_index[t][0..P] (u16): where each partition's run starts inside tile t, [P] = the
+// number of real rows of the tile.  The consumer of partition p gathers one run per tile (tools/gather_runs_bench.hip: ~5 TB/s
+// for 48-row runs) -- short runs are cheap to READ (no partial-line write-back, no merge window).  No histogram pass and no offset
+// scan precede it; part_total[p] += the rows of partition p (one atomic per partition and workgroup, for the consumer's work split).
+// rows_per_wg is a multiple of TILE; out arrays hold ceil(n / TILE) * TILE rows (rows past n sort behind the real rows of the last tile).
+// dynamic LDS: stage_word u64[TILE] | stage_key KT[TILE] | tile_cnt u32[P + 1] | tile_off u32[P + 1] | wg_total u32[P + 1]
+// ---------------------------------------------------------------------------------------------
+template <u32 GBP_TILE, typename KT, typename PartFn, u32 THREADS = RP_THREADS>
+__global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__ keys, const u64 * __restrict__ words, u64 n, u64 rows_per_wg, u32 P,
+                                                         KT * __restrict__ out_keys, u64 * __restrict__ out_words, unsigned short * __restrict__ tile_index,
+                                                         unsigned long long * __restrict__ part_total, PartFn part_fn)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
+    u64 * stage_word = (u64 *)gb_lds;
+    KT * stage_key = (KT *)(stage_word + GBP_TILE);
+    u32 * tile_cnt = (u32 *)(stage_key + GBP_TILE);
+    u32 * tile_off = tile_cnt + (P + 1);
+    u32 * wg_total = tile_off + (P + 1);
+    __shared__ u32 wave_tot[THREADS / 64];
+
+    for (u32 p = threadIdx.x; p <= P; p += THREADS)
+        tile_cnt[p] = 0, wg_total[p] = 0;
+    __syncthreads();
+    const u64 r0 = (u64)blockIdx.x * rows_per_wg;
+    if (r0 >= n)
+        return; // (the whole workgroup: no barrier below is left waiting)
+    // Everything below addresses memory as a workgroup-uniform base + a 32-bit byte offset (the host keeps rows_per_wg * 8 under
+    // 2^32): one VGPR per address instead of two, and the scalar-base form of the load / store instructions.
+    const u32 nrel = (u32)(r0 + rows_per_wg < n ? rows_per_wg : n - r0); // rows of this workgroup
+    const char * kbase = (const char *)(keys + r0);
+    const char * wbase = (const char *)(words + r0);
+    char * okbase = (char *)(out_keys + r0);
+    char * owbase = (char *)(out_words + r0);
+    char * ixbase = (char *)(tile_index + (r0 / GBP_TILE) * (u64)(P + 1));
+    constexpr u32 RPT = GBP_TILE / THREADS;
+    static_assert(RPT % 4 == 0, "whole 16-byte pieces per thread");
+    typedef u64 v2q __attribute__((ext_vector_type(2)));
+    typedef u32 v2d __attribute__((ext_vector_type(2)));
+    typedef u32 v4d __attribute__((ext_vector_type(4)));
+    typedef typename std::conditional<sizeof(KT) == 4, v2d, v2q>::type kpair;
+    auto rel_of = [&](u32 trel, u32 j) -> u32 { return trel + (j >> 1) * (2 * THREADS) + 2 * threadIdx.x + (j & 1); };
+    // Unconditional vector loads into raw pair registers, as in k_rp_scatter: a pair beyond the range re-reads the last whole pair; the
+    // lone last row of an odd range comes as the second element of the pair that ends with it.  The tail select happens where the
+    // row is used (a select scheduled right behind the loads would make the wave wait for every store issued before them).
+    const bool odd_tail = (nrel & 1) != 0;
+    const u32 last_pair = nrel >= 2 ? (nrel - 2) & ~1u : 0;
+    kpair kraw[RPT / 2];
+    v2q wraw[RPT / 2];
+    auto load_tile = [&](u32 trel) {
+#pragma unroll
+        for (u32 j = 0; j < RPT; j += 2)
+        {
+            const u32 i = rel_of(trel, j);
+            const bool tail = odd_tail && i + 1 == nrel;
+            const u32 li = tail ? i - 1 : (i + 1 < nrel ? i : last_pair);
+            kraw[j / 2] = __builtin_nontemporal_load((const kpair *)(kbase + li * (u32)sizeof(KT)));
+            wraw[j / 2] = __builtin_nontemporal_load((const v2q *)(wbase + li * 8u));
+        }
+    };
+    auto key_at = [&](u32 trel, u32 j) -> KT {
+        const bool tail = odd_tail && rel_of(trel, j & ~1u) + 1 == nrel;
+        return ((j & 1) || tail) ? (KT)kraw[j / 2].y : (KT)kraw[j / 2].x;
+    };
+    auto word_at = [&](u32 trel, u32 j) -> u64 {
+        const bool tail = odd_tail && rel_of(trel, j & ~1u) + 1 == nrel;
+        return ((j & 1) || tail) ? wraw[j / 2].y : wraw[j / 2].x;
+    };
+    u32 part[RPT], rank[RPT];
+    auto step_rank = [&](u32 trel) {
+#pragma unroll
+        for (u32 j = 0; j < RPT; ++j)
+            part[j] = rel_of(trel, j) < nrel ? part_fn(key_at(trel, j)) : P;
+#pragma unroll
+        for (u32 j = 0; j < RPT; ++j)
+            rank[j] = atomicAdd(&tile_cnt[part[j]], 1u);
+    };
+    // exclusive scan of tile_cnt[P + 1] -> tile_off (P + 1 <= 2 * threads); between two barriers
+    auto step_scan = [&]() {
+        __syncthreads();
+        const u32 e0 = threadIdx.x * 2, e1 = e0 + 1;
+        const u32 c0 = e0 <= P ? tile_cnt[e0] : 0, c1 = e1 <= P ? tile_cnt[e1] : 0;
+        const u32 v = c0 + c1;
+        const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        u32 inc = v;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1)
+        {
+            const u32 o = __shfl_up(inc, dlt, 64);
+            if (lane >= (u32)dlt)
+                inc += o;
+        }
+        if (lane == 63)
+            wave_tot[wave] = inc;
+        __syncthreads();
+        u32 off = inc - v;
+        for (u32 w = 0; w < wave; ++w)
+            off += wave_tot[w];
+        if (e0 <= P)
+        {
+            tile_off[e0] = off;
+            tile_cnt[e0] = 0;
+            wg_total[e0] += c0;
+        }
+        if (e1 <= P)
+        {
+            tile_off[e1] = off + c0;
+            tile_cnt[e1] = 0;
+            wg_total[e1] += c1;
+        }
+        __syncthreads();
+    };
+    constexpr u32 KPP = 16 / sizeof(KT);                 // keys per 16-byte piece
+    constexpr u32 KPIECES = GBP_TILE / KPP / THREADS;    // key pieces per thread and tile
+    constexpr u32 WPIECES = GBP_TILE / 2 / THREADS;      // word pieces per thread and tile
+    static_assert(GBP_TILE % (KPP * THREADS) == 0 && GBP_TILE % (2 * THREADS) == 0, "whole pieces");
+    const u32 e_idx = threadIdx.x < P ? threadIdx.x : P; // this thread's entry of a tile's index (the threads beyond P repeat entry P)
+    // The same pipeline as k_rp_scatter: a tile's loads are issued before the previous tile's stores and first used after them.  The
+    // prologue issues as many stores as a write-out does (zeros into this workgroup's first tile, by the very threads that
+    // overwrite them in the first write-out) so that the loop's entry path looks like its back edge to the wait-count analysis.
+    load_tile(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (u32 q = 0; q < KPIECES; ++q)
+        __builtin_nontemporal_store(v4d{0, 0, 0, 0}, (v4d *)(okbase + (q * THREADS + threadIdx.x) * 16u));
+#pragma unroll
+    for (u32 q = 0; q < WPIECES; ++q)
+        __builtin_nontemporal_store(v2q{0, 0}, (v2q *)(owbase + (q * THREADS + threadIdx.x) * 16u));
+    *(unsigned short *)(ixbase + e_idx * 2u) = 0;
+    __builtin_amdgcn_sched_barrier(0);
+    step_rank(0);
+    step_scan();
+    u32 tile_no = 0;
+    for (u32 trel = 0; trel < nrel; trel += GBP_TILE, ++tile_no)
+    {
+        // counting sort into the LDS staging arrays
+#pragma unroll
+        for (u32 j = 0; j < RPT; ++j)
+        {
+            const u32 pos = tile_off[part[j]] + rank[j];
+            stage_key[pos] = key_at(trel, j);
+            stage_word[pos] = word_at(trel, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(trel + GBP_TILE); // the next tile, unconditional (beyond the range it re-reads the last pair)
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // the sorted tile goes out in row order: 16-byte pieces, consecutive lanes -> consecutive pieces
+        {
+            v4d kq[KPIECES];
+            v2q wq[WPIECES];
+#pragma unroll
+            for (u32 q = 0; q < KPIECES; ++q)
+                kq[q] = *(const v4d *)((const char *)stage_key + (q * THREADS + threadIdx.x) * 16u);
+#pragma unroll
+            for (u32 q = 0; q < WPIECES; ++q)
+                wq[q] = *(const v2q *)((const char *)stage_word + (q * THREADS + threadIdx.x) * 16u);
+            const u32 eo = tile_off[e_idx];
+#pragma unroll
+            for (u32 q = 0; q < KPIECES; ++q)
+                __builtin_nontemporal_store(kq[q], (v4d *)(okbase + trel * (u32)sizeof(KT) + (q * THREADS + threadIdx.x) * 16u));
+#pragma unroll
+            for (u32 q = 0; q < WPIECES; ++q)
+                __builtin_nontemporal_store(wq[q], (v2q *)(owbase + trel * 8u + (q * THREADS + threadIdx.x) * 16u));
+            *(unsigned short *)(ixbase + (tile_no * (P + 1) + e_idx) * 2u) = (unsigned short)eo; // no branch around a store
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        step_rank(trel + GBP_TILE);
+        step_scan();
+    }
+    // (the surplus tile ranked at the end put all its rows into the dummy bucket P)
+    for (u32 p = threadIdx.x; p < P; p += THREADS)
+        if (wg_total[p])
+            atomicAdd(&part_total[p], (unsigned long long)wg_total[p]);
+}
+
+static inline size_t rp_tilesort_lds_bytes(u32 tile, u32 P, size_t key_bytes)
+{
+    return (size_t)tile * (key_bytes + 8) + (size_t)(P + 1) * 12 + 64;
+}
+
 static inline size_t rp_scatter_lds_bytes(u32 tile, u32 P, size_t key_bytes, bool has_word)
 {
     return (size_t)tile * (key_bytes + (has_word ? 8 : 0)) + (size_t)P * 4 + (size_t)(P + 1) * 12 + 64;
