@@ -1088,11 +1088,15 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
 }
 
 // ---- the TILE-SORTED plan (radix_partition.h, k_rp_tilesort): units and the aggregate pass that gathers one run per tile ----
-// unit_start[p] = first unit of partition p, a partition of r rows gets ceil(r / chunk_rows) units (each an equal share of the TILES:
-// a partition swollen by a hot key is long in every tile, so cutting by tiles cuts its rows evenly), unit_start[P] = number of units.
-__global__ __launch_bounds__(1024) void k_tile_units(const unsigned long long * __restrict__ part_total, u32 P, u64 chunk_rows, u32 n_tiles, u32 * __restrict__ unit_start, u32 * __restrict__ ctr)
+// A partition of r rows gets c = ceil(r / chunk_rows) units, unit (p, j) = the j-th of c equal shares of the TILES (a partition swollen
+// by a hot key is long in every tile, so cutting by tiles cuts its rows evenly).  unit_list is ordered by (j, p): the workgroups draw
+// units in that order, so at any time they work on the SAME stretch of tiles for different partitions -- the lines at the two ends of
+// a run also hold the neighbouring partitions' rows and are then found in L2 / Infinity Cache by the neighbours instead of being
+// fetched from HBM once per partition.  unit_list[u] = p | j << 16 | c << 40; unit_count[0] = number of units.
+__global__ __launch_bounds__(1024) void k_tile_units(const unsigned long long * __restrict__ part_total, u32 P, u64 chunk_rows, u32 n_tiles, u64 * __restrict__ unit_list,
+                                                      u32 max_units, u32 * __restrict__ unit_count, u32 * __restrict__ ctr)
 {
-    __shared__ u32 sc[1024];
+    __shared__ u32 sc[1024], cc[1024];
     const u32 p = threadIdx.x;
     u32 c = 0;
     if (p < P)
@@ -1101,6 +1105,7 @@ __global__ __launch_bounds__(1024) void k_tile_units(const unsigned long long * 
         c = (u32)(c64 < n_tiles ? c64 : n_tiles); // a unit is at least one tile
     }
     sc[p] = c;
+    cc[p] = c;
     __syncthreads();
     for (u32 dlt = 1; dlt < 1024; dlt <<= 1)
     {
@@ -1109,23 +1114,82 @@ __global__ __launch_bounds__(1024) void k_tile_units(const unsigned long long * 
         sc[p] += o;
         __syncthreads();
     }
-    if (p < P)
-        unit_start[p] = sc[p] - c;
-    if (p == P - 1)
-        unit_start[P] = sc[p];
+    const u32 U = sc[1023] < max_units ? sc[1023] : max_units; // (the host sized the list for the bound sum ceil(r_p / chunk) <= n / chunk + P)
+    for (u32 u = threadIdx.x; u < U; u += 1024)
+    {
+        u32 lo = 0, hi = P - 1; // the partition whose units [sc[q] - cc[q], sc[q]) hold u
+        while (lo < hi)
+        {
+            const u32 mid = (lo + hi) >> 1;
+            if (sc[mid] > u)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        const u32 q = lo, j = u - (sc[q] - cc[q]);
+        u32 pos = 0; // units ordered before (j, q): every (j', .) with j' < j, and (j, q') with q' < q
+        for (u32 r = 0; r < P; ++r)
+            pos += (cc[r] < j ? cc[r] : j) + ((r < q && cc[r] > j) ? 1u : 0u);
+        unit_list[pos] = (u64)q | ((u64)j << 16) | ((u64)cc[q] << 40);
+    }
     if (p == 0)
+    {
+        *unit_count = U;
         *ctr = 0;
+    }
+}
+
+// The tile index transposed for the aggregate pass: run_index[p][t] = start | length << 16 of partition p's run in tile t, so that a
+// wave reads the entries of 64 consecutive tiles as ONE 256-byte load (read straight from tile_index[t][p] every entry costs a
+// 128-byte line of its own: one line in seven of the whole pass).  84 MB for 1e9 rows: ~30 us.
+__global__ __launch_bounds__(256) void k_tile_index_transpose(const unsigned short * __restrict__ tile_index, u32 n_tiles, u32 P, u32 * __restrict__ run_index)
+{
+    __shared__ u32 sm[64][65];
+    const u32 tb = blockIdx.x * 64, pb = blockIdx.y * 64;
+    const u32 x = threadIdx.x & 63, y0 = threadIdx.x >> 6;
+    for (u32 y = y0; y < 64; y += 4) // tile tb + y, partition pb + x: consecutive lanes -> consecutive u16 entries
+    {
+        const u32 t = tb + y, pp = pb + x;
+        u32 v = 0;
+        if (t < n_tiles && pp < P)
+        {
+            const u32 a = tile_index[(u64)t * (P + 1) + pp], b = tile_index[(u64)t * (P + 1) + pp + 1];
+            v = a | ((b - a) << 16);
+        }
+        sm[y][x] = v;
+    }
+    __syncthreads();
+    for (u32 y = y0; y < 64; y += 4) // partition pb + y, tile tb + x: consecutive lanes -> consecutive tiles
+    {
+        const u32 t = tb + x, pp = pb + y;
+        if (t < n_tiles && pp < P)
+            run_index[(u64)pp * n_tiles + t] = sm[x][y];
+    }
+}
+
+// A block of 64 entries of run_index, lane l <- the wave's tile ordinal kb + l (kb a multiple of 64: 64 consecutive tiles starting at
+// `first`), 0 beyond the unit's last tile t1.
+__device__ __forceinline__ u32 tiles_load_block(const u32 * __restrict__ run_index_p, u32 first, u32 t1, u32 lane)
+{
+    const u32 tl = first + lane;
+    const bool valid = tl < t1;
+    const u32 v = run_index_p[valid ? tl : t1 - 1];
+    return valid ? v : 0u;
 }
 
 // One workgroup aggregates a unit = (partition p, a range of tiles) in the same compact LDS table as k_agg_part_lds (PartLds), then
-// flushes it into the HBM table.  Every wave takes whole tiles: it reads the two index entries of (tile, p), then the run's rows
-// (lanes beyond the run's length idle: a uniform input gives runs of TILE / P = 48 rows); runs longer than 64 rows (skew) continue
-// in a plain loop.  Three stages are in flight per wave: index entries of set s+2, rows of set s+1, LDS updates of set s.
+// flushes it into the HBM table.  Wave w of the workgroup takes the unit's tiles w, w + 16, w + 32, ...: the index entries (start,
+// length of partition p's run) of its next 64 tiles are fetched by ONE vector load (lane l = the l-th of those tiles) into a register
+// block, two blocks alternate; a step takes PR tiles: their entries come out of the block by v_readlane (wave-uniform, so the row
+// addresses are scalar base + lane), their rows are loaded (lanes beyond the run's length idle: a uniform input gives runs of
+// TILE / P = 48 rows) and the previous step's rows go through the LDS table meanwhile.  Runs longer than 64 rows (skewed keys) are
+// finished by a plain loop after the pipelined one.
+// tile_index: u16 [n_tiles][P + 1]; the two entries of (tile, p) are read as one unaligned 32-bit load.
 // OPS: the compile-time state update code of k_agg_part_lds (one argument word: operations 1, 3, 5, 6).
 template <typename KT, u32 OPS, u32 TILE>
 __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, const KT * __restrict__ keys, const u64 * __restrict__ words0,
-                                                        const unsigned short * __restrict__ tile_index, u32 n_tiles, u32 P, u64 * __restrict__ pending, u32 S, u32 cnt32,
-                                                        const u32 * __restrict__ unit_start, u32 * __restrict__ unit_ctr)
+                                                        const u32 * __restrict__ run_index, u32 n_tiles, u32 P, u64 * __restrict__ pending, u32 S, u32 cnt32,
+                                                        const u64 * __restrict__ unit_list, const u32 * __restrict__ unit_count, u32 * __restrict__ unit_ctr, int experiment)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     typedef typename std::conditional<sizeof(KT) == 4, unsigned int, unsigned long long>::type CasT;
@@ -1137,14 +1201,15 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
     L.keys_bytes = ((u32)sizeof(KT) * L.S1 + 7) & ~7u;
     const u32 lds_bytes = L.keys_bytes + 8 * L.S1 * L.n8 + 4 * L.S1 * (u32)__popc(cnt32);
     __shared__ u32 lzero, sh_unit;
-    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = blockDim.x >> 6;
     const u64 gstride = t.capacity + 1;
     const u64 last_row = (u64)n_tiles * TILE - 1;
     u32 w_off[4];
 #pragma unroll
     for (u32 w = 0; w < 4; ++w)
         w_off[w] = L.off(w);
-    const u32 n_units = unit_start[P];
+    const u32 n_units = unit_count[0];
     for (;;)
     {
         if (threadIdx.x == 0)
@@ -1153,50 +1218,39 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
         const u32 unit = sh_unit;
         if (unit >= n_units)
             break; // (every workgroup reaches this exit)
-        u32 lo = 0, hi = P - 1; // largest p with unit_start[p] <= unit
-        while (lo < hi)
-        {
-            const u32 mid = (lo + hi + 1) >> 1;
-            if (unit_start[mid] <= unit)
-                lo = mid;
-            else
-                hi = mid - 1;
-        }
-        const u32 p = lo;
-        const u32 c_p = unit_start[p + 1] - unit_start[p], j = unit - unit_start[p];
+        const u64 ud = unit_list[unit];
+        const u32 p = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(ud & 0xffffu)), j = (u32)__builtin_amdgcn_readfirstlane((int)(u32)((ud >> 16) & 0xffffffu)),
+                  c_p = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(ud >> 40));
         const u32 t0 = (u32)((u64)n_tiles * j / c_p), t1 = (u32)((u64)n_tiles * (j + 1) / c_p);
         for (u32 s = threadIdx.x; s < lds_bytes / 8 + 1; s += blockDim.x)
             ((u64 *)lds_raw)[s] = 0; // the host rounds the allocation up to 8 bytes past lds_bytes
         if (threadIdx.x == 0)
             lzero = 0;
         __syncthreads();
-        constexpr int PR = 4; // tiles per wave and set
-        const u32 step = n_waves * PR;
-        auto tile_of = [&](u32 set_base, int q) -> u32 { return set_base + (u32)q * n_waves + wave; };
-        auto load_idx = [&](u32 set_base, u32 (&st)[PR], u32 (&ln)[PR]) {
+        constexpr u32 PR = 8; // tiles (= runs of partition p) per wave and step
+        constexpr u32 NS = 7; // 64-row slots the PR runs of a step are packed into: PR x 48 rows on average, 7 x 64 = 448 slots
+        // This wave's tiles: blocks of 64 consecutive tiles, block w, w + n_waves, ... of the unit; ordinal k -> tile
+        // t0 + ((k >> 6) * n_waves + wave) * 64 + (k & 63), beyond t1 = no tile.
+        const u32 n_blocks = (t1 - t0 + 63) / 64;
+        const u32 my_blocks = wave < n_blocks ? (n_blocks - wave + n_waves - 1) / n_waves : 0;
+        const u32 ns = my_blocks * (64 / PR);
+        const u32 * __restrict__ run_index_p = run_index + (u64)p * n_tiles;
+        auto tile_of = [&](u32 k) -> u32 { return t0 + ((k >> 6) * n_waves + wave) * 64 + (k & 63u); };
+        u32 blk0 = tiles_load_block(run_index_p, tile_of(0), t1, lane), blk1 = tiles_load_block(run_index_p, tile_of(64), t1, lane);
+        // A step's PR runs are PACKED: virtual row v = slot * 64 + lane belongs to the run r with cs[r] <= v < cs[r + 1] (cs = running
+        // sum of the run lengths, wave-uniform) and sits at row v + dl[r] of the sorted copy (dl[r] = tile * TILE + start - cs[r], modulo
+        // 2^32: the host keeps this plan below 2^32 rows).  Runs of 48 +- 7 rows fill 86 % of the lanes instead of 75 %, and a single
+        // long run borrows the slack of its neighbours; only a step with more than NS * 64 rows (skewed keys) takes the plain loop.
+        auto row_of = [&](u32 v, const u32 (&cs)[PR + 1], const u32 (&dl)[PR]) -> u32 {
+            // (a sum of masked steps, not a chain of selects: the compiler turns the chain into a look-up in a stack copy of dl[])
+            u32 i = v + dl[0];
 #pragma unroll
-            for (int q = 0; q < PR; ++q)
-            {
-                const u32 tt = tile_of(set_base, q);
-                const bool valid = tt < t1;
-                const u64 e = (u64)(valid ? tt : t1 - 1) * (P + 1) + p;
-                const u32 a = tile_index[e], b = tile_index[e + 1];
-                st[q] = a;
-                ln[q] = valid ? b - a : 0;
-            }
+            for (u32 r = 1; r < PR; ++r)
+                i += v >= cs[r] ? dl[r] - dl[r - 1] : 0u;
+            return i;
         };
-        auto load_rows = [&](u32 set_base, const u32 (&st)[PR], KT (&kv)[PR], u64 (&av)[PR]) {
-#pragma unroll
-            for (int q = 0; q < PR; ++q)
-            {
-                const u32 tt = tile_of(set_base, q);
-                u64 i = (u64)(tt < t1 ? tt : t1 - 1) * TILE + st[q] + lane;
-                i = i < last_row ? i : last_row;
-                kv[q] = __builtin_nontemporal_load(&keys[i]);
-                av[q] = gbp_ops_use(OPS, 1, 3) ? __builtin_nontemporal_load(&words0[i]) : 0;
-            }
-        };
-        auto update_row = [&](u64 i, KT key, u64 b0) {
+        // the LDS update of one row; the row is virtual row v of the step (PACKED_ = true_type) or row v of the sorted copy itself; its index is only needed when the LDS table is full
+        auto update_row = [&](KT key, u64 b0, u32 v, auto packed, const u32 (&cs)[PR + 1], const u32 (&dl)[PR]) {
             u32 ls = ~0u;
             if (key == 0)
             {
@@ -1241,54 +1295,90 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
             }
             else
             {
-                // the LDS table is full around this key's cell: straight into the HBM table, or marked pending for the finish rounds
-                const u64 slot = table_emplace(t, (u64)key, true);
-                if (slot == ~0ull)
-                {
-                    atomicOr((unsigned long long *)&pending[i >> 6], 1ull << (i & 63));
-                    t.ctrl->overflow = 1;
-                }
-                else
-                    add_vals_global(t, d, slot, b0, 0, 1);
+                // the LDS table is full around this key's cell (more groups than promised): the row is left to the finish rounds, which
+                // send pending rows through the HBM table (kept out of this loop: the copies of the row update must stay small)
+                const u64 i = decltype(packed)::value ? row_of(v, cs, dl) : v;
+                atomicOr((unsigned long long *)&pending[i >> 6], 1ull << (i & 63));
+                t.ctrl->overflow = 1;
             }
         };
-        auto process = [&](u32 set_base, const u32 (&st)[PR], const u32 (&ln)[PR], const KT (&kv)[PR], const u64 (&av)[PR]) {
-#pragma unroll
-            for (int q = 0; q < PR; ++q)
+        // step s: its PR index entries out of the blocks (crossing into a new block refills the other one), then its row loads
+        auto fetch = [&](u32 s, u32 (&cs)[PR + 1], u32 (&dl)[PR], KT (&kv)[NS], u64 (&av)[NS]) {
+            const u32 k0 = s * PR;
+            // (the blocks are handled as values: a `cond ? blk1 : blk0` on the captured variables becomes a select of their ADDRESSES and
+            //  pins the whole closure to scratch memory)
+            u32 b0v = blk0, b1v = blk1;
+            if ((k0 & 63u) == 0 && k0 != 0)
             {
-                const u32 tt = tile_of(set_base, q);
-                const u64 row0 = (u64)tt * TILE + st[q];
-                if (lane < ln[q])
-                    update_row(row0 + lane, kv[q], av[q]);
-                for (u32 off = 64; off < ln[q]; off += 64) // a run longer than one wave (skewed keys)
-                    if (off + lane < ln[q])
-                    {
-                        const u64 i = row0 + off + lane;
-                        update_row(i, keys[i], gbp_ops_use(OPS, 1, 3) ? words0[i] : 0);
-                    }
+                const u32 nb = tiles_load_block(run_index_p, tile_of(k0 + 64), t1, lane);
+                const bool odd = ((k0 >> 6) & 1u) != 0;
+                b0v = odd ? nb : b0v;
+                b1v = odd ? b1v : nb;
+                blk0 = b0v;
+                blk1 = b1v;
             }
+            const u32 cur = ((k0 >> 6) & 1u) ? b1v : b0v; // (PR divides 64: a step never straddles two blocks)
+            u32 c = 0;
+#pragma unroll
+            for (u32 r = 0; r < PR; ++r)
+            {
+                const u32 k = k0 + r;
+                const u32 ix = (u32)__builtin_amdgcn_readlane((int)cur, (int)(k & 63u));
+                const u32 tl = tile_of(k);
+                cs[r] = c;
+                dl[r] = (tl < n_tiles ? tl : n_tiles - 1) * TILE + (ix & 0xffffu) - c;
+                c += ix >> 16;
+            }
+            cs[PR] = c;
+#pragma unroll
+            for (u32 m = 0; m < NS; ++m)
+            {
+                u32 i = row_of(m * 64 + lane, cs, dl);
+                i = i < (u32)last_row ? i : (u32)last_row; // (the lanes beyond the step's rows computed anything)
+                kv[m] = __builtin_nontemporal_load(&keys[i]);
+                av[m] = gbp_ops_use(OPS, 1, 3) ? __builtin_nontemporal_load(&words0[i]) : 0;
+            }
+        };
+        auto process = [&](const u32 (&cs)[PR + 1], const u32 (&dl)[PR], const KT (&kv)[NS], const u64 (&av)[NS]) {
+            const u32 total = cs[PR];
+            if (experiment == 1) // timing experiment: the gather alone
+            {
+                u64 acc = 0;
+#pragma unroll
+                for (u32 m = 0; m < NS; ++m)
+                    acc += (u64)kv[m] ^ av[m];
+                if (acc == 0x123456789abcdefull)
+                    lzero = 1;
+                return;
+            }
+#pragma unroll
+            for (u32 m = 0; m < NS; ++m)
+            {
+                const u32 v = m * 64 + lane;
+                if (v < total)
+                    update_row(kv[m], av[m], v, std::true_type{}, cs, dl);
+            }
+            if (total > NS * 64) // (wave-uniform) skewed keys: the rest of the step's rows, unpipelined
+#pragma unroll 1
+                for (u32 v = NS * 64 + lane; v < total; v += 64)
+                {
+                    const u32 i = row_of(v, cs, dl);
+                    update_row(keys[i], gbp_ops_use(OPS, 1, 3) ? words0[i] : 0, i, std::false_type{}, cs, dl);
+                }
         };
         {
-            u32 stA[PR], lnA[PR], stB[PR], lnB[PR], stC[PR], lnC[PR], stD[PR], lnD[PR];
-            KT kA[PR], kB[PR];
-            u64 aA[PR], aB[PR];
-            u32 sb = t0;
-            load_idx(sb, stA, lnA);
-            load_idx(sb + step, stB, lnB);
-            load_rows(sb, stA, kA, aA);
-            for (; sb < t1; sb += 2 * step)
+            u32 csA[PR + 1], dlA[PR], csB[PR + 1], dlB[PR];
+            KT kA[NS], kB[NS];
+            u64 aA[NS], aB[NS];
+            fetch(0, csA, dlA, kA, aA);
+            for (u32 s = 0; s < ns; s += 2)
             {
-                load_idx(sb + 2 * step, stC, lnC);
-                load_rows(sb + step, stB, kB, aB);
+                fetch(s + 1, csB, dlB, kB, aB);
                 __builtin_amdgcn_sched_barrier(0);
-                process(sb, stA, lnA, kA, aA);
-                load_idx(sb + 3 * step, stD, lnD);
-                load_rows(sb + 2 * step, stC, kA, aA);
+                process(csA, dlA, kA, aA);
+                fetch(s + 2, csA, dlA, kA, aA);
                 __builtin_amdgcn_sched_barrier(0);
-                process(sb + step, stB, lnB, kB, aB);
-#pragma unroll
-                for (int q = 0; q < PR; ++q)
-                    stA[q] = stC[q], lnA[q] = lnC[q], stB[q] = stD[q], lnB[q] = lnD[q];
+                process(csB, dlB, kB, aB);
             }
         }
         __syncthreads();
@@ -1638,7 +1728,7 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
         return CHGPU_ERR_NOT_IMPLEMENTED;
     const bool key32 = key_w == 4;
     const u32 TILE = key32 ? 12288u : 8192u;
-    if (n < (u64)TILE * ctx->num_cus || n / TILE >= (1ull << 31))
+    if (n < (u64)TILE * ctx->num_cus || n + TILE >= (1ull << 32)) // (k_agg_tiles_lds indexes the sorted copy with 32 bits)
         return CHGPU_ERR_NOT_IMPLEMENTED;
     // the one argument column
     int arg_j = -1;
@@ -1657,16 +1747,22 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
     const u32 n_tiles = (u32)((n + TILE - 1) / TILE);
     const u64 n_pad = (u64)n_tiles * TILE;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t tot_b = al((size_t)P * 8), unit_b = al((size_t)(GBP_MAX_P + 2) * 4), pend_b = al((n_pad / 64 + 1) * 8),
-                 idx_b = al((size_t)n_tiles * (P + 1) * 2 + 16), keys_b = al((size_t)n_pad * key_w), words_b = al((size_t)n_pad * 8);
+    // (6 % of slack on the unit size: the partitions of a uniform input all get the same number of units, so that units of equal rank
+    //  cover equal stretches of tiles -- see k_tile_units)
+    chunk_rows += chunk_rows / 16;
+    const u32 max_units = (u32)(n / chunk_rows + P);
+    const size_t tot_b = al((size_t)P * 8), unit_b = al((size_t)(max_units + 2) * 8 + 64), pend_b = al((n_pad / 64 + 1) * 8),
+                 idx_b = al((size_t)n_tiles * (P + 1) * 2 + 16), ridx_b = al((size_t)n_tiles * P * 4), keys_b = al((size_t)n_pad * key_w), words_b = al((size_t)n_pad * 8);
     void * scratch = nullptr;
-    CHGPU_TRY(chgpu_scratch(ctx, tot_b + unit_b + pend_b + idx_b + keys_b + words_b, &scratch));
+    CHGPU_TRY(chgpu_scratch(ctx, tot_b + unit_b + pend_b + idx_b + ridx_b + keys_b + words_b, &scratch));
     unsigned long long * part_total = (unsigned long long *)scratch;
-    u32 * unit_start = (u32 *)((char *)scratch + tot_b);
-    u32 * unit_ctr = unit_start + GBP_MAX_P + 1;
+    u64 * unit_list = (u64 *)((char *)scratch + tot_b);
+    u32 * unit_count = (u32 *)(unit_list + max_units + 1);
+    u32 * unit_ctr = unit_count + 1;
     u64 * pending = (u64 *)((char *)scratch + tot_b + unit_b);
     unsigned short * tidx = (unsigned short *)((char *)pending + pend_b);
-    void * pkeys = (char *)tidx + idx_b;
+    u32 * run_index = (u32 *)((char *)tidx + idx_b);
+    void * pkeys = (char *)run_index + ridx_b;
     u64 * pwords = (u64 *)((char *)pkeys + keys_b);
     // the aggregate pass reads the widened words of the sorted copy
     for (u32 j = 0; j < a->n_aggs; ++j)
@@ -1713,6 +1809,7 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
         return CHGPU_ERR_NOT_IMPLEMENTED;
     const u32 G = (u32)ctx->num_cus;
     const u64 rows_per_wg = ((n + G - 1) / G + TILE - 1) / TILE * TILE;
+    static const int tiles_experiment = getenv("CHGPU_EXPERIMENT_TILES") ? atoi(getenv("CHGPU_EXPERIMENT_TILES")) : 0; // timing experiments only (wrong results)
     static const bool debug = getenv("CHGPU_DEBUG") != nullptr;
     if (debug)
         fprintf(stderr, "chgpu: tile-sorted GROUP BY n=%llu hint=%llu S=%u P=%u tile=%u ops=0x%x\n", (unsigned long long)n, (unsigned long long)a->size_hint, S, P, TILE, ops);
@@ -1737,7 +1834,8 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
     }
     if (rc == CHGPU_OK)
     {
-        hipLaunchKernelGGL(k_tile_units, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)part_total, P, chunk_rows, n_tiles, unit_start, unit_ctr);
+        hipLaunchKernelGGL(k_tile_units, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)part_total, P, chunk_rows, n_tiles, unit_list, max_units, unit_count, unit_ctr);
+        hipLaunchKernelGGL(k_tile_index_transpose, dim3((n_tiles + 63) / 64, (P + 63) / 64), dim3(256), 0, ctx->stream, (const unsigned short *)tidx, n_tiles, P, run_index);
         const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
         const size_t keys_lds = ((size_t)key_w * (S + 1) + 7) & ~(size_t)7;
         const size_t lds_ag = keys_lds + (size_t)(S + 1) * (8 * n8 + 4 * n4) + 16;
@@ -1747,8 +1845,8 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
         auto kern = k_agg_tiles_lds<KT_, OPS_, TILE_>;                                                                                                 \
         rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
         if (rc == CHGPU_OK)                                                                                                                           \
-            hipLaunchKernelGGL(kern, dim3(G), dim3(1024), lds_ag, ctx->stream, a->t, d, (const KT_ *)pkeys, (const u64 *)pwords, (const unsigned short *)tidx, n_tiles, P, \
-                               pending, S, cnt32, (const u32 *)unit_start, unit_ctr);                                                                 \
+            hipLaunchKernelGGL(kern, dim3(G), dim3(1024), lds_ag, ctx->stream, a->t, d, (const KT_ *)pkeys, (const u64 *)pwords, (const u32 *)run_index, n_tiles, P, \
+                               pending, S, cnt32, (const u64 *)unit_list, (const u32 *)unit_count, unit_ctr, tiles_experiment);                       \
     } while (0)
 #define GB_TILES_OPS(KT_, TILE_)                              \
     switch (ops)                                              \
