@@ -313,7 +313,8 @@ __global__ __launch_bounds__(THREADS) void k_rp_scatter(const KT * __restrict__ 
     // the second element of the pair that ENDS with it (one row to the left: the hardware takes the misaligned address).  No
     // conditional load anywhere: a load that may or may not have been issued forces s_waitcnt vmcnt(0) on every later wait.
     const bool odd_tail = ((r1 - r0) & 1) != 0;
-    const u64 last_pair = r1 >= r0 + 2 ? ((r1 - r0 - 2) & ~(u64)1) + r0 : r0;
+    // (a workgroup left with a single row re-reads the pair that ENDS with it, not the one that starts with it: never past the column)
+    const u64 last_pair = r1 >= r0 + 2 ? ((r1 - r0 - 2) & ~(u64)1) + r0 : (r0 ? r0 - 1 : r0);
     auto load_tile = [&](u64 tb) {
 #pragma unroll
         for (u32 j = 0; j < RPT; j += 2)
@@ -515,8 +516,11 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__
     // Everything below addresses memory as a workgroup-uniform base + a 32-bit byte offset (the host keeps rows_per_wg * 8 under
     // 2^32): one VGPR per address instead of two, and the scalar-base form of the load / store instructions.
     const u32 nrel = (u32)(r0 + rows_per_wg < n ? rows_per_wg : n - r0); // rows of this workgroup
-    const char * kbase = (const char *)(keys + r0);
-    const char * wbase = (const char *)(words + r0);
+    // (the load bases sit two rows BEFORE the workgroup's first row unless that is row 0: a workgroup left with a single row reads it
+    //  as the second element of the pair that ends with it -- one row to the left, never one past the end of the column)
+    const u32 shift = r0 ? 2u : 0u;
+    const char * kbase = (const char *)(keys + r0 - shift);
+    const char * wbase = (const char *)(words + r0 - shift);
     char * okbase = (char *)(out_keys + r0);
     char * owbase = (char *)(out_words + r0);
     char * ixbase = (char *)(tile_index + (r0 / GBP_TILE) * (u64)(P + 1));
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__
     // lone last row of an odd range comes as the second element of the pair that ends with it.  The tail select happens where the
     // row is used (a select scheduled right behind the loads would make the wave wait for every store issued before them).
     const bool odd_tail = (nrel & 1) != 0;
-    const u32 last_pair = nrel >= 2 ? (nrel - 2) & ~1u : 0;
+    const u32 last_pair = (nrel >= 2 ? (nrel - 2) & ~1u : shift ? ~0u : 0u) + shift; // in shifted rows (a lone row: the pair that ends with it)
     kpair kraw[RPT / 2];
     v2q wraw[RPT / 2];
     auto load_tile = [&](u32 trel) {
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__
         {
             const u32 i = rel_of(trel, j);
             const bool tail = odd_tail && i + 1 == nrel;
-            const u32 li = tail ? i - 1 : (i + 1 < nrel ? i : last_pair);
+            const u32 li = tail ? i + shift - 1 : (i + 1 < nrel ? i + shift : last_pair);
             kraw[j / 2] = __builtin_nontemporal_load((const kpair *)(kbase + li * (u32)sizeof(KT)));
             wraw[j / 2] = __builtin_nontemporal_load((const v2q *)(wbase + li * 8u));
         }

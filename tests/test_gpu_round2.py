@@ -241,6 +241,47 @@ def test_join_probe_agg_region_partitioned_matches_numpy(ch, ctx, kind):
 
 
 # ---- keys128 / keys256: the device dictionary (chgpu_keydict) under GROUP BY and joins ----------------------------------------------
+@pytest.mark.parametrize("key_dtype", [np.uint32, np.uint64])
+@pytest.mark.parametrize("case", ["more_groups_than_promised", "one_key_half_the_rows", "zero_key_and_ragged_end", "f64_sum"])
+def test_groupby_tile_sorted_plan_edge_cases(ch, ctx, key_dtype, case):
+    """The two-pass plan (k_rp_tilesort + k_agg_tiles_lds) where its special paths run: LDS tables that overflow because the hint was
+    far too small (rows left pending for the finish rounds), runs far longer than a wave (a key with half of all rows), the zero key,
+    a row count that ends in the middle of a tile and of a 16-byte pair, Float64 sums (within 1e-9 relative: atomics reorder the adds)."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    n = 7_340_033
+    if case == "more_groups_than_promised":
+        groups, hint = 3_000_000, 20_000
+        k = rng.integers(1, groups, size=n).astype(key_dtype)
+    elif case == "one_key_half_the_rows":
+        groups, hint = 200_000, 200_000
+        k = rng.integers(1, groups, size=n).astype(key_dtype)
+        k[rng.random(n) < 0.5] = 123_457
+    else:
+        groups, hint = 250_000, 250_000
+        k = rng.integers(0, groups, size=n).astype(key_dtype)
+        k[::97] = 0
+    if case == "f64_sum":
+        v = rng.random(n) * 1e6 - 5e5
+        aggs = [(ch.AGG_SUM, np.float64), (ch.AGG_COUNT, None)]
+    else:
+        v = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
+        aggs = [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)]
+    A = ch.Aggregator(key_dtype, aggs, size_hint=hint, ctx=ctx)
+    A.execute_on_block(ctx.upload(k), [ctx.upload(v), None])
+    gk, (gs, gc) = A.convert_to_block()
+    uk, inv = np.unique(k, return_inverse=True)
+    order = np.argsort(gk)
+    assert np.array_equal(gk[order], uk)
+    assert np.array_equal(gc[order], np.bincount(inv, minlength=uk.shape[0]).astype(np.uint64))
+    if case == "f64_sum":
+        want = np.bincount(inv, weights=v, minlength=uk.shape[0])
+        assert np.allclose(gs[order], want, rtol=1e-9, atol=1e-6)
+    else:
+        want = np.zeros(uk.shape[0], dtype=np.uint64)
+        np.add.at(want, inv, v.astype(np.uint64))
+        assert np.array_equal(gs[order].astype(np.uint64), want)
+
+
 @pytest.mark.parametrize("key_dtypes", [(np.uint64, np.uint64), (np.uint64, np.uint32, np.uint16), (np.uint64, np.uint64, np.uint64, np.uint32, np.uint8)])
 def test_keys_fixed_group_by_matches_oracle(ch, ctx, oracle_mod, key_dtypes):
     O = oracle_mod
