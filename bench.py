@@ -457,7 +457,7 @@ def config_c3(args, ctx, ch, torch, np, dev, stream, tj, with_cpu):
     assert np.unique(gk).shape[0] == gk.shape[0] == groups and int(gc.sum()) == rows
     assert int(gs.astype(np.uint64).sum()) == int(v.sum().item()) % 2**64
     algo = 12.0 * rows  # 4 B key + 8 B value per row
-    kernels, ksrc = _kernels_from_profile(["k_gb_", "k_agg_", "k_rp_<GbpPartFn"])
+    kernels, ksrc = _kernels_from_profile(["k_gb_", "k_agg_", "k_tile_", "k_rp_<GbpPartFn"])
     res = {"workload": "GROUP BY UInt32 key (1 M groups), sum(Int64) + count(), HBM-resident, size_hint=1e6",
            "rows": rows, "groups": groups, "calls": 7, "ms": dev_ms, "wall_ms": wall_ms, "rows_per_s": rows / (dev_ms * 1e-3),
            "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": algo / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -79,7 +79,7 @@ def group_bytes(prefixes):
 # configs C3 / C4 of the same command: bytes of their kernel families divided by the number of operator calls the bench made
 cfg = bj.get("configs") or {}
 if "C3" in cfg and cfg["C3"].get("calls"):
-    r, w, split = group_bytes(["k_gb_", "k_agg_", "k_rp_<GbpPartFn"])
+    r, w, split = group_bytes(["k_gb_", "k_agg_", "k_tile_", "k_rp_<GbpPartFn"])
     calls = cfg["C3"]["calls"]
     res["C3_hbm_bytes_per_call"] = (r + w) / calls
     res["C3"] = {"calls": calls, "read_bytes_per_call": r / calls, "write_bytes_per_call": w / calls, "algorithmic_bytes": cfg["C3"]["roofline"]["algorithmic_bytes"],
@@ -98,4 +98,9 @@ if "C4_one_gpu" in cfg and cfg["C4_one_gpu"].get("probe_calls"):
 res["source"] = f"profiles/{tag}_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs) of `python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline`, profiles/collect.sh {tag}"
 with open(os.path.join(out, f"{tag}_traffic.json"), "w") as fo:
     json.dump(res, fo, indent=1)
+# the per-operator views on their own (same numbers)
+for name, key in (("groupby", "C3"), ("join", "C4")):
+    if key in res:
+        with open(os.path.join(out, f"{tag}_traffic_{name}.json"), "w") as fo:
+            json.dump({"source": res["source"], "rows": res.get("rows"), f"{key}_hbm_bytes_per_call": res.get(f"{key}_hbm_bytes_per_call"), key: res[key]}, fo, indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "kernels"}, indent=1)[:6000])
