@@ -1740,7 +1740,11 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
             if (arg_j < 0)
                 arg_j = (int)j;
         }
-    if (arg_j < 0 || chgpu_type_size(a->arg_types[arg_j]) != 8 || ((uintptr_t)arg_cols[arg_j]->data + row_begin * 8) % 16 != 0)
+    // the argument column as it is: 8-byte integers / Float64, or UInt32 / Int32 / Float32 widened inside the partition pass
+    const int arg_t = arg_j >= 0 ? a->arg_types[arg_j] : -1;
+    const size_t arg_w = arg_j >= 0 ? chgpu_type_size(arg_t) : 0;
+    const int arg_ex = arg_t == CHGPU_I32 ? 3 : arg_t == CHGPU_F32 ? 4 : 0;
+    if (arg_j < 0 || (arg_w != 8 && arg_w != 4) || ((uintptr_t)arg_cols[arg_j]->data + row_begin * arg_w) % (2 * arg_w) != 0)
         return CHGPU_ERR_NOT_IMPLEMENTED;
     AggDesc d;
     agg_fill_desc(a, arg_cols, &d);
@@ -1816,22 +1820,29 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
     CHGPU_HIP(hipMemsetAsync(scratch, 0, tot_b + unit_b + pend_b, ctx->stream));
     int rc = CHGPU_OK;
     const size_t lds_sort = rp_tilesort_lds_bytes(TILE, P, key_w);
+#define GB_TILESORT(TILE_, KT_, AT_, EX_)                                                                                                        \
+    do                                                                                                                                          \
+    {                                                                                                                                           \
+        auto kern = k_rp_tilesort<TILE_, KT_, GbpPartFn<KT_>, RP_THREADS, AT_, EX_>;                                                             \
+        rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
+        if (rc == CHGPU_OK)                                                                                                                     \
+            hipLaunchKernelGGL(kern, dim3(G), dim3(RP_THREADS), lds_sort, ctx->stream, (const KT_ *)key_col->data + row_begin, (const AT_ *)arg_cols[arg_j]->data + row_begin, n, \
+                               rows_per_wg, P, (KT_ *)pkeys, pwords, tidx, part_total, GbpPartFn<KT_>{P, GBP_MULT});                             \
+    } while (0)
+#define GB_TILESORT_ARG(TILE_, KT_)                                   \
+    do                                                                \
+    {                                                                 \
+        if (arg_w == 8) GB_TILESORT(TILE_, KT_, u64, 0);              \
+        else if (arg_ex == 3) GB_TILESORT(TILE_, KT_, u32, 3);        \
+        else if (arg_ex == 4) GB_TILESORT(TILE_, KT_, u32, 4);        \
+        else GB_TILESORT(TILE_, KT_, u32, 0);                         \
+    } while (0)
     if (key32)
-    {
-        auto kern = k_rp_tilesort<12288, u32, GbpPartFn<u32>>;
-        rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
-        if (rc == CHGPU_OK)
-            hipLaunchKernelGGL(kern, dim3(G), dim3(RP_THREADS), lds_sort, ctx->stream, (const u32 *)key_col->data + row_begin, (const u64 *)arg_cols[arg_j]->data + row_begin, n, rows_per_wg, P,
-                               (u32 *)pkeys, pwords, tidx, part_total, GbpPartFn<u32>{P, GBP_MULT});
-    }
+        GB_TILESORT_ARG(12288, u32);
     else
-    {
-        auto kern = k_rp_tilesort<8192, u64, GbpPartFn<u64>>;
-        rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
-        if (rc == CHGPU_OK)
-            hipLaunchKernelGGL(kern, dim3(G), dim3(RP_THREADS), lds_sort, ctx->stream, (const u64 *)key_col->data + row_begin, (const u64 *)arg_cols[arg_j]->data + row_begin, n, rows_per_wg, P,
-                               (u64 *)pkeys, pwords, tidx, part_total, GbpPartFn<u64>{P, GBP_MULT});
-    }
+        GB_TILESORT_ARG(8192, u64);
+#undef GB_TILESORT_ARG
+#undef GB_TILESORT
     if (rc == CHGPU_OK)
     {
         hipLaunchKernelGGL(k_tile_units, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)part_total, P, chunk_rows, n_tiles, unit_list, max_units, unit_count, unit_ctr);

@@ -494,8 +494,10 @@ __global__ __launch_bounds__(THREADS) void k_rp_scatter(const KT * __restrict__ 
 // rows_per_wg is a multiple of TILE; out arrays hold ceil(n / TILE) * TILE rows (rows past n sort behind the real rows of the last tile).
 // dynamic LDS: stage_word u64[TILE] | stage_key KT[TILE] | tile_cnt u32[P + 1] | tile_off u32[P + 1] | wg_total u32[P + 1]
 // ---------------------------------------------------------------------------------------------
-template <u32 GBP_TILE, typename KT, typename PartFn, u32 THREADS = RP_THREADS>
-__global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__ keys, const u64 * __restrict__ words, u64 n, u64 rows_per_wg, u32 P,
+// AT / EX: the argument column as stored -- u64 (EX 0), or a 4-byte type widened on the way into LDS: EX 0 zero-extended (UInt32),
+// 3 sign-extended (Int32), 4 Float32 -> Float64 bits; the sorted copy always holds 8-byte words.
+template <u32 GBP_TILE, typename KT, typename PartFn, u32 THREADS = RP_THREADS, typename AT = u64, int EX = 0>
+__global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__ keys, const AT * __restrict__ words, u64 n, u64 rows_per_wg, u32 P,
                                                          KT * __restrict__ out_keys, u64 * __restrict__ out_words, unsigned short * __restrict__ tile_index,
                                                          unsigned long long * __restrict__ part_total, PartFn part_fn)
 {
@@ -537,7 +539,8 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__
     const bool odd_tail = (nrel & 1) != 0;
     const u32 last_pair = (nrel >= 2 ? (nrel - 2) & ~1u : shift ? ~0u : 0u) + shift; // in shifted rows (a lone row: the pair that ends with it)
     kpair kraw[RPT / 2];
-    v2q wraw[RPT / 2];
+    typedef typename std::conditional<sizeof(AT) == 4, v2d, v2q>::type apair;
+    apair wraw[RPT / 2];
     auto load_tile = [&](u32 trel) {
 #pragma unroll
         for (u32 j = 0; j < RPT; j += 2)
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__
             const bool tail = odd_tail && i + 1 == nrel;
             const u32 li = tail ? i + shift - 1 : (i + 1 < nrel ? i + shift : last_pair);
             kraw[j / 2] = __builtin_nontemporal_load((const kpair *)(kbase + li * (u32)sizeof(KT)));
-            wraw[j / 2] = __builtin_nontemporal_load((const v2q *)(wbase + li * 8u));
+            wraw[j / 2] = __builtin_nontemporal_load((const apair *)(wbase + li * (u32)sizeof(AT)));
         }
     };
     auto key_at = [&](u32 trel, u32 j) -> KT {
@@ -555,7 +558,13 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__
     };
     auto word_at = [&](u32 trel, u32 j) -> u64 {
         const bool tail = odd_tail && rel_of(trel, j & ~1u) + 1 == nrel;
-        return ((j & 1) || tail) ? wraw[j / 2].y : wraw[j / 2].x;
+        const auto raw = ((j & 1) || tail) ? wraw[j / 2].y : wraw[j / 2].x;
+        if constexpr (EX == 3)
+            return (u64)(i64)(i32)(u32)raw;
+        else if constexpr (EX == 4)
+            return (u64)__double_as_longlong((double)__uint_as_float((u32)raw));
+        else
+            return (u64)raw;
     };
     u32 part[RPT], rank[RPT];
     auto step_rank = [&](u32 trel) {

@@ -241,6 +241,34 @@ def test_join_probe_agg_region_partitioned_matches_numpy(ch, ctx, kind):
 
 
 # ---- keys128 / keys256: the device dictionary (chgpu_keydict) under GROUP BY and joins ----------------------------------------------
+@pytest.mark.parametrize("arg_dtype", [np.uint32, np.int32, np.float32])
+def test_groupby_tile_sorted_plan_widens_narrow_arguments(ch, ctx, arg_dtype):
+    """sum(UInt32 / Int32 / Float32 column): the partition pass widens the 4-byte values on the way into LDS (zero / sign extension,
+    Float32 -> Float64), the aggregate pass sees 8-byte words; the sums are those of the widened values."""
+    rng = np.random.Generator(np.random.PCG64(78))
+    n, groups = 6_291_461, 150_000
+    k = rng.integers(0, groups, size=n).astype(np.uint32)
+    if arg_dtype == np.float32:
+        v = (rng.random(n) * 2000 - 1000).astype(np.float32)
+    else:
+        info = np.iinfo(arg_dtype)
+        v = rng.integers(info.min, info.max, size=n, endpoint=True).astype(arg_dtype)
+    A = ch.Aggregator(np.uint32, [(ch.AGG_SUM, arg_dtype), (ch.AGG_COUNT, None)], size_hint=groups, ctx=ctx)
+    A.execute_on_block(ctx.upload(k), [ctx.upload(v), None])
+    gk, (gs, gc) = A.convert_to_block()
+    uk, inv = np.unique(k, return_inverse=True)
+    order = np.argsort(gk)
+    assert np.array_equal(gk[order], uk)
+    assert np.array_equal(gc[order], np.bincount(inv, minlength=uk.shape[0]).astype(np.uint64))
+    if arg_dtype == np.float32:
+        want = np.bincount(inv, weights=v.astype(np.float64), minlength=uk.shape[0])
+        assert np.allclose(gs[order], want, rtol=1e-9, atol=1e-6)
+    else:
+        want = np.zeros(uk.shape[0], dtype=np.uint64)
+        np.add.at(want, inv, v.astype(np.int64).astype(np.uint64))
+        assert np.array_equal(gs[order].astype(np.uint64), want)
+
+
 @pytest.mark.parametrize("key_dtype", [np.uint32, np.uint64])
 @pytest.mark.parametrize("case", ["more_groups_than_promised", "one_key_half_the_rows", "zero_key_and_ragged_end", "f64_sum"])
 def test_groupby_tile_sorted_plan_edge_cases(ch, ctx, key_dtype, case):
