@@ -514,6 +514,34 @@ def test_join_filter_only_probe_matches_full_probe(ch, ctx, strict_name):
         ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, key_dtype=np.uint32, ctx=ctx).probe_columns(left, need_right_rows=False)
 
 
+@pytest.mark.parametrize("strict_name", ["SEMI", "ANTI"])
+@pytest.mark.parametrize("domain,with_nulls", [(50_000, True), (3_000_000, False), (3_000_000, True), (1_228_800, False)])
+def test_join_filter_only_probe_dense_keys_lds_slices(ch, ctx, strict_name, domain, with_nulls):
+    """dense UInt32 keys (dimension surrogate keys) and enough left rows: the key set is probed as an LDS-resident bitmap, one pass per
+    150 KiB slice of the key domain (1 and 3 slices here, and a domain that ends exactly at a slice boundary); left keys beyond the
+    domain, the zero key, NULL keys and a row count that is not a multiple of four included"""
+    strict = getattr(ch, "STRICT_" + strict_name)
+    rng = np.random.Generator(np.random.PCG64(domain % 1000 + 3))
+    build = rng.integers(0, domain, size=domain // 5).astype(np.uint32)
+    build[0] = domain - 1
+    build[1] = 0
+    left = rng.integers(0, domain + domain // 3, size=3_000_003).astype(np.uint32)
+    left[::1001] = 0
+    left[-1] = domain - 1
+    left[-2] = domain + 7
+    nulls = (rng.random(left.shape[0]) < 0.02).astype(np.uint8) if with_nulls else None
+    j = ch.HashJoin(ch.JOIN_LEFT, strict, key_dtype=np.uint32, ctx=ctx)
+    j.add_block(build)
+    j.finish_build()
+    r = j.probe_columns(left, null_map=nulls, need_right_rows=False)
+    found = np.isin(left, build)
+    if with_nulls:
+        found &= nulls == 0
+    want = found if strict_name == "SEMI" else ~found
+    assert np.array_equal(r["filter"].numpy().astype(bool), want)
+    assert r["n_out"] == int(want.sum()) and r["consumed"] == left.shape[0]
+
+
 @pytest.mark.parametrize("dtype", [np.uint16, np.int16, np.int8, np.uint8, np.int32])
 def test_narrow_key_types_join_selector_and_pack(ch, ctx, oracle_mod, dtype):
     # UInt16 (Date) / Int16 / Int8 keys: raw bits zero-extended into the 64-bit table key, like every other key type
