@@ -10,6 +10,7 @@
 //                                                                src/AggregateFunctions/AggregateFunctionSum.h:62-103
 //   k_index/k_replicate ColumnVector<T>::indexImpl / replicate    src/Columns/ColumnVector.cpp:1121-1143, 879-907
 #include "chgpu_internal.h"
+#include <vector>
 
 #include <cmath>
 #include <cstdlib>
@@ -908,6 +909,108 @@ __global__ __launch_bounds__(256) void k_filter_scatter(const T * __restrict__ d
     }
 }
 
+// The same compaction for NC columns of one element width at once (IColumn::filter over every column of a Block,
+// FilterTransform.cpp:190-206): the mask bytes are loaded and balloted ONCE per group of rows and every column's rows go out with
+// the same ranks -- per column the pass then costs sizeof(T) * (1 + selectivity) bytes per row instead of 1 + that.
+template <typename T, int NC>
+struct FilterCols
+{
+    const T * data[NC];
+    T * out[NC];
+};
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void k_filter_scatter_multi(FilterCols<T, NC> c, const u8 * __restrict__ mask, u64 n, const u64 * __restrict__ chunk_offsets, u64 n_chunks)
+{
+    constexpr int R = 16 / sizeof(T);
+    constexpr u32 GROUP = 64 * R;
+    constexpr int G = CHUNK_ROWS / GROUP;
+    typedef Vec<T, R> V;
+    typedef Vec<u8, R> MV;
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave0 = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u64 n_waves = ((u64)gridDim.x * 256) >> 6;
+    bool aligned = (((uintptr_t)mask) % R) == 0;
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+        aligned = aligned && (((uintptr_t)c.data[k]) & 15) == 0;
+    for (u64 chunk = wave0; chunk < n_chunks; chunk += n_waves)
+    {
+        const u64 pos0 = chunk_offsets[chunk];
+        const u64 cbase = chunk * CHUNK_ROWS;
+        if (aligned && cbase + CHUNK_ROWS <= n)
+        {
+            MV m[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                m[g] = *(const MV *)(mask + cbase + (u64)g * GROUP + (u64)lane * R);
+            // rank of this lane's first kept row of every group, and what to add per kept row
+            u32 first[G];
+            u32 run = 0;
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+            {
+                u32 before = 0, total = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                {
+                    const u64 b = __ballot(m[g].v[r] != 0);
+                    before += mbcnt(b);
+                    total += __popcll(b);
+                }
+                first[g] = run + before;
+                run += total;
+            }
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+            {
+                V x[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    x[g] = *(const V *)(c.data[k] + cbase + (u64)g * GROUP + (u64)lane * R);
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                {
+                    u64 o = pos0 + first[g];
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (m[g].v[r] != 0)
+                            c.out[k][o++] = x[g].v[r];
+                }
+            }
+        }
+        else
+        {
+            // ragged tail chunk / unaligned view: same order, guarded scalar accesses
+            u64 pos = pos0;
+            for (int g = 0; g < G; ++g)
+            {
+                const u64 row = cbase + (u64)g * GROUP + (u64)lane * R;
+                bool keep[R];
+                u32 before = 0, total = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                {
+                    const bool in = row + r < n;
+                    keep[r] = in && mask[in ? row + r : 0] != 0;
+                    const u64 b = __ballot(keep[r]);
+                    before += mbcnt(b);
+                    total += __popcll(b);
+                }
+#pragma unroll
+                for (int k = 0; k < NC; ++k)
+                {
+                    u64 o = pos + before;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (keep[r])
+                            c.out[k][o++] = c.data[k][row + r];
+                }
+                pos += total;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ u32 count_nonzero_bytes16(const uint4 v);
 
 // countBytesInFilter (ColumnsCommon.cpp:31-58): non-zero bytes of the mask.  16-byte nontemporal loads, four in flight per
@@ -1143,18 +1246,69 @@ extern "C" int chgpu_filter_columns(chgpu_ctx * ctx, uint32_t n_cols, const chgp
     FilterPlan fp;
     if (mask->rows)
         CHGPU_TRY(filter_plan(ctx, mask, &fp)); // the mask is counted and scanned ONCE for the whole Block
-    for (u32 k = 0; k < n_cols; ++k)
-    {
-        const int rc = mask->rows ? filter_apply(ctx, cols[k], mask, fp, &outs[k]) : chgpu_col_new(ctx, cols[k]->type, 0, &outs[k]);
-        if (rc != CHGPU_OK)
-        {
-            for (u32 q = 0; q < k; ++q)
+    auto fail = [&](int rc) {
+        for (u32 q = 0; q < n_cols; ++q)
+            if (outs[q])
             {
                 chgpu_col_free(outs[q]);
                 outs[q] = nullptr;
             }
-            return rc;
+        return rc;
+    };
+    // columns of one element width go through k_filter_scatter_multi four (or three, two) at a time: one read of the mask for all of them
+    static const bool no_multi = getenv("CHGPU_TUNE_FILTER_NO_MULTI") != nullptr;
+    std::vector<char> done(n_cols, 0);
+    if (mask->rows && fp.total && !no_multi)
+        for (size_t w : {(size_t)8, (size_t)4})
+        {
+            std::vector<u32> same;
+            for (u32 k = 0; k < n_cols; ++k)
+                if (chgpu_type_size(cols[k]->type) == w)
+                    same.push_back(k);
+            for (size_t b = 0; b + 1 < same.size();)
+            {
+                const u32 nc = (u32)(same.size() - b >= 4 ? 4 : same.size() - b);
+                if (nc < 2)
+                    break;
+                for (u32 q = 0; q < nc; ++q)
+                {
+                    const int rc = chgpu_col_new(ctx, cols[same[b + q]]->type, fp.total, &outs[same[b + q]]);
+                    if (rc != CHGPU_OK)
+                        return fail(rc);
+                }
+#define FILTER_MULTI(T_, NC_)                                                                                                                  \
+    do                                                                                                                                         \
+    {                                                                                                                                          \
+        FilterCols<T_, NC_> fc;                                                                                                                \
+        for (u32 q = 0; q < NC_; ++q)                                                                                                          \
+        {                                                                                                                                      \
+            fc.data[q] = (const T_ *)cols[same[b + q]]->data;                                                                                  \
+            fc.out[q] = (T_ *)outs[same[b + q]]->data;                                                                                         \
+        }                                                                                                                                      \
+        hipLaunchKernelGGL((k_filter_scatter_multi<T_, NC_>), dim3(fp.grid), dim3(256), 0, ctx->stream, fc, (const u8 *)mask->data, fp.n, (const u64 *)fp.offsets, fp.n_chunks); \
+    } while (0)
+                if (w == 8) { if (nc == 4) FILTER_MULTI(u64, 4); else if (nc == 3) FILTER_MULTI(u64, 3); else FILTER_MULTI(u64, 2); }
+                else        { if (nc == 4) FILTER_MULTI(u32, 4); else if (nc == 3) FILTER_MULTI(u32, 3); else FILTER_MULTI(u32, 2); }
+#undef FILTER_MULTI
+                ctx->counters[6] += 1;
+                if (hipGetLastError() != hipSuccess)
+                    return fail(chgpu_set_error(CHGPU_ERR_DEVICE, "filter launch failed"));
+                for (u32 q = 0; q < nc; ++q)
+                {
+                    done[same[b + q]] = 1;
+                    ctx->counters[0] += fp.total;
+                    ctx->counters[1] += fp.total * w;
+                }
+                b += nc;
+            }
         }
+    for (u32 k = 0; k < n_cols; ++k)
+    {
+        if (done[k])
+            continue;
+        const int rc = mask->rows ? filter_apply(ctx, cols[k], mask, fp, &outs[k]) : chgpu_col_new(ctx, cols[k]->type, 0, &outs[k]);
+        if (rc != CHGPU_OK)
+            return fail(rc);
     }
     *out_rows = fp.total;
     return CHGPU_OK;

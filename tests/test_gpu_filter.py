@@ -53,6 +53,28 @@ def test_filter_ragged_sizes_and_unaligned_views(ch, ctx, oracle_mod, rows):
         assert np.array_equal(got, oracle_mod.filter_column(data[start:start + n], filt[start:start + n]))
 
 
+@pytest.mark.parametrize("n_u32,n_8", [(2, 0), (5, 2), (7, 5), (1, 3), (4, 4)])
+def test_filter_columns_same_width_columns_share_one_mask_pass(ch, ctx, oracle_mod, n_u32, n_8):
+    """columns of one element width are compacted four (three, two) at a time by one kernel that reads the mask once; every batch
+    size, a ragged last chunk, views whose first row is not 16-byte aligned, and masks that keep nothing / everything"""
+    rng = np.random.Generator(np.random.PCG64(100 * n_u32 + n_8))
+    n = 2_500_013
+    cols_np = [rng.integers(0, 2**32, size=n, dtype=np.uint32) for _ in range(n_u32)]
+    cols_np += [rng.integers(-2**62, 2**62, size=n, dtype=np.int64) if i % 2 == 0 else rng.random(n) for i in range(n_8)]
+    cols_np.insert(1, rng.integers(0, 2**16, size=n).astype(np.uint16))        # an odd width between them
+    for filt in ((rng.integers(0, 5, size=n) == 0).astype(np.uint8), np.zeros(n, dtype=np.uint8), np.full(n, 7, dtype=np.uint8)):
+        dev = [ctx.upload(c) for c in cols_np]
+        m = ctx.upload(filt)
+        outs = ch.filter_columns(dev, m)
+        for got, c in zip(outs, cols_np):
+            assert np.array_equal(got.numpy(), c[filt != 0])
+        if filt[0] == 0 and filt.any():
+            for start in (1, 3):                                                  # unaligned views
+                outs = ch.filter_columns([d.cut(start, n - start) for d in dev], m.cut(start, n - start))
+                for got, c in zip(outs, cols_np):
+                    assert np.array_equal(got.numpy(), c[start:][filt[start:] != 0])
+
+
 def test_filter_columns_of_a_block_with_one_mask(ch, ctx, oracle_mod):
     rng = np.random.Generator(np.random.PCG64(19))
     for n in (0, 1, 1025, 300_007):
