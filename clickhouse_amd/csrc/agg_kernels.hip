@@ -1093,8 +1093,9 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
 // units in that order, so at any time they work on the SAME stretch of tiles for different partitions -- the lines at the two ends of
 // a run also hold the neighbouring partitions' rows and are then found in L2 / Infinity Cache by the neighbours instead of being
 // fetched from HBM once per partition.  unit_list[u] = p | j << 16 | c << 40; unit_count[0] = number of units.
+static constexpr u32 TILE_QUEUES = 8; // XCDs of an MI355X
 __global__ __launch_bounds__(1024) void k_tile_units(const unsigned long long * __restrict__ part_total, u32 P, u64 chunk_rows, u32 n_tiles, u64 * __restrict__ unit_list,
-                                                      u32 max_units, u32 * __restrict__ unit_count, u32 * __restrict__ ctr)
+                                                      u32 max_units, u32 * __restrict__ qstart, u32 * __restrict__ ctr)
 {
     __shared__ u32 sc[1024], cc[1024];
     const u32 p = threadIdx.x;
@@ -1114,7 +1115,11 @@ __global__ __launch_bounds__(1024) void k_tile_units(const unsigned long long * 
         sc[p] += o;
         __syncthreads();
     }
-    const u32 U = sc[1023] < max_units ? sc[1023] : max_units; // (the host sized the list for the bound sum ceil(r_p / chunk) <= n / chunk + P)
+    // Eight queues, one per XCD: queue x holds the units of partitions [x * PX, (x + 1) * PX) in (j, p) order, so that the 32
+    // workgroups of an XCD sweep the same tiles for 32 NEIGHBOURING partitions -- the shared boundary lines are then L2 hits, not
+    // just Infinity Cache hits.  (the host sized the list for the bound sum ceil(r_p / chunk) <= n / chunk + P)
+    const u32 PX = (P + TILE_QUEUES - 1) / TILE_QUEUES;
+    const u32 U = sc[1023] < max_units ? sc[1023] : max_units;
     for (u32 u = threadIdx.x; u < U; u += 1024)
     {
         u32 lo = 0, hi = P - 1; // the partition whose units [sc[q] - cc[q], sc[q]) hold u
@@ -1127,16 +1132,21 @@ __global__ __launch_bounds__(1024) void k_tile_units(const unsigned long long * 
                 lo = mid + 1;
         }
         const u32 q = lo, j = u - (sc[q] - cc[q]);
-        u32 pos = 0; // units ordered before (j, q): every (j', .) with j' < j, and (j, q') with q' < q
-        for (u32 r = 0; r < P; ++r)
+        const u32 x = q / PX, r0 = x * PX, r1 = r0 + PX < P ? r0 + PX : P;
+        u32 pos = r0 ? sc[r0 - 1] : 0; // the queue's first unit: all units of the partitions before it
+        for (u32 r = r0; r < r1; ++r) // units of the queue ordered before (j, q): every (j', .) with j' < j, and (j, q') with q' < q
             pos += (cc[r] < j ? cc[r] : j) + ((r < q && cc[r] > j) ? 1u : 0u);
-        unit_list[pos] = (u64)q | ((u64)j << 16) | ((u64)cc[q] << 40);
+        if (pos < max_units)
+            unit_list[pos] = (u64)q | ((u64)j << 16) | ((u64)cc[q] << 40);
     }
-    if (p == 0)
+    if (p <= TILE_QUEUES)
     {
-        *unit_count = U;
-        *ctr = 0;
+        const u32 r0 = p * PX < P ? p * PX : P;
+        const u32 first = r0 ? sc[r0 - 1] : 0;
+        qstart[p] = first < U ? first : U;
     }
+    if (p < TILE_QUEUES)
+        ctr[p] = 0;
 }
 
 // The tile index transposed for the aggregate pass: run_index[p][t] = start | length << 16 of partition p's run in tile t, so that a
@@ -1189,7 +1199,7 @@ __device__ __forceinline__ u32 tiles_load_block(const u32 * __restrict__ run_ind
 template <typename KT, u32 OPS, u32 TILE>
 __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, const KT * __restrict__ keys, const u64 * __restrict__ words0,
                                                         const u32 * __restrict__ run_index, u32 n_tiles, u32 P, u64 * __restrict__ pending, u32 S, u32 cnt32,
-                                                        const u64 * __restrict__ unit_list, const u32 * __restrict__ unit_count, u32 * __restrict__ unit_ctr, int experiment)
+                                                        const u64 * __restrict__ unit_list, const u32 * __restrict__ qstart, u32 * __restrict__ qctr, int experiment)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     typedef typename std::conditional<sizeof(KT) == 4, unsigned int, unsigned long long>::type CasT;
@@ -1209,15 +1219,33 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
 #pragma unroll
     for (u32 w = 0; w < 4; ++w)
         w_off[w] = L.off(w);
-    const u32 n_units = unit_count[0];
+    // units are drawn from the queue of this workgroup's XCD first (HW_REG_XCC_ID only steers the choice: when a queue runs dry the
+    // workgroup goes on with the next one, so every unit is taken whatever the placement)
+    const u32 xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & (TILE_QUEUES - 1);
+    u32 dry = 0; // (thread 0) queues found empty
     for (;;)
     {
         if (threadIdx.x == 0)
-            sh_unit = atomicAdd(unit_ctr, 1u);
+        {
+            u32 got = ~0u;
+            for (u32 a = 0; a < TILE_QUEUES && got == ~0u; ++a)
+            {
+                const u32 y = (xcc + a) & (TILE_QUEUES - 1);
+                if ((dry >> y) & 1u)
+                    continue;
+                const u32 len = qstart[y + 1] - qstart[y];
+                const u32 k = len ? atomicAdd(&qctr[y], 1u) : len;
+                if (k < len)
+                    got = qstart[y] + k;
+                else
+                    dry |= 1u << y;
+            }
+            sh_unit = got;
+        }
         __syncthreads();
         const u32 unit = sh_unit;
-        if (unit >= n_units)
-            break; // (every workgroup reaches this exit)
+        if (unit == ~0u)
+            break; // (every workgroup reaches this exit: all queues are dry)
         const u64 ud = unit_list[unit];
         const u32 p = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(ud & 0xffffu)), j = (u32)__builtin_amdgcn_readfirstlane((int)(u32)((ud >> 16) & 0xffffffu)),
                   c_p = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(ud >> 40));
@@ -1755,14 +1783,14 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
     //  cover equal stretches of tiles -- see k_tile_units)
     chunk_rows += chunk_rows / 16;
     const u32 max_units = (u32)(n / chunk_rows + P);
-    const size_t tot_b = al((size_t)P * 8), unit_b = al((size_t)(max_units + 2) * 8 + 64), pend_b = al((n_pad / 64 + 1) * 8),
+    const size_t tot_b = al((size_t)P * 8), unit_b = al((size_t)(max_units + 2) * 8 + 128), pend_b = al((n_pad / 64 + 1) * 8),
                  idx_b = al((size_t)n_tiles * (P + 1) * 2 + 16), ridx_b = al((size_t)n_tiles * P * 4), keys_b = al((size_t)n_pad * key_w), words_b = al((size_t)n_pad * 8);
     void * scratch = nullptr;
     CHGPU_TRY(chgpu_scratch(ctx, tot_b + unit_b + pend_b + idx_b + ridx_b + keys_b + words_b, &scratch));
     unsigned long long * part_total = (unsigned long long *)scratch;
     u64 * unit_list = (u64 *)((char *)scratch + tot_b);
-    u32 * unit_count = (u32 *)(unit_list + max_units + 1);
-    u32 * unit_ctr = unit_count + 1;
+    u32 * unit_qstart = (u32 *)(unit_list + max_units + 1); // [TILE_QUEUES + 1], then the queues' work counters [TILE_QUEUES]
+    u32 * unit_ctr = unit_qstart + TILE_QUEUES + 1;
     u64 * pending = (u64 *)((char *)scratch + tot_b + unit_b);
     unsigned short * tidx = (unsigned short *)((char *)pending + pend_b);
     u32 * run_index = (u32 *)((char *)tidx + idx_b);
@@ -1845,7 +1873,7 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
 #undef GB_TILESORT
     if (rc == CHGPU_OK)
     {
-        hipLaunchKernelGGL(k_tile_units, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)part_total, P, chunk_rows, n_tiles, unit_list, max_units, unit_count, unit_ctr);
+        hipLaunchKernelGGL(k_tile_units, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)part_total, P, chunk_rows, n_tiles, unit_list, max_units, unit_qstart, unit_ctr);
         hipLaunchKernelGGL(k_tile_index_transpose, dim3((n_tiles + 63) / 64, (P + 63) / 64), dim3(256), 0, ctx->stream, (const unsigned short *)tidx, n_tiles, P, run_index);
         const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
         const size_t keys_lds = ((size_t)key_w * (S + 1) + 7) & ~(size_t)7;
@@ -1857,7 +1885,7 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
         rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
         if (rc == CHGPU_OK)                                                                                                                           \
             hipLaunchKernelGGL(kern, dim3(G), dim3(1024), lds_ag, ctx->stream, a->t, d, (const KT_ *)pkeys, (const u64 *)pwords, (const u32 *)run_index, n_tiles, P, \
-                               pending, S, cnt32, (const u64 *)unit_list, (const u32 *)unit_count, unit_ctr, tiles_experiment);                       \
+                               pending, S, cnt32, (const u64 *)unit_list, (const u32 *)unit_qstart, unit_ctr, tiles_experiment);                      \
     } while (0)
 #define GB_TILES_OPS(KT_, TILE_)                              \
     switch (ops)                                              \
