@@ -11,6 +11,7 @@ from .aggregator import Aggregator, NullableKeyAggregator, group_by_min_max, ser
 from .expression import ActionsDAG, ExpressionActions
 from .lowcardinality import ColumnString, ColumnLowCardinality, LowCardinalityAggregator, LowCardinalityDictionary, PackedKeysAggregator
 from .hashjoin import HashJoin
+from .merging import AggregatedBlock, MergingAggregatedMemoryEfficientTransform
 from .keysfixed import KeyDict, KeysFixedAggregator, KeysFixedHashJoin
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -138,6 +138,21 @@ class LocalEngine:
     def agg_result(self, agg):
         return agg.convert_to_block()
 
+    def agg_finalize(self, agg):
+        keys, cols = agg.finalize_columns()                          # (keys, [result columns], rows), resident in HBM
+        return keys, cols, keys.size()
+
+    def deserialize_states(self, kind, data, rows):
+        return self.ch.deserialize_states(self.ctx, kind, data, [rows])
+
+    def to_column(self, x, dtype):
+        if isinstance(x, self.ch.Column):
+            return x
+        return self.ctx.column(np.ascontiguousarray(np.asarray(x) if dtype is None else np.asarray(x, dtype=dtype)))
+
+    def cut(self, col, begin, rows):
+        return col.cut(begin, rows)
+
     def rows(self, col) -> int:
         return col.size()
 

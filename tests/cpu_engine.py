@@ -95,6 +95,16 @@ class CpuEngine(GlooExchange):
     def agg_result(self, agg):
         return agg.result()
 
+    def agg_finalize(self, agg):
+        k, res = agg.result()
+        return k, res, k.shape[0]
+
+    def to_column(self, x, dtype):
+        return np.ascontiguousarray(np.asarray(x) if dtype is None else np.asarray(x, dtype=dtype))
+
+    def cut(self, col, begin, rows):
+        return col[begin:begin + rows]
+
     def rows(self, col):
         return col.shape[0]
 

@@ -448,3 +448,68 @@ def test_state_bytes_match_reference_vectors_and_round_trip(ch, ctx, golden):
     trunc = ctx.upload(ab.numpy()[:-1])
     with pytest.raises(ch.ChgpuError):
         ch.deserialize_states(ctx, ch.AGG_AVG, trunc, [groups])
+
+
+# ---- MergingAggregatedMemoryEfficientTransform on the device (clickhouse_amd/merging.py; block-order logic: tests/test_merging_transform.py) ----
+@pytest.mark.parametrize("final", [True, False])
+def test_merging_aggregated_transform_over_two_level_exports_and_wire_bytes(ch, ctx, final):
+    """three sources: one hands its two-level export over as state word columns, one as serialized states (the wire form, one block per
+    bucket), one as a single unsplit block; the merged blocks come out in bucket order, each holding exactly the keys of its bucket,
+    and together they equal the aggregation of all rows in one aggregator"""
+    rng = np.random.Generator(np.random.PCG64(31))
+    aggs = [(ch.AGG_AVG, np.int64), (ch.AGG_COUNT, None), (ch.AGG_SUM, np.int64)]
+    srcs = [(rng.integers(0, 60_000, size=300_000, dtype=np.uint64), rng.integers(-2**50, 2**50, size=300_000, dtype=np.int64)) for _ in range(3)]
+    t = ch.MergingAggregatedMemoryEfficientTransform(np.uint64, aggs, num_inputs=3, final=final, ctx=ctx)
+    exports = []
+    for k, v in srcs:
+        A = ch.Aggregator(np.uint64, aggs, ctx=ctx)
+        A.execute_on_block(k, [v, None, v])
+        exports.append(A)
+    # source 2: unsplit
+    k2, w2, n2 = exports[2].export_state_columns()
+    t.add_chunk(2, k2, w2)
+    t.finish_input(2)
+    # sources 0 and 1: split, interleaved bucket by bucket
+    k0, w0, _, c0 = exports[0].export_state_columns_two_level()
+    k1, w1, _, c1 = exports[1].export_state_columns_two_level()
+    avg_b, avg_o = ch.serialize_states(ctx, ch.AGG_AVG, w1[0], w1[1])
+    cnt_b, cnt_o = ch.serialize_states(ctx, ch.AGG_COUNT, w1[2])
+    sum_b, sum_o = ch.serialize_states(ctx, ch.AGG_SUM, w1[3])
+    avg_o, cnt_o, sum_o = avg_o.numpy(), cnt_o.numpy(), sum_o.numpy()
+    out, b0, b1 = [], 0, 0
+    for b in range(256):
+        if c0[b]:
+            t.add_chunk(0, k0.cut(b0, c0[b]), [w.cut(b0, c0[b]) for w in w0], bucket_num=b)
+        if c1[b]:
+            cut = lambda data, off: data.cut(int(off[b1]), int(off[b1 + c1[b]] - off[b1]))
+            t.add_serialized_chunk(1, k1.cut(b1, c1[b]), [cut(avg_b, avg_o), cut(cnt_b, cnt_o), cut(sum_b, sum_o)], bucket_num=b)
+        b0 += c0[b]
+        b1 += c1[b]
+        if b % 64 == 63:
+            got = t.pull()
+            assert all(x.bucket_num < b for x in got)       # the bucket the sources are AT may still grow
+            out += got
+    t.finish_input(0)
+    t.finish_input(1)
+    out += t.pull()
+    assert t.pull() == []
+    nums = [x.bucket_num for x in out]
+    assert nums == sorted(nums) and len(set(nums)) == len(nums) and min(nums) >= 0
+    for x in out[::17]:
+        assert np.all(ch.hash_to_selector(x.keys, 256).numpy() == x.bucket_num)
+    if not final:
+        # the not-final output is itself a two-level source: merge it once more into a final single block set
+        t2 = ch.MergingAggregatedMemoryEfficientTransform(np.uint64, aggs, num_inputs=1, final=True, ctx=ctx)
+        for x in out:
+            t2.add_chunk(0, x.keys, x.columns, bucket_num=x.bucket_num)
+        t2.finish_input(0)
+        out = t2.pull()
+    keys = np.concatenate([x.keys.numpy() for x in out])
+    cols = [np.concatenate([x.columns[j].numpy() for x in out]) for j in range(3)]
+    W = ch.Aggregator(np.uint64, aggs, ctx=ctx)
+    W.execute_on_block(np.concatenate([k for k, _ in srcs]), [np.concatenate([v for _, v in srcs]), None, np.concatenate([v for _, v in srcs])])
+    wk, wr = W.convert_to_block()
+    o, wo = np.argsort(keys), np.argsort(wk)
+    assert np.array_equal(keys[o], wk[wo])
+    assert np.array_equal(cols[1][o], wr[1][wo]) and np.array_equal(cols[2][o], wr[2][wo])
+    assert np.allclose(cols[0][o], wr[0][wo], rtol=1e-12, atol=0)
