@@ -29,8 +29,10 @@
 // reference's error-code meaning; CHGPU_ERR_NOT_IMPLEMENTED is the signal to fall back to the CPU operator.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <optional>
 #include <stdexcept>
@@ -1052,6 +1054,201 @@ private:
     size_t n_words = 0;
     chgpu_agg * local = nullptr;
     chgpu_agg * owner = nullptr;
+};
+
+/// A block of (partially) aggregated data with its BlockInfo (src/Core/BlockInfo.h:21-29): columns[0] = keys, then the state words
+/// (not final: sum / count one word, avg numerator and denominator) or the result columns (final).
+struct AggregatedChunk
+{
+    Chunk chunk;
+    int32_t bucket_num = -1;
+    bool is_overflows = false;
+};
+
+/// MergingAggregatedMemoryEfficientTransform (src/Processors/Transforms/MergingAggregatedMemoryEfficientTransform.h:17-57): the
+/// initiator's side of a distributed GROUP BY.  Every source hands over either one unsplit block (bucket_num -1) or split two-level
+/// blocks in increasing bucket_num, optionally one block of overflows; the blocks of one bucket from all sources are grouped
+/// (GroupingAggregatedTransform, .cpp:33-330), merged (MergingAggregatedBucketTransform -> Aggregator::mergeBlocks) and emitted in
+/// increasing bucket_num (SortingAggregatedTransform).  The contract is the reference's, the work is done in bulk: the blocks of every
+/// bucket that has become complete go into ONE device aggregator (buckets are disjoint key sets) and the result is cut into its
+/// buckets by the bucket hash (chgpu_partition_by_hash = (crc32c(key) >> 24) & 0xFF, TwoLevelHashTable.h:53); an unsplit block that
+/// meets split ones is split the same way (Aggregator::convertBlockToTwoLevel, Aggregator.cpp:3300-3409).
+class GpuMergingAggregatedTransform
+{
+public:
+    static constexpr int32_t NUM_BUCKETS = 256;
+
+    GpuMergingAggregatedTransform(ContextPtr ctx_, int key_type_, std::vector<AggregateDescription> aggregates_, size_t num_inputs, bool final_ = true)
+        : ctx(std::move(ctx_)), key_type(key_type_), aggregates(std::move(aggregates_)), final_result(final_), last_bucket_number(num_inputs, -1), finished(num_inputs, false)
+    {
+        for (auto & a : aggregates)
+        {
+            kinds.push_back(a.kind);
+            types.push_back(a.argument_type);
+            n_words += a.kind == CHGPU_AGG_AVG ? 2 : 1;
+        }
+    }
+
+    /// GroupingAggregatedTransform::addChunk (.cpp:258-291)
+    void addChunk(size_t input, AggregatedChunk c)
+    {
+        if (finished.at(input))
+            throw Exception(CHGPU_ERR_LOGICAL, "GpuMergingAggregatedTransform: input sent a block after it had finished");
+        if (c.chunk.columns.size() != 1 + n_words)
+            throw Exception(CHGPU_ERR_BAD_ARGUMENTS, "GpuMergingAggregatedTransform: a block needs the key column and one column per state word");
+        if (c.chunk.num_rows == 0)
+            return;
+        if (c.is_overflows)
+            overflow_chunks.push_back(std::move(c.chunk));
+        else if (c.bucket_num < 0)
+            single_level_chunks.push_back(std::move(c.chunk));
+        else
+        {
+            if (c.bucket_num >= NUM_BUCKETS || c.bucket_num < last_bucket_number[input] || c.bucket_num < next_bucket_to_push)
+                throw Exception(CHGPU_ERR_LOGICAL, "GpuMergingAggregatedTransform: split blocks must arrive in the order of bucket_num");
+            chunks_map[c.bucket_num].push_back(std::move(c.chunk));
+            has_two_level = true;
+            last_bucket_number[input] = c.bucket_num;
+        }
+    }
+    void finishInput(size_t input) { finished.at(input) = true; }
+
+    /// the merged blocks that are complete now, in increasing bucket_num; once every input has finished: the rest, then the unsplit
+    /// result (only if no source was two-level), then the overflows (tryPushTwoLevelData / SingleLevel / Overflow, .cpp:33-92)
+    std::vector<AggregatedChunk> pull()
+    {
+        std::vector<AggregatedChunk> out;
+        if (done)
+            return out;
+        const bool all_finished = std::all_of(finished.begin(), finished.end(), [](bool f) { return f; });
+        if (has_two_level && !single_level_chunks.empty())
+        {
+            // work() (.cpp:293-318): unsplit blocks become split ones
+            for (auto & c : single_level_chunks)
+                for (auto & part : splitByBucket(c))
+                {
+                    if (part.bucket_num < next_bucket_to_push)
+                        throw Exception(CHGPU_ERR_LOGICAL, "GpuMergingAggregatedTransform: an unsplit block holds a bucket that was already pushed");
+                    chunks_map[part.bucket_num].push_back(std::move(part.chunk));
+                }
+            single_level_chunks.clear();
+        }
+        if (has_two_level)
+        {
+            // a bucket is complete when no unfinished source can still send a block of it; sources may cut a bucket into several blocks
+            // (expect_several_chunks_for_single_bucket_per_source, .cpp:117-123), so the bucket a source is AT is not complete yet
+            int32_t current = NUM_BUCKETS;
+            if (!all_finished)
+                for (size_t i = 0; i < finished.size(); ++i)
+                    if (!finished[i])
+                        current = std::min(current, last_bucket_number[i]);
+            std::vector<Chunk> ready;
+            std::vector<bool> is_ready(NUM_BUCKETS, false);
+            for (auto it = chunks_map.begin(); it != chunks_map.end() && it->first < current;)
+            {
+                is_ready[it->first] = true;
+                for (auto & c : it->second)
+                    ready.push_back(std::move(c));
+                it = chunks_map.erase(it);
+            }
+            if (!ready.empty())
+                for (auto & part : splitByBucket(merge(ready)))
+                {
+                    if (!is_ready[part.bucket_num])
+                        throw Exception(CHGPU_ERR_LOGICAL, "GpuMergingAggregatedTransform: a block holds keys of a bucket it was not declared as");
+                    out.push_back(std::move(part));
+                }
+            next_bucket_to_push = std::max(next_bucket_to_push, std::min(current, NUM_BUCKETS));
+        }
+        if (all_finished)
+        {
+            if (!has_two_level && !single_level_chunks.empty())
+            {
+                out.push_back(AggregatedChunk{merge(single_level_chunks), -1, false});
+                single_level_chunks.clear();
+            }
+            if (!overflow_chunks.empty())
+            {
+                out.push_back(AggregatedChunk{merge(overflow_chunks), -1, true});
+                overflow_chunks.clear();
+            }
+            done = true;
+        }
+        return out;
+    }
+
+private:
+    /// MergingAggregatedBucketTransform::transform -> Aggregator::mergeBlocks(blocks, final)
+    Chunk merge(const std::vector<Chunk> & chunks)
+    {
+        uint64_t hint = 0;
+        for (auto & c : chunks)
+            hint += c.num_rows;
+        chgpu_agg * agg = nullptr;
+        check(chgpu_agg_create(ctx->get(), key_type, static_cast<uint32_t>(aggregates.size()), kinds.data(), types.data(), hint, &agg));
+        struct Free { void operator()(chgpu_agg * a) const { chgpu_agg_free(a); } };
+        std::unique_ptr<chgpu_agg, Free> guard(agg);
+        for (auto & c : chunks)
+        {
+            std::vector<const chgpu_col *> sc;
+            for (size_t w = 0; w < n_words; ++w)
+                sc.push_back(c.columns[1 + w]->handle());
+            check(chgpu_agg_merge_states(agg, c.columns[0]->handle(), sc.data(), c.num_rows));
+        }
+        chgpu_col * keys = nullptr;
+        std::vector<chgpu_col *> cols(final_result ? aggregates.size() : n_words, nullptr);
+        uint64_t groups = 0;
+        check(final_result ? chgpu_agg_finalize(agg, &keys, cols.data(), &groups) : chgpu_agg_export_states(agg, &keys, cols.data(), &groups));
+        Chunk out;
+        out.num_rows = groups;
+        out.columns.push_back(std::make_shared<ColumnVector>(ctx, keys));
+        for (auto * c : cols)
+            out.columns.push_back(std::make_shared<ColumnVector>(ctx, c));
+        return out;
+    }
+
+    /// the rows of `c` cut into their two-level buckets (empty buckets are left out), bucket_num ascending
+    std::vector<AggregatedChunk> splitByBucket(const Chunk & c)
+    {
+        std::vector<const chgpu_col *> ins;
+        for (auto & col : c.columns)
+            ins.push_back(col->handle());
+        std::vector<chgpu_col *> outs(ins.size(), nullptr);
+        uint64_t counts[NUM_BUCKETS] = {};
+        check(chgpu_partition_by_hash(ctx->get(), ins[0], NUM_BUCKETS, static_cast<uint32_t>(ins.size()), ins.data(), outs.data(), counts));
+        Columns whole;
+        for (auto * o : outs)
+            whole.push_back(std::make_shared<ColumnVector>(ctx, o));
+        std::vector<AggregatedChunk> parts;
+        uint64_t begin = 0;
+        for (int32_t b = 0; b < NUM_BUCKETS; ++b)
+        {
+            if (counts[b])
+            {
+                AggregatedChunk p;
+                p.bucket_num = b;
+                p.chunk.num_rows = counts[b];
+                for (auto & col : whole)
+                    p.chunk.columns.push_back(col->cut(begin, counts[b], col));
+                parts.push_back(std::move(p));
+            }
+            begin += counts[b];
+        }
+        return parts;
+    }
+
+    ContextPtr ctx;
+    int key_type;
+    std::vector<AggregateDescription> aggregates;
+    bool final_result;
+    std::vector<int> kinds, types;
+    size_t n_words = 0;
+    std::vector<int32_t> last_bucket_number; // GroupingAggregatedTransform::last_bucket_number
+    std::vector<bool> finished;
+    std::map<int32_t, std::vector<Chunk>> chunks_map;
+    std::vector<Chunk> single_level_chunks, overflow_chunks;
+    bool has_two_level = false, done = false;
+    int32_t next_bucket_to_push = 0;
 };
 
 /// ConcurrentHashJoin (`parallel_hash`, src/Interpreters/ConcurrentHashJoin.h:25-39, .cpp) with one slot per GPU: build rows are

@@ -472,6 +472,83 @@ int main(int argc, char ** argv)
             REQUIRE(v[0] == 7 && v[1] == 9);
         }
 
+        // ---- MergingAggregatedMemoryEfficientTransform: two sources' partial states (one as split two-level blocks bucket by bucket,
+        //      one unsplit) merged on the initiator; blocks come out in bucket order and add up to the aggregation of all rows ---------
+        {
+            const std::vector<AggregateDescription> descr{{CHGPU_AGG_SUM, CHGPU_I64, 0}, {CHGPU_AGG_COUNT, CHGPU_U64, 0}};
+            const int kinds[2] = {CHGPU_AGG_SUM, CHGPU_AGG_COUNT}, types[2] = {CHGPU_I64, CHGPU_U64};
+            const size_t half = n / 2;
+            chgpu_agg * src[2] = {nullptr, nullptr};
+            for (int sidx = 0; sidx < 2; ++sidx)
+            {
+                check(chgpu_agg_create(ctx->get(), CHGPU_U32, 2, kinds, types, 1000, &src[sidx]));
+                const chgpu_col * args[2] = {stripe.columns[0]->handle(), nullptr};
+                check(chgpu_agg_add_block(src[sidx], stripe.columns[1]->handle(), args, sidx == 0 ? 0 : half, sidx == 0 ? half : n));
+            }
+            GpuMergingAggregatedTransform merging(ctx, CHGPU_U32, descr, 2);
+            auto as_chunk = [&](chgpu_col * k, chgpu_col * w0, chgpu_col * w1, uint64_t rows) {
+                Chunk c;
+                c.num_rows = rows;
+                c.columns = {std::make_shared<ColumnVector>(ctx, k), std::make_shared<ColumnVector>(ctx, w0), std::make_shared<ColumnVector>(ctx, w1)};
+                return c;
+            };
+            {
+                chgpu_col * k = nullptr, * w[2] = {nullptr, nullptr};
+                uint64_t groups = 0;
+                check(chgpu_agg_export_states(src[1], &k, w, &groups));
+                merging.addChunk(1, AggregatedChunk{as_chunk(k, w[0], w[1], groups), -1, false}); // unsplit
+                merging.finishInput(1);
+            }
+            std::vector<AggregatedChunk> merged;
+            if (half)
+            {
+                chgpu_col * k = nullptr, * w[2] = {nullptr, nullptr};
+                uint64_t groups = 0, counts[256] = {};
+                check(chgpu_agg_export_states_two_level(src[0], &k, w, &groups, counts));
+                Chunk whole = as_chunk(k, w[0], w[1], groups);
+                uint64_t begin = 0;
+                for (int32_t b = 0; b < 256; ++b)
+                {
+                    if (counts[b])
+                    {
+                        AggregatedChunk c;
+                        c.bucket_num = b;
+                        c.chunk.num_rows = counts[b];
+                        for (auto & col : whole.columns)
+                            c.chunk.columns.push_back(col->cut(begin, counts[b], col));
+                        merging.addChunk(0, std::move(c));
+                    }
+                    begin += counts[b];
+                    if (b == 100)
+                        for (auto & m : merging.pull())
+                        {
+                            REQUIRE(m.bucket_num < 100);
+                            merged.push_back(std::move(m));
+                        }
+                }
+            }
+            merging.finishInput(0);
+            for (auto & m : merging.pull())
+                merged.push_back(std::move(m));
+            REQUIRE(merging.pull().empty());
+            size_t groups_out = 0;
+            int32_t last_bucket = -2;
+            for (auto & m : merged)
+            {
+                REQUIRE(!m.is_overflows && (m.bucket_num > last_bucket || (m.bucket_num == -1 && merged.size() == 1)));
+                last_bucket = m.bucket_num;
+                auto mk = m.chunk.columns[0]->getData<uint32_t>();
+                auto ms = m.chunk.columns[1]->getData<int64_t>();
+                auto mc = m.chunk.columns[2]->getData<uint64_t>();
+                for (size_t i = 0; i < mk.size(); ++i)
+                    REQUIRE(static_cast<uint64_t>(ms[i]) == want.at(mk[i]).first && mc[i] == want.at(mk[i]).second);
+                groups_out += mk.size();
+            }
+            REQUIRE(groups_out == want.size());
+            chgpu_agg_free(src[0]);
+            chgpu_agg_free(src[1]);
+        }
+
         // unsupported surface -> NOT_IMPLEMENTED (CPU fallback signal), not a crash
         bool fell_back = false;
         try
