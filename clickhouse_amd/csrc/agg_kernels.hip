@@ -1196,7 +1196,8 @@ __device__ __forceinline__ u32 tiles_load_block(const u32 * __restrict__ run_ind
 // finished by a plain loop after the pipelined one.
 // tile_index: u16 [n_tiles][P + 1]; the two entries of (tile, p) are read as one unaligned 32-bit load.
 // OPS: the compile-time state update code of k_agg_part_lds (one argument word: operations 1, 3, 5, 6).
-template <typename KT, u32 OPS, u32 TILE>
+// AOS: the sorted copy is one array of 12-byte {word, key} records (words0 = its base; k_rp_tilesort AOS), 4-byte keys only.
+template <typename KT, u32 OPS, u32 TILE, bool AOS = false>
 __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, const KT * __restrict__ keys, const u64 * __restrict__ words0,
                                                         const u32 * __restrict__ run_index, u32 n_tiles, u32 P, u64 * __restrict__ pending, u32 S, u32 cnt32,
                                                         const u64 * __restrict__ unit_list, const u32 * __restrict__ qstart, u32 * __restrict__ qctr, int experiment)
@@ -1363,8 +1364,20 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
             {
                 u32 i = row_of(m * 64 + lane, cs, dl);
                 i = i < (u32)last_row ? i : (u32)last_row; // (the lanes beyond the step's rows computed anything)
-                kv[m] = __builtin_nontemporal_load(&keys[i]);
-                av[m] = gbp_ops_use(OPS, 1, 3) ? __builtin_nontemporal_load(&words0[i]) : 0;
+                if constexpr (AOS)
+                {
+                    // (the word as ONE 8-byte load from its 4-byte aligned place: combining two loaded halves is an operation on the
+                    //  loaded registers, which the scheduler puts right behind the loads -- and the wave then waits for them there)
+                    typedef u64 u64_a4 __attribute__((aligned(4)));
+                    const u32 * r = (const u32 *)words0 + (u64)i * 3;
+                    av[m] = gbp_ops_use(OPS, 1, 3) ? (u64)__builtin_nontemporal_load((const u64_a4 *)r) : 0;
+                    kv[m] = (KT)__builtin_nontemporal_load(r + 2);
+                }
+                else
+                {
+                    kv[m] = __builtin_nontemporal_load(&keys[i]);
+                    av[m] = gbp_ops_use(OPS, 1, 3) ? __builtin_nontemporal_load(&words0[i]) : 0;
+                }
             }
         };
         auto process = [&](const u32 (&cs)[PR + 1], const u32 (&dl)[PR], const KT (&kv)[NS], const u64 (&av)[NS]) {
@@ -1391,7 +1404,13 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
                 for (u32 v = NS * 64 + lane; v < total; v += 64)
                 {
                     const u32 i = row_of(v, cs, dl);
-                    update_row(keys[i], gbp_ops_use(OPS, 1, 3) ? words0[i] : 0, i, std::false_type{}, cs, dl);
+                    if constexpr (AOS)
+                    {
+                        const u32 * r = (const u32 *)words0 + (u64)i * 3;
+                        update_row((KT)r[2], gbp_ops_use(OPS, 1, 3) ? (u64)r[0] | ((u64)r[1] << 32) : 0, i, std::false_type{}, cs, dl);
+                    }
+                    else
+                        update_row(keys[i], gbp_ops_use(OPS, 1, 3) ? words0[i] : 0, i, std::false_type{}, cs, dl);
                 }
         };
         {
@@ -1744,6 +1763,58 @@ static u64 agg_estimate_groups(u64 d, u64 m)
     return (u64)hi;
 }
 
+// The finish rounds of the tile-sorted plan over 12-byte records: the rows k_agg_tiles_lds left pending (LDS table full) go through the
+// HBM table; a row that meets the max-fill limit stays pending for the next round (after the table has grown).
+__global__ __launch_bounds__(AGG_THREADS) void k_agg_tiles_pending_aos(AggTable t, AggDesc d, const u32 * __restrict__ rec, u64 n, u64 * __restrict__ pending)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave0 = ((u64)blockIdx.x * AGG_THREADS + threadIdx.x) >> 6;
+    const u64 n_waves = ((u64)gridDim.x * AGG_THREADS) >> 6;
+    const u64 n_groups64 = (n + 63) / 64;
+    for (u64 g = wave0; g < n_groups64; g += n_waves)
+    {
+        const u64 word = pending[g];
+        if (word == 0)
+            continue;
+        const u64 i = g * 64 + lane;
+        bool failed = false;
+        if (i < n && ((word >> lane) & 1))
+        {
+            const u32 * r = rec + i * 3;
+            const u64 slot = table_emplace(t, (u64)r[2], true); // records are {word, key}
+            if (slot == ~0ull)
+                failed = true;
+            else
+                add_vals_global(t, d, slot, (u64)r[0] | ((u64)r[1] << 32), 0, 1);
+        }
+        const u64 b = __ballot(failed);
+        if (lane == 0)
+            pending[g] = b;
+        if (b != 0 && lane == 0)
+            t.ctrl->overflow = 1;
+    }
+}
+
+static int agg_finish_rounds_aos(chgpu_agg * a, const AggDesc & d, const u32 * rec, u64 n, u64 * pending)
+{
+    chgpu_ctx * ctx = a->ctx;
+    for (int round = 0; round < 64; ++round)
+    {
+        AggCtrl c;
+        CHGPU_TRY(agg_read_ctrl(a, &c));
+        if (!c.overflow && c.n_groups <= a->t.max_fill)
+            return CHGPU_OK;
+        CHGPU_TRY(agg_grow(a, c.n_groups, c.has_zero != 0));
+        if (!c.overflow)
+            return CHGPU_OK;
+        const u32 grid = chgpu_grid_for(ctx, n, AGG_THREADS, 8);
+        hipLaunchKernelGGL(k_agg_tiles_pending_aos, dim3(grid), dim3(AGG_THREADS), 0, ctx->stream, a->t, d, rec, n, pending);
+        ctx->counters[6] += 1;
+        CHGPU_HIP(hipGetLastError());
+    }
+    return chgpu_set_error(CHGPU_ERR_LOGICAL, "aggregation table did not converge after 64 growth rounds");
+}
+
 // The TILE-SORTED plan of a partitioned executeOnBlock (k_rp_tilesort + k_agg_tiles_lds): one level, one 8-byte argument column
 // (or none besides counts), 4- or 8-byte keys, a compile-time state update.  Two passes over the rows instead of three (no histogram),
 // and the partition pass writes whole lines in row order.  NOT_IMPLEMENTED = the shape does not fit (the caller runs the scatter plan).
@@ -1795,7 +1866,11 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
     unsigned short * tidx = (unsigned short *)((char *)pending + pend_b);
     u32 * run_index = (u32 *)((char *)tidx + idx_b);
     void * pkeys = (char *)run_index + ridx_b;
-    u64 * pwords = (u64 *)((char *)pkeys + keys_b);
+    // 4-byte keys: the sorted copy as 12-byte records (one piece per run and tile for the gather instead of two); the records take the
+    // key region and the word region together, and `pwords` is then the base of the record array
+    static const bool no_aos = getenv("CHGPU_TUNE_GB_NO_AOS") != nullptr;
+    const bool aos = key32 && !no_aos;
+    u64 * pwords = aos ? (u64 *)pkeys : (u64 *)((char *)pkeys + keys_b);
     // the aggregate pass reads the widened words of the sorted copy
     for (u32 j = 0; j < a->n_aggs; ++j)
         if (a->kinds[j] != CHGPU_AGG_COUNT && ((agg_mask >> j) & 1))
@@ -1848,27 +1923,29 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
     CHGPU_HIP(hipMemsetAsync(scratch, 0, tot_b + unit_b + pend_b, ctx->stream));
     int rc = CHGPU_OK;
     const size_t lds_sort = rp_tilesort_lds_bytes(TILE, P, key_w);
-#define GB_TILESORT(TILE_, KT_, AT_, EX_)                                                                                                        \
+#define GB_TILESORT(TILE_, KT_, AT_, EX_, AOS_)                                                                                                  \
     do                                                                                                                                          \
     {                                                                                                                                           \
-        auto kern = k_rp_tilesort<TILE_, KT_, GbpPartFn<KT_>, RP_THREADS, AT_, EX_>;                                                             \
+        auto kern = k_rp_tilesort<TILE_, KT_, GbpPartFn<KT_>, RP_THREADS, AT_, EX_, AOS_>;                                                       \
         rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
         if (rc == CHGPU_OK)                                                                                                                     \
             hipLaunchKernelGGL(kern, dim3(G), dim3(RP_THREADS), lds_sort, ctx->stream, (const KT_ *)key_col->data + row_begin, (const AT_ *)arg_cols[arg_j]->data + row_begin, n, \
                                rows_per_wg, P, (KT_ *)pkeys, pwords, tidx, part_total, GbpPartFn<KT_>{P, GBP_MULT});                             \
     } while (0)
-#define GB_TILESORT_ARG(TILE_, KT_)                                   \
+#define GB_TILESORT_ARG(TILE_, KT_, AOS_)                             \
     do                                                                \
     {                                                                 \
-        if (arg_w == 8) GB_TILESORT(TILE_, KT_, u64, 0);              \
-        else if (arg_ex == 3) GB_TILESORT(TILE_, KT_, u32, 3);        \
-        else if (arg_ex == 4) GB_TILESORT(TILE_, KT_, u32, 4);        \
-        else GB_TILESORT(TILE_, KT_, u32, 0);                         \
+        if (arg_w == 8) GB_TILESORT(TILE_, KT_, u64, 0, AOS_);        \
+        else if (arg_ex == 3) GB_TILESORT(TILE_, KT_, u32, 3, AOS_);  \
+        else if (arg_ex == 4) GB_TILESORT(TILE_, KT_, u32, 4, AOS_);  \
+        else GB_TILESORT(TILE_, KT_, u32, 0, AOS_);                   \
     } while (0)
-    if (key32)
-        GB_TILESORT_ARG(12288, u32);
+    if (aos)
+        GB_TILESORT_ARG(12288, u32, true);
+    else if (key32)
+        GB_TILESORT_ARG(12288, u32, false);
     else
-        GB_TILESORT_ARG(8192, u64);
+        GB_TILESORT_ARG(8192, u64, false);
 #undef GB_TILESORT_ARG
 #undef GB_TILESORT
     if (rc == CHGPU_OK)
@@ -1878,33 +1955,37 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
         const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
         const size_t keys_lds = ((size_t)key_w * (S + 1) + 7) & ~(size_t)7;
         const size_t lds_ag = keys_lds + (size_t)(S + 1) * (8 * n8 + 4 * n4) + 16;
-#define GB_TILES(KT_, OPS_, TILE_)                                                                                                                    \
+#define GB_TILES(KT_, OPS_, TILE_, AOS_)                                                                                                              \
     do                                                                                                                                                \
     {                                                                                                                                                 \
-        auto kern = k_agg_tiles_lds<KT_, OPS_, TILE_>;                                                                                                 \
+        auto kern = k_agg_tiles_lds<KT_, OPS_, TILE_, AOS_>;                                                                                           \
         rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ag) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE; \
         if (rc == CHGPU_OK)                                                                                                                           \
             hipLaunchKernelGGL(kern, dim3(G), dim3(1024), lds_ag, ctx->stream, a->t, d, (const KT_ *)pkeys, (const u64 *)pwords, (const u32 *)run_index, n_tiles, P, \
                                pending, S, cnt32, (const u64 *)unit_list, (const u32 *)unit_qstart, unit_ctr, tiles_experiment);                      \
     } while (0)
-#define GB_TILES_OPS(KT_, TILE_)                              \
+#define GB_TILES_OPS(KT_, TILE_, AOS_)                        \
     switch (ops)                                              \
     {                                                         \
-        case 0x51: GB_TILES(KT_, 0x51, TILE_); break;         \
-        case 0x15: GB_TILES(KT_, 0x15, TILE_); break;         \
-        case 0x1: GB_TILES(KT_, 0x1, TILE_); break;           \
-        case 0x53: GB_TILES(KT_, 0x53, TILE_); break;         \
-        case 0x3: GB_TILES(KT_, 0x3, TILE_); break;           \
-        case 0x61: GB_TILES(KT_, 0x61, TILE_); break;         \
-        default: GB_TILES(KT_, 0x16, TILE_); break;           \
+        case 0x51: GB_TILES(KT_, 0x51, TILE_, AOS_); break;   \
+        case 0x15: GB_TILES(KT_, 0x15, TILE_, AOS_); break;   \
+        case 0x1: GB_TILES(KT_, 0x1, TILE_, AOS_); break;     \
+        case 0x53: GB_TILES(KT_, 0x53, TILE_, AOS_); break;   \
+        case 0x3: GB_TILES(KT_, 0x3, TILE_, AOS_); break;     \
+        case 0x61: GB_TILES(KT_, 0x61, TILE_, AOS_); break;   \
+        default: GB_TILES(KT_, 0x16, TILE_, AOS_); break;     \
     }
-        if (key32)
+        if (aos)
         {
-            GB_TILES_OPS(u32, 12288)
+            GB_TILES_OPS(u32, 12288, true)
+        }
+        else if (key32)
+        {
+            GB_TILES_OPS(u32, 12288, false)
         }
         else
         {
-            GB_TILES_OPS(u64, 8192)
+            GB_TILES_OPS(u64, 8192, false)
         }
 #undef GB_TILES_OPS
 #undef GB_TILES
@@ -1914,7 +1995,7 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
     if (rc == CHGPU_OK && hipGetLastError() != hipSuccess)
         rc = CHGPU_ERR_DEVICE;
     if (rc == CHGPU_OK)
-        rc = agg_finish_rounds(a, d, pkeys, key32 ? CHGPU_U32 : CHGPU_U64, 0, n_pad, pending);
+        rc = aos ? agg_finish_rounds_aos(a, d, (const u32 *)pwords, n_pad, pending) : agg_finish_rounds(a, d, pkeys, key32 ? CHGPU_U32 : CHGPU_U64, 0, n_pad, pending);
     else
     {
         (void)hipGetLastError();
