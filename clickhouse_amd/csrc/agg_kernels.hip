@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
             {
                 u32 i = row_of(m * 64 + lane, cs, dl);
                 i = i < (u32)last_row ? i : (u32)last_row; // (the lanes beyond the step's rows computed anything)
-                if constexpr (AOS)
+                if constexpr (AOS && sizeof(KT) == 4)
                 {
                     // (the word as ONE 8-byte load from its 4-byte aligned place: combining two loaded halves is an operation on the
                     //  loaded registers, which the scheduler puts right behind the loads -- and the wave then waits for them there)
@@ -1372,6 +1372,13 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
                     const u32 * r = (const u32 *)words0 + (u64)i * 3;
                     av[m] = gbp_ops_use(OPS, 1, 3) ? (u64)__builtin_nontemporal_load((const u64_a4 *)r) : 0;
                     kv[m] = (KT)__builtin_nontemporal_load(r + 2);
+                }
+                else if constexpr (AOS)
+                {
+                    typedef u64 v2q __attribute__((ext_vector_type(2)));
+                    const v2q rec = __builtin_nontemporal_load((const v2q *)words0 + i); // {word, key}
+                    av[m] = rec.x;
+                    kv[m] = (KT)rec.y;
                 }
                 else
                 {
@@ -1404,11 +1411,13 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
                 for (u32 v = NS * 64 + lane; v < total; v += 64)
                 {
                     const u32 i = row_of(v, cs, dl);
-                    if constexpr (AOS)
+                    if constexpr (AOS && sizeof(KT) == 4)
                     {
                         const u32 * r = (const u32 *)words0 + (u64)i * 3;
                         update_row((KT)r[2], gbp_ops_use(OPS, 1, 3) ? (u64)r[0] | ((u64)r[1] << 32) : 0, i, std::false_type{}, cs, dl);
                     }
+                    else if constexpr (AOS)
+                        update_row((KT)words0[2 * (u64)i + 1], words0[2 * (u64)i], i, std::false_type{}, cs, dl);
                     else
                         update_row(keys[i], gbp_ops_use(OPS, 1, 3) ? words0[i] : 0, i, std::false_type{}, cs, dl);
                 }
@@ -1765,7 +1774,7 @@ static u64 agg_estimate_groups(u64 d, u64 m)
 
 // The finish rounds of the tile-sorted plan over 12-byte records: the rows k_agg_tiles_lds left pending (LDS table full) go through the
 // HBM table; a row that meets the max-fill limit stays pending for the next round (after the table has grown).
-__global__ __launch_bounds__(AGG_THREADS) void k_agg_tiles_pending_aos(AggTable t, AggDesc d, const u32 * __restrict__ rec, u64 n, u64 * __restrict__ pending)
+__global__ __launch_bounds__(AGG_THREADS) void k_agg_tiles_pending_aos(AggTable t, AggDesc d, const u32 * __restrict__ rec, int key64, u64 n, u64 * __restrict__ pending)
 {
     const u32 lane = threadIdx.x & 63;
     const u64 wave0 = ((u64)blockIdx.x * AGG_THREADS + threadIdx.x) >> 6;
@@ -1780,8 +1789,8 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_tiles_pending_aos(AggTable 
         bool failed = false;
         if (i < n && ((word >> lane) & 1))
         {
-            const u32 * r = rec + i * 3;
-            const u64 slot = table_emplace(t, (u64)r[2], true); // records are {word, key}
+            const u32 * r = rec + i * (key64 ? 4 : 3); // records are {word, key}: 12 bytes with a 4-byte key, 16 with an 8-byte key
+            const u64 slot = table_emplace(t, key64 ? (u64)r[2] | ((u64)r[3] << 32) : (u64)r[2], true);
             if (slot == ~0ull)
                 failed = true;
             else
@@ -1795,7 +1804,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_tiles_pending_aos(AggTable 
     }
 }
 
-static int agg_finish_rounds_aos(chgpu_agg * a, const AggDesc & d, const u32 * rec, u64 n, u64 * pending)
+static int agg_finish_rounds_aos(chgpu_agg * a, const AggDesc & d, const u32 * rec, int key64, u64 n, u64 * pending)
 {
     chgpu_ctx * ctx = a->ctx;
     for (int round = 0; round < 64; ++round)
@@ -1808,7 +1817,7 @@ static int agg_finish_rounds_aos(chgpu_agg * a, const AggDesc & d, const u32 * r
         if (!c.overflow)
             return CHGPU_OK;
         const u32 grid = chgpu_grid_for(ctx, n, AGG_THREADS, 8);
-        hipLaunchKernelGGL(k_agg_tiles_pending_aos, dim3(grid), dim3(AGG_THREADS), 0, ctx->stream, a->t, d, rec, n, pending);
+        hipLaunchKernelGGL(k_agg_tiles_pending_aos, dim3(grid), dim3(AGG_THREADS), 0, ctx->stream, a->t, d, rec, key64, n, pending);
         ctx->counters[6] += 1;
         CHGPU_HIP(hipGetLastError());
     }
@@ -1866,10 +1875,10 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
     unsigned short * tidx = (unsigned short *)((char *)pending + pend_b);
     u32 * run_index = (u32 *)((char *)tidx + idx_b);
     void * pkeys = (char *)run_index + ridx_b;
-    // 4-byte keys: the sorted copy as 12-byte records (one piece per run and tile for the gather instead of two); the records take the
-    // key region and the word region together, and `pwords` is then the base of the record array
+    // the sorted copy as {word, key} records (one piece per run and tile for the gather instead of two); the records take the key region
+    // and the word region together, and `pwords` is then the base of the record array
     static const bool no_aos = getenv("CHGPU_TUNE_GB_NO_AOS") != nullptr;
-    const bool aos = key32 && !no_aos;
+    const bool aos = !no_aos;
     u64 * pwords = aos ? (u64 *)pkeys : (u64 *)((char *)pkeys + keys_b);
     // the aggregate pass reads the widened words of the sorted copy
     for (u32 j = 0; j < a->n_aggs; ++j)
@@ -1940,8 +1949,10 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
         else if (arg_ex == 4) GB_TILESORT(TILE_, KT_, u32, 4, AOS_);  \
         else GB_TILESORT(TILE_, KT_, u32, 0, AOS_);                   \
     } while (0)
-    if (aos)
+    if (aos && key32)
         GB_TILESORT_ARG(12288, u32, true);
+    else if (aos)
+        GB_TILESORT_ARG(8192, u64, true);
     else if (key32)
         GB_TILESORT_ARG(12288, u32, false);
     else
@@ -1975,9 +1986,13 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
         case 0x61: GB_TILES(KT_, 0x61, TILE_, AOS_); break;   \
         default: GB_TILES(KT_, 0x16, TILE_, AOS_); break;     \
     }
-        if (aos)
+        if (aos && key32)
         {
             GB_TILES_OPS(u32, 12288, true)
+        }
+        else if (aos)
+        {
+            GB_TILES_OPS(u64, 8192, true)
         }
         else if (key32)
         {
@@ -1995,7 +2010,7 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
     if (rc == CHGPU_OK && hipGetLastError() != hipSuccess)
         rc = CHGPU_ERR_DEVICE;
     if (rc == CHGPU_OK)
-        rc = aos ? agg_finish_rounds_aos(a, d, (const u32 *)pwords, n_pad, pending) : agg_finish_rounds(a, d, pkeys, key32 ? CHGPU_U32 : CHGPU_U64, 0, n_pad, pending);
+        rc = aos ? agg_finish_rounds_aos(a, d, (const u32 *)pwords, key32 ? 0 : 1, n_pad, pending) : agg_finish_rounds(a, d, pkeys, key32 ? CHGPU_U32 : CHGPU_U64, 0, n_pad, pending);
     else
     {
         (void)hipGetLastError();

@@ -496,8 +496,8 @@ __global__ __launch_bounds__(THREADS) void k_rp_scatter(const KT * __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // AT / EX: the argument column as stored -- u64 (EX 0), or a 4-byte type widened on the way into LDS: EX 0 zero-extended (UInt32),
 // 3 sign-extended (Int32), 4 Float32 -> Float64 bits; the sorted copy always holds 8-byte words.
-// AOS (4-byte keys): the sorted copy is ONE array of 12-byte records {word, key} (out_words = its base, out_keys unused) instead of a
-// key array and a word array: a partition's run is then one contiguous piece per tile, not two -- the consumer's gather touches
+// AOS: the sorted copy is ONE array of {word, key} records -- 12 bytes for 4-byte keys, 16 for 8-byte keys (out_words = its base,
+// out_keys unused) -- instead of a key array and a word array: a partition's run is then one contiguous piece per tile, not two -- the consumer's gather touches
 // (576 + 124) / 128 = 5.5 lines per 48-row run instead of 2.5 + 3.9.
 template <u32 GBP_TILE, typename KT, typename PartFn, u32 THREADS = RP_THREADS, typename AT = u64, int EX = 0, bool AOS = false>
 __global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__ keys, const AT * __restrict__ words, u64 n, u64 rows_per_wg, u32 P,
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__
     const char * kbase = (const char *)(keys + r0 - shift);
     const char * wbase = (const char *)(words + r0 - shift);
     char * okbase = (char *)(out_keys + r0);
-    char * owbase = AOS ? (char *)out_words + r0 * 12 : (char *)(out_words + r0);
+    char * owbase = AOS ? (char *)out_words + r0 * (8 + sizeof(KT)) : (char *)(out_words + r0);
     char * ixbase = (char *)(tile_index + (r0 / GBP_TILE) * (u64)(P + 1));
     constexpr u32 RPT = GBP_TILE / THREADS;
     static_assert(RPT % 4 == 0, "whole 16-byte pieces per thread");
@@ -641,14 +641,19 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__
         for (u32 j = 0; j < RPT; ++j)
         {
             const u32 pos = tile_off[part[j]] + rank[j];
-            if constexpr (AOS)
+            if constexpr (AOS && sizeof(KT) == 4)
             {
-                static_assert(!AOS || sizeof(KT) == 4, "12-byte records");
                 u32 * rec = (u32 *)gb_lds + 3 * pos;
                 const u64 w = word_at(trel, j);
                 rec[0] = (u32)w; // word first: the consumer's 12-byte load then puts the 8-byte word into an even-aligned register pair
                 rec[1] = (u32)(w >> 32);
                 rec[2] = (u32)key_at(trel, j);
+            }
+            else if constexpr (AOS)
+            {
+                u64 * rec = (u64 *)gb_lds + 2 * pos; // 16-byte records {word, key}
+                rec[0] = word_at(trel, j);
+                rec[1] = (u64)key_at(trel, j);
             }
             else
             {
@@ -674,10 +679,10 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__
 #pragma unroll
             // (AOS: the LDS image -- word region then key region -- is one record array and goes out as it lies, to one base)
             for (u32 q = 0; q < KPIECES; ++q)
-                __builtin_nontemporal_store(kq[q], (v4d *)((AOS ? owbase + trel * 12u + WPIECES * THREADS * 16u : okbase + trel * (u32)sizeof(KT)) + (q * THREADS + threadIdx.x) * 16u));
+                __builtin_nontemporal_store(kq[q], (v4d *)((AOS ? owbase + trel * (8u + (u32)sizeof(KT)) + WPIECES * THREADS * 16u : okbase + trel * (u32)sizeof(KT)) + (q * THREADS + threadIdx.x) * 16u));
 #pragma unroll
             for (u32 q = 0; q < WPIECES; ++q)
-                __builtin_nontemporal_store(wq[q], (v2q *)(owbase + trel * (AOS ? 12u : 8u) + (q * THREADS + threadIdx.x) * 16u));
+                __builtin_nontemporal_store(wq[q], (v2q *)(owbase + trel * (AOS ? 8u + (u32)sizeof(KT) : 8u) + (q * THREADS + threadIdx.x) * 16u));
             *(unsigned short *)(ixbase + (tile_no * (P + 1) + e_idx) * 2u) = (unsigned short)eo; // no branch around a store
         }
         __builtin_amdgcn_sched_barrier(0);
