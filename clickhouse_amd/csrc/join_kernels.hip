@@ -1705,6 +1705,282 @@ static int join_probe_agg_regions(chgpu_join * j, const chgpu_col * key_col, con
     return chgpu_read_back(ctx, result2, res, 16);
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-staged probe (unique build keys, integer payload): the probe keys are partitioned TWICE -- 64 contiguous first-level partitions
+// by the top bits of the home slot (k_rp_hist_wide + k_rp_scatter, runs of 256 keys), then tile-sorted inside them by the next bits
+// (k_rp_tilesort_keys) -- down to table slices of 8192 cells, which one workgroup stages in LDS as {key, payload} (the payload gathered
+// through the row id while staging: once per build row, not once per probe row) and then answers every key of that slice from LDS.
+// A probe key costs two streaming passes and one LDS look-up instead of an L2 gather; the {key, payload} copy of the table
+// (k_join_fuse_payload) is not needed.  A linear-probing chain that runs past the slice end finds the next slice's first JPL2_TAIL cells
+// in LDS too, and the global table behind them.
+// ---------------------------------------------------------------------------------------------
+static constexpr u32 JPL2_LG_CELLS = 12, JPL2_CELLS = 1u << JPL2_LG_CELLS, JPL2_TAIL = 256, JPL2_TILE = 16384, JPL2_LG_P1 = 6, JPL2_THREADS = 512;
+// (4096-cell slices and 512-thread workgroups: two workgroups per CU, so one's staging round trips overlap the other's probing --
+//  8192 cells x 1024 threads, one per CU: 0.68 ms for C4's 1e8 keys)
+
+struct JoinBucket2Fn
+{
+    u64 mask;
+    u32 shift2; // home slot -> second-level region (slice) number
+    u32 lg_p2;  // slices per first-level partition
+    __device__ __forceinline__ u32 operator()(u64 key, u64 first) const
+    {
+        const u32 r = (u32)((dev_intHash64(key) & mask) >> shift2), r0 = (u32)((dev_intHash64(first) & mask) >> shift2) >> lg_p2 << lg_p2;
+        return r - r0; // 0 .. 2 * P2 - 1 for the tile's own and the next first-level partition (keys sort by partition, so r >= r0)
+    }
+};
+
+__global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, int variant, const u64 * __restrict__ keys2, u64 n, const u64 * __restrict__ off1, u32 G, u32 lg_p2,
+                                                         const unsigned short * __restrict__ tile_index, const u64 * __restrict__ payload,
+                                                         const u64 * __restrict__ block_base, u64 n_blocks, u32 * __restrict__ unit_ctr, u32 * __restrict__ stray_flag,
+                                                         unsigned long long * __restrict__ result2)
+{
+    // The hot loop touches global memory only to stream the keys in: everything a key can meet -- its slice, the cells behind it, the
+    // zero key's cell -- is staged in LDS first, and the one case that is not (a chain longer than the staged window) raises the
+    // stray flag instead of reading the table (the host then discards this run).  A conditional global load inside the loop would
+    // make every wait for the prefetched keys a full drain.
+    extern __shared__ __attribute__((aligned(16))) unsigned char jpl2_lds[];
+    jv2 * cells = (jv2 *)jpl2_lds; // [JPL2_CELLS + JPL2_TAIL] the slice and the cells behind it, then [1] the zero key {present, payload}
+    constexpr u32 P1 = 1u << JPL2_LG_P1, WIN = JPL2_CELLS + JPL2_TAIL;
+    __shared__ u64 s_off[P1 + 1];
+    __shared__ u32 sh_unit;
+    const u32 P2 = 1u << lg_p2, R2 = P1 << lg_p2, PB = 2 * P2;
+    for (u32 p = threadIdx.x; p <= P1; p += JPL2_THREADS)
+        s_off[p] = p < P1 ? off1[(u64)p * G] : n;
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const u64 mask = t.capacity - 1;
+    auto flat_of = [&](u64 rowid) -> u64 { return n_blocks == 1 ? (rowid & 0xFFFFFFFFull) : block_base[rowid >> 32] + (rowid & 0xFFFFFFFFull); };
+    const bool miss_counts = variant == PV_ALL_LEFT || variant == PV_ANY_LEFT || variant == PV_ANTI_LEFT;
+    const bool anti = variant == PV_ANTI_LEFT;
+    if (threadIdx.x == 0)
+    {
+        const bool hz = t.ctrl->has_zero != 0; // the zero key lives out of line (cell `capacity`)
+        cells[WIN] = jv2{hz ? 1ull : 0ull, hz ? payload[flat_of(t.kv[2 * t.capacity + 1])] : 0ull};
+    }
+    u64 cnt = 0, isum = 0;
+    bool stray = false;
+    for (;;)
+    {
+        __syncthreads(); // the previous unit's cells have been read by everyone
+        if (threadIdx.x == 0)
+            sh_unit = atomicAdd(unit_ctr, 1u);
+        __syncthreads();
+        const u32 r2 = sh_unit;
+        if (r2 >= R2)
+            break; // (every workgroup reaches this exit)
+        const u32 p1 = r2 >> lg_p2, p2 = r2 & (P2 - 1);
+        const u64 rb = s_off[p1], re = s_off[p1 + 1];
+        if (rb == re)
+            continue; // no probe key lands in this partition
+        // stage the slice, {key, row id} -> {key, payload}: all the cell loads first, then all the payload loads (two round trips, not 2 x 9)
+        const u64 slice = (u64)r2 * JPL2_CELLS;
+        {
+            constexpr u32 NC = (WIN + JPL2_THREADS - 1) / JPL2_THREADS;
+            jv2 cl[NC];
+#pragma unroll
+            for (u32 i = 0; i < NC; ++i)
+            {
+                const u32 c = threadIdx.x + i * JPL2_THREADS;
+                cl[i] = *(const jv2 *)(t.kv + 2 * ((slice + (c < WIN ? c : 0)) & mask));
+            }
+#pragma unroll
+            for (u32 i = 0; i < NC; ++i)
+                cl[i].y = payload[cl[i].x != 0 ? flat_of(cl[i].y) : 0];
+#pragma unroll
+            for (u32 i = 0; i < NC; ++i)
+            {
+                const u32 c = threadIdx.x + i * JPL2_THREADS;
+                if (c < WIN)
+                    cells[c] = cl[i];
+            }
+        }
+        __syncthreads();
+        const u32 t_lo = (u32)(rb / JPL2_TILE), t_hi = (u32)((re - 1) / JPL2_TILE);
+        // This wave's tiles: t_lo + wave, + NW, ...  Lane k fetches the run of tile k (one round trip for all of them instead of one
+        // per tile); the keys of tile k + 1 are in flight while tile k is answered from LDS.
+        constexpr u32 NW = JPL2_THREADS / 64;
+        const u32 my_tiles = t_lo + wave <= t_hi ? (t_hi - t_lo - wave) / NW + 1 : 0;
+        auto probe_one = [&](u64 key) {
+            bool found;
+            u64 v;
+            if (key == 0)
+            {
+                const jv2 z = cells[WIN];
+                found = z.x != 0;
+                v = z.y;
+            }
+            else
+            {
+                u32 c = (u32)((dev_intHash64(key) & mask) - slice); // the home slot: inside the slice by construction
+                jv2 cell = cells[c];
+                while (cell.x != key && cell.x != 0 && c + 1 < WIN)
+                    cell = cells[++c];
+                stray = stray || (cell.x != key && cell.x != 0); // the chain runs on past the staged window
+                found = cell.x == key;
+                v = cell.y;
+            }
+            cnt += found ? (anti ? 0 : 1) : (miss_counts ? 1 : 0);
+            isum += (found && !anti) ? v : 0;
+        };
+        for (u32 kb = 0; kb < my_tiles; kb += 64)
+        {
+            u32 st_l = 0, ln_l = 0;
+            if (kb + lane < my_tiles)
+            {
+                const u32 tile = t_lo + wave + (kb + lane) * NW;
+                const u64 row0 = (u64)tile * JPL2_TILE;
+                u32 lo = 0, hi = P1 - 1; // the first-level partition that owns the tile's first row: the largest p with s_off[p] <= row0
+                while (lo < hi)          // (empty partitions share their start with the next one: the largest such p is the owner)
+                {
+                    const u32 mid = (lo + hi + 1) >> 1;
+                    if (s_off[mid] <= row0)
+                        lo = mid;
+                    else
+                        hi = mid - 1;
+                }
+                const u32 bucket = (p1 - lo) * P2 + p2;
+                if (bucket < PB) // (else: a tile spanning three partitions -- k_rp_tilesort_keys raised the stray flag, the host discards this run)
+                {
+                    const u32 ia = tile_index[(u64)tile * (PB + 1) + bucket], ib = tile_index[(u64)tile * (PB + 1) + bucket + 1];
+                    st_l = ia;
+                    ln_l = ib - ia;
+                }
+            }
+            const u32 nk = my_tiles - kb < 64 ? my_tiles - kb : 64;
+            constexpr u32 U = 2;
+            auto run_of = [&](u32 k, u64 & row, u32 & len) {
+                const u32 kk = k < nk ? k : nk - 1;
+                const u32 st = (u32)__builtin_amdgcn_readlane((int)st_l, (int)kk);
+                len = k < nk ? (u32)__builtin_amdgcn_readlane((int)ln_l, (int)kk) : 0;
+                row = (u64)(t_lo + wave + (kb + kk) * NW) * JPL2_TILE + st;
+            };
+            auto load_keys = [&](u64 row, u32 len, u32 o0, u64 (&key)[U]) {
+#pragma unroll
+                for (u32 u = 0; u < U; ++u)
+                {
+                    const u32 o = o0 + u * 64 + lane;
+                    key[u] = __builtin_nontemporal_load(&keys2[row + (o < len ? o : 0)]);
+                }
+            };
+            auto probe_keys = [&](u32 len, u32 o0, const u64 (&key)[U]) {
+#pragma unroll
+                for (u32 u = 0; u < U; ++u)
+                    if (o0 + u * 64 + lane < len)
+                        probe_one(key[u]);
+            };
+            // batches of TB tiles: all their key loads are issued before the first look-up (a run is only ~128 keys = two loads per lane:
+            // tile by tile, even double-buffered, the wave had two tiles' worth of loads in flight and waited out the latency each time)
+            constexpr u32 TB = 8;
+            for (u32 k0 = 0; k0 < nk; k0 += TB)
+            {
+                u64 key[TB][U], row[TB];
+                u32 len[TB];
+#pragma unroll
+                for (u32 q = 0; q < TB; ++q)
+                {
+                    run_of(k0 + q, row[q], len[q]);
+                    load_keys(row[q], len[q], 0, key[q]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (u32 q = 0; q < TB; ++q)
+                {
+                    probe_keys(len[q], 0, key[q]);
+                    for (u32 o0 = 64 * U; o0 < len[q]; o0 += 64 * U) // a run longer than 128 keys (skew): the rest, unpipelined
+                    {
+                        u64 kx[U];
+                        load_keys(row[q], len[q], o0, kx);
+                        probe_keys(len[q], o0, kx);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1)
+    {
+        cnt += __shfl_xor(cnt, dlt, 64);
+        isum += __shfl_xor(isum, dlt, 64);
+    }
+    if (lane == 0 && (cnt || isum))
+    {
+        atomicAdd(&result2[0], (unsigned long long)cnt);
+        atomicAdd(&result2[1], (unsigned long long)isum);
+    }
+    if (stray)
+        *stray_flag = 1;
+}
+
+// -> CHGPU_OK with res[] filled, or NOT_IMPLEMENTED (shape does not fit / a tile straddled three partitions): the caller goes on with the region probe
+static int join_probe_agg_lds(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * right_payload, int variant, u64 res[2])
+{
+    chgpu_ctx * ctx = j->ctx;
+    const u64 n = key_col->rows, cap = j->t.capacity;
+    static const bool off = getenv("CHGPU_TUNE_JOIN_NO_LDS_PROBE") != nullptr;
+    static const u64 min_rows = getenv("CHGPU_TUNE_JOIN_LDS_MIN_ROWS") ? strtoull(getenv("CHGPU_TUNE_JOIN_LDS_MIN_ROWS"), nullptr, 10) : (8ull << 20);
+    u32 lg_cap = 0;
+    while ((1ull << lg_cap) < cap)
+        ++lg_cap;
+    if (off || !j->unique_keys || j->t.pf || !right_payload || chgpu_type_is_float(right_payload->type) || chgpu_type_size(right_payload->type) != 8
+        || chgpu_type_size(j->key_type) != 8 || n < min_rows
+        || n + JPL2_TILE + RP_SCATTER_SLACK >= (1ull << 32) || lg_cap < JPL2_LG_CELLS + JPL2_LG_P1 || lg_cap > JPL2_LG_CELLS + JPL2_LG_P1 + 7 || ((uintptr_t)key_col->data % 16) != 0)
+        return CHGPU_ERR_NOT_IMPLEMENTED;
+    const u32 lg_r2 = lg_cap - JPL2_LG_CELLS, lg_p2 = lg_r2 - JPL2_LG_P1, P1 = 1u << JPL2_LG_P1, PB = 2u << lg_p2;
+    const JoinRegionFn fn1{cap - 1, lg_cap - JPL2_LG_P1};
+    const JoinBucket2Fn fn2{cap - 1, JPL2_LG_CELLS, lg_p2};
+    const u32 G = (u32)ctx->num_cus;
+    const u64 rows_per_wg = ((n + G - 1) / G + 63) / 64 * 64;
+    const u64 rows_per_wg2 = ((n + G - 1) / G + JPL2_TILE - 1) / JPL2_TILE * JPL2_TILE;
+    const u64 n_tiles = (n + JPL2_TILE - 1) / JPL2_TILE, n_pad = n_tiles * JPL2_TILE;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const u64 m = (u64)P1 * G;
+    const size_t cnt_b = al(m * 4), off_b = al(m * 8 + 8), tmp_b = chgpu_scan_tmp_bytes(m), k1_b = al((n + RP_SCATTER_SLACK) * 8), k2_b = al(n_pad * 8 + 64), // (+ slack: an empty run at the very end of the last tile is addressed one row past it)
+                 ix_b = al(n_tiles * (PB + 1) * 2 + 16);
+    void * scratch = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, cnt_b + off_b + 256 + tmp_b + k1_b + k2_b + ix_b + 256, &scratch));
+    u32 * counts = (u32 *)scratch;
+    u64 * offsets = (u64 *)((char *)scratch + cnt_b);
+    u64 * total_dev = (u64 *)((char *)scratch + cnt_b + off_b); // [0] scan total, [2..3] the result, [4] unit counter + stray flag
+    void * tmp = (char *)scratch + cnt_b + off_b + 256;
+    u64 * keys1 = (u64 *)((char *)tmp + tmp_b);
+    u64 * keys2 = (u64 *)((char *)keys1 + k1_b);
+    unsigned short * tidx = (unsigned short *)((char *)keys2 + k2_b);
+    unsigned long long * result2 = (unsigned long long *)(total_dev + 2);
+    u32 * unit_ctr = (u32 *)(total_dev + 4), * stray = unit_ctr + 1;
+    CHGPU_HIP(hipMemsetAsync(total_dev, 0, 64, ctx->stream));
+    hipLaunchKernelGGL((k_rp_hist_wide<u64, JoinRegionFn>), dim3(G), dim3(RP_THREADS), 0, ctx->stream, (const u64 *)key_col->data, n, rows_per_wg, P1, counts, fn1);
+    CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, counts, offsets, m, total_dev, tmp, tmp_b));
+    {
+        const size_t lds = rp_scatter_lds_bytes(12288, P1, 8, false);
+        auto scat = k_rp_scatter<12288, u64, false, JoinRegionFn>;
+        CHGPU_HIP(hipFuncSetAttribute((const void *)scat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(scat, dim3(G), dim3(RP_THREADS), lds, ctx->stream, (const u64 *)key_col->data, (const u64 *)nullptr, n, rows_per_wg, P1, (const u64 *)offsets, keys1,
+                           (u64 *)nullptr, fn1);
+    }
+    {
+        const size_t lds = (size_t)JPL2_TILE * 8 + (size_t)(PB + 1) * 8 + 64;
+        auto sortk = k_rp_tilesort_keys<JPL2_TILE, JoinBucket2Fn>;
+        CHGPU_HIP(hipFuncSetAttribute((const void *)sortk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(sortk, dim3(G), dim3(RP_THREADS), lds, ctx->stream, (const u64 *)keys1, n, rows_per_wg2, PB, keys2, tidx, fn2, stray);
+    }
+    {
+        const size_t lds = (size_t)(JPL2_CELLS + JPL2_TAIL + 1) * 16;
+        CHGPU_HIP(hipFuncSetAttribute((const void *)k_join_probe_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_join_probe_lds, dim3(2 * G), dim3(JPL2_THREADS), lds, ctx->stream, j->t, variant, (const u64 *)keys2, n, (const u64 *)offsets, G, lg_p2,
+                           (const unsigned short *)tidx, (const u64 *)right_payload->data, (const u64 *)j->block_base_dev, (u64)j->blocks.size(), unit_ctr, stray, result2);
+    }
+    ctx->counters[6] += 5;
+    CHGPU_HIP(hipGetLastError());
+    u64 back[3];
+    CHGPU_TRY(chgpu_read_back(ctx, result2, back, 24));
+    if ((back[2] >> 32) != 0) // the stray flag: some tile spanned three first-level partitions (tiny partitions): not this plan
+        return CHGPU_ERR_NOT_IMPLEMENTED;
+    res[0] = back[0];
+    res[1] = back[1];
+    return CHGPU_OK;
+}
+
 extern "C" int chgpu_join_probe_agg(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map, const chgpu_col * right_payload,
                                     uint64_t * count_out, void * sum_out)
 {
@@ -1735,7 +2011,13 @@ extern "C" int chgpu_join_probe_agg(chgpu_join * j, const chgpu_col * key_col, c
     else variant = PV_ANY_LEFT;
     const bool is_float = right_payload && chgpu_type_is_float(right_payload->type);
     u64 res[2] = {0, 0};
-    int plan = n && !null_map ? join_probe_agg_regions(j, key_col, right_payload, variant, res) : CHGPU_ERR_NOT_IMPLEMENTED;
+    int plan = CHGPU_ERR_NOT_IMPLEMENTED;
+    if (n && !null_map)
+    {
+        plan = join_probe_agg_lds(j, key_col, right_payload, variant, res); // table slices staged in LDS (unique keys, integer payload)
+        if (plan == CHGPU_ERR_NOT_IMPLEMENTED)
+            plan = join_probe_agg_regions(j, key_col, right_payload, variant, res); // table regions resident in L2
+    }
     if (plan != CHGPU_OK && plan != CHGPU_ERR_NOT_IMPLEMENTED)
         return plan;
     if (n && plan != CHGPU_OK)

@@ -695,6 +695,144 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__
             atomicAdd(&part_total[p], (unsigned long long)wg_total[p]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_rp_tilesort_keys: the tile sort for 8-byte keys alone, with the bucket of a row taken RELATIVE to the tile's first row --
+// the second level of a two-level partition: the rows arrive partitioned once (contiguous first-level partitions), a tile lies inside
+// one first-level partition or straddles two, and bucket_fn(key, first_key_of_the_tile) numbers the second-level buckets of those
+// (at most) two partitions 0 .. P-1; anything else goes to the dummy bucket (the caller guarantees there is none).
+// Output as k_rp_tilesort: the sorted tile in its own row range + tile_index[t][0..P] (u16).  16384-row tiles: 128 KiB of LDS.
+// dynamic LDS: stage_key u64[TILE] | tile_cnt u32[P + 1] | tile_off u32[P + 1]
+// ---------------------------------------------------------------------------------------------
+template <u32 GBP_TILE, typename BucketFn, u32 THREADS = RP_THREADS>
+__global__ __launch_bounds__(THREADS) void k_rp_tilesort_keys(const u64 * __restrict__ keys, u64 n, u64 rows_per_wg, u32 P, u64 * __restrict__ out_keys,
+                                                              unsigned short * __restrict__ tile_index, BucketFn bucket_fn, u32 * __restrict__ stray_flag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
+    u64 * stage_key = (u64 *)gb_lds;
+    u32 * tile_cnt = (u32 *)(stage_key + GBP_TILE);
+    u32 * tile_off = tile_cnt + (P + 1);
+    __shared__ u32 wave_tot[THREADS / 64];
+    for (u32 p = threadIdx.x; p <= P; p += THREADS)
+        tile_cnt[p] = 0;
+    __syncthreads();
+    const u64 r0 = (u64)blockIdx.x * rows_per_wg;
+    if (r0 >= n)
+        return; // (the whole workgroup: no barrier below is left waiting)
+    const u32 nrel = (u32)(r0 + rows_per_wg < n ? rows_per_wg : n - r0);
+    const u32 shift = r0 ? 2u : 0u; // see k_rp_tilesort: a lone last row is read as the second element of the pair that ends with it
+    const char * kbase = (const char *)(keys + r0 - shift);
+    char * okbase = (char *)(out_keys + r0);
+    char * ixbase = (char *)(tile_index + (r0 / GBP_TILE) * (u64)(P + 1));
+    constexpr u32 RPT = GBP_TILE / THREADS;
+    static_assert(RPT % 2 == 0, "row pairs");
+    typedef u64 v2q __attribute__((ext_vector_type(2)));
+    auto rel_of = [&](u32 trel, u32 j) -> u32 { return trel + (j >> 1) * (2 * THREADS) + 2 * threadIdx.x + (j & 1); };
+    const bool odd_tail = (nrel & 1) != 0;
+    const u32 last_pair = (nrel >= 2 ? (nrel - 2) & ~1u : shift ? ~0u : 0u) + shift;
+    v2q kraw[RPT / 2];
+    u64 first_key = 0;
+    auto load_tile = [&](u32 trel) {
+#pragma unroll
+        for (u32 j = 0; j < RPT; j += 2)
+        {
+            const u32 i = rel_of(trel, j);
+            const bool tail = odd_tail && i + 1 == nrel;
+            const u32 li = tail ? i + shift - 1 : (i + 1 < nrel ? i + shift : last_pair);
+            kraw[j / 2] = __builtin_nontemporal_load((const v2q *)(kbase + li * 8u));
+        }
+        first_key = *(const u64 *)(kbase + ((trel < nrel ? trel : nrel - 1) + shift) * 8u); // the tile's first row (every lane the same address)
+    };
+    auto key_at = [&](u32 trel, u32 j) -> u64 {
+        const bool tail = odd_tail && rel_of(trel, j & ~1u) + 1 == nrel;
+        return ((j & 1) || tail) ? kraw[j / 2].y : kraw[j / 2].x;
+    };
+    u32 part[RPT], rank[RPT];
+    bool stray = false; // a real row whose bucket is out of range (a tile spanning more than two first-level partitions): the caller must not use the result
+    auto step_rank = [&](u32 trel) {
+#pragma unroll
+        for (u32 j = 0; j < RPT; ++j)
+        {
+            const u32 b = bucket_fn(key_at(trel, j), first_key);
+            const bool real = rel_of(trel, j) < nrel;
+            part[j] = (real && b < P) ? b : P;
+            stray |= real && b >= P;
+        }
+#pragma unroll
+        for (u32 j = 0; j < RPT; ++j)
+            rank[j] = atomicAdd(&tile_cnt[part[j]], 1u);
+    };
+    auto step_scan = [&]() {
+        __syncthreads();
+        const u32 e0 = threadIdx.x * 2, e1 = e0 + 1;
+        const u32 c0 = e0 <= P ? tile_cnt[e0] : 0, c1 = e1 <= P ? tile_cnt[e1] : 0;
+        const u32 v = c0 + c1;
+        const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        u32 inc = v;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1)
+        {
+            const u32 o = __shfl_up(inc, dlt, 64);
+            if (lane >= (u32)dlt)
+                inc += o;
+        }
+        if (lane == 63)
+            wave_tot[wave] = inc;
+        __syncthreads();
+        u32 off = inc - v;
+        for (u32 w = 0; w < wave; ++w)
+            off += wave_tot[w];
+        if (e0 <= P)
+        {
+            tile_off[e0] = off;
+            tile_cnt[e0] = 0;
+        }
+        if (e1 <= P)
+        {
+            tile_off[e1] = off + c0;
+            tile_cnt[e1] = 0;
+        }
+        __syncthreads();
+    };
+    constexpr u32 KPIECES = GBP_TILE / 2 / THREADS;
+    const u32 e_idx = threadIdx.x < P ? threadIdx.x : P;
+    load_tile(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (u32 q = 0; q < KPIECES; ++q)
+        __builtin_nontemporal_store(v2q{0, 0}, (v2q *)(okbase + (q * THREADS + threadIdx.x) * 16u));
+    *(unsigned short *)(ixbase + e_idx * 2u) = 0;
+    __builtin_amdgcn_sched_barrier(0);
+    step_rank(0);
+    step_scan();
+    u32 tile_no = 0;
+    for (u32 trel = 0; trel < nrel; trel += GBP_TILE, ++tile_no)
+    {
+#pragma unroll
+        for (u32 j = 0; j < RPT; ++j)
+            stage_key[tile_off[part[j]] + rank[j]] = key_at(trel, j);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(trel + GBP_TILE);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        {
+            v2q kq[KPIECES];
+#pragma unroll
+            for (u32 q = 0; q < KPIECES; ++q)
+                kq[q] = *(const v2q *)((const char *)stage_key + (q * THREADS + threadIdx.x) * 16u);
+            const u32 eo = tile_off[e_idx];
+#pragma unroll
+            for (u32 q = 0; q < KPIECES; ++q)
+                __builtin_nontemporal_store(kq[q], (v2q *)(okbase + trel * 8u + (q * THREADS + threadIdx.x) * 16u));
+            *(unsigned short *)(ixbase + (tile_no * (P + 1) + e_idx) * 2u) = (unsigned short)eo;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        step_rank(trel + GBP_TILE);
+        step_scan();
+    }
+    if (stray)
+        *stray_flag = 1;
+}
+
 static inline size_t rp_tilesort_lds_bytes(u32 tile, u32 P, size_t key_bytes)
 {
     return (size_t)tile * (key_bytes + 8) + (size_t)(P + 1) * 12 + 64;

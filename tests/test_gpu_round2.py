@@ -240,6 +240,39 @@ def test_join_probe_agg_region_partitioned_matches_numpy(ch, ctx, kind):
     assert c2 == int(m2.sum()) + (int((m2 == 0).sum()) if kind == "LEFT" else 0)
 
 
+# ---- fused join -> aggregate, unique build keys: probe keys partitioned twice, table slices staged in LDS ----------------------------
+@pytest.mark.parametrize("kind,strict", [("INNER", "ALL"), ("LEFT", "ALL"), ("LEFT", "SEMI"), ("LEFT", "ANTI")])
+@pytest.mark.parametrize("nb,blocks", [(400_000, 1), (3_000_000, 2)])
+def test_join_probe_agg_lds_staged_slices_match_numpy(ch, ctx, kind, strict, nb, blocks):
+    """unique build keys + integer payload + >= 8 Mi probe rows: k_rp_hist_wide / k_rp_scatter (64 partitions) -> k_rp_tilesort_keys ->
+    k_join_probe_lds (8192-cell table slices in LDS).  Tables of 2^21 and 2^24 cells (2 and 16 slices per first-level partition), one and
+    two right blocks, the zero key on both sides, probe keys beyond the build key range, every join variant chgpu_join_probe_agg takes."""
+    K_ = {"INNER": ch.JOIN_INNER, "LEFT": ch.JOIN_LEFT}[kind]
+    S_ = {"ALL": ch.STRICT_ALL, "SEMI": ch.STRICT_SEMI, "ANTI": ch.STRICT_ANTI}[strict]
+    rng = np.random.Generator(np.random.PCG64(nb % 97))
+    bk = (rng.permutation(nb).astype(np.uint64) * np.uint64(2654435761)) % np.uint64(2**40)   # unique (odd multiplier mod 2^40), contains 0
+    assert np.unique(bk).shape[0] == nb
+    bv = rng.integers(-2**50, 2**50, size=nb, dtype=np.int64)
+    npb = 9_000_017
+    pk = np.where(rng.random(npb) < 0.5, bk[rng.integers(0, nb, size=npb)], rng.integers(0, 2**41, size=npb, dtype=np.uint64))
+    pk[::100_003] = 0
+    j = ch.HashJoin(K_, S_, ctx=ctx)
+    cut = nb // blocks
+    for b in range(blocks):
+        j.add_block(bk[b * cut:(b + 1) * cut if b + 1 < blocks else nb])
+    c, s = j.probe_count_sum(ctx.upload(pk), ctx.upload(bv))
+    order = np.argsort(bk)
+    pos = np.searchsorted(bk[order], pk)
+    pos[pos == nb] = 0
+    hit = bk[order][pos] == pk
+    if strict == "ANTI":
+        want_c, want_s = int((~hit).sum()), 0
+    else:
+        want_c = int(hit.sum()) + (int((~hit).sum()) if (kind == "LEFT" and strict == "ALL") else 0)
+        want_s = int(bv[order][pos[hit]].astype(np.uint64).sum(dtype=np.uint64))
+    assert c == want_c and s % 2**64 == want_s
+
+
 # ---- keys128 / keys256: the device dictionary (chgpu_keydict) under GROUP BY and joins ----------------------------------------------
 @pytest.mark.parametrize("arg_dtype", [np.uint32, np.int32, np.float32])
 def test_groupby_tile_sorted_plan_widens_narrow_arguments(ch, ctx, arg_dtype):
