@@ -703,13 +703,16 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort(const KT * __restrict__
 // Output as k_rp_tilesort: the sorted tile in its own row range + tile_index[t][0..P] (u16).  16384-row tiles: 128 KiB of LDS.
 // dynamic LDS: stage_key u64[TILE] | tile_cnt u32[P + 1] | tile_off u32[P + 1]
 // ---------------------------------------------------------------------------------------------
-template <u32 GBP_TILE, typename BucketFn, u32 THREADS = RP_THREADS>
+// HAS_WORD: every key carries an 8-byte word (the join build: the row id); LDS then holds TILE x 16 bytes (8192-row tiles).
+template <u32 GBP_TILE, typename BucketFn, u32 THREADS = RP_THREADS, bool HAS_WORD = false>
 __global__ __launch_bounds__(THREADS) void k_rp_tilesort_keys(const u64 * __restrict__ keys, u64 n, u64 rows_per_wg, u32 P, u64 * __restrict__ out_keys,
-                                                              unsigned short * __restrict__ tile_index, BucketFn bucket_fn, u32 * __restrict__ stray_flag)
+                                                              unsigned short * __restrict__ tile_index, BucketFn bucket_fn, u32 * __restrict__ stray_flag,
+                                                              const u64 * __restrict__ words = nullptr, u64 * __restrict__ out_words = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
     u64 * stage_key = (u64 *)gb_lds;
-    u32 * tile_cnt = (u32 *)(stage_key + GBP_TILE);
+    u64 * stage_word = stage_key + GBP_TILE; // (HAS_WORD)
+    u32 * tile_cnt = (u32 *)(stage_key + (HAS_WORD ? 2 : 1) * GBP_TILE);
     u32 * tile_off = tile_cnt + (P + 1);
     __shared__ u32 wave_tot[THREADS / 64];
     for (u32 p = threadIdx.x; p <= P; p += THREADS)
@@ -722,6 +725,8 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort_keys(const u64 * __rest
     const u32 shift = r0 ? 2u : 0u; // see k_rp_tilesort: a lone last row is read as the second element of the pair that ends with it
     const char * kbase = (const char *)(keys + r0 - shift);
     char * okbase = (char *)(out_keys + r0);
+    const char * wbase = (const char *)(words + r0 - shift);
+    char * owbase = (char *)(out_words + r0);
     char * ixbase = (char *)(tile_index + (r0 / GBP_TILE) * (u64)(P + 1));
     constexpr u32 RPT = GBP_TILE / THREADS;
     static_assert(RPT % 2 == 0, "row pairs");
@@ -730,6 +735,7 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort_keys(const u64 * __rest
     const bool odd_tail = (nrel & 1) != 0;
     const u32 last_pair = (nrel >= 2 ? (nrel - 2) & ~1u : shift ? ~0u : 0u) + shift;
     v2q kraw[RPT / 2];
+    v2q wraw[HAS_WORD ? RPT / 2 : 1];
     u64 first_key = 0;
     auto load_tile = [&](u32 trel) {
 #pragma unroll
@@ -739,12 +745,18 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort_keys(const u64 * __rest
             const bool tail = odd_tail && i + 1 == nrel;
             const u32 li = tail ? i + shift - 1 : (i + 1 < nrel ? i + shift : last_pair);
             kraw[j / 2] = __builtin_nontemporal_load((const v2q *)(kbase + li * 8u));
+            if constexpr (HAS_WORD)
+                wraw[j / 2] = __builtin_nontemporal_load((const v2q *)(wbase + li * 8u));
         }
         first_key = *(const u64 *)(kbase + ((trel < nrel ? trel : nrel - 1) + shift) * 8u); // the tile's first row (every lane the same address)
     };
     auto key_at = [&](u32 trel, u32 j) -> u64 {
         const bool tail = odd_tail && rel_of(trel, j & ~1u) + 1 == nrel;
         return ((j & 1) || tail) ? kraw[j / 2].y : kraw[j / 2].x;
+    };
+    auto word_at = [&](u32 trel, u32 j) -> u64 {
+        const bool tail = odd_tail && rel_of(trel, j & ~1u) + 1 == nrel;
+        return ((j & 1) || tail) ? wraw[j / 2].y : wraw[j / 2].x;
     };
     u32 part[RPT], rank[RPT];
     bool stray = false; // a real row whose bucket is out of range (a tile spanning more than two first-level partitions): the caller must not use the result
@@ -799,7 +811,11 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort_keys(const u64 * __rest
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (u32 q = 0; q < KPIECES; ++q)
+    {
         __builtin_nontemporal_store(v2q{0, 0}, (v2q *)(okbase + (q * THREADS + threadIdx.x) * 16u));
+        if constexpr (HAS_WORD)
+            __builtin_nontemporal_store(v2q{0, 0}, (v2q *)(owbase + (q * THREADS + threadIdx.x) * 16u));
+    }
     *(unsigned short *)(ixbase + e_idx * 2u) = 0;
     __builtin_amdgcn_sched_barrier(0);
     step_rank(0);
@@ -809,20 +825,34 @@ __global__ __launch_bounds__(THREADS) void k_rp_tilesort_keys(const u64 * __rest
     {
 #pragma unroll
         for (u32 j = 0; j < RPT; ++j)
-            stage_key[tile_off[part[j]] + rank[j]] = key_at(trel, j);
+        {
+            const u32 pos = tile_off[part[j]] + rank[j];
+            stage_key[pos] = key_at(trel, j);
+            if constexpr (HAS_WORD)
+                stage_word[pos] = word_at(trel, j);
+        }
         __builtin_amdgcn_sched_barrier(0);
         load_tile(trel + GBP_TILE);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         {
             v2q kq[KPIECES];
+            v2q wq[HAS_WORD ? KPIECES : 1];
 #pragma unroll
             for (u32 q = 0; q < KPIECES; ++q)
+            {
                 kq[q] = *(const v2q *)((const char *)stage_key + (q * THREADS + threadIdx.x) * 16u);
+                if constexpr (HAS_WORD)
+                    wq[q] = *(const v2q *)((const char *)stage_word + (q * THREADS + threadIdx.x) * 16u);
+            }
             const u32 eo = tile_off[e_idx];
 #pragma unroll
             for (u32 q = 0; q < KPIECES; ++q)
+            {
                 __builtin_nontemporal_store(kq[q], (v2q *)(okbase + trel * 8u + (q * THREADS + threadIdx.x) * 16u));
+                if constexpr (HAS_WORD)
+                    __builtin_nontemporal_store(wq[q], (v2q *)(owbase + trel * 8u + (q * THREADS + threadIdx.x) * 16u));
+            }
             *(unsigned short *)(ixbase + (tile_no * (P + 1) + e_idx) * 2u) = (unsigned short)eo;
         }
         __builtin_amdgcn_sched_barrier(0);

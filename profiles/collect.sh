@@ -9,6 +9,7 @@ TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
+rm -rf $OUT/prof_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG $OUT/prof_${TAG}_c5
 cd /tmp && export TMPDIR=/tmp
 # C5 (the SSB plan) reuses the join / GROUP BY kernels of C3 / C4: it is profiled in its own pass so the per-config kernel averages and
 # PMC sums of C3 / C4 stay attributable

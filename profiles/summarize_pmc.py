@@ -18,7 +18,9 @@ out = os.path.join(root, "gpurun_out")
 
 def per_kernel(dirname, counter):
     vals = {}
-    for path in glob.glob(os.path.join(out, dirname, "**", "*counter_collection.csv"), recursive=True):
+    paths = glob.glob(os.path.join(out, dirname, "**", "*counter_collection.csv"), recursive=True)
+    # only the newest pass: gpurun_out/ accumulates the files of earlier calls next to it
+    for path in sorted(paths, key=os.path.getmtime)[-1:]:
         with open(path) as f:
             for row in csv.DictReader(f):
                 if row.get("Counter_Name") != counter:
@@ -86,11 +88,11 @@ if "C3" in cfg and cfg["C3"].get("calls"):
                  "kernels_total_over_all_calls": split}
 if "C4_one_gpu" in cfg and cfg["C4_one_gpu"].get("probe_calls"):
     c4 = cfg["C4_one_gpu"]
-    r, w, split = group_bytes(["k_join_", "k_jp_", "k_rp_<JoinRegionFn"])
+    r, w, split = group_bytes(["k_join_", "k_jp_", "k_rp_<JoinRegionFn", "k_rp_<JoinBucket2Fn", "k_rp_<JoinSliceFn"])
     # build and probe run a different number of times: weigh each kernel by the calls of its phase
     per_call = 0.0
     for name, v in split.items():
-        is_build = any(t in name for t in ("k_join_insert", "k_join_fill", "k_join_root", "k_join_finalize", "k_join_stage"))
+        is_build = any(t in name for t in ("k_join_insert", "k_join_fill", "k_join_root", "k_join_finalize", "k_join_stage", "k_join_build_slices", "k_join_iota", "JoinSliceFn"))
         per_call += (v["read_bytes"] + v["write_bytes"]) / (c4["build_calls"] if is_build else c4["probe_calls"])
     res["C4_hbm_bytes_per_call"] = per_call
     res["C4"] = {"build_calls": c4["build_calls"], "probe_calls": c4["probe_calls"], "algorithmic_bytes": c4["roofline"]["algorithmic_bytes"],

@@ -242,7 +242,7 @@ def test_join_probe_agg_region_partitioned_matches_numpy(ch, ctx, kind):
 
 # ---- fused join -> aggregate, unique build keys: probe keys partitioned twice, table slices staged in LDS ----------------------------
 @pytest.mark.parametrize("kind,strict", [("INNER", "ALL"), ("LEFT", "ALL"), ("LEFT", "SEMI"), ("LEFT", "ANTI")])
-@pytest.mark.parametrize("nb,blocks", [(400_000, 1), (3_000_000, 2)])
+@pytest.mark.parametrize("nb,blocks", [(400_000, 1), (3_000_000, 2), (3_000_000, 1)])
 def test_join_probe_agg_lds_staged_slices_match_numpy(ch, ctx, kind, strict, nb, blocks):
     """unique build keys + integer payload + >= 8 Mi probe rows: k_rp_hist_wide / k_rp_scatter (64 partitions) -> k_rp_tilesort_keys ->
     k_join_probe_lds (8192-cell table slices in LDS).  Tables of 2^21 and 2^24 cells (2 and 16 slices per first-level partition), one and
@@ -271,6 +271,36 @@ def test_join_probe_agg_lds_staged_slices_match_numpy(ch, ctx, kind, strict, nb,
         want_c = int(hit.sum()) + (int((~hit).sum()) if (kind == "LEFT" and strict == "ALL") else 0)
         want_s = int(bv[order][pos[hit]].astype(np.uint64).sum(dtype=np.uint64))
     assert c == want_c and s % 2**64 == want_s
+
+
+# ---- the unique-key build through LDS-built table slices (join_build_slices) --------------------------------------------------------
+@pytest.mark.parametrize("dups", [False, True])
+def test_join_slice_build_gives_the_same_table_as_the_generic_build(ch, ctx, dups):
+    """one right block of 2.6 M rows without a prefilter: unique keys are partitioned down to 4096-cell slices, built in LDS and written out
+    whole (rows whose chain leaves a slice go through an overflow list); a duplicate key anywhere makes the build fall back to the
+    generic path.  Either way the ordered joinBlock over the table -- offsets and right row ids -- equals numpy's, the zero key included."""
+    rng = np.random.Generator(np.random.PCG64(5 + dups))
+    nb = 2_600_000
+    bk = (rng.permutation(nb).astype(np.uint64) * np.uint64(2654435761)) % np.uint64(2**40)
+    if dups:
+        bk[-3:] = bk[:3]
+    left = np.concatenate([bk[rng.integers(0, nb, size=300_000)], rng.integers(0, 2**41, size=300_000, dtype=np.uint64), np.zeros(3, dtype=np.uint64)])
+    j = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, ctx=ctx)
+    j.add_block(bk)
+    r = j.probe_columns(left)
+    assert r["consumed"] == left.shape[0]
+    off = r["offsets"].numpy().astype(np.int64)
+    rid = r["right_rowid"].numpy()
+    counts = np.diff(np.concatenate([[0], off]))
+    order = np.argsort(bk, kind="stable")
+    lo = np.searchsorted(bk[order], left, side="left")
+    hi = np.searchsorted(bk[order], left, side="right")
+    assert np.array_equal(counts, hi - lo)
+    rows = (rid & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    assert np.all((rid >> np.uint64(32)) == 0) and np.array_equal(bk[rows], np.repeat(left, counts))      # every emitted right row carries the left row's key
+    if not dups:
+        assert r["n_out"] == int(np.isin(left, bk).sum())
+    assert j.n_keys == np.unique(bk).shape[0]
 
 
 # ---- keys128 / keys256: the device dictionary (chgpu_keydict) under GROUP BY and joins ----------------------------------------------
