@@ -102,7 +102,8 @@ struct chgpu_join
     int kind = CHGPU_JOIN_INNER, strictness = CHGPU_STRICT_ALL, any_take_last_row = 0;
     std::vector<BuildBlock> blocks;
     u64 total_rows = 0;
-    bool finished = false;
+    bool finished = false;     // the hash table exists (join_build_table)
+    bool build_closed = false; // onBuildPhaseFinish was called: no more right blocks; the table itself is built by the first consumer that needs it
     JoinTable t{};
     void * table_mem = nullptr;
     size_t table_class = 0;
@@ -749,7 +750,7 @@ extern "C" int chgpu_join_add_block(chgpu_join * j, const chgpu_col * key_col, c
 {
     ChgpuDeviceGuard _dev_guard(j ? j->ctx : nullptr);
     CHGPU_REQUIRE(j && key_col, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
-    CHGPU_REQUIRE(!j->finished, CHGPU_ERR_LOGICAL, "addBlockToJoin after onBuildPhaseFinish");
+    CHGPU_REQUIRE(!j->finished && !j->build_closed, CHGPU_ERR_LOGICAL, "addBlockToJoin after onBuildPhaseFinish");
     CHGPU_REQUIRE(key_col->type == j->key_type, CHGPU_ERR_BAD_ARGUMENTS, "key column has type %d, expected %d", key_col->type, j->key_type);
     CHGPU_REQUIRE(key_col->rows < 0xFFFFFFFFull, CHGPU_ERR_TOO_MANY_ROWS, "Too many rows in right table block for HashJoin: %llu", (unsigned long long)key_col->rows); // HashJoin.cpp:563-564
     CHGPU_REQUIRE(j->blocks.size() < 0x7FFFFFFFull, CHGPU_ERR_TOO_MANY_ROWS, "too many right blocks"); // bit 63 of a row id tags packed multi-row values
@@ -1045,20 +1046,37 @@ static int join_build_slices(chgpu_join * j, JoinTable & t)
     return CHGPU_OK;
 }
 
+static int join_build_table(chgpu_join * j);
+static u64 join_capacity_for(u64 rows)
+{
+    static const u32 cap_shift = getenv("CHGPU_TUNE_JOIN_CAP_SHIFT") ? (u32)atoi(getenv("CHGPU_TUNE_JOIN_CAP_SHIFT")) : 1;
+    return jpow2_ceil(rows + rows * 3 / 7 + 1) << cap_shift;
+}
+
+// IJoin::onBuildPhaseFinish: the right side is complete.  The hash table is built by the first consumer that needs it (joinBlock, the
+// key count, non-joined rows ...): the fused probe of a large unique-key build side never does -- it joins partition by partition
+// (join_probe_agg_radix).  CHGPU_TUNE_JOIN_EAGER_BUILD=1 builds here, as before.
 extern "C" int chgpu_join_finish_build(chgpu_join * j)
 {
     ChgpuDeviceGuard _dev_guard(j ? j->ctx : nullptr);
     CHGPU_REQUIRE(j, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    static const bool eager = getenv("CHGPU_TUNE_JOIN_EAGER_BUILD") != nullptr;
+    j->build_closed = true;
+    return eager ? join_build_table(j) : CHGPU_OK;
+}
+
+static int join_build_table(chgpu_join * j)
+{
     if (j->finished)
         return CHGPU_OK;
+    j->build_closed = true;
     chgpu_ctx * ctx = j->ctx;
     const bool maps_all = j->strictness == CHGPU_STRICT_ALL;
     const bool flagged = j->kind == CHGPU_JOIN_INNER && j->strictness == CHGPU_STRICT_ANY;
     // load factor in (0.175, 0.35]: a probe then resolves at its home cell nearly always (1.1 cells per hit, 1.3 per miss, against 1.75 / 3.6
     // at 0.6).  Measured at C4: build 1.00 -> 0.90 ms (fewer retried claims), probe 3.40 -> 2.26 ms region-partitioned, 4.83 -> 3.39 ms
     // one-pass.  The table is immutable after the build and 288 GB of HBM make the doubled footprint (512 MB of cells for 1e7 rows) cheap.
-    static const u32 cap_shift = getenv("CHGPU_TUNE_JOIN_CAP_SHIFT") ? (u32)atoi(getenv("CHGPU_TUNE_JOIN_CAP_SHIFT")) : 1;
-    const u64 cap = jpow2_ceil(j->total_rows + j->total_rows * 3 / 7 + 1) << cap_shift;
+    const u64 cap = join_capacity_for(j->total_rows);
     CHGPU_REQUIRE(cap + 1 < 0xFFFFFFFFull, CHGPU_ERR_NOT_IMPLEMENTED, "build side of %llu rows exceeds the 32-bit cell index", (unsigned long long)j->total_rows);
     const u64 cells = cap + 1;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -1200,7 +1218,7 @@ extern "C" int chgpu_join_non_joined_rows(chgpu_join * j, chgpu_col ** right_row
     CHGPU_REQUIRE(j && right_rowid_u64 && rows_out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(jf_track_used(j), CHGPU_ERR_LOGICAL, "non-joined rows exist for RIGHT / FULL joins only");
     if (!j->finished)
-        CHGPU_TRY(chgpu_join_finish_build(j));
+        CHGPU_TRY(join_build_table(j));
     chgpu_ctx * ctx = j->ctx;
     const u64 n = j->total_rows;
     chgpu_col * out = nullptr;
@@ -1286,7 +1304,7 @@ extern "C" int chgpu_join_total_rows(chgpu_join * j, uint64_t * rows, uint64_t *
     if (keys)
     {
         if (!j->finished)
-            CHGPU_TRY(chgpu_join_finish_build(j));
+            CHGPU_TRY(join_build_table(j));
         *keys = j->n_keys;
     }
     return CHGPU_OK;
@@ -1302,7 +1320,7 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
     if (null_map)
         CHGPU_REQUIRE(null_map->type == CHGPU_U8 && null_map->rows == key_col->rows, CHGPU_ERR_SIZES_MISMATCH, "null map size mismatch");
     if (!j->finished)
-        CHGPU_TRY(chgpu_join_finish_build(j));
+        CHGPU_TRY(join_build_table(j));
     chgpu_ctx * ctx = j->ctx;
     const u64 n = key_col->rows;
     const bool need_filter = jf_need_filter(j), need_repl = jf_need_replication(j);
@@ -2001,10 +2019,15 @@ struct JoinBucket2Fn
     }
 };
 
+// FROM_ROWS: there is no table -- the slice's LDS cells are filled from the BUILD ROWS of the slice, which were partitioned the same way
+// (bkeys2 / bwords2 = keys and payloads tile-sorted inside 64 partitions, boff1 / btidx their offsets and run index; t only carries the
+// capacity).  A duplicate build key raises dup_flag (the caller then builds the table and takes the other paths).
+template <bool FROM_ROWS>
 __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, int variant, const u64 * __restrict__ keys2, u64 n, const u64 * __restrict__ off1, u32 G, u32 lg_p2,
                                                          const unsigned short * __restrict__ tile_index, const u64 * __restrict__ payload,
                                                          const u64 * __restrict__ block_base, u64 n_blocks, u32 * __restrict__ unit_ctr, u32 * __restrict__ stray_flag,
-                                                         unsigned long long * __restrict__ result2)
+                                                         unsigned long long * __restrict__ result2, const u64 * __restrict__ bkeys2, const u64 * __restrict__ bwords2,
+                                                         const u64 * __restrict__ boff1, const unsigned short * __restrict__ btidx, u64 nb, u32 * __restrict__ dup_flag)
 {
     // The hot loop touches global memory only to stream the keys in: everything a key can meet -- its slice, the cells behind it, the
     // zero key's cell -- is staged in LDS first, and the one case that is not (a chain longer than the staged window) raises the
@@ -2016,21 +2039,27 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
     __shared__ u64 s_off[P1 + 1];
     __shared__ u32 sh_unit;
     const u32 P2 = 1u << lg_p2, R2 = P1 << lg_p2, PB = 2 * P2;
+    __shared__ u64 s_boff[P1 + 1];
     for (u32 p = threadIdx.x; p <= P1; p += JPL2_THREADS)
+    {
         s_off[p] = p < P1 ? off1[(u64)p * G] : n;
+        if constexpr (FROM_ROWS)
+            s_boff[p] = p < P1 ? boff1[(u64)p * G] : nb;
+    }
     const u32 lane = threadIdx.x & 63;
     const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 mask = t.capacity - 1;
     auto flat_of = [&](u64 rowid) -> u64 { return n_blocks == 1 ? (rowid & 0xFFFFFFFFull) : block_base[rowid >> 32] + (rowid & 0xFFFFFFFFull); };
     const bool miss_counts = variant == PV_ALL_LEFT || variant == PV_ANY_LEFT || variant == PV_ANTI_LEFT;
     const bool anti = variant == PV_ANTI_LEFT;
-    if (threadIdx.x == 0)
-    {
-        const bool hz = t.ctrl->has_zero != 0; // the zero key lives out of line (cell `capacity`)
-        cells[WIN] = jv2{hz ? 1ull : 0ull, hz ? payload[flat_of(t.kv[2 * t.capacity + 1])] : 0ull};
-    }
+    if constexpr (!FROM_ROWS)
+        if (threadIdx.x == 0)
+        {
+            const bool hz = t.ctrl->has_zero != 0; // the zero key lives out of line (cell `capacity`)
+            cells[WIN] = jv2{hz ? 1ull : 0ull, hz ? payload[flat_of(t.kv[2 * t.capacity + 1])] : 0ull};
+        }
     u64 cnt = 0, isum = 0;
-    bool stray = false;
+    bool stray = false, dup = false;
     for (;;)
     {
         __syncthreads(); // the previous unit's cells have been read by everyone
@@ -2046,6 +2075,64 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
             continue; // no probe key lands in this partition
         // stage the slice, {key, row id} -> {key, payload}: all the cell loads first, then all the payload loads (two round trips, not 2 x 9)
         const u64 slice = (u64)r2 * JPL2_CELLS;
+        if constexpr (FROM_ROWS)
+        {
+            // build the slice's cells from its build rows: LDS compare-and-swap, linear probing inside the window (it is private to this
+            // unit, so a chain may run on into the cells behind the slice); the zero key sits in the extra cell
+            constexpr u32 NWB = JPL2_THREADS / 64;
+            u64 * cw = (u64 *)cells;
+            for (u32 c = threadIdx.x; c <= WIN; c += JPL2_THREADS)
+                cells[c] = jv2{0, 0};
+            __syncthreads();
+            const u64 bb = s_boff[p1], be = s_boff[p1 + 1];
+            if (bb != be)
+            {
+                const u32 bt_lo = (u32)(bb / JBS_TILE), bt_hi = (u32)((be - 1) / JBS_TILE);
+                for (u32 tile = bt_lo + wave; tile <= bt_hi; tile += NWB)
+                {
+                    const u64 row0 = (u64)tile * JBS_TILE;
+                    u32 lo = 0, hi = P1 - 1;
+                    while (lo < hi)
+                    {
+                        const u32 mid = (lo + hi + 1) >> 1;
+                        if (s_boff[mid] <= row0)
+                            lo = mid;
+                        else
+                            hi = mid - 1;
+                    }
+                    const u32 bucket = (p1 - lo) * P2 + p2;
+                    if (bucket >= PB)
+                        continue; // (stray flag raised by the tile sort)
+                    const u32 a = btidx[(u64)tile * (PB + 1) + bucket], b = btidx[(u64)tile * (PB + 1) + bucket + 1];
+                    for (u32 o = lane; o < b - a; o += 64)
+                    {
+                        const u64 key = bkeys2[row0 + a + o], pay = bwords2[row0 + a + o];
+                        u32 c = key == 0 ? WIN : (u32)((dev_intHash64(key) & mask) - slice);
+                        const u64 want = key == 0 ? 1ull : key; // the zero key's cell holds {present, payload}
+                        for (;;)
+                        {
+                            const u64 old = atomicCAS((unsigned long long *)&cw[2 * c], 0ull, (unsigned long long)want);
+                            if (old == 0)
+                            {
+                                cw[2 * c + 1] = pay; // nobody reads it before the barrier below
+                                break;
+                            }
+                            if (old == want || key == 0)
+                            {
+                                dup = true;
+                                break;
+                            }
+                            if (++c >= WIN)
+                            {
+                                stray = true; // the window is too short for this chain: not this plan
+                                break;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        else
         {
             constexpr u32 NC = (WIN + JPL2_THREADS - 1) / JPL2_THREADS;
             jv2 cl[NC];
@@ -2181,6 +2268,8 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
     }
     if (stray)
         *stray_flag = 1;
+    if (dup)
+        *dup_flag = 1;
 }
 
 // -> CHGPU_OK with res[] filled, or NOT_IMPLEMENTED (shape does not fit / a tile straddled three partitions): the caller goes on with the region probe
@@ -2237,15 +2326,121 @@ static int join_probe_agg_lds(chgpu_join * j, const chgpu_col * key_col, const c
     }
     {
         const size_t lds = (size_t)(JPL2_CELLS + JPL2_TAIL + 1) * 16;
-        CHGPU_HIP(hipFuncSetAttribute((const void *)k_join_probe_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_join_probe_lds, dim3(2 * G), dim3(JPL2_THREADS), lds, ctx->stream, j->t, variant, (const u64 *)keys2, n, (const u64 *)offsets, G, lg_p2,
-                           (const unsigned short *)tidx, (const u64 *)right_payload->data, (const u64 *)j->block_base_dev, (u64)j->blocks.size(), unit_ctr, stray, result2);
+        CHGPU_HIP(hipFuncSetAttribute((const void *)k_join_probe_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_join_probe_lds<false>, dim3(2 * G), dim3(JPL2_THREADS), lds, ctx->stream, j->t, variant, (const u64 *)keys2, n, (const u64 *)offsets, G, lg_p2,
+                           (const unsigned short *)tidx, (const u64 *)right_payload->data, (const u64 *)j->block_base_dev, (u64)j->blocks.size(), unit_ctr, stray, result2,
+                           (const u64 *)nullptr, (const u64 *)nullptr, (const u64 *)nullptr, (const unsigned short *)nullptr, (u64)0, stray);
     }
     ctx->counters[6] += 5;
     CHGPU_HIP(hipGetLastError());
     u64 back[3];
     CHGPU_TRY(chgpu_read_back(ctx, result2, back, 24));
     if ((back[2] >> 32) != 0) // the stray flag: some tile spanned three first-level partitions (tiny partitions): not this plan
+        return CHGPU_ERR_NOT_IMPLEMENTED;
+    res[0] = back[0];
+    res[1] = back[1];
+    return CHGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fused probe WITHOUT a hash table in HBM (a radix join): while the table has not been built yet -- the build side is one block of
+// staged keys -- both sides are partitioned down to 4096-cell slices of the table that WOULD be built (build rows {key, payload}: 0.16 ms
+// for 1e7 rows; probe keys as in join_probe_agg_lds) and k_join_probe_lds<FROM_ROWS> fills every slice's LDS cells from its build
+// rows and answers its probe keys.  Neither the global table (0.62 ms to build) nor the per-probe payload gathers exist.  Duplicate
+// build keys, an overflowing window or tiny partitions raise a flag: NOT_IMPLEMENTED, and the caller builds the table after all.
+// ---------------------------------------------------------------------------------------------
+static int join_probe_agg_radix(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * right_payload, int variant, u64 res[2])
+{
+    chgpu_ctx * ctx = j->ctx;
+    static const bool off = getenv("CHGPU_TUNE_JOIN_NO_RADIX") != nullptr;
+    static const u64 min_rows = getenv("CHGPU_TUNE_JOIN_LDS_MIN_ROWS") ? strtoull(getenv("CHGPU_TUNE_JOIN_LDS_MIN_ROWS"), nullptr, 10) : (8ull << 20);
+    const u64 n = key_col->rows, nb = j->total_rows;
+    if (off || j->finished || j->blocks.size() != 1 || j->blocks[0].valid || nb < (1u << 20) || !right_payload || chgpu_type_is_float(right_payload->type)
+        || chgpu_type_size(right_payload->type) != 8 || chgpu_type_size(j->key_type) != 8 || n < min_rows || n + JPL2_TILE + RP_SCATTER_SLACK >= (1ull << 32)
+        || nb + JBS_TILE + RP_SCATTER_SLACK >= (1ull << 32) || ((uintptr_t)key_col->data % 16) != 0 || ((uintptr_t)right_payload->data % 16) != 0
+        || ((uintptr_t)j->blocks[0].keys % 16) != 0)
+        return CHGPU_ERR_NOT_IMPLEMENTED;
+    const u64 cap = join_capacity_for(nb);
+    u32 lg_cap = 0;
+    while ((1ull << lg_cap) < cap)
+        ++lg_cap;
+    if (lg_cap < JPL2_LG_CELLS + JPL2_LG_P1 || lg_cap > JPL2_LG_CELLS + JPL2_LG_P1 + 7)
+        return CHGPU_ERR_NOT_IMPLEMENTED;
+    static_assert(JPL2_LG_CELLS == JBS_LG_CELLS && JPL2_LG_P1 == JBS_LG_P1, "one slice geometry for both sides");
+    const u32 lg_p2 = lg_cap - JPL2_LG_CELLS - JPL2_LG_P1, P1 = 1u << JPL2_LG_P1, PB = 2u << lg_p2;
+    const JoinRegionFn fn1{cap - 1, lg_cap - JPL2_LG_P1};
+    const JoinBucket2Fn fn2{cap - 1, JPL2_LG_CELLS, lg_p2};
+    const u32 G = (u32)ctx->num_cus;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const u64 m = (u64)P1 * G;
+    const u64 p_rpw = ((n + G - 1) / G + 63) / 64 * 64, p_rpw2 = ((n + G - 1) / G + JPL2_TILE - 1) / JPL2_TILE * JPL2_TILE;
+    const u64 b_rpw = ((nb + G - 1) / G + 63) / 64 * 64, b_rpw2 = ((nb + G - 1) / G + JBS_TILE - 1) / JBS_TILE * JBS_TILE;
+    const u64 p_tiles = (n + JPL2_TILE - 1) / JPL2_TILE, b_tiles = (nb + JBS_TILE - 1) / JBS_TILE;
+    const size_t cnt_b = al(m * 4), off_b = al(m * 8 + 8), tmp_b = chgpu_scan_tmp_bytes(m);
+    const size_t pk1_b = al((n + RP_SCATTER_SLACK) * 8), pk2_b = al(p_tiles * JPL2_TILE * 8 + 64), pix_b = al(p_tiles * (PB + 1) * 2 + 16);
+    const size_t bk1_b = al((nb + RP_SCATTER_SLACK) * 8), bk2_b = al(b_tiles * JBS_TILE * 8 + 64), bix_b = al(b_tiles * (PB + 1) * 2 + 16);
+    void * scratch = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, 2 * (cnt_b + off_b) + 256 + tmp_b + pk1_b + pk2_b + pix_b + 2 * bk1_b + 2 * bk2_b + bix_b + 256, &scratch));
+    char * p = (char *)scratch;
+    u32 * p_counts = (u32 *)p; p += cnt_b;
+    u64 * p_offsets = (u64 *)p; p += off_b;
+    u32 * b_counts = (u32 *)p; p += cnt_b;
+    u64 * b_offsets = (u64 *)p; p += off_b;
+    u64 * total_dev = (u64 *)p; p += 256; // [0] scan total, [2..3] the result, [4] unit counter | stray flag, [5] dup flag
+    void * tmp = p; p += tmp_b;
+    u64 * pk1 = (u64 *)p; p += pk1_b;
+    u64 * pk2 = (u64 *)p; p += pk2_b;
+    unsigned short * pix = (unsigned short *)p; p += pix_b;
+    u64 * bk1 = (u64 *)p; p += bk1_b;
+    u64 * bw1 = (u64 *)p; p += bk1_b;
+    u64 * bk2 = (u64 *)p; p += bk2_b;
+    u64 * bw2 = (u64 *)p; p += bk2_b;
+    unsigned short * bix = (unsigned short *)p;
+    unsigned long long * result2 = (unsigned long long *)(total_dev + 2);
+    u32 * unit_ctr = (u32 *)(total_dev + 4), * stray = unit_ctr + 1, * dupf = (u32 *)(total_dev + 5);
+    CHGPU_HIP(hipMemsetAsync(total_dev, 0, 64, ctx->stream));
+    // the build side: rows {key, payload}
+    const u64 * bkeys0 = j->blocks[0].keys;
+    hipLaunchKernelGGL((k_rp_hist_wide<u64, JoinRegionFn>), dim3(G), dim3(RP_THREADS), 0, ctx->stream, bkeys0, nb, b_rpw, P1, b_counts, fn1);
+    CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, b_counts, b_offsets, m, total_dev, tmp, tmp_b));
+    {
+        const size_t lds = rp_scatter_lds_bytes(8192, P1, 8, true);
+        auto scat = k_rp_scatter<8192, u64, true, JoinRegionFn>;
+        CHGPU_HIP(hipFuncSetAttribute((const void *)scat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(scat, dim3(G), dim3(RP_THREADS), lds, ctx->stream, bkeys0, (const u64 *)right_payload->data, nb, b_rpw, P1, (const u64 *)b_offsets, bk1, bw1, fn1);
+        const size_t lds2 = (size_t)JBS_TILE * 16 + (size_t)(PB + 1) * 8 + 64;
+        auto sortk = k_rp_tilesort_keys<JBS_TILE, JoinBucket2Fn, RP_THREADS, true>;
+        CHGPU_HIP(hipFuncSetAttribute((const void *)sortk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(sortk, dim3(G), dim3(RP_THREADS), lds2, ctx->stream, (const u64 *)bk1, nb, b_rpw2, PB, bk2, bix, fn2, stray, (const u64 *)bw1, bw2);
+    }
+    // the probe side: keys
+    hipLaunchKernelGGL((k_rp_hist_wide<u64, JoinRegionFn>), dim3(G), dim3(RP_THREADS), 0, ctx->stream, (const u64 *)key_col->data, n, p_rpw, P1, p_counts, fn1);
+    CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, p_counts, p_offsets, m, total_dev, tmp, tmp_b));
+    {
+        const size_t lds = rp_scatter_lds_bytes(12288, P1, 8, false);
+        auto scat = k_rp_scatter<12288, u64, false, JoinRegionFn>;
+        CHGPU_HIP(hipFuncSetAttribute((const void *)scat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(scat, dim3(G), dim3(RP_THREADS), lds, ctx->stream, (const u64 *)key_col->data, (const u64 *)nullptr, n, p_rpw, P1, (const u64 *)p_offsets, pk1,
+                           (u64 *)nullptr, fn1);
+        const size_t lds2 = (size_t)JPL2_TILE * 8 + (size_t)(PB + 1) * 8 + 64;
+        auto sortk = k_rp_tilesort_keys<JPL2_TILE, JoinBucket2Fn>;
+        CHGPU_HIP(hipFuncSetAttribute((const void *)sortk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(sortk, dim3(G), dim3(RP_THREADS), lds2, ctx->stream, (const u64 *)pk1, n, p_rpw2, PB, pk2, pix, fn2, stray, (const u64 *)nullptr, (u64 *)nullptr);
+    }
+    {
+        JoinTable vt{}; // only the capacity is read
+        vt.capacity = cap;
+        const size_t lds = (size_t)(JPL2_CELLS + JPL2_TAIL + 1) * 16;
+        CHGPU_HIP(hipFuncSetAttribute((const void *)k_join_probe_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_join_probe_lds<true>, dim3(2 * G), dim3(JPL2_THREADS), lds, ctx->stream, vt, variant, (const u64 *)pk2, n, (const u64 *)p_offsets, G, lg_p2,
+                           (const unsigned short *)pix, (const u64 *)nullptr, (const u64 *)nullptr, (u64)1, unit_ctr, stray, result2, (const u64 *)bk2, (const u64 *)bw2,
+                           (const u64 *)b_offsets, (const unsigned short *)bix, nb, dupf);
+    }
+    ctx->counters[6] += 9;
+    CHGPU_HIP(hipGetLastError());
+    u64 back[4];
+    CHGPU_TRY(chgpu_read_back(ctx, result2, back, 32));
+    if ((back[2] >> 32) != 0 || (u32)back[3] != 0) // stray rows / a duplicate build key: not this plan
         return CHGPU_ERR_NOT_IMPLEMENTED;
     res[0] = back[0];
     res[1] = back[1];
@@ -2264,8 +2459,6 @@ extern "C" int chgpu_join_probe_agg(chgpu_join * j, const chgpu_col * key_col, c
     CHGPU_REQUIRE(!(j->kind == CHGPU_JOIN_INNER && j->strictness == CHGPU_STRICT_ANY), CHGPU_ERR_NOT_IMPLEMENTED,
                   "INNER ANY consumes right rows across joinBlock calls (setUsedOnce): use chgpu_join_probe");
     CHGPU_REQUIRE(!jf_track_used(j), CHGPU_ERR_NOT_IMPLEMENTED, "RIGHT / FULL joins emit non-joined rows afterwards: use chgpu_join_probe");
-    if (!j->finished)
-        CHGPU_TRY(chgpu_join_finish_build(j));
     if (right_payload)
     {
         CHGPU_REQUIRE(chgpu_type_size(right_payload->type) != 0, CHGPU_ERR_BAD_ARGUMENTS, "payload type %d", right_payload->type);
@@ -2283,7 +2476,16 @@ extern "C" int chgpu_join_probe_agg(chgpu_join * j, const chgpu_col * key_col, c
     const bool is_float = right_payload && chgpu_type_is_float(right_payload->type);
     u64 res[2] = {0, 0};
     int plan = CHGPU_ERR_NOT_IMPLEMENTED;
-    if (n && !null_map)
+    j->build_closed = true; // (a probe ends the build phase, as a joinBlock does)
+    if (n && !null_map && !j->finished)
+    {
+        plan = join_probe_agg_radix(j, key_col, right_payload, variant, res); // no table at all: both sides partitioned, slices built and probed in LDS
+        if (plan != CHGPU_OK && plan != CHGPU_ERR_NOT_IMPLEMENTED)
+            return plan;
+    }
+    if (plan != CHGPU_OK && !j->finished)
+        CHGPU_TRY(join_build_table(j));
+    if (plan != CHGPU_OK && n && !null_map)
     {
         plan = join_probe_agg_lds(j, key_col, right_payload, variant, res); // table slices staged in LDS (unique keys, integer payload)
         if (plan == CHGPU_ERR_NOT_IMPLEMENTED)

@@ -456,6 +456,8 @@ int chgpu_join_create(chgpu_ctx * ctx, int key_type, int kind, int strictness, i
    block_index_out receives the index the block got (0,1,2...).  rows >= 2^32 -> CHGPU_ERR_TOO_MANY_ROWS. */
 int chgpu_join_add_block(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map_u8,
                          const chgpu_col * join_mask_u8, uint32_t * block_index_out);
+/* IJoin::onBuildPhaseFinish: no more right blocks.  The hash table is built lazily, by the first call that needs it (chgpu_join_probe, the key
+   count of chgpu_join_total_rows, chgpu_join_non_joined_rows); chgpu_join_probe_agg over a large unique-key build side joins without one. */
 int chgpu_join_finish_build(chgpu_join * j);
 int chgpu_join_total_rows(chgpu_join * j, uint64_t * rows, uint64_t * keys);
 /* joinRightColumns over the left key column.  Outputs (all device columns, caller frees; unused ones are NULL):

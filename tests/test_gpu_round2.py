@@ -271,6 +271,11 @@ def test_join_probe_agg_lds_staged_slices_match_numpy(ch, ctx, kind, strict, nb,
         want_c = int(hit.sum()) + (int((~hit).sum()) if (kind == "LEFT" and strict == "ALL") else 0)
         want_s = int(bv[order][pos[hit]].astype(np.uint64).sum(dtype=np.uint64))
     assert c == want_c and s % 2**64 == want_s
+    # the first probe of a one-block build side ran without a hash table (join_probe_agg_radix); asking for the key count builds the
+    # table, and the same probe then goes through the table's slices (join_probe_agg_lds): same answer
+    assert j.n_keys == nb
+    c2, s2 = j.probe_count_sum(ctx.upload(pk), ctx.upload(bv))
+    assert (c2, s2) == (c, s)
 
 
 # ---- the unique-key build through LDS-built table slices (join_build_slices) --------------------------------------------------------
