@@ -308,6 +308,25 @@ def test_join_slice_build_gives_the_same_table_as_the_generic_build(ch, ctx, dup
     assert j.n_keys == np.unique(bk).shape[0]
 
 
+def test_join_build_phase_contract_with_the_lazy_table(ch, ctx):
+    """onBuildPhaseFinish closes the build phase at once although the table is built later: a right block after it is a LOGICAL_ERROR,
+    so is one after the first probe; total_rows needs no table, the key count builds it"""
+    j = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, ctx=ctx)
+    j.add_block(np.arange(1, 1001, dtype=np.uint64))
+    assert j.total_rows == 1000
+    j.finish_build()
+    with pytest.raises(ch.ChgpuError) as e:
+        j.add_block(np.arange(5, dtype=np.uint64))
+    assert e.value.code == ch._capi.ERR_LOGICAL
+    assert j.n_keys == 1000
+    assert j.probe_count_sum(np.array([1, 5, 5000], dtype=np.uint64), np.arange(1000, dtype=np.int64)) == (2, 0 + 4)
+    j2 = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, ctx=ctx)
+    j2.add_block(np.arange(1, 11, dtype=np.uint64))
+    assert j2.probe_count_sum(np.array([3], dtype=np.uint64), np.arange(10, dtype=np.int64)) == (1, 2)   # no finish_build: the probe ends the phase
+    with pytest.raises(ch.ChgpuError):
+        j2.add_block(np.arange(5, dtype=np.uint64))
+
+
 # ---- keys128 / keys256: the device dictionary (chgpu_keydict) under GROUP BY and joins ----------------------------------------------
 @pytest.mark.parametrize("arg_dtype", [np.uint32, np.int32, np.float32])
 def test_groupby_tile_sorted_plan_widens_narrow_arguments(ch, ctx, arg_dtype):
