@@ -2057,6 +2057,7 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
         {
             const bool hz = t.ctrl->has_zero != 0; // the zero key lives out of line (cell `capacity`)
             cells[WIN] = jv2{hz ? 1ull : 0ull, hz ? payload[flat_of(t.kv[2 * t.capacity + 1])] : 0ull};
+            cells[WIN + 1] = jv2{0, 0};
         }
     u64 cnt = 0, isum = 0;
     bool stray = false, dup = false;
@@ -2081,7 +2082,7 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
             // unit, so a chain may run on into the cells behind the slice); the zero key sits in the extra cell
             constexpr u32 NWB = JPL2_THREADS / 64;
             u64 * cw = (u64 *)cells;
-            for (u32 c = threadIdx.x; c <= WIN; c += JPL2_THREADS)
+            for (u32 c = threadIdx.x; c <= WIN + 1; c += JPL2_THREADS)
                 cells[c] = jv2{0, 0};
             __syncthreads();
             const u64 bb = s_boff[p1], be = s_boff[p1 + 1];
@@ -2159,27 +2160,37 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
         // per tile); the keys of tile k + 1 are in flight while tile k is answered from LDS.
         constexpr u32 NW = JPL2_THREADS / 64;
         const u32 my_tiles = t_lo + wave <= t_hi ? (t_hi - t_lo - wave) / NW + 1 : 0;
-        auto probe_one = [&](u64 key) {
-            bool found;
-            u64 v;
-            if (key == 0)
+        // One look-up, straight-line for all but the longest chains: the home cell and its successor are read unconditionally and the
+        // answer is selected; the zero key is the same look-up aimed at the extra cell (which holds {1, payload} when present); lanes
+        // without a key carry valid = false.  (With a branch per case the loop spent ~100 scalar instructions per 64 look-ups on
+        // exec-mask bookkeeping -- PMC: 1.9e8 SALU against 1.4e8 VALU instructions for 1e8 keys -- but removing them did not move the
+        // kernel's 0.69 ms: 59 % of its wave cycles are waits)
+        auto probe_one = [&](u64 key, bool valid) {
+            const bool zk = key == 0;
+            const u64 want = zk ? 1ull : key;
+            u32 c = zk ? WIN : (u32)((dev_intHash64(key) & mask) - slice); // the home slot: inside the slice by construction
+            const jv2 c0 = cells[c], c1 = cells[c + 1];
+            bool found = c0.x == want;
+            u64 v = c0.y;
+            const bool second = !found && c0.x != 0 && !zk;
+            found = found || (second && c1.x == want);
+            v = (second && c1.x == want) ? c1.y : v;
+            bool more = valid && second && c1.x != want && c1.x != 0; // a chain of three or more cells: rare at this load factor
+            if (__any(more))
             {
-                const jv2 z = cells[WIN];
-                found = z.x != 0;
-                v = z.y;
+                if (more)
+                {
+                    c += 2;
+                    jv2 cell = c < WIN ? cells[c] : jv2{0, 0};
+                    while (cell.x != want && cell.x != 0 && c + 1 < WIN)
+                        cell = cells[++c];
+                    stray = stray || (cell.x != want && cell.x != 0); // the chain runs on past the staged window
+                    found = cell.x == want;
+                    v = cell.y;
+                }
             }
-            else
-            {
-                u32 c = (u32)((dev_intHash64(key) & mask) - slice); // the home slot: inside the slice by construction
-                jv2 cell = cells[c];
-                while (cell.x != key && cell.x != 0 && c + 1 < WIN)
-                    cell = cells[++c];
-                stray = stray || (cell.x != key && cell.x != 0); // the chain runs on past the staged window
-                found = cell.x == key;
-                v = cell.y;
-            }
-            cnt += found ? (anti ? 0 : 1) : (miss_counts ? 1 : 0);
-            isum += (found && !anti) ? v : 0;
+            cnt += !valid ? 0 : found ? (anti ? 0 : 1) : (miss_counts ? 1 : 0);
+            isum += (valid && found && !anti) ? v : 0;
         };
         for (u32 kb = 0; kb < my_tiles; kb += 64)
         {
@@ -2224,8 +2235,7 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
             auto probe_keys = [&](u32 len, u32 o0, const u64 (&key)[U]) {
 #pragma unroll
                 for (u32 u = 0; u < U; ++u)
-                    if (o0 + u * 64 + lane < len)
-                        probe_one(key[u]);
+                    probe_one(key[u], o0 + u * 64 + lane < len);
             };
             // batches of TB tiles: all their key loads are issued before the first look-up (a run is only ~128 keys = two loads per lane:
             // tile by tile, even double-buffered, the wave had two tiles' worth of loads in flight and waited out the latency each time)
@@ -2325,7 +2335,7 @@ static int join_probe_agg_lds(chgpu_join * j, const chgpu_col * key_col, const c
         hipLaunchKernelGGL(sortk, dim3(G), dim3(RP_THREADS), lds, ctx->stream, (const u64 *)keys1, n, rows_per_wg2, PB, keys2, tidx, fn2, stray, (const u64 *)nullptr, (u64 *)nullptr);
     }
     {
-        const size_t lds = (size_t)(JPL2_CELLS + JPL2_TAIL + 1) * 16;
+        const size_t lds = (size_t)(JPL2_CELLS + JPL2_TAIL + 2) * 16;
         CHGPU_HIP(hipFuncSetAttribute((const void *)k_join_probe_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_join_probe_lds<false>, dim3(2 * G), dim3(JPL2_THREADS), lds, ctx->stream, j->t, variant, (const u64 *)keys2, n, (const u64 *)offsets, G, lg_p2,
                            (const unsigned short *)tidx, (const u64 *)right_payload->data, (const u64 *)j->block_base_dev, (u64)j->blocks.size(), unit_ctr, stray, result2,
@@ -2430,7 +2440,7 @@ static int join_probe_agg_radix(chgpu_join * j, const chgpu_col * key_col, const
     {
         JoinTable vt{}; // only the capacity is read
         vt.capacity = cap;
-        const size_t lds = (size_t)(JPL2_CELLS + JPL2_TAIL + 1) * 16;
+        const size_t lds = (size_t)(JPL2_CELLS + JPL2_TAIL + 2) * 16;
         CHGPU_HIP(hipFuncSetAttribute((const void *)k_join_probe_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_join_probe_lds<true>, dim3(2 * G), dim3(JPL2_THREADS), lds, ctx->stream, vt, variant, (const u64 *)pk2, n, (const u64 *)p_offsets, G, lg_p2,
                            (const unsigned short *)pix, (const u64 *)nullptr, (const u64 *)nullptr, (u64)1, unit_ctr, stray, result2, (const u64 *)bk2, (const u64 *)bw2,
