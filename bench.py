@@ -509,7 +509,9 @@ def config_c3(args, ctx, ch, torch, np, dev, stream, tj, with_cpu):
 def config_c4(args, ctx, ch, torch, np, dev, stream, tj, with_cpu):
     """BASELINE.json configs[3], the share of ONE GPU: 1e8-row probe INNER JOIN 1e7-row build on a UInt64 key (unique build keys, ~50 %
     hits), checksum form SELECT count(), sum(bv).  build = chgpu_join_create + add_block + finish_build; probe = the join with the
-    aggregation fused behind it."""
+    aggregation fused behind it.  The hash table is lazy (built by the first joinBlock / key-count consumer): this fused probe joins
+    without one -- every timed probe call partitions the build rows and the probe keys and builds + probes the slices in LDS -- so the
+    build phase is the key staging alone and the whole cost of the join sits in probe_ms."""
     nb, npb = args.c4_build_rows, args.c4_probe_rows
     g = torch.Generator(device=dev).manual_seed(5)
     bk = (torch.randperm(nb, device=dev, generator=g).to(torch.int64) + 1) * 2654435761
@@ -545,6 +547,8 @@ def config_c4(args, ctx, ch, torch, np, dev, stream, tj, with_cpu):
     kernels, ksrc = _kernels_from_profile(["k_join_", "k_jp_", "k_rp_<JoinRegionFn", "k_rp_<JoinBucket2Fn", "k_rp_<JoinSliceFn"])
     tot = b_ms + p_ms
     res = {"workload": "100 M-row probe INNER JOIN 10 M-row build on UInt64 (ALL, unique build keys, ~50 % hits), SELECT count(), sum(bv); one GPU",
+           "plan": "radix join: build rows {key, payload} and probe keys partitioned twice down to 4096-cell slices, every slice built and probed in LDS; "
+                   "no hash table in HBM (it is lazy: joinBlock / key-count consumers build it), so build_ms is key staging and probe_ms the whole join",
            "build_rows": nb, "probe_rows": npb, "matches": cnt, "build_calls": 5, "probe_calls": 6, "build_ms": b_ms, "probe_ms": p_ms, "ms": tot, "wall_ms": b_wall + p_wall,
            "rows_per_s": (nb + npb) / (tot * 1e-3), "probe_rows_per_s": npb / (p_ms * 1e-3),
            "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": algo / (tot * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
