@@ -2050,6 +2050,8 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
     const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 mask = t.capacity - 1;
     auto flat_of = [&](u64 rowid) -> u64 { return n_blocks == 1 ? (rowid & 0xFFFFFFFFull) : block_base[rowid >> 32] + (rowid & 0xFFFFFFFFull); };
+    const int experiment = variant >> 8; // timing experiments only (CHGPU_EXPERIMENT_JOIN_LDS: 1 = no slice build, 2 = no look-ups)
+    variant &= 0xff;
     const bool miss_counts = variant == PV_ALL_LEFT || variant == PV_ANY_LEFT || variant == PV_ANTI_LEFT;
     const bool anti = variant == PV_ANTI_LEFT;
     if constexpr (!FROM_ROWS)
@@ -2086,48 +2088,83 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
                 cells[c] = jv2{0, 0};
             __syncthreads();
             const u64 bb = s_boff[p1], be = s_boff[p1 + 1];
-            if (bb != be)
+            if (bb != be && experiment != 1)
             {
                 const u32 bt_lo = (u32)(bb / JBS_TILE), bt_hi = (u32)((be - 1) / JBS_TILE);
-                for (u32 tile = bt_lo + wave; tile <= bt_hi; tile += NWB)
-                {
-                    const u64 row0 = (u64)tile * JBS_TILE;
-                    u32 lo = 0, hi = P1 - 1;
-                    while (lo < hi)
+                const u32 my_bt = bt_lo + wave <= bt_hi ? (bt_hi - bt_lo - wave) / NWB + 1 : 0;
+                auto insert_row = [&](u64 key, u64 pay) {
+                    u32 c = key == 0 ? WIN : (u32)((dev_intHash64(key) & mask) - slice);
+                    const u64 want = key == 0 ? 1ull : key; // the zero key's cell holds {present, payload}
+                    for (;;)
                     {
-                        const u32 mid = (lo + hi + 1) >> 1;
-                        if (s_boff[mid] <= row0)
-                            lo = mid;
-                        else
-                            hi = mid - 1;
-                    }
-                    const u32 bucket = (p1 - lo) * P2 + p2;
-                    if (bucket >= PB)
-                        continue; // (stray flag raised by the tile sort)
-                    const u32 a = btidx[(u64)tile * (PB + 1) + bucket], b = btidx[(u64)tile * (PB + 1) + bucket + 1];
-                    for (u32 o = lane; o < b - a; o += 64)
-                    {
-                        const u64 key = bkeys2[row0 + a + o], pay = bwords2[row0 + a + o];
-                        u32 c = key == 0 ? WIN : (u32)((dev_intHash64(key) & mask) - slice);
-                        const u64 want = key == 0 ? 1ull : key; // the zero key's cell holds {present, payload}
-                        for (;;)
+                        const u64 old = atomicCAS((unsigned long long *)&cw[2 * c], 0ull, (unsigned long long)want);
+                        if (old == 0)
                         {
-                            const u64 old = atomicCAS((unsigned long long *)&cw[2 * c], 0ull, (unsigned long long)want);
-                            if (old == 0)
-                            {
-                                cw[2 * c + 1] = pay; // nobody reads it before the barrier below
-                                break;
-                            }
-                            if (old == want || key == 0)
-                            {
-                                dup = true;
-                                break;
-                            }
-                            if (++c >= WIN)
-                            {
-                                stray = true; // the window is too short for this chain: not this plan
-                                break;
-                            }
+                            cw[2 * c + 1] = pay; // nobody reads it before the barrier below
+                            break;
+                        }
+                        if (old == want || key == 0)
+                        {
+                            dup = true;
+                            break;
+                        }
+                        if (++c >= WIN)
+                        {
+                            stray = true; // the window is too short for this chain: not this plan
+                            break;
+                        }
+                    }
+                };
+                // as on the probe side: lane k fetches the run of this wave's k-th build tile, then the rows of TBB tiles are loaded
+                // together (a run is ~60 rows: tile by tile the wave sat out an index and a row round trip per tile -- half the kernel)
+                for (u32 kb = 0; kb < my_bt; kb += 64)
+                {
+                    u32 st_l = 0, ln_l = 0;
+                    if (kb + lane < my_bt)
+                    {
+                        const u32 tile = bt_lo + wave + (kb + lane) * NWB;
+                        const u64 row0 = (u64)tile * JBS_TILE;
+                        u32 lo = 0, hi = P1 - 1;
+                        while (lo < hi)
+                        {
+                            const u32 mid = (lo + hi + 1) >> 1;
+                            if (s_boff[mid] <= row0)
+                                lo = mid;
+                            else
+                                hi = mid - 1;
+                        }
+                        const u32 bucket = (p1 - lo) * P2 + p2;
+                        if (bucket < PB) // (else: stray flag raised by the tile sort)
+                        {
+                            const u32 ia = btidx[(u64)tile * (PB + 1) + bucket], ib = btidx[(u64)tile * (PB + 1) + bucket + 1];
+                            st_l = ia;
+                            ln_l = ib - ia;
+                        }
+                    }
+                    const u32 nkb = my_bt - kb < 64 ? my_bt - kb : 64;
+                    constexpr u32 TBB = 4;
+                    for (u32 k0 = 0; k0 < nkb; k0 += TBB)
+                    {
+                        u64 bkey[TBB], bpay[TBB], brow[TBB];
+                        u32 blen[TBB];
+#pragma unroll
+                        for (u32 q = 0; q < TBB; ++q)
+                        {
+                            const u32 kk = k0 + q < nkb ? k0 + q : nkb - 1;
+                            const u32 st = (u32)__builtin_amdgcn_readlane((int)st_l, (int)kk);
+                            blen[q] = k0 + q < nkb ? (u32)__builtin_amdgcn_readlane((int)ln_l, (int)kk) : 0;
+                            brow[q] = (u64)(bt_lo + wave + (kb + kk) * NWB) * JBS_TILE + st;
+                            const u64 at = brow[q] + (lane < blen[q] ? lane : 0);
+                            bkey[q] = bkeys2[at];
+                            bpay[q] = bwords2[at];
+                        }
+#pragma unroll
+                        for (u32 q = 0; q < TBB; ++q)
+                        {
+                            if (lane < blen[q])
+                                insert_row(bkey[q], bpay[q]);
+                            for (u32 o = 64 + lane; o < blen[q]; o += 64) // a run longer than a wave (skew)
+                                insert_row(bkeys2[brow[q] + o], bwords2[brow[q] + o]);
                         }
                     }
                 }
@@ -2159,7 +2196,7 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
         // This wave's tiles: t_lo + wave, + NW, ...  Lane k fetches the run of tile k (one round trip for all of them instead of one
         // per tile); the keys of tile k + 1 are in flight while tile k is answered from LDS.
         constexpr u32 NW = JPL2_THREADS / 64;
-        const u32 my_tiles = t_lo + wave <= t_hi ? (t_hi - t_lo - wave) / NW + 1 : 0;
+        const u32 my_tiles = (t_lo + wave <= t_hi && experiment != 2) ? (t_hi - t_lo - wave) / NW + 1 : 0;
         // One look-up, straight-line for all but the longest chains: the home cell and its successor are read unconditionally and the
         // answer is selected; the zero key is the same look-up aimed at the extra cell (which holds {1, payload} when present); lanes
         // without a key carry valid = false.  (With a branch per case the loop spent ~100 scalar instructions per 64 look-ups on
@@ -2442,7 +2479,8 @@ static int join_probe_agg_radix(chgpu_join * j, const chgpu_col * key_col, const
         vt.capacity = cap;
         const size_t lds = (size_t)(JPL2_CELLS + JPL2_TAIL + 2) * 16;
         CHGPU_HIP(hipFuncSetAttribute((const void *)k_join_probe_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_join_probe_lds<true>, dim3(2 * G), dim3(JPL2_THREADS), lds, ctx->stream, vt, variant, (const u64 *)pk2, n, (const u64 *)p_offsets, G, lg_p2,
+        static const int jexp = getenv("CHGPU_EXPERIMENT_JOIN_LDS") ? atoi(getenv("CHGPU_EXPERIMENT_JOIN_LDS")) : 0;
+        hipLaunchKernelGGL(k_join_probe_lds<true>, dim3(2 * G), dim3(JPL2_THREADS), lds, ctx->stream, vt, variant | (jexp << 8), (const u64 *)pk2, n, (const u64 *)p_offsets, G, lg_p2,
                            (const unsigned short *)pix, (const u64 *)nullptr, (const u64 *)nullptr, (u64)1, unit_ctr, stray, result2, (const u64 *)bk2, (const u64 *)bw2,
                            (const u64 *)b_offsets, (const unsigned short *)bix, nb, dupf);
     }
