@@ -544,7 +544,7 @@ def config_c4(args, ctx, ch, torch, np, dev, stream, tj, with_cpu):
     assert (cnt, sm % 2**64) == (want_cnt, want_sum), ("C4", cnt, sm, want_cnt, want_sum)
     del sbk, order, pos, hit
     algo = 8.0 * npb + 16.0 * nb + 8.0 * cnt  # probe keys + build keys and payload + payload per matched row
-    kernels, ksrc = _kernels_from_profile(["k_join_", "k_jp_", "k_rp_<JoinRegionFn", "k_rp_<JoinBucket2Fn", "k_rp_<JoinSliceFn"])
+    kernels, ksrc = _kernels_from_profile(["k_join_", "k_jp_", "k_rp_<JoinRegionFn", "k_rp_<JoinBucket2Fn", "k_rp_<JoinSliceFn", "k_rp_<JoinRadixFn"])
     tot = b_ms + p_ms
     res = {"workload": "100 M-row probe INNER JOIN 10 M-row build on UInt64 (ALL, unique build keys, ~50 % hits), SELECT count(), sum(bv); one GPU",
            "plan": "radix join: build rows {key, payload} and probe keys partitioned twice down to 4096-cell slices, every slice built and probed in LDS; "

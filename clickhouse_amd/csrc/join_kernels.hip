@@ -2019,6 +2019,26 @@ struct JoinBucket2Fn
     }
 };
 
+// The radix join has no table whose placement it must match, so it places keys by ONE 64-bit multiply (top lg_cap bits of key x odd
+// constant) instead of intHash64's two multiplies and three shift-xors: the hash is evaluated once per key in each of the four passes, and
+// a 64-bit multiply is four quarter-rate instructions.  (A key set that clusters under it overflows a slice's window: the stray flag
+// sends the call to the table paths.)
+__device__ __forceinline__ u64 join_radix_slot(u64 key, u32 lg_cap) { return (key * 0x9E3779B97F4A7C15ull) >> (64 - lg_cap); }
+struct JoinRadixFn1
+{
+    u32 lg_cap, shift;
+    __device__ __forceinline__ u32 operator()(u64 key) const { return (u32)(join_radix_slot(key, lg_cap) >> shift); }
+};
+struct JoinRadixFn2
+{
+    u32 lg_cap, shift2, lg_p2;
+    __device__ __forceinline__ u32 operator()(u64 key, u64 first) const
+    {
+        const u32 r = (u32)(join_radix_slot(key, lg_cap) >> shift2), r0 = (u32)(join_radix_slot(first, lg_cap) >> shift2) >> lg_p2 << lg_p2;
+        return r - r0;
+    }
+};
+
 // FROM_ROWS: there is no table -- the slice's LDS cells are filled from the BUILD ROWS of the slice, which were partitioned the same way
 // (bkeys2 / bwords2 = keys and payloads tile-sorted inside 64 partitions, boff1 / btidx their offsets and run index; t only carries the
 // capacity).  A duplicate build key raises dup_flag (the caller then builds the table and takes the other paths).
@@ -2049,6 +2069,10 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
     const u32 lane = threadIdx.x & 63;
     const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 mask = t.capacity - 1;
+    u32 lg_cap = 0;
+    while ((1ull << lg_cap) < t.capacity)
+        ++lg_cap;
+    auto slot_of = [&](u64 key) -> u64 { return FROM_ROWS ? join_radix_slot(key, lg_cap) : (dev_intHash64(key) & mask); };
     auto flat_of = [&](u64 rowid) -> u64 { return n_blocks == 1 ? (rowid & 0xFFFFFFFFull) : block_base[rowid >> 32] + (rowid & 0xFFFFFFFFull); };
     const int experiment = variant >> 8; // timing experiments only (CHGPU_EXPERIMENT_JOIN_LDS: 1 = no slice build, 2 = no look-ups)
     variant &= 0xff;
@@ -2093,7 +2117,7 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
                 const u32 bt_lo = (u32)(bb / JBS_TILE), bt_hi = (u32)((be - 1) / JBS_TILE);
                 const u32 my_bt = bt_lo + wave <= bt_hi ? (bt_hi - bt_lo - wave) / NWB + 1 : 0;
                 auto insert_row = [&](u64 key, u64 pay) {
-                    u32 c = key == 0 ? WIN : (u32)((dev_intHash64(key) & mask) - slice);
+                    u32 c = key == 0 ? WIN : (u32)(slot_of(key) - slice);
                     const u64 want = key == 0 ? 1ull : key; // the zero key's cell holds {present, payload}
                     for (;;)
                     {
@@ -2205,7 +2229,7 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
         auto probe_one = [&](u64 key, bool valid) {
             const bool zk = key == 0;
             const u64 want = zk ? 1ull : key;
-            u32 c = zk ? WIN : (u32)((dev_intHash64(key) & mask) - slice); // the home slot: inside the slice by construction
+            u32 c = zk ? WIN : (u32)(slot_of(key) - slice); // the home slot: inside the slice by construction
             const jv2 c0 = cells[c], c1 = cells[c + 1];
             bool found = c0.x == want;
             u64 v = c0.y;
@@ -2415,8 +2439,8 @@ static int join_probe_agg_radix(chgpu_join * j, const chgpu_col * key_col, const
         return CHGPU_ERR_NOT_IMPLEMENTED;
     static_assert(JPL2_LG_CELLS == JBS_LG_CELLS && JPL2_LG_P1 == JBS_LG_P1, "one slice geometry for both sides");
     const u32 lg_p2 = lg_cap - JPL2_LG_CELLS - JPL2_LG_P1, P1 = 1u << JPL2_LG_P1, PB = 2u << lg_p2;
-    const JoinRegionFn fn1{cap - 1, lg_cap - JPL2_LG_P1};
-    const JoinBucket2Fn fn2{cap - 1, JPL2_LG_CELLS, lg_p2};
+    const JoinRadixFn1 fn1{lg_cap, lg_cap - JPL2_LG_P1};
+    const JoinRadixFn2 fn2{lg_cap, JPL2_LG_CELLS, lg_p2};
     const u32 G = (u32)ctx->num_cus;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     const u64 m = (u64)P1 * G;
@@ -2448,29 +2472,29 @@ static int join_probe_agg_radix(chgpu_join * j, const chgpu_col * key_col, const
     CHGPU_HIP(hipMemsetAsync(total_dev, 0, 64, ctx->stream));
     // the build side: rows {key, payload}
     const u64 * bkeys0 = j->blocks[0].keys;
-    hipLaunchKernelGGL((k_rp_hist_wide<u64, JoinRegionFn>), dim3(G), dim3(RP_THREADS), 0, ctx->stream, bkeys0, nb, b_rpw, P1, b_counts, fn1);
+    hipLaunchKernelGGL((k_rp_hist_wide<u64, JoinRadixFn1>), dim3(G), dim3(RP_THREADS), 0, ctx->stream, bkeys0, nb, b_rpw, P1, b_counts, fn1);
     CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, b_counts, b_offsets, m, total_dev, tmp, tmp_b));
     {
         const size_t lds = rp_scatter_lds_bytes(8192, P1, 8, true);
-        auto scat = k_rp_scatter<8192, u64, true, JoinRegionFn>;
+        auto scat = k_rp_scatter<8192, u64, true, JoinRadixFn1>;
         CHGPU_HIP(hipFuncSetAttribute((const void *)scat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(scat, dim3(G), dim3(RP_THREADS), lds, ctx->stream, bkeys0, (const u64 *)right_payload->data, nb, b_rpw, P1, (const u64 *)b_offsets, bk1, bw1, fn1);
         const size_t lds2 = (size_t)JBS_TILE * 16 + (size_t)(PB + 1) * 8 + 64;
-        auto sortk = k_rp_tilesort_keys<JBS_TILE, JoinBucket2Fn, RP_THREADS, true>;
+        auto sortk = k_rp_tilesort_keys<JBS_TILE, JoinRadixFn2, RP_THREADS, true>;
         CHGPU_HIP(hipFuncSetAttribute((const void *)sortk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(sortk, dim3(G), dim3(RP_THREADS), lds2, ctx->stream, (const u64 *)bk1, nb, b_rpw2, PB, bk2, bix, fn2, stray, (const u64 *)bw1, bw2);
     }
     // the probe side: keys
-    hipLaunchKernelGGL((k_rp_hist_wide<u64, JoinRegionFn>), dim3(G), dim3(RP_THREADS), 0, ctx->stream, (const u64 *)key_col->data, n, p_rpw, P1, p_counts, fn1);
+    hipLaunchKernelGGL((k_rp_hist_wide<u64, JoinRadixFn1>), dim3(G), dim3(RP_THREADS), 0, ctx->stream, (const u64 *)key_col->data, n, p_rpw, P1, p_counts, fn1);
     CHGPU_TRY(chgpu_scan_exclusive_u32_u64(ctx, p_counts, p_offsets, m, total_dev, tmp, tmp_b));
     {
         const size_t lds = rp_scatter_lds_bytes(12288, P1, 8, false);
-        auto scat = k_rp_scatter<12288, u64, false, JoinRegionFn>;
+        auto scat = k_rp_scatter<12288, u64, false, JoinRadixFn1>;
         CHGPU_HIP(hipFuncSetAttribute((const void *)scat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(scat, dim3(G), dim3(RP_THREADS), lds, ctx->stream, (const u64 *)key_col->data, (const u64 *)nullptr, n, p_rpw, P1, (const u64 *)p_offsets, pk1,
                            (u64 *)nullptr, fn1);
         const size_t lds2 = (size_t)JPL2_TILE * 8 + (size_t)(PB + 1) * 8 + 64;
-        auto sortk = k_rp_tilesort_keys<JPL2_TILE, JoinBucket2Fn>;
+        auto sortk = k_rp_tilesort_keys<JPL2_TILE, JoinRadixFn2>;
         CHGPU_HIP(hipFuncSetAttribute((const void *)sortk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(sortk, dim3(G), dim3(RP_THREADS), lds2, ctx->stream, (const u64 *)pk1, n, p_rpw2, PB, pk2, pix, fn2, stray, (const u64 *)nullptr, (u64 *)nullptr);
     }

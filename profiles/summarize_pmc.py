@@ -88,7 +88,7 @@ if "C3" in cfg and cfg["C3"].get("calls"):
                  "kernels_total_over_all_calls": split}
 if "C4_one_gpu" in cfg and cfg["C4_one_gpu"].get("probe_calls"):
     c4 = cfg["C4_one_gpu"]
-    r, w, split = group_bytes(["k_join_", "k_jp_", "k_rp_<JoinRegionFn", "k_rp_<JoinBucket2Fn", "k_rp_<JoinSliceFn"])
+    r, w, split = group_bytes(["k_join_", "k_jp_", "k_rp_<JoinRegionFn", "k_rp_<JoinBucket2Fn", "k_rp_<JoinSliceFn", "k_rp_<JoinRadixFn"])
     # build and probe run a different number of times: weigh each kernel by the calls of its phase
     per_call = 0.0
     for name, v in split.items():
