@@ -16,7 +16,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
 rng = np.random.Generator(np.random.PCG64(seed))
 ctx = ch.Context(0)
 t0 = time.time()
-n_cases = {"groupby": 0, "semi": 0, "filter": 0}
+n_cases = {"groupby": 0, "semi": 0, "filter": 0, "join_agg": 0}
 print("seed", seed, flush=True)
 
 
@@ -108,9 +108,56 @@ def case_filter():
     n_cases["filter"] += 1
 
 
+def case_join_agg():
+    """the fused probe over one- and two-block build sides: the radix join (no table), the table's LDS-staged slices after the key count
+    has built it, duplicate build keys (both fall back), every join variant; against a sorted-search join in numpy"""
+    nb = int(rng.choice([1_100_000, 2_097_152, int(rng.integers(1_000_000, 4_500_000))]))
+    npb = int(rng.integers(8_400_000, 10_500_000))
+    space = int(rng.choice([2**40, 2**63, nb * 3]))
+    if space == nb * 3:
+        bk = rng.permutation(nb * 3)[:nb].astype(np.uint64)                      # dense small keys (incl. 0)
+    else:
+        bk = (rng.permutation(nb).astype(np.uint64) * np.uint64(2654435761) + np.uint64(int(rng.integers(0, 1000)))) % np.uint64(space)
+        bk = np.unique(bk)
+        nb = bk.shape[0]
+        rng.shuffle(bk)
+    dups = rng.random() < 0.25
+    if dups:
+        bk[-5:] = bk[:5]
+    bv = rng.integers(-2**45, 2**45, size=nb, dtype=np.int64)
+    pk = np.where(rng.random(npb) < rng.choice([0.1, 0.5, 0.95]), bk[rng.integers(0, nb, size=npb)], rng.integers(0, min(space * 2, 2**63), size=npb, dtype=np.uint64))
+    kind, strict = [(ch.JOIN_INNER, ch.STRICT_ALL), (ch.JOIN_LEFT, ch.STRICT_ALL), (ch.JOIN_LEFT, ch.STRICT_SEMI), (ch.JOIN_LEFT, ch.STRICT_ANTI)][int(rng.integers(0, 4))]
+    j = ch.HashJoin(kind, strict, ctx=ctx)
+    blocks = 1 if rng.random() < 0.7 else 2
+    cut = nb // blocks
+    for b in range(blocks):
+        j.add_block(bk[b * cut:(b + 1) * cut if b + 1 < blocks else nb])
+    pkc, bvc = ctx.upload(pk), ctx.upload(bv)
+    c, s = j.probe_count_sum(pkc, bvc)
+    mult_keys, mult = np.unique(bk, return_counts=True)
+    sums = np.zeros(mult_keys.shape[0], dtype=np.uint64)
+    np.add.at(sums, np.searchsorted(mult_keys, bk), bv.astype(np.uint64))
+    pos = np.searchsorted(mult_keys, pk)
+    pos[pos == mult_keys.shape[0]] = 0
+    hit = mult_keys[pos] == pk
+    if strict == ch.STRICT_ANTI:
+        want_c, want_s = int((~hit).sum()), 0
+    elif strict == ch.STRICT_SEMI:
+        want_c, want_s = int(hit.sum()), None if dups else int(sums[pos[hit]].sum(dtype=np.uint64))   # with duplicates SEMI takes ONE of the rows
+    else:
+        want_c = int(mult[pos[hit]].sum()) + (int((~hit).sum()) if kind == ch.JOIN_LEFT else 0)
+        want_s = int(sums[pos[hit]].sum(dtype=np.uint64))
+    assert c == want_c and (want_s is None or s % 2**64 == want_s), ("join_agg", nb, npb, space, dups, blocks, kind, strict, c, want_c)
+    if rng.random() < 0.5:
+        assert j.n_keys == mult_keys.shape[0]                                    # builds the table
+        c2, s2 = j.probe_count_sum(pkc, bvc)
+        assert c2 == c and (want_s is None or s2 == s), ("join_agg after the table", nb, npb, dups, blocks, kind, strict)
+    n_cases["join_agg"] += 1
+
+
 while time.time() - t0 < budget:
     x = rng.random()
-    (case_groupby if x < 0.6 else case_semi if x < 0.85 else case_filter)()
+    (case_groupby if x < 0.45 else case_semi if x < 0.65 else case_filter if x < 0.75 else case_join_agg)()
     if sum(n_cases.values()) % 5 == 0:
         print(f"{time.time() - t0:6.1f}s {n_cases}", flush=True)
 print("fuzz_round2 OK", n_cases, flush=True)
