@@ -219,3 +219,77 @@ def test_native_block_header_walk():
     s = bytes(varuint(1) + varuint(3) + string("s") + string("String") + b"\x01a\x01b\x01c")
     arr_s = (C.c_uint8 * len(s)).from_buffer_copy(s)
     assert K.lib().chgpu_native_walk_block(arr_s, len(s), 0, 2, cols, C.byref(ncols), C.byref(nrows), None, None, C.byref(used)) == K.ERR_NOT_IMPLEMENTED
+
+
+def _synthetic_lz4_block(rng, target, small):
+    """a valid LZ4 block built sequence by sequence together with the bytes it decodes to: literal and match lengths on both sides of the
+    token's 4-bit fields, offsets 1.. (overlapping matches of every period), near and far match sources -- shapes a real compressor
+    rarely emits but the format allows"""
+    out, blk = bytearray(), bytearray()
+    while len(out) < target:
+        lit = int(rng.choice([0, 1, 3, 4, 8, 13, 14, 15, 16, 40, 300])) if not small else int(rng.integers(0, 14))
+        if not out and lit == 0:
+            lit = 1
+        ml = int(rng.choice([4, 5, 8, 15, 16, 17, 18, 19, 20, 60, 274, 700, 3000])) if not small else int(rng.integers(4, 17))
+        lits = rng.integers(0, 256, size=lit, dtype=np.uint8).tobytes()
+        have = len(out) + lit
+        far = have if rng.random() < 0.15 else min(have, int(rng.choice([1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 31, 64, 100, 2047, 2048, 2049, 5000])))
+        offset = int(rng.integers(1, min(far, 65535) + 1))
+        token = (min(lit, 15) << 4) | min(ml - 4, 15)
+        blk.append(token)
+        if lit >= 15:
+            r = lit - 15
+            while r >= 255:
+                blk.append(255)
+                r -= 255
+            blk.append(r)
+        blk += lits
+        out += lits
+        blk += struct.pack("<H", offset)
+        if ml - 4 >= 15:
+            r = ml - 19
+            while r >= 255:
+                blk.append(255)
+                r -= 255
+            blk.append(r)
+        start = len(out) - offset
+        for k in range(ml):
+            out.append(out[start + k])
+    tail = rng.integers(0, 256, size=int(rng.integers(12, 40)), dtype=np.uint8).tobytes()   # the last sequence: literals only
+    blk.append(min(len(tail), 15) << 4)
+    if len(tail) >= 15:
+        blk.append(len(tail) - 15)
+    blk += tail
+    out += tail
+    return bytes(blk), bytes(out)
+
+
+def _synthetic_frames(rng, n_frames):
+    bufs, raws = [], []
+    for i in range(n_frames):
+        blk, raw = _synthetic_lz4_block(rng, int(rng.choice([50, 700, 5000, 30_000])), small=bool(i % 2))
+        bufs.append(OC._framed(OC._stage(OC.METHOD_LZ4, blk, len(raw))))
+        raws.append(raw)
+    return b"".join(bufs), b"".join(raws)
+
+
+def test_oracle_decodes_synthetic_sequences():
+    rng = np.random.Generator(np.random.PCG64(21))
+    buf, raw = _synthetic_frames(rng, 23)
+    assert OC.read_frames(buf) == raw
+
+
+@pytest.mark.gpu
+def test_gpu_decodes_synthetic_sequences():
+    """frame counts around the grid's stride, short and long sequences side by side, every small overlapping period on the fast path,
+    matches on both sides of what the LDS ring serves (offsets 2047 / 2048 / 2049 / far)"""
+    import clickhouse_amd as ch
+    from clickhouse_amd import compression as CC
+    ctx = ch.Context()
+    rng = np.random.Generator(np.random.PCG64(22))
+    for n_frames in (1, 2, 3, 5, 64, 257):
+        buf, raw = _synthetic_frames(rng, n_frames)
+        frames = CC.parse_frames(buf)
+        assert len(frames) == n_frames
+        out = CC.decompress_frames(ctx, ctx.upload(np.frombuffer(buf, dtype=np.uint8)), frames).numpy().tobytes()
+        assert out == raw, n_frames
