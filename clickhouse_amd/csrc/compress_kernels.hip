@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256) void k_lz4_decode(const u8 * __restrict__ src,
                 {
                     const u32 offset = (u32)__builtin_amdgcn_readlane((int)hb, (int)(1 + lit)) | ((u32)__builtin_amdgcn_readlane((int)hb, (int)(2 + lit)) << 8);
                     const u32 ml = mlt + 4;
-                    if (offset - 1 < (op + lit < LZ_CHUNK ? op + lit : LZ_CHUNK)) // 1 <= offset <= min(bytes written, what the ring serves)
+                    // 1 <= offset <= min(bytes written, what the ring serves).  A fast-path sequence writes at most 32 bytes, all after its
+                    // reads, so the ring serves it from anywhere in the last LZ_RING - 64 bytes (the chunked general path: LZ_CHUNK) --
+                    // C2's column has 15 % of its matches more than 2 KiB back and 5 % more than 4 KiB
+                    if (offset - 1 < (op + lit < LZ_RING - 64 ? op + lit : LZ_RING - 64))
                     {
                         // the literals are bytes 1..lit of the window: lane l takes lane l+1's byte (DPP wave shift, no LDS read)
                         const u32 litb = (u32)__builtin_amdgcn_update_dpp(0, (int)hb, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
