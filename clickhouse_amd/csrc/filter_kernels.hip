@@ -830,10 +830,13 @@ __global__ __launch_bounds__(256) void k_mask_chunk_counts(const u8 * __restrict
     }
 }
 
-template <typename T>
+template <typename T, bool STAGED = false>
 __global__ __launch_bounds__(256) void k_filter_scatter(const T * __restrict__ data, const u8 * __restrict__ mask, u64 n,
                                                         const u64 * __restrict__ chunk_offsets, u64 n_chunks, T * __restrict__ out)
 {
+    // STAGED: see k_filter_scatter_multi
+    __shared__ T stage[STAGED ? 4 : 1][STAGED ? CHUNK_ROWS : 1];
+    T * const st = stage[STAGED ? (threadIdx.x >> 6) : 0];
     constexpr int R = 16 / sizeof(T);        // rows per lane per group
     constexpr u32 GROUP = 64 * R;            // rows per wave per group
     constexpr int G = CHUNK_ROWS / GROUP;    // groups per chunk
@@ -859,23 +862,51 @@ __global__ __launch_bounds__(256) void k_filter_scatter(const T * __restrict__ d
                 x[g] = *(const V *)(data + row);
                 m[g] = *(const MV *)(mask + row);
             }
-#pragma unroll
-            for (int g = 0; g < G; ++g)
+            if constexpr (STAGED)
             {
-                u32 before = 0, total = 0;
+                u32 run = 0;
 #pragma unroll
-                for (int r = 0; r < R; ++r)
+                for (int g = 0; g < G; ++g)
                 {
-                    const u64 b = __ballot(m[g].v[r] != 0);
-                    before += mbcnt(b);
-                    total += __popcll(b);
-                }
-                u64 o = pos + before;
+                    u32 before = 0, total = 0;
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (m[g].v[r] != 0)
-                        out[o++] = x[g].v[r]; // plain store: L2 merges the partial lines (nontemporal stores here: +25 % time)
-                pos += total;
+                    for (int r = 0; r < R; ++r)
+                    {
+                        const u64 b = __ballot(m[g].v[r] != 0);
+                        before += mbcnt(b);
+                        total += __popcll(b);
+                    }
+                    u32 o = run + before;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (m[g].v[r] != 0)
+                            st[o++] = x[g].v[r];
+                    run += total;
+                }
+                T * const dst = out + pos;
+                for (u32 i = lane; i < run; i += 64) // LDS operations of one wave complete in order: no barrier
+                    dst[i] = st[i];
+            }
+            else
+            {
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                {
+                    u32 before = 0, total = 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                    {
+                        const u64 b = __ballot(m[g].v[r] != 0);
+                        before += mbcnt(b);
+                        total += __popcll(b);
+                    }
+                    u64 o = pos + before;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (m[g].v[r] != 0)
+                            out[o++] = x[g].v[r]; // plain store: L2 merges the partial lines (nontemporal stores here: +25 % time)
+                    pos += total;
+                }
             }
         }
         else
@@ -918,9 +949,13 @@ struct FilterCols
     const T * data[NC];
     T * out[NC];
 };
-template <typename T, int NC>
+template <typename T, int NC, bool STAGED = false>
 __global__ __launch_bounds__(256) void k_filter_scatter_multi(FilterCols<T, NC> c, const u8 * __restrict__ mask, u64 n, const u64 * __restrict__ chunk_offsets, u64 n_chunks)
 {
+    // STAGED: the kept rows of a chunk are compacted in a wave-private LDS buffer first and leave as full 64-lane stores of consecutive
+    // elements (run / 64 store instructions per column instead of one sparse store per row slot)
+    __shared__ T stage[STAGED ? 4 : 1][STAGED ? CHUNK_ROWS : 1];
+    T * const st = stage[STAGED ? (threadIdx.x >> 6) : 0];
     constexpr int R = 16 / sizeof(T);
     constexpr u32 GROUP = 64 * R;
     constexpr int G = CHUNK_ROWS / GROUP;
@@ -967,14 +1002,32 @@ __global__ __launch_bounds__(256) void k_filter_scatter_multi(FilterCols<T, NC> 
 #pragma unroll
                 for (int g = 0; g < G; ++g)
                     x[g] = *(const V *)(c.data[k] + cbase + (u64)g * GROUP + (u64)lane * R);
-#pragma unroll
-                for (int g = 0; g < G; ++g)
+                if constexpr (STAGED)
                 {
-                    u64 o = pos0 + first[g];
 #pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        if (m[g].v[r] != 0)
-                            c.out[k][o++] = x[g].v[r];
+                    for (int g = 0; g < G; ++g)
+                    {
+                        u32 o = first[g];
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (m[g].v[r] != 0)
+                                st[o++] = x[g].v[r];
+                    }
+                    T * const dst = c.out[k] + pos0;
+                    for (u32 i = lane; i < run; i += 64) // LDS operations of one wave complete in order: no barrier
+                        dst[i] = st[i];
+                }
+                else
+                {
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                    {
+                        u64 o = pos0 + first[g];
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (m[g].v[r] != 0)
+                                c.out[k][o++] = x[g].v[r];
+                    }
                 }
             }
         }
@@ -1119,6 +1172,12 @@ static int filter_plan(chgpu_ctx * ctx, const chgpu_col * mask, FilterPlan * fp)
     fp->grid = chgpu_grid_for(ctx, n_chunks * 64, 256, wg_sc);
     return CHGPU_OK;
 }
+// 4- and 8-byte columns: kept rows compacted in LDS, full-width stores (A/B: CHGPU_TUNE_FILTER_NO_STAGED)
+static bool filter_staged()
+{
+    static const bool on = getenv("CHGPU_TUNE_FILTER_NO_STAGED") == nullptr;
+    return on;
+}
 static int filter_apply(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * mask, const FilterPlan & fp, chgpu_col ** out)
 {
     chgpu_col * res = nullptr;
@@ -1128,10 +1187,16 @@ static int filter_apply(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col 
         switch (chgpu_type_size(col->type))
         {
             case 8:
-                hipLaunchKernelGGL(k_filter_scatter<u64>, dim3(fp.grid), dim3(256), 0, ctx->stream, (const u64 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u64 *)res->data);
+                if (filter_staged())
+                    hipLaunchKernelGGL((k_filter_scatter<u64, true>), dim3(fp.grid), dim3(256), 0, ctx->stream, (const u64 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u64 *)res->data);
+                else
+                    hipLaunchKernelGGL((k_filter_scatter<u64, false>), dim3(fp.grid), dim3(256), 0, ctx->stream, (const u64 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u64 *)res->data);
                 break;
             case 4:
-                hipLaunchKernelGGL(k_filter_scatter<u32>, dim3(fp.grid), dim3(256), 0, ctx->stream, (const u32 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u32 *)res->data);
+                if (filter_staged())
+                    hipLaunchKernelGGL((k_filter_scatter<u32, true>), dim3(fp.grid), dim3(256), 0, ctx->stream, (const u32 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u32 *)res->data);
+                else
+                    hipLaunchKernelGGL((k_filter_scatter<u32, false>), dim3(fp.grid), dim3(256), 0, ctx->stream, (const u32 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u32 *)res->data);
                 break;
             case 2:
                 hipLaunchKernelGGL(k_filter_scatter<u16>, dim3(fp.grid), dim3(256), 0, ctx->stream, (const u16 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u16 *)res->data);
@@ -1255,8 +1320,9 @@ extern "C" int chgpu_filter_columns(chgpu_ctx * ctx, uint32_t n_cols, const chgp
             }
         return rc;
     };
-    // columns of one element width go through k_filter_scatter_multi four (or three, two) at a time: one read of the mask for all of them
+    // columns of one element width go through k_filter_scatter_multi up to six at a time: one read of the mask for all of them
     static const bool no_multi = getenv("CHGPU_TUNE_FILTER_NO_MULTI") != nullptr;
+    const bool staged = filter_staged();
     std::vector<char> done(n_cols, 0);
     if (mask->rows && fp.total && !no_multi)
         for (size_t w : {(size_t)8, (size_t)4})
@@ -1267,7 +1333,7 @@ extern "C" int chgpu_filter_columns(chgpu_ctx * ctx, uint32_t n_cols, const chgp
                     same.push_back(k);
             for (size_t b = 0; b + 1 < same.size();)
             {
-                const u32 nc = (u32)(same.size() - b >= 4 ? 4 : same.size() - b);
+                const u32 nc = (u32)(same.size() - b >= 6 ? 6 : same.size() - b);
                 if (nc < 2)
                     break;
                 for (u32 q = 0; q < nc; ++q)
@@ -1285,10 +1351,13 @@ extern "C" int chgpu_filter_columns(chgpu_ctx * ctx, uint32_t n_cols, const chgp
             fc.data[q] = (const T_ *)cols[same[b + q]]->data;                                                                                  \
             fc.out[q] = (T_ *)outs[same[b + q]]->data;                                                                                         \
         }                                                                                                                                      \
-        hipLaunchKernelGGL((k_filter_scatter_multi<T_, NC_>), dim3(fp.grid), dim3(256), 0, ctx->stream, fc, (const u8 *)mask->data, fp.n, (const u64 *)fp.offsets, fp.n_chunks); \
+        if (staged)                                                                                                                            \
+            hipLaunchKernelGGL((k_filter_scatter_multi<T_, NC_, true>), dim3(fp.grid), dim3(256), 0, ctx->stream, fc, (const u8 *)mask->data, fp.n, (const u64 *)fp.offsets, fp.n_chunks); \
+        else                                                                                                                                   \
+            hipLaunchKernelGGL((k_filter_scatter_multi<T_, NC_, false>), dim3(fp.grid), dim3(256), 0, ctx->stream, fc, (const u8 *)mask->data, fp.n, (const u64 *)fp.offsets, fp.n_chunks); \
     } while (0)
-                if (w == 8) { if (nc == 4) FILTER_MULTI(u64, 4); else if (nc == 3) FILTER_MULTI(u64, 3); else FILTER_MULTI(u64, 2); }
-                else        { if (nc == 4) FILTER_MULTI(u32, 4); else if (nc == 3) FILTER_MULTI(u32, 3); else FILTER_MULTI(u32, 2); }
+                if (w == 8) { if (nc == 6) FILTER_MULTI(u64, 6); else if (nc == 5) FILTER_MULTI(u64, 5); else if (nc == 4) FILTER_MULTI(u64, 4); else if (nc == 3) FILTER_MULTI(u64, 3); else FILTER_MULTI(u64, 2); }
+                else        { if (nc == 6) FILTER_MULTI(u32, 6); else if (nc == 5) FILTER_MULTI(u32, 5); else if (nc == 4) FILTER_MULTI(u32, 4); else if (nc == 3) FILTER_MULTI(u32, 3); else FILTER_MULTI(u32, 2); }
 #undef FILTER_MULTI
                 ctx->counters[6] += 1;
                 if (hipGetLastError() != hipSuccess)
