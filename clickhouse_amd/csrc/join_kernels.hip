@@ -370,6 +370,22 @@ __global__ __launch_bounds__(JT) void k_join_finalize_values(JoinTable t, int ma
     }
 }
 
+// largest staged build key (NULL rows staged as 0), for the dense-prefilter decision of build sides beyond 2 Mi rows
+__global__ __launch_bounds__(JT) void k_join_max_key(const u64 * __restrict__ keys, u64 n, unsigned long long * __restrict__ out)
+{
+    u64 m = 0;
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+        m = keys[i] > m ? keys[i] : m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        const u64 x = __shfl_xor(m, o);
+        m = x > m ? x : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m)
+        atomicMax(out, (unsigned long long)m);
+}
+
 __global__ __launch_bounds__(JT) void k_fill_u64(u64 * p, u64 n, u64 v)
 {
     for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
@@ -982,7 +998,7 @@ static int join_build_slices(chgpu_join * j, JoinTable & t)
     u32 lg_cap = 0;
     while ((1ull << lg_cap) < cap)
         ++lg_cap;
-    if (off || t.pf || j->blocks.size() != 1 || j->blocks[0].valid || n < (1u << 20) || n + JBS_TILE + RP_SCATTER_SLACK >= (1ull << 32)
+    if (off || j->blocks.size() != 1 || j->blocks[0].valid || n < (1u << 20) || n + JBS_TILE + RP_SCATTER_SLACK >= (1ull << 32)
         || lg_cap < JBS_LG_CELLS + JBS_LG_P1 || lg_cap > JBS_LG_CELLS + JBS_LG_P1 + 7 || ((uintptr_t)j->blocks[0].keys % 16) != 0)
         return CHGPU_ERR_NOT_IMPLEMENTED;
     const u32 lg_p2 = lg_cap - JBS_LG_CELLS - JBS_LG_P1, P1 = 1u << JBS_LG_P1, PB = 2u << lg_p2;
@@ -1087,7 +1103,28 @@ static int join_build_table(chgpu_join * j)
     u64 pf_bits = 1ull << 16;
     while (pf_bits < 16 * j->total_rows && pf_bits < (1ull << 25))
         pf_bits <<= 1;
-    const bool use_pf = pf_bits >= 16 * j->total_rows && !getenv("CHGPU_TUNE_JOIN_NO_PREFILTER");
+    bool use_pf = pf_bits >= 16 * j->total_rows && !getenv("CHGPU_TUNE_JOIN_NO_PREFILTER");
+    // A larger build side of narrow DENSE keys (a filtered dimension table joined on its surrogate key: SSB's customer, 6 M of the keys
+    // 1..30 M) still gets the exact bitmap if max_key + 1 bits fit the 4 MiB limit: the misses of the probe then stop at a bitmap that
+    // lives in L2 / Infinity Cache instead of costing one HBM sector each.
+    if (!use_pf && chgpu_type_size(j->key_type) <= 4 && !getenv("CHGPU_TUNE_JOIN_NO_PREFILTER") && !getenv("CHGPU_TUNE_JOIN_NO_DENSE_PREFILTER"))
+    {
+        void * scratch0 = nullptr;
+        CHGPU_TRY(chgpu_scratch(ctx, 256, &scratch0));
+        CHGPU_HIP(hipMemsetAsync(scratch0, 0, 8, ctx->stream));
+        for (const BuildBlock & b : j->blocks)
+            if (b.rows)
+                hipLaunchKernelGGL(k_join_max_key, dim3(chgpu_grid_for(ctx, b.rows, JT, 4)), dim3(JT), 0, ctx->stream, (const u64 *)b.keys, b.rows, (unsigned long long *)scratch0);
+        u64 mk = 0;
+        CHGPU_TRY(chgpu_read_back(ctx, scratch0, &mk, sizeof(mk)));
+        if (mk < (1ull << 25))
+        {
+            pf_bits = 1ull << 16;
+            while (pf_bits <= mk)
+                pf_bits <<= 1;
+            use_pf = true;
+        }
+    }
     size_t off_pf = off_rowids + (maps_all ? al(j->total_rows * 8) : 0);
     size_t total_b = off_pf + (use_pf ? al(pf_bits / 8) : 0) + 256;
     void * m = nullptr;
@@ -1106,7 +1143,8 @@ static int join_build_table(chgpu_join * j)
     t.pf_mask = pf_bits - 1;
     if (use_pf)
         CHGPU_HIP(hipMemsetAsync(t.pf, 0, pf_bits / 8, ctx->stream));
-    // unique keys, one right block, no prefilter: the table slices are built in LDS and written out whole (join_build_slices); only the
+    // unique keys, one right block: the table slices are built in LDS and written out whole (join_build_slices; a prefilter is filled by
+    // k_join_finalize_values afterwards); only the
     // control block and the zero key's cell need clearing first.  Anything else -- or a duplicate key met on the way -- takes the
     // generic build over a zeroed table.
     CHGPU_HIP(hipMemsetAsync(m, 0, off_keys, ctx->stream));
