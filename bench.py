@@ -534,7 +534,7 @@ def config_c4(args, ctx, ch, torch, np, dev, stream, tj, with_cpu):
     # two warm-up builds: a join table lives in the context's column pool, and with one build alive while the next is made the pool
     # cycles two blocks -- the timed builds then reuse them (the steady state of a pipeline; a cold hipMalloc of 1.5 GB costs ~30 ms)
     b_ms, b_wall, j = _timed(build, torch, stream, reps=3, warmup=2)
-    p_ms, p_wall, (cnt, sm) = _timed(lambda: probe(j, pkc), torch, stream, reps=5, warmup=1)
+    p_ms, p_wall, (cnt, sm) = _timed(lambda: probe(j, pkc), torch, stream, reps=5, warmup=3)
     # independent check at full size: membership by a sorted-array search, payload through the same permutation
     sbk, order = torch.sort(bk)
     pos = torch.searchsorted(sbk, pk).clamp_(max=nb - 1)
@@ -585,7 +585,7 @@ def config_c5(args, ctx, ch, torch, np, dev, stream, with_cpu):
     lo_t = ssb.gen_lineorder_torch(rows, C, S, P, dev)
     lo = {k: ctx.wrap(v.data_ptr(), np.uint32, rows, keepalive=v) for k, v in lo_t.items()}
     dims_dev = ssb.upload_dims(ctx, dims)
-    dev_ms, wall_ms, res = _timed(lambda: ssb.q41_gpu(ch, ctx, dims_dev, lo), torch, stream, reps=3, warmup=1)
+    dev_ms, wall_ms, res = _timed(lambda: ssb.q41_gpu(ch, ctx, dims_dev, lo), torch, stream, reps=5, warmup=3)
     algo = 24.0 * rows  # six 4-byte lineorder columns
     out = {"workload": "SSB Q4.1-style: 2 semi joins + 2 inner joins with payload + GROUP BY (year, nation), sum(revenue) - sum(supplycost); one GPU's share "
                        "of the 6 B-row lineorder table, dimension columns resident in HBM (their filters and the four hash-table builds inside the timed plan)",
