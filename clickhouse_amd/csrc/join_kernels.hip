@@ -370,6 +370,22 @@ __global__ __launch_bounds__(JT) void k_join_finalize_values(JoinTable t, int ma
     }
 }
 
+// prefilter bits straight from the build keys (after a slice build: unique keys, no NULLs, nothing else to finalise -- a pass over
+// the build rows instead of k_join_finalize_values' pass over every cell)
+__global__ __launch_bounds__(JT) void k_join_pf_fill(JoinTable t, const u64 * __restrict__ keys, u64 n)
+{
+    const PfView pf = jt_pf_view(t);
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+    {
+        const u64 key = keys[i];
+        if (key)
+        {
+            const u64 pos = jt_pf_pos(pf, key);
+            atomicOr(&t.pf[pos >> 5], 1u << (pos & 31));
+        }
+    }
+}
+
 // largest staged build key (NULL rows staged as 0), for the dense-prefilter decision of build sides beyond 2 Mi rows
 __global__ __launch_bounds__(JT) void k_join_max_key(const u64 * __restrict__ keys, u64 n, unsigned long long * __restrict__ out)
 {
@@ -1214,7 +1230,15 @@ static int join_build_table(chgpu_join * j)
     else if (maps_all)
         j->inserted = after_insert.n_keys;
     // (without duplicates and without a prefilter there is nothing to finalise: the value word of an empty cell is never read)
-    if (!unique || t.pf)
+    if (sliced && unique)
+    {
+        if (t.pf)
+        {
+            hipLaunchKernelGGL(k_join_pf_fill, dim3(chgpu_grid_for(ctx, j->blocks[0].rows, JT, 8)), dim3(JT), 0, ctx->stream, t, (const u64 *)j->blocks[0].keys, j->blocks[0].rows);
+            ctx->counters[6] += 1;
+        }
+    }
+    else if (!unique || t.pf)
     {
         hipLaunchKernelGGL(k_join_finalize_values, dim3(chgpu_grid_for(ctx, cells, JT, 8)), dim3(JT), 0, ctx->stream, t, maps_all ? 1 : 0, take_last ? 1 : 0, unique ? 1 : 0);
         ctx->counters[6] += 1;

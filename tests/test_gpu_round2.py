@@ -308,6 +308,49 @@ def test_join_slice_build_gives_the_same_table_as_the_generic_build(ch, ctx, dup
     assert j.n_keys == np.unique(bk).shape[0]
 
 
+@pytest.mark.parametrize("shape", ["dense", "dense_dups", "dense_two_blocks", "beyond_the_bitmap", "signed"])
+def test_join_dense_prefilter_for_large_narrow_key_build_sides(ch, ctx, shape):
+    """a filtered dimension table of more than 2 Mi rows joined on its 4-byte surrogate key (SSB's customer): the exact bitmap over
+    [0, max key] is kept although the build side is beyond the usual prefilter limit -- after a slice build it is filled from the build
+    keys, after the generic build (duplicates, two right blocks) by the finalise pass; keys beyond 32 Mi or negative ones get none.  The
+    ordered joinBlock and the fused count / sum equal numpy's in every shape, zero key and out-of-range probes included."""
+    rng = np.random.Generator(np.random.PCG64(31))
+    nb = 2_300_000
+    top = {"beyond_the_bitmap": 2**31 - 1, "signed": 2**31 - 1}.get(shape, 20_000_000)
+    bk = rng.choice(top, size=nb, replace=False).astype(np.int64)
+    dt = np.int32 if shape == "signed" else np.uint32
+    if shape == "signed":
+        bk[:1000] = -bk[:1000] - 1
+    if shape == "dense_dups":
+        bk[-4:] = bk[:4]
+    bk = bk.astype(dt)
+    left = np.concatenate([bk[rng.integers(0, nb, size=400_000)], rng.integers(0, top, size=1_200_000).astype(dt), np.array([0, top, 2**31 - 1], dtype=dt)])
+    rng.shuffle(left)
+    pay = rng.integers(-2**40, 2**40, size=nb, dtype=np.int64)
+    j = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, key_dtype=dt, ctx=ctx)
+    if shape == "dense_two_blocks":
+        j.add_block(bk[:nb // 2])
+        j.add_block(bk[nb // 2:])
+    else:
+        j.add_block(bk)
+    r = j.probe_columns(left)
+    off = r["offsets"].numpy().astype(np.int64)
+    counts = np.diff(np.concatenate([[0], off]))
+    order = np.argsort(bk, kind="stable")
+    sk = bk[order]
+    lo, hi = np.searchsorted(sk, left, side="left"), np.searchsorted(sk, left, side="right")
+    assert np.array_equal(counts, hi - lo)
+    rid = r["right_rowid"].numpy()
+    base = np.array([0, nb // 2], dtype=np.int64) if shape == "dense_two_blocks" else np.array([0], dtype=np.int64)
+    rows = base[(rid >> np.uint64(32)).astype(np.int64)] + (rid & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    assert np.array_equal(bk[rows], np.repeat(left, counts))
+    hit = counts > 0
+    want_sum = sum(int(pay[order[a:b]].sum()) for a, b in zip(lo[hit][:2000], hi[hit][:2000]))   # the fused form over the first 2000 matching rows
+    c, s_ = j.probe_count_sum(ctx.upload(left[hit][:2000]), ctx.upload(pay))
+    assert c == int(counts[hit][:2000].sum()) and s_ % 2**64 == want_sum % 2**64
+    assert j.n_keys == np.unique(bk).shape[0]
+
+
 def test_join_build_phase_contract_with_the_lazy_table(ch, ctx):
     """onBuildPhaseFinish closes the build phase at once although the table is built later: a right block after it is a LOGICAL_ERROR,
     so is one after the first probe; total_rows needs no table, the key count builds it"""
