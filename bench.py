@@ -533,8 +533,9 @@ def config_c4(args, ctx, ch, torch, np, dev, stream, tj, with_cpu):
 
     # two warm-up builds: a join table lives in the context's column pool, and with one build alive while the next is made the pool
     # cycles two blocks -- the timed builds then reuse them (the steady state of a pipeline; a cold hipMalloc of 1.5 GB costs ~30 ms)
-    b_ms, b_wall, j = _timed(build, torch, stream, reps=3, warmup=2)
-    p_ms, p_wall, (cnt, sm) = _timed(lambda: probe(j, pkc), torch, stream, reps=5, warmup=3)
+    b_reps, b_warm, p_reps, p_warm = 3, 2, 5, 3
+    b_ms, b_wall, j = _timed(build, torch, stream, reps=b_reps, warmup=b_warm)
+    p_ms, p_wall, (cnt, sm) = _timed(lambda: probe(j, pkc), torch, stream, reps=p_reps, warmup=p_warm)
     # independent check at full size: membership by a sorted-array search, payload through the same permutation
     sbk, order = torch.sort(bk)
     pos = torch.searchsorted(sbk, pk).clamp_(max=nb - 1)
@@ -549,7 +550,7 @@ def config_c4(args, ctx, ch, torch, np, dev, stream, tj, with_cpu):
     res = {"workload": "100 M-row probe INNER JOIN 10 M-row build on UInt64 (ALL, unique build keys, ~50 % hits), SELECT count(), sum(bv); one GPU",
            "plan": "radix join: build rows {key, payload} and probe keys partitioned twice down to 4096-cell slices, every slice built and probed in LDS; "
                    "no hash table in HBM (it is lazy: joinBlock / key-count consumers build it), so build_ms is key staging and probe_ms the whole join",
-           "build_rows": nb, "probe_rows": npb, "matches": cnt, "build_calls": 5, "probe_calls": 6, "build_ms": b_ms, "probe_ms": p_ms, "ms": tot, "wall_ms": b_wall + p_wall,
+           "build_rows": nb, "probe_rows": npb, "matches": cnt, "build_calls": b_reps + b_warm, "probe_calls": p_reps + p_warm, "build_ms": b_ms, "probe_ms": p_ms, "ms": tot, "wall_ms": b_wall + p_wall,
            "rows_per_s": (nb + npb) / (tot * 1e-3), "probe_rows_per_s": npb / (p_ms * 1e-3),
            "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": algo / (tot * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tj.get("C4_hbm_bytes_per_call"),
