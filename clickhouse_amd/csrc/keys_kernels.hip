@@ -115,7 +115,7 @@ extern "C" int chgpu_unpack_fixed_key(chgpu_ctx * ctx, const chgpu_col * packed_
 // mapped_cache[row]).  Here the host resolves the block's dictionary against the query-wide one (a few thousand entries,
 // low_cardinality_max_dictionary_size = 8192) and the rows are translated on the device:
 //   k_lc_remap<I>   out[i] = remap[indexes[i]]   — the mapped_cache walk; the table sits in LDS when it fits
-// Streaming geometry: 16 input bytes per lane (16 / 8 / 4 / 2 rows), table lookups from LDS, 16-byte stores.
+// Streaming geometry: four rows per lane and step (a 4- / 8- / 16-byte load), table lookups from LDS, 16-byte stores on consecutive addresses.
 // Algorithmic bytes: sizeof(I) + 4 per row.  Out-of-range indexes (a caller bug) read entry 0 instead of faulting.
 // ---------------------------------------------------------------------------------------------
 static constexpr u32 LC_LDS_ENTRIES = 32768; // 128 KiB of UInt32 ids
@@ -138,26 +138,38 @@ __global__ __launch_bounds__(256) void k_lc_remap(const I * __restrict__ idx, u6
         else
             return remap[k];
     };
-    constexpr u32 R = 16 / sizeof(I); // rows per lane per vector
     const u64 stride = (u64)gridDim.x * 256;
     u64 done = 0;
-    if constexpr (VEC && R >= 4)
+    if constexpr (VEC && sizeof(I) <= 4)
     {
-        typedef I vin __attribute__((ext_vector_type(R)));
+        // FOUR rows per lane and step whatever the index width (a 4- / 8- / 16-byte load), so that every store instruction writes 16 bytes
+        // per lane to CONSECUTIVE addresses: 1 KiB per wave and instruction.  (16 input bytes per lane made a UInt8 lane own 16 rows and
+        // each of its four 16-byte stores hit a quarter of 64 different lines: 1.86 ms per 1e9 UInt8 rows against ~1.0 here.)  Four steps
+        // are in flight per lane.
+        typedef I vin __attribute__((ext_vector_type(4)));
         typedef u32 v4u __attribute__((ext_vector_type(4)));
-        const u64 nvec = n / R;
-        for (u64 v = (u64)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride)
+        const u64 nvec = n / 4;
+        constexpr int U = 4;
+        for (u64 v0 = (u64)blockIdx.x * 256 + threadIdx.x; v0 < nvec; v0 += stride * U)
         {
-            const vin x = __builtin_nontemporal_load((const vin *)idx + v);
+            vin x[U];
 #pragma unroll
-            for (u32 q = 0; q < R; q += 4)
+            for (int u = 0; u < U; ++u)
             {
+                const u64 v = v0 + (u64)u * stride;
+                x[u] = __builtin_nontemporal_load((const vin *)idx + (v < nvec ? v : v0));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                const u64 v = v0 + (u64)u * stride;
                 v4u o;
-                o.x = look((u64)x[q]), o.y = look((u64)x[q + 1]), o.z = look((u64)x[q + 2]), o.w = look((u64)x[q + 3]);
-                *((v4u *)out + v * (R / 4) + q / 4) = o; // result columns are 64-byte aligned (nontemporal stores here: 0.36 -> 1.14 ms per 2e8 rows)
+                o.x = look((u64)x[u][0]), o.y = look((u64)x[u][1]), o.z = look((u64)x[u][2]), o.w = look((u64)x[u][3]);
+                if (v < nvec)
+                    *((v4u *)out + v) = o; // result columns are 64-byte aligned (nontemporal stores here: 0.36 -> 1.14 ms per 2e8 rows)
             }
         }
-        done = nvec * R;
+        done = nvec * 4;
     }
     for (u64 i = done + (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
         out[i] = look((u64)idx[i]);
@@ -171,7 +183,7 @@ static int lc_launch(chgpu_ctx * ctx, const chgpu_col * indexes, const u32 * rm,
     const size_t lds = in_lds ? (size_t)((dict + 3) & ~3u) * 4 : 0;
     const bool vec = ((uintptr_t)indexes->data & 15) == 0 && sizeof(I) <= 4;
     const u32 per_cu = lds > 64 * 1024 ? 1 : lds > 32 * 1024 ? 2 : 4; // LDS bounds the residency
-    const u64 items = vec ? (n + 16 / sizeof(I) - 1) / (16 / sizeof(I)) : n;
+    const u64 items = vec ? (n + 15) / 16 : n; // four steps of four rows per lane
     const u32 grid = chgpu_grid_for(ctx, items, 256, per_cu);
     const I * ip = (const I *)indexes->data;
 #define LC_GO(L, V)                                                                                                                   \
