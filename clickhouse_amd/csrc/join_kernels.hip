@@ -619,6 +619,124 @@ __global__ __launch_bounds__(1024) void k_join_probe_filter_lds(const u32 * __re
     }
 }
 
+// The same probe for a key set of SEVERAL slices in ONE sweep over the rows.  k_join_probe_filter_lds takes one pass over all rows per
+// slice (keys read again from HBM each time, the filter bytes of the passes before read back and rewritten); here a workgroup takes a PART
+// of 64 Ki rows through all slices before it moves on: the part's keys come from HBM once and from L2 / Infinity Cache for the other
+// slices, the hit bits of a thread's 64 rows wait in two registers between slices (a row's key lies in exactly one slice), and the filter
+// bytes are written once, after the last slice.  Between slices the workgroup reloads its 150 KiB of LDS from the bitmap (L2-resident);
+// consecutive parts walk the slices in opposite directions, so the slice a part ends with is the one the next part starts with.
+// JPM_QPT: quads (of four rows) per thread and part
+template <bool HAS_NULL, u32 JPM_QPT = 16>
+__global__ __launch_bounds__(1024) void k_join_probe_filter_lds_multi(const u32 * __restrict__ pf_words, u32 dense_bits, u32 n_slices, int anti, int has_zero,
+                                                                      const u32 * __restrict__ keys, const u8 * __restrict__ null_map, u64 n,
+                                                                      u8 * __restrict__ filter, JoinCtrl * __restrict__ ctrl)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 jpl_bits[];
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    constexpr u32 JPM_PART_Q = 1024 * JPM_QPT; // quads per part
+    static_assert(JPM_QPT % 4 == 0 && JPM_QPT <= 16, "a thread's hit bits live in one 64-bit register");
+    const u64 nq = n / 4; // whole groups of four rows; the last n % 4 rows are done at the end
+    const u64 n_parts = (nq + JPM_PART_Q - 1) / JPM_PART_Q;
+    u32 kept = 0;
+    u32 loaded = ~0u;
+    bool up = true;
+    for (u64 part = blockIdx.x; part < n_parts; part += gridDim.x, up = !up)
+    {
+        const u64 q0 = part * JPM_PART_Q;
+        u64 hits = 0; // bit 4 * k + b: row b of this thread's k-th quad of the part
+        for (u32 si = 0; si < n_slices; ++si)
+        {
+            const u32 sl = up ? si : n_slices - 1 - si;
+            const u32 slice_lo = sl * JPL_SLICE_BITS;
+            const u32 slice_bits = dense_bits - slice_lo < JPL_SLICE_BITS ? dense_bits - slice_lo : JPL_SLICE_BITS;
+            if (loaded != sl)
+            {
+                __syncthreads(); // every wave has finished probing the slice that is about to be replaced
+                const u32 n_words = (slice_bits + 31) / 32;
+                const u32 * src = pf_words + slice_lo / 32;
+                for (u32 w = threadIdx.x * 4; w < n_words; w += 1024 * 4) // (slices start on 16-byte boundaries: JPL_SLICE_BITS % 128 == 0)
+                {
+                    if (w + 4 <= n_words)
+                        *(v4u *)(jpl_bits + w) = *(const v4u *)(src + w);
+                    else
+                        for (u32 x = w; x < n_words; ++x)
+                            jpl_bits[x] = src[x];
+                }
+                __syncthreads();
+                loaded = sl;
+            }
+            const bool last = si + 1 == n_slices;
+            auto found_in_slice = [&](u32 k) -> u32 {
+                const u32 rel = k - slice_lo;
+                const bool in = k != 0 && rel < slice_bits;
+                const u32 r = in ? rel : 0;
+                const u32 bit = (jpl_bits[r >> 5] >> (r & 31)) & 1u;
+                return in ? bit : 0u;
+            };
+            constexpr int U = 4;
+#pragma unroll 1
+            for (u32 kb = 0; kb < JPM_QPT; kb += U) // (unrolled, the sixteen loads are hoisted together and spill)
+            {
+                v4u kk[U];
+                u32 nm[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                {
+                    const u64 q = q0 + (u64)(kb + u) * 1024 + threadIdx.x;
+                    const u64 qc = q < nq ? q : nq - 1;
+                    kk[u] = *((const v4u *)keys + qc); // plain loads: the other slices of this part find the lines in L2 / Infinity Cache
+                    nm[u] = (HAS_NULL && last) ? *((const u32 *)null_map + qc) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                {
+                    const u64 q = q0 + (u64)(kb + u) * 1024 + threadIdx.x;
+                    const u32 k4[4] = {kk[u].x, kk[u].y, kk[u].z, kk[u].w};
+                    u32 h = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        h |= found_in_slice(k4[b]) << b;
+                    hits |= (u64)h << (4 * (kb + u));
+                    if (last)
+                    {
+                        const u32 hb = (u32)(hits >> (4 * (kb + u))) & 15u;
+                        u32 acc = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                        {
+                            const bool ok = !HAS_NULL || ((nm[u] >> (8 * b)) & 0xffu) == 0; // HashJoinMethodsImpl.h:451-452
+                            const u32 f = ok ? (((hb >> b) & 1u) | ((k4[b] == 0 && has_zero) ? 1u : 0u)) : 0u; // the zero key lives out of line (HashTable.h:874-898)
+                            acc |= f << (8 * b);
+                        }
+                        acc = anti ? acc ^ 0x01010101u : acc; // :515-519, :535-536
+                        if (q < nq)
+                        {
+                            kept += (u32)__popc(acc);
+                            __builtin_nontemporal_store(acc, (u32 *)filter + q);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (u32)(n & 3))
+    {
+        // the last n % 4 rows, against the whole bitmap in global memory
+        const u64 i = nq * 4 + threadIdx.x;
+        const u32 k = keys[i];
+        const bool ok = !(HAS_NULL && null_map[i]);
+        const bool found = ok && (k == 0 ? has_zero != 0 : (k < dense_bits && ((pf_words[k >> 5] >> (k & 31)) & 1u) != 0));
+        const u8 f = anti ? !found : found;
+        filter[i] = f;
+        kept += f;
+    }
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1)
+        kept += __shfl_xor(kept, dlt, 64);
+    if ((threadIdx.x & 63) == 0 && kept)
+        atomicAdd((unsigned long long *)&ctrl->n_out, (unsigned long long)kept);
+}
+
 // probe pass 2b: where does max_joined_block_rows cut?  offsets are inclusive cumulative counts.
 __global__ void k_join_cut(const u64 * __restrict__ offsets, u64 n, u64 max_rows, JoinCtrl * __restrict__ ctrl)
 {
@@ -1424,6 +1542,25 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
             && n >= (1u << 20) && (uintptr_t)key_col->data % 16 == 0 && (!null_map || (uintptr_t)null_map->data % 4 == 0))
         {
             const u32 passes = (u32)((dense_bits + JPL_SLICE_BITS - 1) / JPL_SLICE_BITS);
+            static const bool no_multi = getenv("CHGPU_TUNE_JOIN_NO_LDS_FILTER_MULTI") != nullptr;
+            if (passes > 1 && !no_multi)
+            {
+                // several slices: one sweep, every part of the rows through all slices (k_join_probe_filter_lds_multi)
+                static const u32 qpt = getenv("CHGPU_TUNE_JOIN_LDS_FILTER_QPT") ? (u32)atoi(getenv("CHGPU_TUNE_JOIN_LDS_FILTER_QPT")) : 16;
+                auto kern = qpt == 8 ? (null_map ? k_join_probe_filter_lds_multi<true, 8> : k_join_probe_filter_lds_multi<false, 8>)
+                          : qpt == 4 ? (null_map ? k_join_probe_filter_lds_multi<true, 4> : k_join_probe_filter_lds_multi<false, 4>)
+                                     : (null_map ? k_join_probe_filter_lds_multi<true, 16> : k_join_probe_filter_lds_multi<false, 16>);
+                e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(JPL_SLICE_BITS / 8));
+                if (e == hipSuccess)
+                {
+                    hipLaunchKernelGGL(kern, dim3((u32)ctx->num_cus), dim3(1024), (size_t)(JPL_SLICE_BITS / 8), ctx->stream, (const u32 *)j->t.pf, (u32)dense_bits, passes,
+                                       variant == PV_ANTI_LEFT ? 1 : 0, j->has_zero ? 1 : 0, (const u32 *)key_col->data, null_map ? (const u8 *)null_map->data : nullptr, n,
+                                       (u8 *)fcol->data, j->t.ctrl);
+                    ctx->counters[6] += 1;
+                    e = hipGetLastError();
+                }
+            }
+            else
             for (u32 d = 0; d < passes && e == hipSuccess; ++d)
             {
                 const u32 lo = d * JPL_SLICE_BITS;
