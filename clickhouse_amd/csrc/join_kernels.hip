@@ -1319,6 +1319,24 @@ static int join_build_table(chgpu_join * j)
                            (u64)bi, maps_all ? 1 : 0, take_last ? 1 : 0, slot_of_row + b.base);
         ctx->counters[6] += 1;
     }
+    // first flat row of every right block: row ids (block << 32 | row) -> position in payload columns glued over all blocks.  Uploaded
+    // here so that the read-back below -- which waits for the stream -- also covers this copy out of a host temporary.
+    const u64 nb_blocks = j->blocks.size();
+    std::vector<u64> bases(nb_blocks ? nb_blocks : 1, 0);
+    for (u64 b = 0; b < nb_blocks; ++b)
+        bases[b] = j->blocks[b].base;
+    {
+        void * um = nullptr, * bm = nullptr;
+        if (jf_track_used(j))
+        {
+            CHGPU_TRY(chgpu_pool_alloc(ctx, j->total_rows + 64, &um, &j->used_class));
+            j->used = (u8 *)um;
+            CHGPU_HIP(hipMemsetAsync(j->used, 0, j->total_rows + 64, ctx->stream));
+        }
+        CHGPU_TRY(chgpu_pool_alloc(ctx, bases.size() * sizeof(u64), &bm, &j->base_class));
+        j->block_base_dev = (u64 *)bm;
+        CHGPU_HIP(hipMemcpyAsync(j->block_base_dev, bases.data(), bases.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    }
     // did any key get a second row?  (one small read-back; the common primary-key build then skips four passes over the table)
     JoinCtrl after_insert;
     CHGPU_TRY(chgpu_read_back(ctx, t.ctrl, &after_insert, sizeof(after_insert)));
@@ -1362,29 +1380,14 @@ static int join_build_table(chgpu_join * j)
         ctx->counters[6] += 1;
     }
     CHGPU_HIP(hipGetLastError());
-    JoinCtrl c;
-    CHGPU_TRY(chgpu_read_back(ctx, t.ctrl, &c, sizeof(c)));
+    // unique keys: nothing after the inserts touches the control block -- the read-back above already holds the final key count, the
+    // largest key and the zero-key flag (one host synchronisation per build instead of three)
+    JoinCtrl c = after_insert;
+    if (!unique)
+        CHGPU_TRY(chgpu_read_back(ctx, t.ctrl, &c, sizeof(c)));
     j->n_keys = c.n_keys;
     j->max_key = c.max_key;
     j->has_zero = c.has_zero != 0;
-    {
-        // first flat row of every right block: row ids (block << 32 | row) -> position in payload columns glued over all blocks
-        const u64 nb = j->blocks.size();
-        std::vector<u64> bases(nb ? nb : 1, 0);
-        for (u64 b = 0; b < nb; ++b)
-            bases[b] = j->blocks[b].base;
-        void * um = nullptr, * bm = nullptr;
-        if (jf_track_used(j))
-        {
-            CHGPU_TRY(chgpu_pool_alloc(ctx, j->total_rows + 64, &um, &j->used_class));
-            j->used = (u8 *)um;
-            CHGPU_HIP(hipMemsetAsync(j->used, 0, j->total_rows + 64, ctx->stream));
-        }
-        CHGPU_TRY(chgpu_pool_alloc(ctx, bases.size() * sizeof(u64), &bm, &j->base_class));
-        j->block_base_dev = (u64 *)bm;
-        CHGPU_HIP(hipMemcpyAsync(j->block_base_dev, bases.data(), bases.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
-        CHGPU_HIP(hipStreamSynchronize(ctx->stream)); // `bases` is a host temporary
-    }
     j->finished = true;
     return CHGPU_OK;
 }
