@@ -1670,12 +1670,8 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
         chgpu_set_error(CHGPU_ERR_DEVICE, "join probe launch: %s", hipGetErrorString(e));
         return fail(CHGPU_ERR_DEVICE);
     }
-    // the scratch buffers (slot_of_left, counts) are reused by the next call on this context: finish reading them now
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess)
-    {
-        chgpu_set_error(CHGPU_ERR_DEVICE, "join probe failed");
-        return fail(CHGPU_ERR_DEVICE);
-    }
+    // (the scratch buffers -- slot_of_left, counts -- are reused by the next call on this context, which launches on the same stream and so
+    //  runs after the kernels above; chgpu_scratch drains the stream itself before it ever frees a buffer: no host synchronisation here)
     j->left_seq += c.consumed; // rows not consumed are resubmitted by the caller and bid again
     // outputs are cut to the consumed prefix (offsets_to_replicate->resize(i), filter.resize(i): :439-441)
     if (filter)
