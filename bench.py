@@ -593,6 +593,13 @@ def config_c5(args, ctx, ch, torch, np, dev, stream, with_cpu):
            "lineorder_rows": rows, "groups": len(res), "ms": wall_ms, "device_ms": dev_ms, "rows_per_s": rows / (wall_ms * 1e-3),
            "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": algo / (wall_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+    try:  # the last committed PMC collection of the plan on its own (tools/gpu_pmc_c5.sh), quoted only for the same workload
+        ts = json.load(open(os.path.join(REPO, "profiles", "r02_traffic_ssb.json")))
+        if ts.get("algorithmic_bytes") == algo:
+            out["roofline"]["traffic"] = ts.get("C5_hbm_bytes_per_run")
+            out["roofline"]["traffic_source"] = "profiles/r02_traffic_ssb.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --only-c5`, tools/gpu_pmc_c5.sh"
+    except Exception:
+        pass
     if with_cpu:
         import oracle
         oracle.build()
