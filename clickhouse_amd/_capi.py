@@ -75,6 +75,7 @@ SIGNATURES = {
     "chgpu_expr_free": (_i, [_vp]),
     "chgpu_index": (_i, [_vp, _vp, _vp, _u64, _i, _pp]),
     "chgpu_replicate": (_i, [_vp, _vp, _vp, _pp]),
+    "chgpu_replicate_columns": (_i, [_vp, _u32, _vp, _vp, _vp]),
     "chgpu_sort_permutation": (_i, [_vp, _vp, _vp, _i, _i, _pp]),
     "chgpu_sort_permutation_limit": (_i, [_vp, _vp, _i, _i, _u64, _pp]),
     "chgpu_filter_to_indices": (_i, [_vp, _vp, _pp, _pu64]),

@@ -256,6 +256,16 @@ def filter_columns(cols, filt: Column, result_size_hint: int = 0):
     return [Column(filt.ctx, C.c_void_p(outs[k])) for k in range(n)]
 
 
+def replicate_columns(cols, offsets: Column):
+    """Every column of a Block replicated by one offsets_to_replicate (joinBlock's loop over the left columns): one host synchronisation,
+    columns of one width share a kernel."""
+    n = len(cols)
+    cp = (C.c_void_p * max(1, n))(*[c._h for c in cols])
+    outs = (C.c_void_p * max(1, n))()
+    K.check(K.lib().chgpu_replicate_columns(offsets.ctx._h, n, cp, offsets._h, outs))
+    return [Column(offsets.ctx, C.c_void_p(outs[k])) for k in range(n)]
+
+
 def hash_to_selector(keys: Column, num_shards: int) -> Column:
     h = C.c_void_p()
     K.check(K.lib().chgpu_hash_to_selector(keys.ctx._h, keys._h, num_shards, C.byref(h)))

@@ -1473,6 +1473,116 @@ extern "C" int chgpu_replicate(chgpu_ctx * ctx, const chgpu_col * col, const chg
     return CHGPU_OK;
 }
 
+// The same for every column of a Block (joinBlock replicates all left columns with one offsets_to_replicate,
+// HashJoinMethodsImpl.h:186-194): one read-back of the total, and columns of one element width go through one kernel up to four at a
+// time -- the 8-byte offsets are read once for all of them instead of once per column.
+template <typename T, int NC>
+struct ReplCols
+{
+    const T * data[NC];
+    T * out[NC];
+};
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void k_replicate_multi(ReplCols<T, NC> c, const u64 * __restrict__ offsets, u64 n)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        const u64 end = offsets[i];
+        const u64 begin = i ? offsets[i - 1] : 0;
+        T v[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+            v[k] = c.data[k][i];
+        for (u64 o = begin; o < end; ++o)
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                c.out[k][o] = v[k];
+    }
+}
+
+extern "C" int chgpu_replicate_columns(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, const chgpu_col * offsets, chgpu_col ** outs)
+{
+    ChgpuDeviceGuard _dev_guard(ctx);
+    CHGPU_REQUIRE(ctx && offsets && (n_cols == 0 || (cols && outs)), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(offsets->type == CHGPU_U64, CHGPU_ERR_BAD_ARGUMENTS, "offsets must be UInt64");
+    for (u32 k = 0; k < n_cols; ++k)
+    {
+        CHGPU_REQUIRE(cols[k], CHGPU_ERR_BAD_ARGUMENTS, "NULL column");
+        CHGPU_REQUIRE(offsets->rows == cols[k]->rows, CHGPU_ERR_SIZES_MISMATCH, "Size of offsets doesn't match size of column."); // ColumnVector.cpp:881-883
+        outs[k] = nullptr;
+    }
+    const u64 n = offsets->rows;
+    u64 total = 0;
+    if (n)
+        CHGPU_TRY(chgpu_read_back(ctx, (const u64 *)offsets->data + (n - 1), &total, sizeof(total)));
+    auto fail = [&](int rc) {
+        for (u32 q = 0; q < n_cols; ++q)
+            if (outs[q])
+            {
+                chgpu_col_free(outs[q]);
+                outs[q] = nullptr;
+            }
+        return rc;
+    };
+    for (u32 k = 0; k < n_cols; ++k)
+    {
+        const int rc = chgpu_col_new(ctx, cols[k]->type, total, &outs[k]);
+        if (rc != CHGPU_OK)
+            return fail(rc);
+    }
+    if (!total)
+        return CHGPU_OK;
+    const u32 grid = chgpu_grid_for(ctx, n, 256, 8);
+    std::vector<char> done(n_cols, 0);
+    for (size_t w : {(size_t)8, (size_t)4})
+    {
+        std::vector<u32> same;
+        for (u32 k = 0; k < n_cols; ++k)
+            if (chgpu_type_size(cols[k]->type) == w)
+                same.push_back(k);
+        for (size_t b = 0; b + 1 < same.size();)
+        {
+            const u32 nc = (u32)(same.size() - b >= 4 ? 4 : same.size() - b);
+            if (nc < 2)
+                break;
+#define REPL_MULTI(T_, NC_)                                                                                                        \
+    do                                                                                                                             \
+    {                                                                                                                              \
+        ReplCols<T_, NC_> rc_;                                                                                                     \
+        for (u32 q = 0; q < NC_; ++q)                                                                                              \
+        {                                                                                                                          \
+            rc_.data[q] = (const T_ *)cols[same[b + q]]->data;                                                                     \
+            rc_.out[q] = (T_ *)outs[same[b + q]]->data;                                                                            \
+        }                                                                                                                          \
+        hipLaunchKernelGGL((k_replicate_multi<T_, NC_>), dim3(grid), dim3(256), 0, ctx->stream, rc_, (const u64 *)offsets->data, n); \
+    } while (0)
+            if (w == 8) { if (nc == 4) REPL_MULTI(u64, 4); else if (nc == 3) REPL_MULTI(u64, 3); else REPL_MULTI(u64, 2); }
+            else        { if (nc == 4) REPL_MULTI(u32, 4); else if (nc == 3) REPL_MULTI(u32, 3); else REPL_MULTI(u32, 2); }
+#undef REPL_MULTI
+            ctx->counters[6] += 1;
+            for (u32 q = 0; q < nc; ++q)
+                done[same[b + q]] = 1;
+            b += nc;
+        }
+    }
+    for (u32 k = 0; k < n_cols; ++k)
+    {
+        if (done[k])
+            continue;
+        switch (chgpu_type_size(cols[k]->type))
+        {
+            case 8: hipLaunchKernelGGL(k_replicate<u64>, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)cols[k]->data, (const u64 *)offsets->data, n, (u64 *)outs[k]->data); break;
+            case 4: hipLaunchKernelGGL(k_replicate<u32>, dim3(grid), dim3(256), 0, ctx->stream, (const u32 *)cols[k]->data, (const u64 *)offsets->data, n, (u32 *)outs[k]->data); break;
+            case 2: hipLaunchKernelGGL(k_replicate<u16>, dim3(grid), dim3(256), 0, ctx->stream, (const u16 *)cols[k]->data, (const u64 *)offsets->data, n, (u16 *)outs[k]->data); break;
+            default: hipLaunchKernelGGL(k_replicate<u8>, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)cols[k]->data, (const u64 *)offsets->data, n, (u8 *)outs[k]->data); break;
+        }
+        ctx->counters[6] += 1;
+    }
+    if (hipGetLastError() != hipSuccess)
+        return fail(chgpu_set_error(CHGPU_ERR_DEVICE, "replicate launch failed"));
+    return CHGPU_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // and / arithmetic columns, and the fused multi-predicate filter + value expression + sum
 // ---------------------------------------------------------------------------------------------

@@ -348,6 +348,21 @@ inline void filterColumns(Columns & columns, const ColumnVector & filter, ssize_
         columns[k] = std::make_shared<ColumnVector>(filter.context(), out[k]);
 }
 
+/// joinBlock's `columns[i] = columns[i]->replicate(offsets)` over every left column (HashJoinMethodsImpl.h:186-194) as ONE call: the total
+/// is read back once, columns of one element width share a kernel.
+inline void replicateColumns(Columns & columns, const ColumnVector & offsets)
+{
+    if (columns.empty())
+        return;
+    std::vector<const chgpu_col *> in;
+    for (auto & c : columns)
+        in.push_back(c->handle());
+    std::vector<chgpu_col *> out(columns.size(), nullptr);
+    check(chgpu_replicate_columns(offsets.context()->get(), static_cast<uint32_t>(in.size()), in.data(), offsets.handle(), out.data()));
+    for (size_t k = 0; k < columns.size(); ++k)
+        columns[k] = std::make_shared<ColumnVector>(offsets.context(), out[k]);
+}
+
 class GpuFilterTransform : public ISimpleTransform
 {
 public:
@@ -847,14 +862,11 @@ public:
         }
         Chunk res;
         for (auto & col : block.columns)
-        {
-            ColumnPtr c = consumed < block.num_rows ? col->cut(0, consumed, col) : col;
-            if (offsets_c)
-                c = c->replicate(*offsets_c); // HashJoinMethodsImpl.h:182-197
-            else if (filter_c)
-                c = c->filter(*filter_c, -1); // :122-123
-            res.columns.push_back(c);
-        }
+            res.columns.push_back(consumed < block.num_rows ? col->cut(0, consumed, col) : col);
+        if (offsets_c)
+            replicateColumns(res.columns, *offsets_c); // HashJoinMethodsImpl.h:182-197, every left column in one call
+        else if (filter_c)
+            filterColumns(res.columns, *filter_c, -1); // :122-123
         for (auto & payload : right_payload)
             res.columns.push_back(payload->index(*rowid_c, 0, /*default_for_missing*/ true));
         res.num_rows = n_out;

@@ -313,6 +313,10 @@ int chgpu_index(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * indexe
                 int default_for_missing, chgpu_col ** out);
 /* offsets: CHGPU_U64 cumulative (IColumn::Offsets) */
 int chgpu_replicate(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * offsets_u64, chgpu_col ** out);
+/* every column of a Block replicated by one offsets_to_replicate (joinBlock's loop over the left columns,
+   src/Interpreters/HashJoin/HashJoinMethodsImpl.h:186-194): one host synchronisation for all of them, columns of one element width share
+   a kernel (the offsets are read once).  outs[n_cols] receives the new columns. */
+int chgpu_replicate_columns(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, const chgpu_col * offsets_u64, chgpu_col ** outs);
 
 /* §8(f) rank 4 — ordered output: IColumn::getPermutation(direction, Stable, limit = 0, nan_direction_hint, res) for
    ColumnVector<T> (src/Columns/ColumnVector.cpp:245-330), the step under sortBlock / MergeSortingTransform.  LSD radix sort on

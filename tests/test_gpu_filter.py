@@ -333,3 +333,29 @@ def test_size_independent_properties_at_scale(ch, ctx):
     assert kept.size() == c_lt and int(ch.sum_add_many(kept)[0]) == int(s_lt)
     # order preserved: equals torch's boolean-mask selection
     assert np.array_equal(kept.numpy(), t[t < thr].cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_replicate_columns_matches_numpy_repeat():
+    """joinBlock's replicate over every column of a Block in one call: columns of one width share a kernel (2, 3, 4 and more of them),
+    the other widths go one by one; zero-length and long runs, an empty Block, a size mismatch"""
+    import clickhouse_amd as ch
+    ctx = ch.Context()
+    rng = np.random.Generator(np.random.PCG64(77))
+    n = 200_003
+    counts = rng.choice([0, 0, 0, 1, 1, 2, 7], size=n).astype(np.uint64)
+    counts[5] = 1000
+    off = np.cumsum(counts).astype(np.uint64)
+    dts = [np.uint32, np.int64, np.uint32, np.uint8, np.float64, np.uint32, np.uint16, np.int32, np.uint32, np.uint32, np.uint64]
+    cols = [rng.integers(0, 200, size=n).astype(dt) for dt in dts]
+    for k in (1, 2, 3, 5, len(cols)):
+        outs = ch.replicate_columns([ctx.upload(c) for c in cols[:k]], ctx.upload(off))
+        for c, o in zip(cols[:k], outs):
+            assert np.array_equal(o.numpy(), np.repeat(c, counts.astype(np.int64)))
+    outs = ch.replicate_columns([ctx.upload(cols[0][:0]), ctx.upload(cols[1][:0])], ctx.upload(off[:0]))
+    assert [o.size() for o in outs] == [0, 0]
+    outs = ch.replicate_columns([ctx.upload(cols[0]), ctx.upload(cols[2])], ctx.upload(np.zeros(n, dtype=np.uint64)))
+    assert [o.size() for o in outs] == [0, 0]
+    with pytest.raises(ch.ChgpuError) as e:
+        ch.replicate_columns([ctx.upload(cols[0]), ctx.upload(cols[1][:10])], ctx.upload(off))
+    assert e.value.code == ch._capi.ERR_SIZES_MISMATCH

@@ -100,11 +100,11 @@ def q41_gpu(ch, ctx, dims, lo):
         cust, date, rev, cost = ch.filter_columns([lo[k] for k in ("lo_custkey", "lo_orderdate", "lo_revenue", "lo_supplycost")], r["filter"])
     r = j_c.probe_columns(cust)
     off = r["offsets"]
-    date, rev, cost = (c.replicate(off) for c in (date, rev, cost))
+    date, rev, cost = ch.replicate_columns([date, rev, cost], off)
     nation = cn.index(r["right_rowid"], default_for_missing=True)
     r = j_d.probe_columns(date)
     off = r["offsets"]
-    rev, cost, nation = (c.replicate(off) for c in (rev, cost, nation))
+    rev, cost, nation = ch.replicate_columns([rev, cost, nation], off)
     year = d_year.index(r["right_rowid"], default_for_missing=True)
     # ---- GROUP BY d_year, c_nation (keys64: packFixed) ----
     key = ch.pack_fixed_keys([year, nation])
