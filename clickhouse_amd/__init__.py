@@ -10,7 +10,7 @@ from .columns import (Column, Context, and_, arith, concat, expr_filter_sum, cmp
 from .aggregator import Aggregator, NullableKeyAggregator, group_by_min_max, serialize_states, deserialize_states
 from .expression import ActionsDAG, ExpressionActions
 from .lowcardinality import ColumnString, ColumnLowCardinality, LowCardinalityAggregator, LowCardinalityDictionary, PackedKeysAggregator
-from .hashjoin import HashJoin
+from .hashjoin import HashJoin, join_probe_chain
 from .merging import AggregatedBlock, MergingAggregatedMemoryEfficientTransform
 from .keysfixed import KeyDict, KeysFixedAggregator, KeysFixedHashJoin
 

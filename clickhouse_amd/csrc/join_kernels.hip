@@ -2800,3 +2800,4 @@ extern "C" int chgpu_join_probe_agg(chgpu_join * j, const chgpu_col * key_col, c
     ctx->counters[4] += res[0];
     return CHGPU_OK;
 }
+#include "join_chain.h"

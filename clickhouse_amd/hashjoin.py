@@ -143,3 +143,33 @@ class HashJoin:
             left = np.arange(c, dtype=np.int64)
         assert left.shape[0] == r["added_block"].shape[0]
         return left, r["added_block"], r["added_row"], c
+
+
+def join_probe_chain(joins, keys, null_maps=None, right_rows=None, carry=None, want_indexes=True, want_filter=False):
+    """A chain of filter-form JoiningTransforms (LEFT SEMI / LEFT ANTI / ALL over unique build keys) answered in one sweep over the left
+    key columns, before any left column is copied (chgpu_join_probe_chain): keys[s] is probed against joins[s].
+    right_rows[s] truthy: also return joins[s]'s matched build row per survivor; carry: left Columns to gather at the survivors.
+    -> dict(kept, indexes, right_rowid=[Column | None per step], carry=[Column ...], filter)"""
+    assert len(joins) == len(keys) and len(joins) >= 1
+    ctx = joins[0].ctx
+    n = len(joins)
+    cols = [j._col(k, j.key_dtype) for j, k in zip(joins, keys)]
+    nms = [None] * n if null_maps is None else [j._col(m, np.uint8) if m is not None else None for j, m in zip(joins, null_maps)]
+    carry = list(carry or [])
+    jh = (C.c_void_p * n)(*[j._h for j in joins])
+    kh = (C.c_void_p * n)(*[c._h for c in cols])
+    nh = (C.c_void_p * n)(*[(m._h if m is not None else None) for m in nms])
+    want = (C.c_int * n)(*[int(bool(right_rows[s])) if right_rows is not None else 0 for s in range(n)])
+    rh = (C.c_void_p * n)()
+    nc = len(carry)
+    ch_in = (C.c_void_p * max(nc, 1))(*[c._h for c in carry])
+    ch_out = (C.c_void_p * max(nc, 1))()
+    ih, fh = C.c_void_p(), C.c_void_p()
+    kept = C.c_uint64(0)
+    K.check(K.lib().chgpu_join_probe_chain(n, jh, kh, nh if null_maps is not None else None, want, nc, ch_in if nc else None,
+                                           C.byref(ih) if want_indexes else None, rh, ch_out if nc else None,
+                                           C.byref(fh) if want_filter else None, C.byref(kept)))
+    return dict(kept=int(kept.value), indexes=Column(ctx, ih) if want_indexes else None,
+                right_rowid=[Column(ctx, C.c_void_p(rh[s])) if rh[s] else None for s in range(n)],
+                carry=[Column(ctx, C.c_void_p(ch_out[c])) for c in range(nc)],
+                filter=Column(ctx, fh) if want_filter else None)

@@ -486,6 +486,23 @@ int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const chgpu_col 
    Float sums are reduced in a fixed order: run-to-run reproducible. */
 int chgpu_join_probe_agg(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * null_map_u8, const chgpu_col * right_payload,
                          uint64_t * count_out, void * sum_out);
+/* A CHAIN of JoiningTransforms answered in one sweep over the left key columns (late materialisation).  When every join of the chain is of
+   the filter form -- LEFT SEMI, LEFT ANTI, or ALL over a build side without duplicate keys: HashJoinMethodsImpl.h:68-202 then computes a
+   filter and calls `block.filter(filter)` (:122-123) on EVERY left column, once per join -- the left rows that survive the whole chain are
+   the AND of the joins' filters and no join changes a row's multiplicity.  This entry computes that AND before any left column is copied
+   (key_cols[s] is probed against joins[s]; null_maps / null_maps[s] may be NULL): dense dimension key sets are staged in LDS, the other
+   steps are probed only for the rows still alive.  Outputs, all sized by the survivors (*n_kept) and in ascending left-row order; every
+   output pointer may be NULL when not wanted:
+     indexes_u64          the surviving left row numbers (filterToIndices, src/Columns/FilterDescription.cpp:113-116)
+     right_rowid_u64[s]   for steps with want_right_rows[s] != 0: the matched build row (block << 32 | row) of joins[s], all-ones where the
+                          join adds a default row (LEFT joins without a match, ANTI) -- what chgpu_join_probe would return over the survivors
+     carry_out[c]         carry_cols[c] gathered at the survivors (IColumn::index; the chain's `block.filter` over the left columns)
+     filter_u8 [rows]     the chain's IColumn::Filter itself, 1 = the row survives every join
+   LEFT ANY / LEFT ALL steps keep every left row (they only contribute right_rowid).  INNER ANY, RIGHT, FULL (stateful across calls) and ALL
+   over duplicate build keys (replicates rows) -> CHGPU_ERR_NOT_IMPLEMENTED: run those joins one by one with chgpu_join_probe. */
+int chgpu_join_probe_chain(uint32_t n_steps, chgpu_join * const * joins, const chgpu_col * const * key_cols, const chgpu_col * const * null_maps,
+                           const int * want_right_rows, uint32_t n_carry, const chgpu_col * const * carry_cols, chgpu_col ** indexes_u64,
+                           chgpu_col ** right_rowid_u64, chgpu_col ** carry_out, chgpu_col ** filter_u8, uint64_t * n_kept);
 /* (block_index << 32 | row) ids -> running ordinal of the row over all right blocks in insertion order (all-ones stays
    all-ones): the index into payload columns concatenated with chgpu_col_concat, i.e. fillFromBlocksAndRowNumbers
    (src/Columns/IColumn.cpp:515-526) for many right Blocks */

@@ -26,16 +26,19 @@ def test_ssb_q41_oracle_plan_matches_numpy(oracle_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("two_filters", [False, True])
-def test_ssb_q41_gpu_matches_oracle(oracle_mod, monkeypatch, two_filters):
-    """both shapes of the plan: the two semi joins sharing one filter (ANTI filter of the first = null map of the second) and the
-    reference's one FilterTransform per JoiningTransform"""
+@pytest.mark.parametrize("plan", ["chain", "per_join", "two_filters"])
+def test_ssb_q41_gpu_matches_oracle(oracle_mod, monkeypatch, plan):
+    """the three shapes of the plan: the join chain answered as one filter over the fact keys (chgpu_join_probe_chain, late
+    materialisation); one joinBlock per join with the two semi joins sharing one filter (ANTI filter of the first = null map of the
+    second); and the reference's one FilterTransform per JoiningTransform"""
     import clickhouse_amd as ch
     ctx = ch.Context(0)
-    if two_filters:
+    monkeypatch.delenv("SSB_PLAN_TWO_FILTERS", raising=False)
+    monkeypatch.delenv("SSB_PLAN_PER_JOIN", raising=False)
+    if plan == "two_filters":
         monkeypatch.setenv("SSB_PLAN_TWO_FILTERS", "1")
-    else:
-        monkeypatch.delenv("SSB_PLAN_TWO_FILTERS", raising=False)
+    elif plan == "per_join":
+        monkeypatch.setenv("SSB_PLAN_PER_JOIN", "1")
     dims = ssb.gen_dims(300_000, 20_000, 20_000)
     lo = ssb.gen_lineorder_numpy(3_000_000, 300_000, 20_000, 20_000)
     want = ssb.q41_cpu(oracle_mod, dims, lo)

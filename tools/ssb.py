@@ -11,7 +11,13 @@ Plan (the reference's shape: filtered dimension tables become the right sides of
 JoiningTransforms, then AggregatingTransform).  sum(a - b) is evaluated as sum(a) - sum(b) — identical for
 wrap-around integer sums — so no arithmetic function is needed yet (expression fusion is SURVEY §8f rank 1).
 
-The two semi joins share ONE filter on the GPU: the supplier join is probed in its ANTI form and its filter becomes the null map of the
+Default GPU plan (round 3): the four joins are answered as ONE filter over the fact table's key columns (chgpu_join_probe_chain: every join of
+Q4.1 is of the filter form -- two semi joins and two INNER ALL joins over unique dimension keys); for the ~1.6 % surviving rows the same
+call returns the matched customer / date rows and the gathered revenue / supplycost values.  No fact column is ever copied whole.
+SSB_PLAN_PER_JOIN=1 runs the per-operator plan below (one joinBlock + filter / replicate per join), which is what the C++ shim's
+JoiningTransform chain does.
+
+Per-operator plan: the two semi joins share ONE filter on the GPU: the supplier join is probed in its ANTI form and its filter becomes the null map of the
 part join's key column (a NULL key matches nothing, HashJoinMethodsImpl.h:451-452), so the fact columns are compacted once at 8 % instead of
 five columns at 20 % and four more at 40 % of that (C5 11.15 -> 10.2 ms on one box).  SSB_PLAN_TWO_FILTERS=1 runs the reference's shape,
 one FilterTransform per JoiningTransform; q41_cpu always does.
@@ -77,7 +83,8 @@ def q41_gpu(ch, ctx, dims, lo):
     # the supplier join is probed in its ANTI form: its filter (1 = no supplier of the region) is handed to the part join as the null map
     # of lo_partkey -- a row with a NULL key matches nothing -- so the two semi joins yield ONE filter and the fact columns are compacted
     # once, at 8 %, instead of five columns at 20 % and four more at 40 % of that
-    j_s = ch.HashJoin(ch.JOIN_LEFT, ch.STRICT_SEMI if os.environ.get("SSB_PLAN_TWO_FILTERS") else ch.STRICT_ANTI, key_dtype=np.uint32, ctx=ctx)
+    chain = not os.environ.get("SSB_PLAN_PER_JOIN") and not os.environ.get("SSB_PLAN_TWO_FILTERS")
+    j_s = ch.HashJoin(ch.JOIN_LEFT, ch.STRICT_SEMI if (chain or os.environ.get("SSB_PLAN_TWO_FILTERS")) else ch.STRICT_ANTI, key_dtype=np.uint32, ctx=ctx)
     j_s.add_block(up(dims["s_suppkey"]).filter(sm))
     pm = ch.cmp_const(up(dims["p_mfgr"]), ch.LE, 2)
     j_p = ch.HashJoin(ch.JOIN_LEFT, ch.STRICT_SEMI, key_dtype=np.uint32, ctx=ctx)
@@ -88,6 +95,13 @@ def q41_gpu(ch, ctx, dims, lo):
     for j in (j_c, j_s, j_p, j_d):
         j.finish_build()
     # ---- the fact table through the joins (JoiningTransform x4), most selective first ----
+    if chain:
+        r = ch.join_probe_chain([j_s, j_p, j_c, j_d], [lo["lo_suppkey"], lo["lo_partkey"], lo["lo_custkey"], lo["lo_orderdate"]],
+                                right_rows=[False, False, True, True], carry=[lo["lo_revenue"], lo["lo_supplycost"]], want_indexes=False)
+        rev, cost = r["carry"]
+        nation = cn.index(r["right_rowid"][2], default_for_missing=True)   # AddedColumns' lazy gather over the survivors
+        year = d_year.index(r["right_rowid"][3], default_for_missing=True)
+        return _q41_group_by(ch, ctx, year, nation, rev, cost)
     r = j_s.probe_columns(lo["lo_suppkey"], need_right_rows=False)   # semi joins: the dimension contributes no column
     f = r["filter"]
     if os.environ.get("SSB_PLAN_TWO_FILTERS"):                       # the reference's shape: one FilterTransform per join
@@ -106,6 +120,10 @@ def q41_gpu(ch, ctx, dims, lo):
     off = r["offsets"]
     rev, cost, nation = ch.replicate_columns([rev, cost, nation], off)
     year = d_year.index(r["right_rowid"], default_for_missing=True)
+    return _q41_group_by(ch, ctx, year, nation, rev, cost)
+
+
+def _q41_group_by(ch, ctx, year, nation, rev, cost):
     # ---- GROUP BY d_year, c_nation (keys64: packFixed) ----
     key = ch.pack_fixed_keys([year, nation])
     agg = ch.Aggregator(np.uint64, [(ch.AGG_SUM, np.uint32), (ch.AGG_SUM, np.uint32), (ch.AGG_COUNT, None)], ctx=ctx)
