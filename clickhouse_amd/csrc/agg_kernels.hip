@@ -3019,17 +3019,27 @@ static int agg_export(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** word_co
     view.ctx = ctx;
     view.rows = cells;
     view.owns = false;
-    // keys
+    // keys and every state word in ONE filter call: one count + scan + read-back instead of one per column (all 8-byte columns: they share
+    // a compaction kernel)
     chgpu_col * k64 = nullptr;
-    view.type = CHGPU_U64;
-    view.data = a->t.keys;
-    rc = chgpu_filter(ctx, &view, mask, 0, &k64, &n_out);
-    for (u32 w = 0; w < a->n_words && rc == CHGPU_OK; ++w)
     {
-        view.type = ((a->word_is_f64 >> w) & 1) ? CHGPU_F64 : CHGPU_U64;
-        view.data = a->t.words + (u64)w * cells;
-        u64 nw = 0;
-        rc = chgpu_filter(ctx, &view, mask, 0, &word_cols[w], &nw);
+        chgpu_col views[1 + AGG_MAX_WORDS];
+        const chgpu_col * vin[1 + AGG_MAX_WORDS];
+        chgpu_col * vout[1 + AGG_MAX_WORDS] = {nullptr};
+        for (u32 c = 0; c <= a->n_words; ++c)
+        {
+            views[c] = view;
+            views[c].type = c == 0 ? CHGPU_U64 : (((a->word_is_f64 >> (c - 1)) & 1) ? CHGPU_F64 : CHGPU_U64);
+            views[c].data = c == 0 ? (void *)a->t.keys : (void *)(a->t.words + (u64)(c - 1) * cells);
+            vin[c] = &views[c];
+        }
+        rc = chgpu_filter_columns(ctx, 1 + a->n_words, vin, mask, 0, vout, &n_out);
+        if (rc == CHGPU_OK)
+        {
+            k64 = vout[0];
+            for (u32 w = 0; w < a->n_words; ++w)
+                word_cols[w] = vout[1 + w];
+        }
     }
     chgpu_col_free(mask);
     auto drop_words = [&]() {

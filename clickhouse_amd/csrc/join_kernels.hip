@@ -118,6 +118,13 @@ struct chgpu_join
     size_t used_class = 0;
     u64 * block_base_dev = nullptr; // [n_blocks] first flat row of every build block
     size_t base_class = 0;
+    // Key set only (join_build_keyset): the exact bitmap over [0, max_key] of a build side of <= 4-byte keys, built WITHOUT the hash table
+    // for consumers that only ask "is the key present" (the SEMI / ANTI steps of chgpu_join_probe_chain).  Superseded by t.pf once the
+    // table exists.
+    u32 * ks_pf = nullptr;
+    size_t ks_class = 0;
+    u64 ks_bits = 0;
+    bool ks_ready = false;
 };
 
 // the left-side behaviour of the four kinds: RIGHT probes like INNER, FULL like LEFT (JoinFeatures.h:20-40: add_missing for LEFT / FULL)
@@ -889,6 +896,8 @@ extern "C" int chgpu_join_free(chgpu_join * j)
         chgpu_pool_free(j->ctx, j->used, j->used_class);
     if (j->block_base_dev)
         chgpu_pool_free(j->ctx, j->block_base_dev, j->base_class);
+    if (j->ks_pf)
+        chgpu_pool_free(j->ctx, j->ks_pf, j->ks_class);
     chgpu_ctx * ctx = j->ctx;
     delete j;
     chgpu_ctx_release(ctx);
@@ -928,8 +937,12 @@ extern "C" int chgpu_join_add_block(chgpu_join * j, const chgpu_col * key_col, c
         hipLaunchKernelGGL(k_join_stage_keys, dim3(chgpu_grid_for(ctx, b.rows, JT, 8)), dim3(JT), 0, ctx->stream, (const void *)key_col->data, key_col->type,
                            null_map ? (const u8 *)null_map->data : nullptr, join_mask ? (const u8 *)join_mask->data : nullptr, b.rows, b.keys, b.valid);
         ctx->counters[6] += 1;
-        // the caller may free its column right after this call returns
-        CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+        // the caller may free its columns right after this call returns.  Columns that own pool memory go back to this context's pool, whose
+        // reuse is ordered on this stream behind the staging kernel; anything else (wrapped caller memory, views) may be released or
+        // overwritten by means this stream does not order: wait.
+        auto pooled_here = [&](const chgpu_col * c) { return !c || (c->owns && c->ctx == ctx); };
+        if (!pooled_here(key_col) || !pooled_here(null_map) || !pooled_here(join_mask))
+            CHGPU_HIP(hipStreamSynchronize(ctx->stream));
     }
     if (block_index_out)
         *block_index_out = (u32)j->blocks.size();

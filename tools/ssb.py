@@ -76,7 +76,7 @@ def q41_gpu(ch, ctx, dims, lo):
     # ---- right sides: filtered dimension tables -> hash tables (FillingRightJoinSideTransform) ----
     c_region, c_custkey, c_nation = up(dims["c_region"]), up(dims["c_custkey"]), up(dims["c_nation"])
     cm = ch.cmp_const(c_region, ch.EQ, AMERICA)
-    ck, cn = c_custkey.filter(cm), c_nation.filter(cm)
+    ck, cn = ch.filter_columns([c_custkey, c_nation], cm)
     j_c = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, key_dtype=np.uint32, ctx=ctx)
     j_c.add_block(ck)
     sm = ch.cmp_const(up(dims["s_region"]), ch.EQ, AMERICA)
