@@ -132,56 +132,66 @@ __global__ __launch_bounds__(JC_THREADS) void k_chain_lds(ChainLdsArgs a, u64 n,
             kk[kb] = jc_load_quad(first, kb);
     }
     u32 loaded = ~0u;
-    for (u64 part = blockIdx.x; part < n_parts; part += gridDim.x)
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // stage slice `sl` of step `st`'s bitmap (+ a zero pad word behind it).  Whole KiB pieces go global -> LDS directly (LDS-DMA: one
+    // instruction per wave and KiB, no register round trip, no ds_write issue); the ragged end and the pad word are written by hand.
+    auto stage = [&](const ChainLdsStep & st, u32 id, u32 sl, u32 lo, u32 nb) {
+        if (loaded == id)
+            return;
+#if defined(JC_EXP) && (JC_EXP & 2)
+        if (loaded != ~0u) // experiment: no restaging (wrong results): the cost of the stages
+            return;
+#endif
+        __syncthreads(); // every wave has finished probing the slice that is about to be replaced
+        const u32 n_words = nb / 32; // (dense_bits and JC_SLICE_BITS are multiples of 32)
+        const u32 * src = st.pf + lo / 32;
+        const u32 full = n_words / 256;
+        for (u32 c = wave; c < full; c += JC_THREADS / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + c * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void *)(jc_bits + c * 256), 16, 0, 0);
+        for (u32 x = full * 256 + threadIdx.x; x < n_words + 1; x += JC_THREADS)
+            jc_bits[x] = x < n_words ? src[x] : 0u; // the pad word answers every key outside the slice
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): this wave's pieces have landed (the keys prefetched before them too)
+        if (sl == 0 && threadIdx.x == 0)    // the zero key lives out of line (HashTable.h:874-898): bit 0 stands for it
+            jc_bits[0] = (jc_bits[0] & ~1u) | (st.has_zero ? 1u : 0u);
+        __syncthreads();
+        loaded = id;
+    };
+    u32 iter = 0;
+    for (u64 part = blockIdx.x; part < n_parts; part += gridDim.x, ++iter)
     {
-        const u64 next_part = part + gridDim.x < n_parts ? part + gridDim.x : part;
+        // odd turns walk the steps and the slices backwards: the slice a part ends with is the one the next part starts with (one stage saved
+        // per part); the AND over the steps does not care about their order
+        const bool rev = iter & 1u;
+        const bool more = part + gridDim.x < n_parts;
         u32 alive_lo = ~0u, alive_hi = ~0u;
-        for (u32 s = 0; s < L; ++s)
+        for (u32 si = 0; si < L; ++si)
         {
+            const u32 s = rev ? L - 1 - si : si;
             const ChainLdsStep & st = a.s[s];
             u32 f_lo = 0, f_hi = 0;
-            const bool last_step = s + 1 == L;
-            const ChainLdsStep & nx = a.s[last_step ? 0 : s + 1];
-            const u64 nx_part = last_step ? next_part : part;
-            const __amdgpu_buffer_rsrc_t next_base = jc_part_rsrc((const jc_v4u *)nx.keys + nx_part * JC_PART_Q);
-            // stage slice `sl` of this step's bitmap (+ a zero pad word behind it)
-            auto stage = [&](u32 sl, u32 lo, u32 nb) {
-                const u32 id = s * JC_MAX_SLICES + sl;
-                if (loaded == id)
-                    return;
-                __syncthreads(); // every wave has finished probing the slice that is about to be replaced
-                const u32 n_words = nb / 32; // (dense_bits and JC_SLICE_BITS are multiples of 32)
-                const u32 * src = st.pf + lo / 32;
-                for (u32 w = threadIdx.x * 4; w < n_words + 1; w += JC_THREADS * 4)
-                {
-                    if (w + 4 <= n_words)
-                        *(jc_v4u *)(jc_bits + w) = *(const jc_v4u *)(src + w);
-                    else
-                        for (u32 x = w; x < n_words + 1 && x < w + 4; ++x)
-                            jc_bits[x] = x < n_words ? src[x] : 0u; // the pad word answers every key outside the slice
-                }
-                if (sl == 0)
-                {
-                    __syncthreads();
-                    if (threadIdx.x == 0) // the zero key lives out of line (HashTable.h:874-898): bit 0 stands for it
-                        jc_bits[0] = (jc_bits[0] & ~1u) | (st.has_zero ? 1u : 0u);
-                }
-                __syncthreads();
-                loaded = id;
-            };
+            const bool last_step = si + 1 == L;
+            // what the key registers are refilled with during the step's last pass: the next step of this part, or the first step of the
+            // next part (which walks the other way); nothing left: this part's column again, harmlessly
+            const u32 nx_s = !last_step ? (rev ? s - 1 : s + 1) : (more ? (rev ? 0u : L - 1) : s);
+            const u64 nx_part = (last_step && more) ? part + gridDim.x : part;
+            const __amdgpu_buffer_rsrc_t next_base = jc_part_rsrc((const jc_v4u *)a.s[nx_s].keys + nx_part * JC_PART_Q);
             // (two separate loops, not one loop with an if / else around the two pass flavours: hipcc hoists the code the flavours share --
             //  64 subtractions -- above the branch and the keys no longer fit the register file)
-            u32 sl = 0;
-            for (; sl + 1 < st.n_slices; ++sl)
+            u32 k = 0;
+            for (; k + 1 < st.n_slices; ++k)
             {
+                const u32 sl = rev ? st.n_slices - 1 - k : k;
                 const u32 lo = sl * JC_SLICE_BITS;
-                stage(sl, lo, JC_SLICE_BITS);
-                jc_slice_pass<false>(kk, f_lo, f_hi, jc_bits, lo, JC_SLICE_BITS, next_base);
+                const u32 nb = st.dense_bits - lo < JC_SLICE_BITS ? st.dense_bits - lo : JC_SLICE_BITS;
+                stage(st, s * JC_MAX_SLICES + sl, sl, lo, nb);
+                jc_slice_pass<false>(kk, f_lo, f_hi, jc_bits, lo, nb, next_base);
             }
             {
+                const u32 sl = rev ? st.n_slices - 1 - k : k;
                 const u32 lo = sl * JC_SLICE_BITS;
-                const u32 nb = st.dense_bits - lo; // <= JC_SLICE_BITS
-                stage(sl, lo, nb);
+                const u32 nb = st.dense_bits - lo < JC_SLICE_BITS ? st.dense_bits - lo : JC_SLICE_BITS;
+                stage(st, s * JC_MAX_SLICES + sl, sl, lo, nb);
                 jc_slice_pass<true>(kk, f_lo, f_hi, jc_bits, lo, nb, next_base);
             }
             if (st.null_map)
