@@ -34,6 +34,7 @@ SIGNATURES = {
     "chgpu_ctx_destroy": (_i, [_vp]),
     "chgpu_ctx_synchronize": (_i, [_vp]),
     "chgpu_ctx_trim": (_i, [_vp]),
+    "chgpu_ctx_set_option": (_i, [_vp, C.c_char_p, _i64]),
     "chgpu_ctx_counters": (_i, [_vp, _pu64]),
     "chgpu_timer_start": (_i, [_vp]),
     "chgpu_timer_stop_ms": (_i, [_vp, C.POINTER(C.c_double)]),
@@ -124,6 +125,7 @@ SIGNATURES = {
     "chgpu_comm_stats": (_i, [_vp, _pu64]),
     "chgpu_all_to_all_counts": (_i, [_vp, _pu64, _pu64]),
     "chgpu_all_to_all": (_i, [_vp, _vp, _pu64, _pu64, _pp]),
+    "chgpu_all_to_all_multi": (_i, [_vp, _u32, _pp, _pu64, _pu64, _pp]),
     "chgpu_all_reduce_u64": (_i, [_vp, _vp]),
     "chgpu_all_reduce_u64_host": (_i, [_vp, _pu64, _u32]),
     "chgpu_comm_barrier": (_i, [_vp]),

@@ -26,6 +26,29 @@ def sum_result_dtype(tag: int):
     return np.float64
 
 
+_OPTION_ENV_PREFIXES = ("CHGPU_TUNE_", "CHGPU_EXPERIMENT_", "CHGPU_TEST_", "CHGPU_AGG_NO_PARTITION", "CHGPU_DEBUG")
+
+
+def options_from_env(environ=None) -> dict:
+    """The A/B scripts under tools/ select plans with CHGPU_TUNE_* variables.  The library takes options only through chgpu_ctx_set_option;
+    this harness turns such variables into those calls when a Context is made (CHGPU_TUNE_GB_NO_TILED=1 -> "tune_gb_no_tiled" = 1)."""
+    import os
+    env = os.environ if environ is None else environ
+    out = {}
+    for k, v in env.items():
+        if k.startswith(_OPTION_ENV_PREFIXES):
+            try:
+                out[k[len("CHGPU_"):].lower()] = int(v) if v != "" else 1
+            except ValueError:
+                out[k[len("CHGPU_"):].lower()] = 1
+    return out
+
+
+def set_default_option(name: str, value: int = 1):
+    """process-wide default (chgpu_ctx_set_option with no context): what context-less code such as the expression compiler reads"""
+    K.check(K.lib().chgpu_ctx_set_option(None, name.encode(), int(value)))
+
+
 class Context:
     """One device + one HIP stream (one per pipeline thread, IProcessor.h:176-193)."""
 
@@ -35,6 +58,18 @@ class Context:
         self._h = h
         self._closed = False
         self.device = device
+        for name, value in options_from_env().items():   # developer harness only: the library itself never reads the environment
+            try:
+                self.set_option(name, value)
+                if name == "tune_jit_unroll":          # read by the context-less source generator
+                    set_default_option(name, value)
+            except K.ChgpuError as e:
+                import sys
+                print(f"clickhouse_amd: environment option ignored: {e}", file=sys.stderr)
+
+    def set_option(self, name: str, value: int = 1):
+        """chgpu_ctx_set_option: a developer option of this context (plan-level A/B switches, launch geometry; tools/README.md)"""
+        K.check(K.lib().chgpu_ctx_set_option(self._h, name.encode(), int(value)))
 
     def close(self):
         """chgpu_ctx_destroy: columns / aggregations / joins made on this context keep the C context alive until the last of them is

@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
         };
         auto process = [&](const u32 (&cs)[PR + 1], const u32 (&dl)[PR], const KT (&kv)[NS], const u64 (&av)[NS]) {
             const u32 total = cs[PR];
-            if (experiment == 1) // timing experiment: the gather alone
+            if (CHGPU_EXPERIMENT_VALUE(experiment) == 1) // timing experiment: the gather alone
             {
                 u64 acc = 0;
 #pragma unroll
@@ -1725,7 +1725,7 @@ static size_t agg_part_cell_bytes(const chgpu_agg * a, u64 n, u32 * cnt32_out)
 {
     const bool key32 = chgpu_type_size(a->key_type) <= 4;
     u32 cnt32 = 0;
-    static const bool no_cnt32 = getenv("CHGPU_TUNE_GB_NOCNT32") != nullptr;
+    const bool no_cnt32 = chgpu_opt(a->ctx, "tune_gb_nocnt32", 0) != 0;
     if (n < (1ull << 32) && !no_cnt32)
         for (u32 j = 0; j < a->n_aggs; ++j)
         {
@@ -1741,10 +1741,10 @@ static size_t agg_part_cell_bytes(const chgpu_agg * a, u64 n, u32 * cnt32_out)
 }
 
 // Largest power-of-two cell count whose table fits ~150 KiB of LDS (at most 8192).
-static u32 agg_part_max_cells(size_t cell_b)
+static u32 agg_part_max_cells(const chgpu_ctx * ctx, size_t cell_b)
 {
-    static const u32 s_max = getenv("CHGPU_TUNE_GB_S") ? (u32)atoi(getenv("CHGPU_TUNE_GB_S")) : 8192;
-    static const u32 s_kib = getenv("CHGPU_TUNE_GB_KIB") ? (u32)atoi(getenv("CHGPU_TUNE_GB_KIB")) : 150;
+    const u32 s_max = (u32)chgpu_opt(ctx, "tune_gb_s", 8192);
+    const u32 s_kib = (u32)chgpu_opt(ctx, "tune_gb_kib", 150);
     u32 S = s_max;
     while ((size_t)(S + 1) * cell_b + 32 > (size_t)s_kib * 1024 && S > 256)
         S >>= 1;
@@ -1877,7 +1877,7 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
     void * pkeys = (char *)run_index + ridx_b;
     // the sorted copy as {word, key} records (one piece per run and tile for the gather instead of two); the records take the key region
     // and the word region together, and `pwords` is then the base of the record array
-    static const bool no_aos = getenv("CHGPU_TUNE_GB_NO_AOS") != nullptr;
+    const bool no_aos = chgpu_opt(ctx, "tune_gb_no_aos", 0) != 0;
     const bool aos = !no_aos;
     u64 * pwords = aos ? (u64 *)pkeys : (u64 *)((char *)pkeys + keys_b);
     // the aggregate pass reads the widened words of the sorted copy
@@ -1925,8 +1925,8 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
         return CHGPU_ERR_NOT_IMPLEMENTED;
     const u32 G = (u32)ctx->num_cus;
     const u64 rows_per_wg = ((n + G - 1) / G + TILE - 1) / TILE * TILE;
-    static const int tiles_experiment = getenv("CHGPU_EXPERIMENT_TILES") ? atoi(getenv("CHGPU_EXPERIMENT_TILES")) : 0; // timing experiments only (wrong results)
-    static const bool debug = getenv("CHGPU_DEBUG") != nullptr;
+    const int tiles_experiment = CHGPU_EXPERIMENT(ctx, "experiment_tiles"); // timing experiments only (wrong results): -DCHGPU_EXPERIMENTS builds
+    const bool debug = chgpu_opt(ctx, "debug", 0) != 0;
     if (debug)
         fprintf(stderr, "chgpu: tile-sorted GROUP BY n=%llu hint=%llu S=%u P=%u tile=%u ops=0x%x\n", (unsigned long long)n, (unsigned long long)a->size_hint, S, P, TILE, ops);
     CHGPU_HIP(hipMemsetAsync(scratch, 0, tot_b + unit_b + pend_b, ctx->stream));
@@ -2035,7 +2035,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     u32 cnt32 = 0;
     const size_t cell_b = agg_part_cell_bytes(a, n, &cnt32);
     const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
-    const u32 S = agg_part_max_cells(cell_b);
+    const u32 S = agg_part_max_cells(a->ctx, cell_b);
     // partitions so that a partition's expected groups fill at most 70 % of the LDS table (fewer partitions = longer runs in
     // the scatter: an estimate of 1.25 M groups still gets 256 partitions)
     const u64 part_cap = (u64)S * 7 / 10;
@@ -2051,7 +2051,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     u64 mult = GBP_MULT;
     u32 P1 = 0;
     // (want_p already allows LDS tables 70 % full: up to ~5.9 M groups one level is the faster plan, 16 vs 24 ms at 5 M)
-    if (want_p > GBP_MAX_P && level == 0 && !getenv("CHGPU_TUNE_GB_NO_TWO_LEVEL"))
+    if (want_p > GBP_MAX_P && level == 0 && !chgpu_opt(ctx, "tune_gb_no_two_level", 0))
     {
         const u64 sub_groups = (u64)(GBP_MAX_P / 2) * (S / 2); // leaves the second level at half its partition budget
         for (P1 = 2; (u64)P1 * sub_groups < a->size_hint && P1 < 256; P1 <<= 1)
@@ -2066,7 +2066,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         return CHGPU_ERR_NOT_IMPLEMENTED;
     // work units of the aggregate pass: half an average partition each, so a uniform input gives every workgroup two
     // units and a partition swollen by a hot key is spread over many workgroups; each unit flushes its LDS table once
-    static const u32 unit_div = getenv("CHGPU_TUNE_GB_UNITDIV") ? (u32)atoi(getenv("CHGPU_TUNE_GB_UNITDIV")) : 2;
+    const u32 unit_div = (u32)chgpu_opt(ctx, "tune_gb_unitdiv", 2);
     u64 chunk_rows = (n / ((u64)P * unit_div) + 63) / 64 * 64;
     if (chunk_rows < 65536)
         chunk_rows = 65536;
@@ -2081,27 +2081,27 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         CHGPU_TRY(agg_grow(a, c0.n_groups, c0.has_zero != 0));
     }
     // one level, one argument word: the tile-sorted plan (two passes, streaming writes) where its shape fits
-    static const bool no_tiled = getenv("CHGPU_TUNE_GB_NO_TILED") != nullptr;
+    const bool no_tiled = chgpu_opt(ctx, "tune_gb_no_tiled", 0) != 0;
     if (level == 0 && K == 1 && !no_tiled)
     {
         const int rc_t = agg_add_block_tiled(a, key_col, arg_cols, row_begin, n, P, S, cnt32, agg_mask, chunk_rows);
         if (rc_t != CHGPU_ERR_NOT_IMPLEMENTED)
             return rc_t;
     }
-    static const int gmajor_x = getenv("CHGPU_EXPERIMENT_GMAJOR") ? 1 : 0; // timing experiment only: the aggregate pass still reads p-major
+    const int gmajor_x = CHGPU_EXPERIMENT(ctx, "experiment_gmajor") ? 1 : 0; // timing experiment only (-DCHGPU_EXPERIMENTS builds): the aggregate pass still reads p-major
     // (carried tails measured SLOWER than plain runs -- 8.5 / 7.3 vs 6.4 ms at C3 -- and wrote more, not fewer, bytes (PMC WRITE_SIZE 21 GB
     //  vs 13 GB): a partition's line is then written by two instructions a barrier apart; kept selectable for A/B runs)
-    static const int carry_mode = getenv("CHGPU_TUNE_GB_CARRY") ? atoi(getenv("CHGPU_TUNE_GB_CARRY")) : 0;
+    const int carry_mode = chgpu_opt(ctx, "tune_gb_carry", 0);
     // (two scatter workgroups per CU in carry mode 2: the histogram is cut into the same row ranges)
     const bool carry_shape = carry_mode && K == 1 && P <= 256 && n < (1ull << 32);
     // (experiment: several smaller scatter workgroups per CU so that one's rank / scan phases overlap another's loads and stores)
-    static const int wgs_per_cu_x = getenv("CHGPU_TUNE_GB_SCATTER_WGS") ? atoi(getenv("CHGPU_TUNE_GB_SCATTER_WGS")) : 1;
+    const int wgs_per_cu_x = chgpu_opt(ctx, "tune_gb_scatter_wgs", 1);
     const bool multi_wg = !carry_mode && (wgs_per_cu_x == 2 || wgs_per_cu_x == 4) && K == 1 && key32 && P <= 256;
     const u32 G = (u32)ctx->num_cus * (multi_wg ? (u32)wgs_per_cu_x : carry_shape && carry_mode == 2 ? 2 : GBP_WG_PER_CU);
     u64 rows_per_wg = (n + G - 1) / G;
     // the scatter's LDS image is tile*(8*K + key bytes) + 24*P bytes and must stay under ~159 KiB (160 KiB per workgroup, 64 B static)
     const size_t row_lds = 8 * K + (key32 ? 4 : 8);
-    static const u32 tile_cap = getenv("CHGPU_TUNE_GB_TILE") ? (u32)atoi(getenv("CHGPU_TUNE_GB_TILE")) : 12288;
+    const u32 tile_cap = (u32)chgpu_opt(ctx, "tune_gb_tile", 12288);
     u32 tile = 4096;
     for (u32 cand : {8192u, 12288u})
         if (cand <= tile_cap && cand * row_lds + (size_t)P * 24 + 64 <= 159 * 1024)
@@ -2109,7 +2109,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     if (multi_wg)
         tile = 12288 / (u32)wgs_per_cu_x;
     rows_per_wg = (rows_per_wg + tile - 1) / tile * tile;
-    static const bool debug = getenv("CHGPU_DEBUG") != nullptr;
+    const bool debug = chgpu_opt(ctx, "debug", 0) != 0;
     if (debug)
         fprintf(stderr, "chgpu: partitioned GROUP BY level=%d n=%llu hint=%llu S=%u P=%u G=%u tile=%u\n", level, (unsigned long long)n, (unsigned long long)a->size_hint, S, P, G, tile);
 
@@ -2173,7 +2173,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     bool wide = (key_w == 4 || key_w == 8) && ((uintptr_t)key_col->data + row_begin * key_w) % 16 == 0;
     for (u32 c = 0; c < K; ++c)
         wide = wide && chgpu_type_size(gc.type[c]) == 8 && ((uintptr_t)gc.src[c] + row_begin * 8) % 16 == 0;
-    static const bool no_wide = getenv("CHGPU_TUNE_GB_NOWIDE") != nullptr;
+    const bool no_wide = chgpu_opt(ctx, "tune_gb_nowide", 0) != 0;
     wide = wide && !no_wide;
     if (wide && key_w == 4)
         hipLaunchKernelGGL((k_rp_hist_wide<u32, GbpPartFn<u32>>), dim3(G), dim3(RP_THREADS), 0, ctx->stream, (const u32 *)key_col->data + row_begin, n, rows_per_wg, P, counts, GbpPartFn<u32>{P, mult}, gmajor_x);
@@ -2197,7 +2197,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     } while (0)
         // carried-tail scatter (radix_partition.h): one 8-byte word, wide loads, P <= 256, < 2^32 rows.  carry_mode 2 = 512 threads x
         // 4096-row tiles x 8-row pieces, two workgroups per CU; 1 = 1024 x 8192 x 16-row pieces, one per CU
-        static const bool old_scatter = getenv("CHGPU_TUNE_GB_OLD_SCATTER") != nullptr;
+        const bool old_scatter = chgpu_opt(ctx, "tune_gb_old_scatter", 0) != 0;
         if (!carry_mode && !old_scatter && wide && K == 1 && n + RP_SCATTER_SLACK < (1ull << 32) && P + 1 <= 2 * RP_THREADS)
         {
             // the branch-free scatter (radix_partition.h): one 8-byte word, wide loads
@@ -2333,7 +2333,7 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         u32 grid = (u32)ctx->num_cus;
         // the update of the state words as a compile-time code where the common shapes allow it (see k_agg_part_lds, OPS)
         u32 ops = 0;
-        static const bool no_ops = getenv("CHGPU_TUNE_GB_NOOPS") != nullptr;
+        const bool no_ops = chgpu_opt(ctx, "tune_gb_noops", 0) != 0;
         {
             u32 word_op[AGG_MAX_WORDS] = {0};
             bool ok = !no_ops && a->n_words <= 4;
@@ -2539,7 +2539,7 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
     // Callers that gave no size hint (the reference adapts too: consecutive-key cache hit rate, Aggregator.cpp:944-958;
     // two-level conversion, :83-89): the first 1 Mi rows go through the LDS-staged kernel and the number of groups they
     // produced is extrapolated to the whole input.
-    const u32 lds_cells = agg_part_max_cells(agg_part_cell_bytes(a, n, nullptr));
+    const u32 lds_cells = agg_part_max_cells(a->ctx, agg_part_cell_bytes(a, n, nullptr));
     const u64 lds_groups = (u64)lds_cells * 7 / 10;
     if (a->size_hint <= lds_groups && a->n_groups > lds_groups)
         a->size_hint = a->n_groups * 2; // the table already outgrew the LDS strategy
@@ -2559,8 +2559,8 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
     // a WHERE mask is fused only into the RANGE-mode kernel; every other strategy gets the filtered block materialised first
     if (filter)
     {
-        const bool partitioned = a->size_hint > lds_groups && n >= (4u << 20) && !getenv("CHGPU_AGG_NO_PARTITION");
-        const bool will_range = !partitioned && a->size_hint <= 65536 && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED");
+        const bool partitioned = a->size_hint > lds_groups && n >= (4u << 20) && !chgpu_opt(ctx, "agg_no_partition", 0);
+        const bool will_range = !partitioned && a->size_hint <= 65536 && n < (1ull << 32) && !chgpu_opt(ctx, "tune_agg_no_ranged", 0);
         if (!will_range)
             return agg_add_block_materialised(a, key_col, arg_cols, row_begin, row_end, filter);
         // The aggregation kernel is issue-bound: it spends nearly the same time on a masked-out row as on a kept one, while
@@ -2594,13 +2594,13 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
         for (u32 j = 0; j < a->n_aggs; ++j)
             if (a->kinds[j] != CHGPU_AGG_COUNT)
                 ++n_argwords;
-        if (a->size_hint > lds_groups && n >= (4u << 20) && n_argwords <= GBP_MAX_K && !getenv("CHGPU_AGG_NO_PARTITION"))
+        if (a->size_hint > lds_groups && n >= (4u << 20) && n_argwords <= GBP_MAX_K && !chgpu_opt(ctx, "agg_no_partition", 0))
         {
             int rc = agg_add_block_partitioned(a, key_col, arg_cols, row_begin, n, n_argwords);
             if (rc != CHGPU_ERR_NOT_IMPLEMENTED)
                 return rc;
         }
-        else if (a->size_hint > lds_groups && n >= (4u << 20) && !getenv("CHGPU_AGG_NO_PARTITION"))
+        else if (a->size_hint > lds_groups && n >= (4u << 20) && !chgpu_opt(ctx, "agg_no_partition", 0))
         {
             // more argument columns than a partition buffer row carries: several partitioned calls over the same rows, each with
             // two of them (plus every count() in the first) -- ~12 ms per 1e9 rows and call, against one HBM atomic per row
@@ -2644,7 +2644,7 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
     // width (8, 4 or 1 B), so the aggregate functions are split into PASSES over the same rows -- each pass re-reads the key
     // column and updates its own state words of the same groups (TPC-H Q1's seven sums and averages: 4 passes x ~20 B/row
     // instead of one trip through the generic kernel, which is 6x slower per row).
-    bool ranged = use_lds && n < (1ull << 32) && !getenv("CHGPU_TUNE_AGG_NO_RANGED"); // keys of 1, 2, 4 or 8 bytes: every key type
+    bool ranged = use_lds && n < (1ull << 32) && !chgpu_opt(ctx, "tune_agg_no_ranged", 0); // keys of 1, 2, 4 or 8 bytes: every key type
 
     if (ranged)
     {
@@ -2681,7 +2681,7 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
         const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
         // cells: four times the promised groups (4096 when nothing was promised), bounded by ~150 KiB of LDS; tables of up
         // to ~76 KiB let two 1024-thread workgroups share a CU
-        static const u32 s_dflt = getenv("CHGPU_TUNE_AGG_RANGED_S") ? (u32)atoi(getenv("CHGPU_TUNE_AGG_RANGED_S")) : 4096;
+        const u32 s_dflt = (u32)chgpu_opt(ctx, "tune_agg_ranged_s", 4096);
         u32 S = s_dflt;
         if (a->size_hint)
             for (S = 1024; S < 4 * a->size_hint && S < lds_cells; S <<= 1)
@@ -2774,7 +2774,7 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
             S >>= 1;
         // flushes may claim up to grid * (S+1) cells above max fill: keep that inside the slack (capacity/2)
         u64 max_grid = (a->t.capacity / 2) / (S + 1);
-        static const u32 lds_threads = getenv("CHGPU_TUNE_AGG_LDS_THREADS") ? (u32)atoi(getenv("CHGPU_TUNE_AGG_LDS_THREADS")) : 512;
+        const u32 lds_threads = (u32)chgpu_opt(ctx, "tune_agg_lds_threads", 512);
         u32 grid = chgpu_grid_for(ctx, n, lds_threads, lds_threads >= 1024 ? 2 : 4);
         if (grid > max_grid)
             grid = (u32)(max_grid ? max_grid : 1);

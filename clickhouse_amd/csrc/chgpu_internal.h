@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <string>
 #include <vector>
 
 #include "../../include/chgpu.h"
@@ -88,7 +89,22 @@ struct chgpu_ctx
     hipEvent_t upload_done[UPLOAD_RING] = {nullptr};
     hipEvent_t upload_gate = nullptr; // recorded on `stream` when the destination buffer is handed out; the copy waits for it
     u64 upload_next_ticket = 1;
+    std::map<std::string, long long> options; // chgpu_ctx_set_option
 };
+
+// Developer options (plan-level A/B switches, launch geometry): set through chgpu_ctx_set_option, never read from the environment by an
+// operator.  Looked up per context, then in the process-wide defaults (ctx == NULL), else `dflt`.
+long long chgpu_opt(const chgpu_ctx * ctx, const char * name, long long dflt);
+
+// Timing experiments that make a kernel SKIP work (wrong results) exist only in builds made with -DCHGPU_EXPERIMENTS; csrc/Makefile never
+// sets it, so in the product every such switch is the constant 0 and the branches fold away.
+#ifdef CHGPU_EXPERIMENTS
+#define CHGPU_EXPERIMENT(ctx, name) ((int)chgpu_opt(ctx, name, 0))
+#define CHGPU_EXPERIMENT_VALUE(x) (x)
+#else
+#define CHGPU_EXPERIMENT(ctx, name) 0
+#define CHGPU_EXPERIMENT_VALUE(x) 0
+#endif
 
 void chgpu_ctx_retain(chgpu_ctx * ctx);
 void chgpu_ctx_release(chgpu_ctx * ctx); // tears a zombie context down when the last reference goes

@@ -258,6 +258,83 @@ extern "C" int chgpu_all_to_all(chgpu_comm * c, const chgpu_col * send, const ui
     return CHGPU_OK;
 }
 
+// One exchange of a whole set of columns that share their partition boundaries (the key column and every state / payload column of
+// chgpu_partition_by_hash's output): ONE count exchange (a host read-back: the receive side must be sized) and ONE grouped send / recv over
+// every column and peer -- not a collective per column.  recv_counts (out, [world]) = rows received from each rank.
+extern "C" int chgpu_all_to_all_multi(chgpu_comm * c, uint32_t n_cols, const chgpu_col * const * send, const uint64_t * send_counts, uint64_t * recv_counts,
+                                      chgpu_col ** recv_out)
+{
+    CHGPU_REQUIRE(c && send_counts && recv_counts && (n_cols == 0 || (send && recv_out)), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    chgpu_ctx * ctx = c->ctx;
+    ChgpuDeviceGuard guard(ctx);
+    const int W = c->world;
+    u64 stot = 0;
+    for (int p = 0; p < W; ++p)
+        stot += send_counts[p];
+    for (u32 k = 0; k < n_cols; ++k)
+    {
+        CHGPU_REQUIRE(send[k], CHGPU_ERR_BAD_ARGUMENTS, "column %u is NULL", k);
+        CHGPU_REQUIRE(send[k]->rows == stot, CHGPU_ERR_SIZES_MISMATCH, "send counts add up to %llu rows, column %u has %llu", (unsigned long long)stot, k,
+                      (unsigned long long)send[k]->rows);
+        recv_out[k] = nullptr;
+    }
+    CHGPU_TRY(chgpu_all_to_all_counts(c, send_counts, recv_counts));
+    u64 rtot = 0;
+    std::vector<u64> soff((size_t)W + 1, 0), roff((size_t)W + 1, 0);
+    for (int p = 0; p < W; ++p)
+    {
+        rtot += recv_counts[p];
+        soff[p + 1] = soff[p] + send_counts[p];
+        roff[p + 1] = roff[p] + recv_counts[p];
+    }
+    auto fail = [&](int code) {
+        for (u32 k = 0; k < n_cols; ++k)
+        {
+            chgpu_col_free(recv_out[k]);
+            recv_out[k] = nullptr;
+        }
+        return code;
+    };
+    for (u32 k = 0; k < n_cols; ++k)
+    {
+        const int rc = chgpu_col_new(ctx, send[k]->type, rtot, &recv_out[k]);
+        if (rc != CHGPU_OK)
+            return fail(rc);
+        const size_t es = chgpu_type_size(send[k]->type);
+        if (send_counts[c->rank]) // own partition: device-to-device, no transport
+        {
+            const hipError_t e = hipMemcpyAsync((char *)recv_out[k]->data + roff[c->rank] * es, (const char *)send[k]->data + soff[c->rank] * es,
+                                                send_counts[c->rank] * es, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess)
+                return fail(chgpu_set_error(CHGPU_ERR_DEVICE, "all_to_all local copy: %s", hipGetErrorString(e)));
+        }
+    }
+    if (W > 1 && n_cols)
+    {
+        int r = g_rccl.GroupStart();
+        for (u32 k = 0; k < n_cols && r == nccl_Success; ++k)
+        {
+            const size_t es = chgpu_type_size(send[k]->type);
+            for (int p = 0; p < W && r == nccl_Success; ++p)
+            {
+                if (p == c->rank)
+                    continue;
+                if (send_counts[p])
+                    r = g_rccl.Send((const char *)send[k]->data + soff[p] * es, send_counts[p] * es, nccl_Uint8, p, c->comm, ctx->stream);
+                if (r == nccl_Success && recv_counts[p])
+                    r = g_rccl.Recv((char *)recv_out[k]->data + roff[p] * es, recv_counts[p] * es, nccl_Uint8, p, c->comm, ctx->stream);
+            }
+            c->bytes_sent += (stot - send_counts[c->rank]) * es;
+            c->bytes_received += (rtot - recv_counts[c->rank]) * es;
+        }
+        const int r2 = g_rccl.GroupEnd();
+        if (r != nccl_Success || r2 != nccl_Success)
+            return fail(chgpu_set_error(CHGPU_ERR_DEVICE, "all_to_all_multi: %s", g_rccl.GetErrorString(r != nccl_Success ? r : r2)));
+    }
+    c->collectives += 1;
+    return CHGPU_OK;
+}
+
 // element-wise wrap-around sum over all ranks, in place, of a UInt64 / Int64 device column (integer states and counters)
 extern "C" int chgpu_all_reduce_u64(chgpu_comm * c, chgpu_col * inout)
 {

@@ -3,6 +3,8 @@
 // ProfileEvents counters (src/Common/ProfileEvents.cpp:1034-1035,245-247), IProcessor::elapsed_ns (IProcessor.h:359-364).
 #include "chgpu_internal.h"
 
+#include <mutex>
+
 static thread_local char g_last_error[512] = "";
 
 int chgpu_set_error(int code, const char * fmt, ...)
@@ -108,6 +110,54 @@ extern "C" int chgpu_ctx_synchronize(chgpu_ctx * ctx)
     ChgpuDeviceGuard _dev_guard(ctx);
     CHGPU_REQUIRE(ctx, CHGPU_ERR_BAD_ARGUMENTS, "ctx is NULL");
     CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return CHGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// developer options
+// ---------------------------------------------------------------------------------------------
+static std::mutex g_opt_mu;
+static std::map<std::string, long long> g_opt_defaults;
+static const char * const CHGPU_OPTION_NAMES[] = {
+    "agg_no_partition", "debug", "experiment_gmajor", "experiment_join_lds", "experiment_tiles", "test_keydict_weak_tags", "tune_agg_lds_threads",
+    "tune_agg_no_ranged", "tune_agg_ranged_s", "tune_cmp_wg", "tune_expr_wg", "tune_exprn_wg", "tune_fcount_wg", "tune_filter_no_multi",
+    "tune_filter_no_staged", "tune_fs2_wg", "tune_fs_wg", "tune_fscatter_wg", "tune_gb_carry", "tune_gb_kib", "tune_gb_no_aos", "tune_gb_no_tiled",
+    "tune_gb_no_two_level", "tune_gb_nocnt32", "tune_gb_noops", "tune_gb_nowide", "tune_gb_old_scatter", "tune_gb_s", "tune_gb_scatter_wgs",
+    "tune_gb_tile", "tune_gb_unitdiv", "tune_jit_unroll", "tune_jit_wg_map", "tune_jit_wg_sum", "tune_join_cap_shift", "tune_join_eager_build",
+    "tune_join_lds_filter_qpt", "tune_join_lds_min_rows", "tune_join_no_dense_prefilter", "tune_join_no_fused_payload", "tune_join_no_lds_filter",
+    "tune_join_no_lds_filter_multi", "tune_join_no_lds_probe", "tune_join_no_prefilter", "tune_join_no_radix", "tune_join_no_regions",
+    "tune_join_no_slice_build", "tune_join_region_kib", "tune_join_region_min_rows", "tune_gb_no_tiled2", "tune_agg_no_det_f64",
+};
+
+long long chgpu_opt(const chgpu_ctx * ctx, const char * name, long long dflt)
+{
+    if (ctx && !ctx->options.empty())
+    {
+        auto it = ctx->options.find(name);
+        if (it != ctx->options.end())
+            return it->second;
+    }
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    if (g_opt_defaults.empty())
+        return dflt;
+    auto it = g_opt_defaults.find(name);
+    return it != g_opt_defaults.end() ? it->second : dflt;
+}
+
+extern "C" int chgpu_ctx_set_option(chgpu_ctx * ctx, const char * name, int64_t value)
+{
+    CHGPU_REQUIRE(name, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    bool known = false;
+    for (const char * n : CHGPU_OPTION_NAMES)
+        known = known || strcmp(n, name) == 0;
+    CHGPU_REQUIRE(known, CHGPU_ERR_BAD_ARGUMENTS, "unknown option '%s'", name);
+    if (ctx)
+        ctx->options[name] = value;
+    else
+    {
+        std::lock_guard<std::mutex> lk(g_opt_mu);
+        g_opt_defaults[name] = value;
+    }
     return CHGPU_OK;
 }
 

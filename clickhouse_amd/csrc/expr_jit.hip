@@ -424,13 +424,15 @@ struct KernelSpec
     u32 vec = 1;
 };
 
-static int jit_env(const char * name, int dflt)
-{
-    const char * v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+static int jit_env(const chgpu_ctx * ctx, const char * name, int dflt) { return (int)chgpu_opt(ctx, name, dflt); } // developer knobs (chgpu_ctx_set_option)
 // vectors in flight per lane and column / workgroups per CU: developer overrides for A/B runs (CHGPU_TUNE_JIT_UNROLL, _WG_MAP, _WG_SUM)
-static const int JIT_UNROLL = jit_env("CHGPU_TUNE_JIT_UNROLL", 4);
+// (the source generator has no context: the process-wide default, chgpu_ctx_set_option(NULL, ...), fixed at the first compilation)
+static int jit_unroll()
+{
+    static const int v = jit_env(nullptr, "tune_jit_unroll", 4);
+    return v;
+}
+#define JIT_UNROLL jit_unroll()
 constexpr u32 JIT_MAX_COLS = 8;
 
 struct JitArgs
@@ -996,7 +998,7 @@ extern "C" int chgpu_expr_execute(chgpu_ctx * ctx, const chgpu_expr * e, uint32_
     a.n = rows;
     if (rows)
     {
-        static const int wg_map = jit_env("CHGPU_TUNE_JIT_WG_MAP", 4);
+        const int wg_map = jit_env(ctx, "tune_jit_wg_map", 4);
         const u32 grid = chgpu_grid_for(ctx, (rows + ks.vec * JIT_UNROLL - 1) / (ks.vec * JIT_UNROLL), 256, wg_map);
         void * params[] = {&a};
         const hipError_t le = hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr);
@@ -1032,7 +1034,7 @@ extern "C" int chgpu_expr_filter_sum_node(chgpu_ctx * ctx, const chgpu_expr * e,
         hipFunction_t fn = nullptr, fin = nullptr;
         CHGPU_HIP(hipModuleGetFunction(&fn, mod, "k_run"));
         CHGPU_HIP(hipModuleGetFunction(&fin, mod, "k_fin"));
-        static const int wg_sum = jit_env("CHGPU_TUNE_JIT_WG_SUM", 2);
+        const int wg_sum = jit_env(ctx, "tune_jit_wg_sum", 2);
         const u32 grid = chgpu_grid_for(ctx, (rows + ks.vec * JIT_UNROLL - 1) / (ks.vec * JIT_UNROLL), 256, wg_sum);
         void * scratch = nullptr;
         CHGPU_TRY(chgpu_scratch(ctx, ((size_t)grid + 1) * 2 * sizeof(u64), &scratch));

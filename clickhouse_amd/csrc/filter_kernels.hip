@@ -16,11 +16,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-static u32 tune_env(const char * name, u32 dflt)
-{
-    const char * v = getenv(name); // developer knob for A/B runs; unset in production
-    return v ? (u32)atoi(v) : dflt;
-}
+static u32 tune_env(const chgpu_ctx * ctx, const char * name, u32 dflt) { return (u32)chgpu_opt(ctx, name, dflt); } // developer knobs (chgpu_ctx_set_option)
 
 // ---------------------------------------------------------------------------------------------
 // predicates
@@ -445,7 +441,7 @@ static int launch_filter_sum_t(chgpu_ctx * ctx, const void * pred, const void * 
     const bool same = (pred == val);
     const bool aligned = (((uintptr_t)pred | (uintptr_t)val) & 15) == 0 && (!cond || ((uintptr_t)cond % VECW) == 0);
     // persistent grid: FS_WG_PER_CU 256-thread workgroups per CU (see the measurement note above k_filter_sum)
-    static const u32 wg_same = tune_env("CHGPU_TUNE_FS_WG", FS_WG_PER_CU), wg_two = tune_env("CHGPU_TUNE_FS2_WG", FS_WG_PER_CU);
+    const u32 wg_same = tune_env(ctx, "tune_fs_wg", FS_WG_PER_CU), wg_two = tune_env(ctx, "tune_fs2_wg", FS_WG_PER_CU);
     const u32 grid = chgpu_grid_for(ctx, (n + VECW - 1) / VECW, FS_THREADS, same ? wg_same : wg_two);
     void * scratch = nullptr;
     CHGPU_TRY(chgpu_scratch(ctx, (size_t)grid * 2 * sizeof(u64), &scratch));
@@ -710,7 +706,7 @@ static int launch_cmp_t(chgpu_ctx * ctx, const void * a, u64 n, Pred p, u8 * c)
 {
     constexpr int VECW = 16 / sizeof(T);
     const bool aligned = ((uintptr_t)a & 15) == 0 && ((uintptr_t)c % VECW) == 0;
-    static const u32 wg_per_cu = tune_env("CHGPU_TUNE_CMP_WG", 2);
+    const u32 wg_per_cu = tune_env(ctx, "tune_cmp_wg", 2);
     const u32 grid = chgpu_grid_for(ctx, (n + VECW - 1) / VECW, 256, wg_per_cu);
     if (aligned)
         hipLaunchKernelGGL((k_cmp_mask<T, VECW, Pred>), dim3(grid), dim3(256), 0, ctx->stream, (const T *)a, n, p, c);
@@ -1160,7 +1156,7 @@ static int filter_plan(chgpu_ctx * ctx, const chgpu_col * mask, FilterPlan * fp)
     u64 * offsets = (u64 *)((char *)scratch + counts_b);
     u64 * total_dev = (u64 *)((char *)scratch + counts_b + offs_b);
     void * tmp = (char *)scratch + counts_b + offs_b + 256;
-    static const u32 wg_cnt = tune_env("CHGPU_TUNE_FCOUNT_WG", 8), wg_sc = tune_env("CHGPU_TUNE_FSCATTER_WG", 8);
+    const u32 wg_cnt = tune_env(ctx, "tune_fcount_wg", 8), wg_sc = tune_env(ctx, "tune_fscatter_wg", 8);
     const u32 grid_cnt = chgpu_grid_for(ctx, n_chunks * 64, 256, wg_cnt);
     hipLaunchKernelGGL(k_mask_chunk_counts, dim3(grid_cnt), dim3(256), 0, ctx->stream, (const u8 *)mask->data, n, counts, n_chunks);
     ctx->counters[6] += 1;
@@ -1173,9 +1169,9 @@ static int filter_plan(chgpu_ctx * ctx, const chgpu_col * mask, FilterPlan * fp)
     return CHGPU_OK;
 }
 // 4- and 8-byte columns: kept rows compacted in LDS, full-width stores (A/B: CHGPU_TUNE_FILTER_NO_STAGED)
-static bool filter_staged()
+static bool filter_staged(const chgpu_ctx * ctx)
 {
-    static const bool on = getenv("CHGPU_TUNE_FILTER_NO_STAGED") == nullptr;
+    const bool on = chgpu_opt(ctx, "tune_filter_no_staged", 0) == 0;
     return on;
 }
 static int filter_apply(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col * mask, const FilterPlan & fp, chgpu_col ** out)
@@ -1187,13 +1183,13 @@ static int filter_apply(chgpu_ctx * ctx, const chgpu_col * col, const chgpu_col 
         switch (chgpu_type_size(col->type))
         {
             case 8:
-                if (filter_staged())
+                if (filter_staged(ctx))
                     hipLaunchKernelGGL((k_filter_scatter<u64, true>), dim3(fp.grid), dim3(256), 0, ctx->stream, (const u64 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u64 *)res->data);
                 else
                     hipLaunchKernelGGL((k_filter_scatter<u64, false>), dim3(fp.grid), dim3(256), 0, ctx->stream, (const u64 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u64 *)res->data);
                 break;
             case 4:
-                if (filter_staged())
+                if (filter_staged(ctx))
                     hipLaunchKernelGGL((k_filter_scatter<u32, true>), dim3(fp.grid), dim3(256), 0, ctx->stream, (const u32 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u32 *)res->data);
                 else
                     hipLaunchKernelGGL((k_filter_scatter<u32, false>), dim3(fp.grid), dim3(256), 0, ctx->stream, (const u32 *)col->data, (const u8 *)mask->data, fp.n, fp.offsets, fp.n_chunks, (u32 *)res->data);
@@ -1321,8 +1317,8 @@ extern "C" int chgpu_filter_columns(chgpu_ctx * ctx, uint32_t n_cols, const chgp
         return rc;
     };
     // columns of one element width go through k_filter_scatter_multi up to six at a time: one read of the mask for all of them
-    static const bool no_multi = getenv("CHGPU_TUNE_FILTER_NO_MULTI") != nullptr;
-    const bool staged = filter_staged();
+    const bool no_multi = chgpu_opt(ctx, "tune_filter_no_multi", 0) != 0;
+    const bool staged = filter_staged(ctx);
     std::vector<char> done(n_cols, 0);
     if (mask->rows && fp.total && !no_multi)
         for (size_t w : {(size_t)8, (size_t)4})
@@ -2234,7 +2230,7 @@ extern "C" int chgpu_expr_filter_sum(chgpu_ctx * ctx, uint32_t n_cols, const chg
         narrow = narrow && chgpu_type_size(cols[k]->type) <= 4;
     // workgroups per CU (measured on the 4-column Q1.1 shape): same-type kernel 3; narrow mixed kernel 6 (86 VGPRs, 2 units
     // per lane: 2.36 ms vs 3.02 ms with 3; 3-4 units per lane 2.7 ms)
-    static const u32 ex_wg = tune_env("CHGPU_TUNE_EXPR_WG", 3), exn_wg = tune_env("CHGPU_TUNE_EXPRN_WG", 6);
+    const u32 ex_wg = tune_env(ctx, "tune_expr_wg", 3), exn_wg = tune_env(ctx, "tune_exprn_wg", 6);
     const u32 grid = chgpu_grid_for(ctx, (n + vecw - 1) / vecw, FS_THREADS, (!one_type && narrow) ? exn_wg : ex_wg);
     void * scratch = nullptr;
     const u32 grid_cap = (u32)ctx->num_cus * 8;

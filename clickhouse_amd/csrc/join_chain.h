@@ -138,10 +138,6 @@ __global__ __launch_bounds__(JC_THREADS) void k_chain_lds(ChainLdsArgs a, u64 n,
     auto stage = [&](const ChainLdsStep & st, u32 id, u32 sl, u32 lo, u32 nb) {
         if (loaded == id)
             return;
-#if defined(JC_EXP) && (JC_EXP & 2)
-        if (loaded != ~0u) // experiment: no restaging (wrong results): the cost of the stages
-            return;
-#endif
         __syncthreads(); // every wave has finished probing the slice that is about to be replaced
         const u32 n_words = nb / 32; // (dense_bits and JC_SLICE_BITS are multiples of 32)
         const u32 * src = st.pf + lo / 32;

@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(JT) void k_join_insert_pairs(JoinTable t, const u64
 static int join_build_slices(chgpu_join * j, JoinTable & t)
 {
     chgpu_ctx * ctx = j->ctx;
-    static const bool off = getenv("CHGPU_TUNE_JOIN_NO_SLICE_BUILD") != nullptr;
+    const bool off = chgpu_opt(ctx, "tune_join_no_slice_build", 0) != 0;
     const u64 n = j->total_rows, cap = t.capacity;
     u32 lg_cap = 0;
     while ((1ull << lg_cap) < cap)
@@ -1210,9 +1210,9 @@ static int join_build_slices(chgpu_join * j, JoinTable & t)
 }
 
 static int join_build_table(chgpu_join * j);
-static u64 join_capacity_for(u64 rows)
+static u64 join_capacity_for(const chgpu_ctx * ctx, u64 rows)
 {
-    static const u32 cap_shift = getenv("CHGPU_TUNE_JOIN_CAP_SHIFT") ? (u32)atoi(getenv("CHGPU_TUNE_JOIN_CAP_SHIFT")) : 1;
+    const u32 cap_shift = (u32)chgpu_opt(ctx, "tune_join_cap_shift", 1);
     return jpow2_ceil(rows + rows * 3 / 7 + 1) << cap_shift;
 }
 
@@ -1223,7 +1223,7 @@ extern "C" int chgpu_join_finish_build(chgpu_join * j)
 {
     ChgpuDeviceGuard _dev_guard(j ? j->ctx : nullptr);
     CHGPU_REQUIRE(j, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
-    static const bool eager = getenv("CHGPU_TUNE_JOIN_EAGER_BUILD") != nullptr;
+    const bool eager = chgpu_opt(j->ctx, "tune_join_eager_build", 0) != 0;
     j->build_closed = true;
     return eager ? join_build_table(j) : CHGPU_OK;
 }
@@ -1239,7 +1239,7 @@ static int join_build_table(chgpu_join * j)
     // load factor in (0.175, 0.35]: a probe then resolves at its home cell nearly always (1.1 cells per hit, 1.3 per miss, against 1.75 / 3.6
     // at 0.6).  Measured at C4: build 1.00 -> 0.90 ms (fewer retried claims), probe 3.40 -> 2.26 ms region-partitioned, 4.83 -> 3.39 ms
     // one-pass.  The table is immutable after the build and 288 GB of HBM make the doubled footprint (512 MB of cells for 1e7 rows) cheap.
-    const u64 cap = join_capacity_for(j->total_rows);
+    const u64 cap = join_capacity_for(j->ctx, j->total_rows);
     CHGPU_REQUIRE(cap + 1 < 0xFFFFFFFFull, CHGPU_ERR_NOT_IMPLEMENTED, "build side of %llu rows exceeds the 32-bit cell index", (unsigned long long)j->total_rows);
     const u64 cells = cap + 1;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -1250,11 +1250,11 @@ static int join_build_table(chgpu_join * j)
     u64 pf_bits = 1ull << 16;
     while (pf_bits < 16 * j->total_rows && pf_bits < (1ull << 25))
         pf_bits <<= 1;
-    bool use_pf = pf_bits >= 16 * j->total_rows && !getenv("CHGPU_TUNE_JOIN_NO_PREFILTER");
+    bool use_pf = pf_bits >= 16 * j->total_rows && !chgpu_opt(ctx, "tune_join_no_prefilter", 0);
     // A larger build side of narrow DENSE keys (a filtered dimension table joined on its surrogate key: SSB's customer, 6 M of the keys
     // 1..30 M) still gets the exact bitmap if max_key + 1 bits fit the 4 MiB limit: the misses of the probe then stop at a bitmap that
     // lives in L2 / Infinity Cache instead of costing one HBM sector each.
-    if (!use_pf && chgpu_type_size(j->key_type) <= 4 && !getenv("CHGPU_TUNE_JOIN_NO_PREFILTER") && !getenv("CHGPU_TUNE_JOIN_NO_DENSE_PREFILTER"))
+    if (!use_pf && chgpu_type_size(j->key_type) <= 4 && !chgpu_opt(ctx, "tune_join_no_prefilter", 0) && !chgpu_opt(ctx, "tune_join_no_dense_prefilter", 0))
     {
         void * scratch0 = nullptr;
         CHGPU_TRY(chgpu_scratch(ctx, 256, &scratch0));
@@ -1552,17 +1552,17 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
         CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U8, n, &fcol));
         hipError_t e = hipMemsetAsync(&j->t.ctrl->n_out, 0, sizeof(u64), ctx->stream);
         // dense 4-byte keys whose key set fits a few LDS slices: k_join_probe_filter_lds (the tail of a bitmap beyond max_key is zero)
-        static const bool no_lds_filter = getenv("CHGPU_TUNE_JOIN_NO_LDS_FILTER") != nullptr;
+        const bool no_lds_filter = chgpu_opt(ctx, "tune_join_no_lds_filter", 0) != 0;
         const u64 dense_bits = (j->max_key + 32) / 32 * 32;
         if (e == hipSuccess && !no_lds_filter && j->t.pf && j->max_key <= j->t.pf_mask && chgpu_type_size(j->key_type) == 4 && dense_bits <= 4ull * JPL_SLICE_BITS
             && n >= (1u << 20) && (uintptr_t)key_col->data % 16 == 0 && (!null_map || (uintptr_t)null_map->data % 4 == 0))
         {
             const u32 passes = (u32)((dense_bits + JPL_SLICE_BITS - 1) / JPL_SLICE_BITS);
-            static const bool no_multi = getenv("CHGPU_TUNE_JOIN_NO_LDS_FILTER_MULTI") != nullptr;
+            const bool no_multi = chgpu_opt(ctx, "tune_join_no_lds_filter_multi", 0) != 0;
             if (passes > 1 && !no_multi)
             {
                 // several slices: one sweep, every part of the rows through all slices (k_join_probe_filter_lds_multi)
-                static const u32 qpt = getenv("CHGPU_TUNE_JOIN_LDS_FILTER_QPT") ? (u32)atoi(getenv("CHGPU_TUNE_JOIN_LDS_FILTER_QPT")) : 16;
+                const u32 qpt = (u32)chgpu_opt(ctx, "tune_join_lds_filter_qpt", 16);
                 auto kern = qpt == 8 ? (null_map ? k_join_probe_filter_lds_multi<true, 8> : k_join_probe_filter_lds_multi<false, 8>)
                           : qpt == 4 ? (null_map ? k_join_probe_filter_lds_multi<true, 4> : k_join_probe_filter_lds_multi<false, 4>)
                                      : (null_map ? k_join_probe_filter_lds_multi<true, 16> : k_join_probe_filter_lds_multi<false, 16>);
@@ -2126,14 +2126,14 @@ static int join_probe_agg_regions(chgpu_join * j, const chgpu_col * key_col, con
 {
     chgpu_ctx * ctx = j->ctx;
     const u64 n = key_col->rows, cap = j->t.capacity;
-    static const bool off = getenv("CHGPU_TUNE_JOIN_NO_REGIONS") != nullptr;
-    static const u64 min_rows = getenv("CHGPU_TUNE_JOIN_REGION_MIN_ROWS") ? strtoull(getenv("CHGPU_TUNE_JOIN_REGION_MIN_ROWS"), nullptr, 10) : (4ull << 20);
+    const bool off = chgpu_opt(ctx, "tune_join_no_regions", 0) != 0;
+    const u64 min_rows = chgpu_opt(ctx, "tune_join_region_min_rows", (4ull << 20));
     // worth it when the table is far larger than the XCDs' L2s together (32 MB) and there are enough keys to pay two extra passes
     if (off || chgpu_type_size(j->key_type) != 8 || n < min_rows || n + RP_SCATTER_SLACK >= (1ull << 32) || cap * 16 < (64ull << 20) || ((uintptr_t)key_col->data % 16) != 0)
         return CHGPU_ERR_NOT_IMPLEMENTED;
     if (right_payload && chgpu_type_is_float(right_payload->type))
         return CHGPU_ERR_NOT_IMPLEMENTED; // a Float64 sum keeps the one-pass probe's fixed reduction order
-    static const u32 region_kib = getenv("CHGPU_TUNE_JOIN_REGION_KIB") ? (u32)atoi(getenv("CHGPU_TUNE_JOIN_REGION_KIB")) : 1024;
+    const u32 region_kib = (u32)chgpu_opt(ctx, "tune_join_region_kib", 1024);
     u32 lg_cap = 0;
     while ((1ull << lg_cap) < cap)
         ++lg_cap;
@@ -2174,7 +2174,7 @@ static int join_probe_agg_regions(chgpu_join * j, const chgpu_col * key_col, con
     const void * pp = right_payload ? right_payload->data : nullptr;
     const int pt = right_payload ? right_payload->type : CHGPU_U64;
     const u32 grid = (u32)ctx->num_cus * 4;
-    static const bool no_fuse = getenv("CHGPU_TUNE_JOIN_NO_FUSED_PAYLOAD") != nullptr;
+    const bool no_fuse = chgpu_opt(ctx, "tune_join_no_fused_payload", 0) != 0;
     if (j->unique_keys && right_payload && !j->t.pf && !no_fuse)
     {
         // {key, payload} cells: one 16-byte read answers a hit completely (k_join_fuse_payload); rebuilt per call -- the payload column
@@ -2285,7 +2285,7 @@ __global__ __launch_bounds__(JPL2_THREADS) void k_join_probe_lds(JoinTable t, in
         ++lg_cap;
     auto slot_of = [&](u64 key) -> u64 { return FROM_ROWS ? join_radix_slot(key, lg_cap) : (dev_intHash64(key) & mask); };
     auto flat_of = [&](u64 rowid) -> u64 { return n_blocks == 1 ? (rowid & 0xFFFFFFFFull) : block_base[rowid >> 32] + (rowid & 0xFFFFFFFFull); };
-    const int experiment = variant >> 8; // timing experiments only (CHGPU_EXPERIMENT_JOIN_LDS: 1 = no slice build, 2 = no look-ups)
+    const int experiment = CHGPU_EXPERIMENT_VALUE(variant >> 8); // timing experiments only, -DCHGPU_EXPERIMENTS builds (CHGPU_EXPERIMENT_JOIN_LDS: 1 = no slice build, 2 = no look-ups)
     variant &= 0xff;
     const bool miss_counts = variant == PV_ALL_LEFT || variant == PV_ANY_LEFT || variant == PV_ANTI_LEFT;
     const bool anti = variant == PV_ANTI_LEFT;
@@ -2559,8 +2559,8 @@ static int join_probe_agg_lds(chgpu_join * j, const chgpu_col * key_col, const c
 {
     chgpu_ctx * ctx = j->ctx;
     const u64 n = key_col->rows, cap = j->t.capacity;
-    static const bool off = getenv("CHGPU_TUNE_JOIN_NO_LDS_PROBE") != nullptr;
-    static const u64 min_rows = getenv("CHGPU_TUNE_JOIN_LDS_MIN_ROWS") ? strtoull(getenv("CHGPU_TUNE_JOIN_LDS_MIN_ROWS"), nullptr, 10) : (8ull << 20);
+    const bool off = chgpu_opt(ctx, "tune_join_no_lds_probe", 0) != 0;
+    const u64 min_rows = chgpu_opt(ctx, "tune_join_lds_min_rows", (8ull << 20));
     u32 lg_cap = 0;
     while ((1ull << lg_cap) < cap)
         ++lg_cap;
@@ -2634,15 +2634,15 @@ static int join_probe_agg_lds(chgpu_join * j, const chgpu_col * key_col, const c
 static int join_probe_agg_radix(chgpu_join * j, const chgpu_col * key_col, const chgpu_col * right_payload, int variant, u64 res[2])
 {
     chgpu_ctx * ctx = j->ctx;
-    static const bool off = getenv("CHGPU_TUNE_JOIN_NO_RADIX") != nullptr;
-    static const u64 min_rows = getenv("CHGPU_TUNE_JOIN_LDS_MIN_ROWS") ? strtoull(getenv("CHGPU_TUNE_JOIN_LDS_MIN_ROWS"), nullptr, 10) : (8ull << 20);
+    const bool off = chgpu_opt(ctx, "tune_join_no_radix", 0) != 0;
+    const u64 min_rows = chgpu_opt(ctx, "tune_join_lds_min_rows", (8ull << 20));
     const u64 n = key_col->rows, nb = j->total_rows;
     if (off || j->finished || j->blocks.size() != 1 || j->blocks[0].valid || nb < (1u << 20) || !right_payload || chgpu_type_is_float(right_payload->type)
         || chgpu_type_size(right_payload->type) != 8 || chgpu_type_size(j->key_type) != 8 || n < min_rows || n + JPL2_TILE + RP_SCATTER_SLACK >= (1ull << 32)
         || nb + JBS_TILE + RP_SCATTER_SLACK >= (1ull << 32) || ((uintptr_t)key_col->data % 16) != 0 || ((uintptr_t)right_payload->data % 16) != 0
         || ((uintptr_t)j->blocks[0].keys % 16) != 0)
         return CHGPU_ERR_NOT_IMPLEMENTED;
-    const u64 cap = join_capacity_for(nb);
+    const u64 cap = join_capacity_for(j->ctx, nb);
     u32 lg_cap = 0;
     while ((1ull << lg_cap) < cap)
         ++lg_cap;
@@ -2714,7 +2714,7 @@ static int join_probe_agg_radix(chgpu_join * j, const chgpu_col * key_col, const
         vt.capacity = cap;
         const size_t lds = (size_t)(JPL2_CELLS + JPL2_TAIL + 2) * 16;
         CHGPU_HIP(hipFuncSetAttribute((const void *)k_join_probe_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        static const int jexp = getenv("CHGPU_EXPERIMENT_JOIN_LDS") ? atoi(getenv("CHGPU_EXPERIMENT_JOIN_LDS")) : 0;
+        const int jexp = CHGPU_EXPERIMENT(ctx, "experiment_join_lds");
         hipLaunchKernelGGL(k_join_probe_lds<true>, dim3(2 * G), dim3(JPL2_THREADS), lds, ctx->stream, vt, variant | (jexp << 8), (const u64 *)pk2, n, (const u64 *)p_offsets, G, lg_p2,
                            (const unsigned short *)pix, (const u64 *)nullptr, (const u64 *)nullptr, (u64)1, unit_ctr, stray, result2, (const u64 *)bk2, (const u64 *)bw2,
                            (const u64 *)b_offsets, (const unsigned short *)bix, nb, dupf);

@@ -360,7 +360,7 @@ extern "C" int chgpu_keydict_create(chgpu_ctx * ctx, uint32_t key_bytes, uint64_
     d->key_bytes = key_bytes;
     d->W = key_bytes / 8;
     d->t.W = d->W;
-    d->weak_tags = getenv("CHGPU_TEST_KEYDICT_WEAK_TAGS") ? 1 : 0;
+    d->weak_tags = chgpu_opt(ctx, "test_keydict_weak_tags", 0) ? 1 : 0; // test hook: 20-bit tags, so that tag collisions happen
     chgpu_ctx_retain(ctx);
     const int rc = kd_ensure(d, size_hint ? size_hint : 1024);
     if (rc != CHGPU_OK)

@@ -79,6 +79,17 @@ class Comm:
         K.check(K.lib().chgpu_all_to_all(self._h, col._h, snd, rcv, C.byref(h)))
         return Column(self.ctx, h)
 
+    def all_to_all_multi(self, cols, send_counts):
+        """every column of one partitioned Block in one exchange: -> ([received Columns], recv_counts)"""
+        from .columns import Column
+        n = len(cols)
+        snd = (C.c_uint64 * self.world)(*[int(x) for x in send_counts])
+        rcv = (C.c_uint64 * self.world)()
+        hin = (C.c_void_p * max(1, n))(*[c._h for c in cols])
+        hout = (C.c_void_p * max(1, n))()
+        K.check(K.lib().chgpu_all_to_all_multi(self._h, n, hin, snd, rcv, hout))
+        return [Column(self.ctx, C.c_void_p(hout[k])) for k in range(n)], [int(x) for x in rcv]
+
     def all_reduce_u64(self, values):
         n = len(values)
         buf = (C.c_uint64 * max(1, n))(*[int(v) % 2**64 for v in values])
@@ -115,6 +126,10 @@ class LocalEngine:
 
     def all_to_all(self, col, counts, recv_counts):
         return self.comm.all_to_all(col, counts, recv_counts)
+
+    def exchange(self, parts, counts):
+        """the whole partitioned Block in ONE exchange (chgpu_all_to_all_multi): -> ([received columns], recv_counts)"""
+        return self.comm.all_to_all_multi(parts, counts)
 
     def all_reduce_u64(self, values):
         return self.comm.all_reduce_u64(values) if self.comm is not None else [int(v) % 2**64 for v in values]
@@ -205,8 +220,7 @@ class ShardedGroupBy:
             return self.local
         keys, words, rows = self.e.agg_export(self.local)                       # convertToBlockImplNotFinal
         parts, counts = self.e.partition_by_hash(keys, [keys] + words, self.world)
-        recv_counts = self.e.exchange_counts(counts)
-        got = [self.e.all_to_all(p, counts, recv_counts) for p in parts]         # THE exchange step
+        got, recv_counts = self.e.exchange(parts, counts)                         # THE exchange step: every column in one group
         self.owner = self.e.Aggregator(self.key_dtype, self.aggs, size_hint=max(int(sum(recv_counts)), 1))
         self.e.agg_merge_states(self.owner, got[0], got[1:])                      # mergeBucketImpl on the owner
         return self.owner
@@ -234,8 +248,7 @@ class ShardedHashJoin:
         if self.world == 1:
             return keys, list(cols)
         parts, counts = self.e.partition_by_hash(keys, [keys] + list(cols), self.world)
-        recv_counts = self.e.exchange_counts(counts)
-        got = [self.e.all_to_all(p, counts, recv_counts) for p in parts]
+        got, _ = self.e.exchange(parts, counts)
         return got[0], got[1:]
 
     def add_build_rows(self, keys, payload_cols=()):

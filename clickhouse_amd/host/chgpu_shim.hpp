@@ -943,6 +943,8 @@ public:
         return recv;
     }
     ColumnPtr allToAll(const ColumnVector & send, const std::vector<uint64_t> & send_counts, const std::vector<uint64_t> & recv_counts) const;
+    /// every column of one partitioned Block in ONE exchange (one count exchange + one grouped send / recv): -> received columns, rows per peer
+    Columns allToAllMulti(const Columns & send, const std::vector<uint64_t> & send_counts, std::vector<uint64_t> & recv_counts) const;
     void allReduce(std::vector<uint64_t> & values) const { check(chgpu_all_reduce_u64_host(h, values.data(), static_cast<uint32_t>(values.size()))); }
     void barrier() const { check(chgpu_comm_barrier(h)); }
 
@@ -959,9 +961,23 @@ inline ColumnPtr Communicator::allToAll(const ColumnVector & send, const std::ve
     return std::make_shared<ColumnVector>(ctx, out);
 }
 
+inline Columns Communicator::allToAllMulti(const Columns & send, const std::vector<uint64_t> & send_counts, std::vector<uint64_t> & recv_counts) const
+{
+    std::vector<const chgpu_col *> in;
+    for (auto & c : send)
+        in.push_back(c->handle());
+    std::vector<chgpu_col *> out(in.size(), nullptr);
+    recv_counts.assign(send_counts.size(), 0);
+    check(chgpu_all_to_all_multi(h, static_cast<uint32_t>(in.size()), in.data(), send_counts.data(), recv_counts.data(), out.data()));
+    Columns res;
+    for (auto * o : out)
+        res.push_back(std::make_shared<ColumnVector>(ctx, o));
+    return res;
+}
+
 /// ConcurrentHashJoin::dispatchBlock (ConcurrentHashJoin.cpp:538-565: hashToSelector :426-440 + scatterBlocksWithSelector :518-536) with
 /// the slots living on different GPUs: the rows of `block` are split by shard = bucket(key) & (world - 1) and every shard travels
-/// to its owner in ONE all-to-all per column; the result is the chunk of rows THIS rank owns (its own shard + what the peers sent).
+/// to its owner in ONE exchange for the whole Block; the result is the chunk of rows THIS rank owns (its own shard + what the peers sent).
 inline Chunk dispatchBlock(const Communicator & comm, const Chunk & block, size_t key_position)
 {
     const uint32_t world = static_cast<uint32_t>(comm.world());
@@ -977,10 +993,9 @@ inline Chunk dispatchBlock(const Communicator & comm, const Chunk & block, size_
     Columns sends;
     for (auto * p : parts)
         sends.push_back(std::make_shared<ColumnVector>(ctx, p));
-    const auto recv_counts = comm.allToAllCounts(counts);
+    std::vector<uint64_t> recv_counts;
     Chunk mine;
-    for (auto & c : sends)
-        mine.columns.push_back(comm.allToAll(*c, counts, recv_counts));
+    mine.columns = comm.allToAllMulti(sends, counts, recv_counts);
     for (auto r : recv_counts)
         mine.num_rows += r;
     return mine;

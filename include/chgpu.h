@@ -89,6 +89,11 @@ int chgpu_ctx_destroy(chgpu_ctx * ctx);
 int chgpu_ctx_synchronize(chgpu_ctx * ctx);
 /* give the context's cached device memory (column pool + scratch arena) back to the driver; synchronizes */
 int chgpu_ctx_trim(chgpu_ctx * ctx);
+/* Developer options: plan-level A/B switches and launch geometry (names: tools/README.md; e.g. "tune_join_no_radix", "tune_gb_tile").  No
+   operator reads the environment: an option is set here, per context, or with ctx == NULL as the process-wide default.  Unknown names ->
+   CHGPU_ERR_BAD_ARGUMENTS.  Results never depend on an option (only the plan taken does); the timing experiments that skip work exist only in
+   builds made with -DCHGPU_EXPERIMENTS. */
+int chgpu_ctx_set_option(chgpu_ctx * ctx, const char * name, int64_t value);
 /* ProfileEvents-style counters of this context (src/Common/ProfileEvents.cpp:1034-1035, 245-247):
    [0] FilterTransformPassedRows [1] FilterTransformPassedBytes [2] JoinBuildTableRowCount
    [3] JoinProbeTableRowCount [4] JoinResultRowCount [5] AggregatedRows [6] kernel launches [7] table rehashes */
@@ -541,6 +546,12 @@ int chgpu_all_to_all_counts(chgpu_comm * comm, const uint64_t * send_counts, uin
    sum(recv_counts) rows, what ranks 0..world-1 sent here in rank order.  One grouped send/recv: every xGMI link carries its peer's
    partition at once; the own partition is a device copy.  Asynchronous on the context's stream. */
 int chgpu_all_to_all(chgpu_comm * comm, const chgpu_col * send, const uint64_t * send_counts, const uint64_t * recv_counts, chgpu_col ** recv_out);
+/* The exchange of a whole Block: n_cols columns that share their partition boundaries (chgpu_partition_by_hash's outputs: the key column
+   and every state / payload column) leave in ONE grouped send / recv over all columns and peers, after ONE exchange of the row counts
+   (recv_counts [world] is an output: the rows each rank sent here).  What dispatchBlock + the shard's input port do for one Block
+   (src/Interpreters/ConcurrentHashJoin.cpp:538-565).  chgpu_all_to_all_counts + chgpu_all_to_all remain for a single column. */
+int chgpu_all_to_all_multi(chgpu_comm * comm, uint32_t n_cols, const chgpu_col * const * send, const uint64_t * send_counts, uint64_t * recv_counts,
+                           chgpu_col ** recv_out);
 /* mergeWithoutKeyDataImpl across ranks (src/Interpreters/Aggregator.cpp:2584-2628): element-wise wrap-around sum of a UInt64 / Int64
    device column over all ranks, in place (asynchronous); _host: the same for <= 64 host values (synchronises) */
 int chgpu_all_reduce_u64(chgpu_comm * comm, chgpu_col * inout_u64);

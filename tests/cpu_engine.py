@@ -33,6 +33,11 @@ class GlooExchange:
         dist.all_to_all_single(recv, raw, output_split_sizes=[int(c) * es for c in recv_counts], input_split_sizes=[int(c) * es for c in counts])
         return recv.numpy().view(arr.dtype)
 
+    def exchange(self, parts, counts):
+        """the engine's one-exchange-per-Block entry: counts first, then every column"""
+        recv_counts = self.exchange_counts(counts)
+        return [self.all_to_all(p, counts, recv_counts) for p in parts], recv_counts
+
     def all_reduce_u64(self, values):
         t = torch.from_numpy(np.array([int(v) % 2**64 for v in values], dtype=np.uint64).view(np.int64).copy())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)  # two's complement: the wrap-around sum

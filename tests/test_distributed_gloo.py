@@ -87,6 +87,24 @@ def _worker(rank, world, init_file, out_dir):
             assert pairs == set(zip(ol.tolist(), orow.tolist()))
             assert sum(x[0].shape[0] for x in gathered) == ol.shape[0]
             assert cnt == ol.shape[0] and sm == int(bv_all[orow].astype(np.uint64).sum(dtype=np.uint64))
+        # 4. BASELINE.json configs[4] sharded: lineorder rows split by range, dimensions replicated, every rank runs the SSB Q4.1 plan over
+        #    its rows, the (year, nation) partial states meet at their owners -- the union of the ranks' groups == the one-process plan
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import ssb
+        dims = ssb.gen_dims(30_000, 2_000, 2_000)
+        lo_all = ssb.gen_lineorder_numpy(200_000, 30_000, 2_000, 2_000)
+        rlo, rhi = rank * 200_000 // world, (rank + 1) * 200_000 // world
+        mine = ssb.q41_sharded_cpu(O, D, eng, dims, {k: v[rlo:rhi] for k, v in lo_all.items()})
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        if rank == 0:
+            want = ssb.q41_cpu(O, dims, lo_all)
+            union = {}
+            for g_ in gathered:
+                assert not (set(g_) & set(union)), "a group lives on two ranks"
+                union.update(g_)
+            assert union == want and len(want) > 20
+            assert all(len(g_) > 0 for g_ in gathered), "every rank should own some of the 35 groups"
         dist.barrier()
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:

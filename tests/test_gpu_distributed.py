@@ -90,6 +90,24 @@ def _worker(rank, world, init_file, out_dir):
             assert (pk_all[got[:, 0]] == bk_all[got[:, 1]]).all()
             assert len({(int(a), int(b)) for a, b in got}) == want_rows
             assert cnt == want_rows and sm == int(bv_all[got[:, 1]].astype(np.uint64).sum(dtype=np.uint64))
+        # BASELINE.json configs[4] sharded, real kernels: the join chain + gather on this rank's lineorder rows, dimensions replicated, the
+        # (year, nation) partial states exchanged and merged by their owners; the union of the ranks' groups == the oracle plan over all rows
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import oracle as O
+        import ssb
+        dims = ssb.gen_dims(300_000, 20_000, 20_000)
+        lo_all = ssb.gen_lineorder_numpy(2_400_000, 300_000, 20_000, 20_000)
+        rlo, rhi = rank * 2_400_000 // world, (rank + 1) * 2_400_000 // world
+        mine = ssb.q41_sharded_gpu(ch, D, eng, dims, {k: ctx.upload(v[rlo:rhi]) for k, v in lo_all.items()})
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        if rank == 0:
+            want = ssb.q41_cpu(O, dims, lo_all)
+            union = {}
+            for g_ in gathered:
+                assert not (set(g_) & set(union)), "a group lives on two ranks"
+                union.update(g_)
+            assert union == want and len(want) == 35
         dist.barrier()
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:

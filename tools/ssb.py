@@ -69,9 +69,11 @@ def upload_dims(ctx, dims):
     return {k: ctx.upload(v) for k, v in dims.items()}
 
 
-def q41_gpu(ch, ctx, dims, lo):
+def q41_gpu(ch, ctx, dims, lo, group_by=None):
     """dims: numpy arrays (uploaded inside the timed plan) or device Columns (see upload_dims); lo: dict of device Columns
-    (UInt32).  Returns {(year, nation): profit}."""
+    (UInt32).  Returns {(year, nation): (profit, count)}.  group_by: None = this GPU's own Aggregator; else a callable
+    (packed key Column, [revenue, supplycost]) -> (keys ndarray, [sum(revenue), sum(supplycost), count] ndarrays) -- q41_sharded passes
+    the sharded GROUP BY, whose result is the groups THIS rank owns."""
     up = lambda x: x if isinstance(x, ch.Column) else ctx.upload(x)
     # ---- right sides: filtered dimension tables -> hash tables (FillingRightJoinSideTransform) ----
     c_region, c_custkey, c_nation = up(dims["c_region"]), up(dims["c_custkey"]), up(dims["c_nation"])
@@ -101,7 +103,7 @@ def q41_gpu(ch, ctx, dims, lo):
         rev, cost = r["carry"]
         nation = cn.index(r["right_rowid"][2], default_for_missing=True)   # AddedColumns' lazy gather over the survivors
         year = d_year.index(r["right_rowid"][3], default_for_missing=True)
-        return _q41_group_by(ch, ctx, year, nation, rev, cost)
+        return _q41_group_by(ch, ctx, year, nation, rev, cost, group_by)
     r = j_s.probe_columns(lo["lo_suppkey"], need_right_rows=False)   # semi joins: the dimension contributes no column
     f = r["filter"]
     if os.environ.get("SSB_PLAN_TWO_FILTERS"):                       # the reference's shape: one FilterTransform per join
@@ -120,12 +122,25 @@ def q41_gpu(ch, ctx, dims, lo):
     off = r["offsets"]
     rev, cost, nation = ch.replicate_columns([rev, cost, nation], off)
     year = d_year.index(r["right_rowid"], default_for_missing=True)
-    return _q41_group_by(ch, ctx, year, nation, rev, cost)
+    return _q41_group_by(ch, ctx, year, nation, rev, cost, group_by)
 
 
-def _q41_group_by(ch, ctx, year, nation, rev, cost):
+Q41_AGGS = lambda M: [(M.AGG_SUM, np.uint32), (M.AGG_SUM, np.uint32), (M.AGG_COUNT, None)]
+
+
+def _decode_groups(keys, s_rev, s_cost, cnt):
+    """packFixed<UInt64>: 4 bytes year, 1 byte nation"""
+    keys = np.asarray(keys, dtype=np.uint64)
+    return {(int(k & np.uint64(0xFFFFFFFF)), int((k >> np.uint64(32)) & np.uint64(0xFF))): (int(a) - int(b), int(c))
+            for k, a, b, c in zip(keys, s_rev, s_cost, cnt)}
+
+
+def _q41_group_by(ch, ctx, year, nation, rev, cost, group_by=None):
     # ---- GROUP BY d_year, c_nation (keys64: packFixed) ----
     key = ch.pack_fixed_keys([year, nation])
+    if group_by is not None:
+        keys, (s_rev, s_cost, cnt) = group_by(key, [rev, cost])
+        return _decode_groups(keys, s_rev, s_cost, cnt)
     agg = ch.Aggregator(np.uint64, [(ch.AGG_SUM, np.uint32), (ch.AGG_SUM, np.uint32), (ch.AGG_COUNT, None)], ctx=ctx)
     agg.execute_on_block(key, [rev, cost, None])
     keys_c, (s_rev, s_cost, cnt) = agg.finalize_columns()
@@ -135,10 +150,11 @@ def _q41_group_by(ch, ctx, year, nation, rev, cost):
     return {(int(y), int(n)): (int(a) - int(b), int(c)) for y, n, a, b, c in zip(yy, nn, s_rev, s_cost, cnt)}
 
 
-def q41_cpu(O, dims, lo, block_rows=65409, threads=1):
+def q41_cpu(O, dims, lo, block_rows=65409, threads=1, make_agg=None):
     """Same plan over the oracle, fact table in Blocks of `block_rows` (lo: dict of numpy arrays).  threads > 1: the reference's pipeline
     shape -- the four right-side tables are built once and shared (joinBlock is concurrent on an immutable table, IJoin.h:92-93), every
-    stream pushes its own Blocks through the joins into its own AggregatedDataVariants, the variants are merged at the end."""
+    stream pushes its own Blocks through the joins into its own AggregatedDataVariants, the variants are merged at the end.
+    make_agg (threads == 1): factory of the aggregation sink (execute_on_block / convert_to_block) -- the sharded plan passes a ShardedGroupBy."""
     import threading
     cm = O.cmp_const(dims["c_region"], O.EQ, AMERICA)
     ck, cn = O.filter_column(dims["c_custkey"], cm), O.filter_column(dims["c_nation"], cm)
@@ -154,7 +170,7 @@ def q41_cpu(O, dims, lo, block_rows=65409, threads=1):
     n = lo["lo_custkey"].shape[0]
     n_blocks = (n + block_rows - 1) // block_rows
     threads = max(1, min(threads, n_blocks))
-    aggs = [O.Aggregator(np.uint64, aggs_spec) for _ in range(threads)]
+    aggs = [make_agg() if make_agg is not None else O.Aggregator(np.uint64, aggs_spec) for _ in range(threads)]
 
     def stream(t):
         agg = aggs[t]
@@ -191,5 +207,35 @@ def q41_cpu(O, dims, lo, block_rows=65409, threads=1):
         for a in aggs[1:]:
             aggs[0].merge(a)
     keys, (s_rev, s_cost, cnt) = aggs[0].convert_to_block()
-    return {(int(k & np.uint64(0xFFFFFFFF)), int((k >> np.uint64(32)) & np.uint64(0xFF))): (int(a) - int(b), int(c))
-            for k, a, b, c in zip(keys, s_rev, s_cost, cnt)}
+    return _decode_groups(keys, s_rev, s_cost, cnt)
+
+
+class ShardedSink:
+    """A ShardedGroupBy (clickhouse_amd.distributed) behind the Aggregator calls the plans make: rows in on every rank, the groups this rank
+    OWNS out (partial states routed by key hash in one exchange, owner-side merge)."""
+
+    def __init__(self, sharded_group_by):
+        self.sg = sharded_group_by
+
+    def execute_on_block(self, key, args):
+        self.sg.add_block(key, args)
+
+    def convert_to_block(self):
+        return self.sg.finish()
+
+
+def q41_sharded_gpu(ch, D, engine, dims, lo_share):
+    """BASELINE.json configs[4] across ranks: the lineorder rows are sharded by row range (lo_share = THIS rank's rows), the dimension tables
+    are replicated -- the reference's shared probe map (src/Interpreters/ConcurrentHashJoin.h:25-39) -- every rank runs the Q4.1 plan over its
+    rows, and the partial (year, nation) states meet at their owners through the sharded GROUP BY (one exchange;
+    AggregatingTransform.cpp:120-136 / Aggregator::mergeBucketImpl).  -> {(year, nation): (profit, count)} of the groups this rank owns."""
+    def group_by(key, args):
+        sink = ShardedSink(D.ShardedGroupBy(engine, np.uint64, Q41_AGGS(ch)))
+        sink.execute_on_block(key, args + [None])
+        return sink.convert_to_block()
+    return q41_gpu(ch, engine.ctx, dims, lo_share, group_by=group_by)
+
+
+def q41_sharded_cpu(O, D, engine, dims, lo_share, block_rows=65409):
+    """the same orchestration over the oracle (engine: tests/cpu_engine.CpuEngine over gloo)"""
+    return q41_cpu(O, dims, lo_share, block_rows=block_rows, make_agg=lambda: ShardedSink(D.ShardedGroupBy(engine, np.uint64, Q41_AGGS(O))))
