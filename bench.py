@@ -238,6 +238,16 @@ def main():
                     out["configs"]["C5_one_gpu_share"] = config_c5(args, ctx, ch, torch, np, dev, stream, not args.no_cpu_baseline)
                 except Exception as e:  # noqa: BLE001 -- the wider plan must not cost the headline line
                     out["configs"]["C5_one_gpu_share"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+                ctx.trim()
+                torch.cuda.empty_cache()
+            if not args.only_c5:
+                for name, fn in (("Q11", config_q11), ("C2_from_host_blocks", config_c2_from_host_blocks)):
+                    try:
+                        out["configs"][name] = fn(args, ctx, ch, torch, np, dev, stream, not args.no_cpu_baseline, out.get("cpu_baseline"))
+                    except Exception as e:  # noqa: BLE001
+                        out["configs"][name] = {"error": f"{type(e).__name__}: {e}"[:400]}
+                    ctx.trim()
+                    torch.cuda.empty_cache()
         emit(out)
         return
 
@@ -429,6 +439,93 @@ def sharded_configs(args, ctx, ch, torch, np, dev, stream, rank, world, dist):
         del lo, lo_t, dims_dev
     res["transport"] = f"chgpu_all_to_all_multi / chgpu_all_reduce_u64 over RCCL (C ABI), world {world}"
     comm.close()
+    return res
+
+
+def config_q11(args, ctx, ch, torch, np, dev, stream, with_cpu, _headline_cpu):
+    """The query shape north_star's target names: SSB Q1.1 -- SELECT sum(lo_extendedprice * lo_discount) WHERE lo_orderdate BETWEEN 19930101 AND
+    19931231 AND lo_discount BETWEEN 1 AND 3 AND lo_quantity < 25 -- over the schema's real widths (UInt32 orderdate / extendedprice, UInt8
+    discount / quantity: 10 B/row), HBM-resident.  The whole ExpressionActions DAG (five comparisons, four `and`s, one multiply) + FilterTransform
+    + sum / count run as ONE generated kernel (chgpu_expr_filter_sum_node); the reference materialises every intermediate column."""
+    rows = args.rows
+    g = torch.Generator(device=dev).manual_seed(3)
+    od = torch.randint(0, 70000, (rows,), dtype=torch.int32, device=dev, generator=g) + 19920101
+    disc = torch.randint(0, 11, (rows,), dtype=torch.int32, device=dev, generator=g).to(torch.uint8)
+    qty = torch.randint(1, 51, (rows,), dtype=torch.int32, device=dev, generator=g).to(torch.uint8)
+    price = torch.randint(90_000, 10_000_000, (rows,), dtype=torch.int32, device=dev, generator=g)
+    ts = [od, disc, qty, price]
+    cols = [ctx.wrap(t.data_ptr(), np.uint32 if t.dtype == torch.int32 else np.uint8, rows, keepalive=t) for t in ts]
+    d = ch.ActionsDAG()
+    iod, idisc, iqty, iprice = d.add_input(0, np.uint32), d.add_input(1, np.uint8), d.add_input(2, np.uint8), d.add_input(3, np.uint32)
+    c = d.add_column
+    f = d.add_function("and", d.add_function("greaterOrEquals", iod, c(19930101, np.uint32)), d.add_function("lessOrEquals", iod, c(19931231, np.uint32)))
+    f = d.add_function("and", f, d.add_function("greaterOrEquals", idisc, c(1, np.uint8)))
+    f = d.add_function("and", f, d.add_function("lessOrEquals", idisc, c(3, np.uint8)))
+    f = d.add_function("and", f, d.add_function("less", iqty, c(25, np.uint8)))
+    v = d.add_function("multiply", iprice, idisc)
+    ex = d.compile()
+    ex.filter_sum(ctx, [c_.cut(0, 4096) for c_ in cols], f, v)   # the first use compiles the kernel (hiprtc): outside the timed region
+    dev_ms, wall_ms, (s, cnt) = _timed(lambda: ex.filter_sum(ctx, cols, f, v), torch, stream, reps=10, warmup=2)
+    algo = 10.0 * rows
+    res = {"workload": "SSB Q1.1-style: sum(lo_extendedprice * lo_discount) under 5 predicates on 3 columns, real column widths (UInt32, UInt8, UInt8, UInt32), "
+                       "HBM-resident; the expression DAG + filter + sum as one run-time generated kernel",
+           "rows": rows, "selected_rows": int(cnt), "ms": dev_ms, "wall_ms": wall_ms, "rows_per_s": rows / (dev_ms * 1e-3),
+           "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": algo / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+    if with_cpu:
+        import oracle
+        oracle.build()
+        m = min(rows, 400_000_000)
+        host = [t[:m].cpu().numpy().view(np.uint32 if t.dtype == torch.int32 else np.uint8) for t in ts]
+        preds = [(0, oracle.GE, 19930101), (0, oracle.LE, 19931231), (1, oracle.GE, 1), (1, oracle.LE, 3), (2, oracle.LT, 25)]
+        cores = max(1, len(os.sched_getaffinity(0)))
+        bestN = None
+        for _ in range(5):
+            t0 = time.perf_counter()
+            rN = oracle.expr_filter_sum_pipeline(host, preds, oracle.VAL_MUL, 3, 1, threads=cores)
+            dt = time.perf_counter() - t0
+            bestN = dt if bestN is None else min(bestN, dt)
+        m1 = min(m, 50_000_000)
+        t0 = time.perf_counter()
+        oracle.expr_filter_sum_pipeline([h[:m1] for h in host], preds, oracle.VAL_MUL, 3, 1, threads=1)
+        t1 = time.perf_counter() - t0
+        sg, cg = ex.filter_sum(ctx, [c_.cut(0, m) for c_ in cols], f, v)
+        assert (int(sg), int(cg)) == (int(rN[0]), int(rN[1])), "Q11: GPU differs from the CPU restatement"
+        res["cpu_baseline"] = {"value": m / bestN, "unit": "rows/s", "cores": cores, "kind": "port",
+                               "sample": f"first {m} rows, Blocks of 65409 rows, per Block: five comparisons -> UInt8 masks, four `and`s, the product column, "
+                                         f"IColumn::filter, sum (the reference's one-function-per-action execution), best of 5 on {cores} threads; "
+                                         f"single thread over {m1} rows: {m1 / t1:.4g} rows/s",
+                               "single_thread_value": m1 / t1}
+        res["gpu_over_cpu_all_cores"] = rows / (dev_ms * 1e-3) / (m / bestN)
+        res["parity"] = "sum and count bit-exact on the sample"
+    return res
+
+
+def config_c2_from_host_blocks(args, ctx, ch, torch, np, dev, stream, with_cpu, headline_cpu):
+    """The honest end-to-end of configs[1]: the Int64 rows START IN HOST MEMORY as Blocks of 65 409 rows.  The C++ shim (host/pipeline_demo
+    --bench-host-blocks) runs `streams` pipeline threads, each gluing its Blocks into pinned stripes (StripeBuilder), uploading them asynchronously
+    and running the fused filter + sum per stripe: rows/s INCLUDING the upload -- bounded by the host link, never the `value`."""
+    import subprocess
+    exe = os.path.join(REPO, "clickhouse_amd", "host", "pipeline_demo")
+    rows = min(args.rows, 400_000_000)
+    best = None
+    for streams in (4, 8):
+        p = subprocess.run([exe, "--bench-host-blocks", str(rows), str(streams)], capture_output=True, text=True, timeout=600)
+        if p.returncode != 0:
+            raise RuntimeError(f"pipeline_demo --bench-host-blocks failed: {p.stderr[-300:]}")
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        if best is None or r["rows_per_s_pcie_inclusive"] > best["rows_per_s_pcie_inclusive"]:
+            best = r
+    res = {"workload": "configs[1] fed from HOST Blocks of 65409 Int64 rows: pinned stripes (StripeBuilder), asynchronous uploads overlapped with the fused "
+                       "filter + sum of the previous stripe, several pipeline streams (C++ shim, host/pipeline_demo --bench-host-blocks); PCIe-inclusive",
+           "rows": rows, "streams": best["streams"], "stripe_rows": best["stripe_rows"], "rows_per_s": best["rows_per_s_pcie_inclusive"],
+           "host_link_GBps": best["host_GBps"], "parity": "sum and count equal to the host's own loop over the same rows (checked inside the run)"}
+    if headline_cpu:
+        res["cpu_all_cores_rows_per_s"] = headline_cpu["value"]
+        res["vs_cpu_all_cores"] = best["rows_per_s_pcie_inclusive"] / headline_cpu["value"]
+        res["crossover"] = ("data that starts in host memory moves at the host link's rate: the GPU path wins only against fewer than about "
+                            f"{best['rows_per_s_pcie_inclusive'] / headline_cpu['single_thread_value']:.0f} CPU threads of this box for this one-pass query; "
+                            "the >= 10x target holds for HBM-resident stripes (the headline) and for plans that reuse uploaded columns")
     return res
 
 

@@ -2861,6 +2861,10 @@ extern "C" int chgpu_agg_merge(chgpu_agg * dst, const chgpu_agg * src)
     ChgpuDeviceGuard _dev_guard(dst ? dst->ctx : nullptr);
     CHGPU_REQUIRE(dst && src, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(agg_same_shape(dst, src), CHGPU_ERR_BAD_ARGUMENTS, "cannot merge aggregation states of different shape");
+    // variants of different pipeline streams live on different contexts: the source's kernels run on ITS stream and must have finished
+    // before this context's stream reads its table (the reference merges after every stream has finished consuming)
+    if (src->ctx != dst->ctx)
+        CHGPU_HIP(hipStreamSynchronize(src->ctx->stream));
     if (dst->key_type < 0)
     {
         // mergeWithoutKeyDataImpl (Aggregator.cpp:2584-2628)

@@ -40,6 +40,7 @@
 #include <type_traits>
 #include <unordered_map>
 #include <array>
+#include <atomic>
 #include <exception>
 #include <utility>
 #include <vector>
@@ -117,8 +118,23 @@ public:
         return std::make_shared<ColumnVector>(ctx, c);
     }
 
-    size_t size() const { return chgpu_col_rows(h); }
-    int getDataType() const { return chgpu_col_type(h); }
+    /// ColumnConst (src/Columns/ColumnConst.h): one stored value standing for `rows` equal rows; the data column keeps its single row in HBM
+    static MutableColumnPtr createConst(const ColumnPtr & one_row, size_t rows)
+    {
+        if (one_row->size() != 1)
+            throw Exception(CHGPU_ERR_BAD_ARGUMENTS, "ColumnConst: the data column must have one row");
+        auto c = std::make_shared<ColumnVector>(one_row->ctx, nullptr, one_row);
+        c->const_data = one_row;
+        c->const_rows = rows;
+        return c;
+    }
+    bool isConst() const { return const_data != nullptr; }
+    const ColumnPtr & getDataColumnPtr() const { return const_data; }
+    /// ColumnConst::cut / cloneResized: a constant of another length shares the stored value (FilterTransform.cpp:248-249)
+    ColumnPtr cutConst(size_t length) const { return createConst(const_data, length); }
+
+    size_t size() const { return const_data ? const_rows : chgpu_col_rows(h); }
+    int getDataType() const { return chgpu_col_type(const_data ? const_data->h : h); }
     chgpu_col * handle() const { return h; }
     const ContextPtr & context() const { return ctx; }
 
@@ -176,6 +192,28 @@ private:
     ContextPtr ctx;
     chgpu_col * h;
     std::shared_ptr<const void> keepalive;
+    ColumnPtr const_data;  // set: this is a ColumnConst of const_rows rows
+    size_t const_rows = 0;
+};
+
+/// ConstantFilterDescription (src/Columns/FilterDescription.cpp:20-48): a constant UInt8 filter column keeps every row or none; the one
+/// stored byte is read back once.
+struct ConstantFilterDescription
+{
+    bool always_false = false;
+    bool always_true = false;
+    ConstantFilterDescription() = default;
+    explicit ConstantFilterDescription(const ColumnVector & column)
+    {
+        if (!column.isConst())
+            return;
+        if (column.getDataType() != CHGPU_U8)
+            throw Exception(CHGPU_ERR_BAD_ARGUMENTS, "Illegal type of column for constant filter. Must be UInt8 or Nullable(UInt8).");
+        if (column.getDataColumnPtr()->getData<uint8_t>().at(0))
+            always_true = true;
+        else
+            always_false = true;
+    }
 };
 
 /// Chunk (src/Processors/Chunk.h:55-128): columns + row count, move-only in spirit.
@@ -368,12 +406,77 @@ class GpuFilterTransform : public ISimpleTransform
 public:
     GpuFilterTransform(size_t filter_arg_position_, FunctionComparisonConst predicate_)
         : filter_arg_position(filter_arg_position_), predicate(std::move(predicate_)) {}
+    /// the filter column is already in the chunk (an ExpressionTransform in front computed it, or the planner folded it to a constant)
+    GpuFilterTransform(size_t filter_column_position_, bool remove_filter_column_)
+        : filter_arg_position(filter_column_position_), has_filter_column(true), remove_filter_column(remove_filter_column_) {}
     std::string getName() const override { return "GpuFilterTransform"; }
     uint64_t passed_rows = 0; // ProfileEvents::FilterTransformPassedRows
 
 protected:
+    void removeFilterIfNeed(Columns & columns) const
+    {
+        if (has_filter_column && remove_filter_column)
+            columns.erase(columns.begin() + static_cast<std::ptrdiff_t>(filter_arg_position));
+    }
+    /// FilterTransform::doTransform over a filter column of the chunk (FilterTransform.cpp:153-252)
+    void transformWithFilterColumn(Chunk & chunk)
+    {
+        const ColumnPtr filter_column = chunk.columns.at(filter_arg_position);
+        // :168-176 -- a column that turned out constant: every row or none, no kernel
+        const ConstantFilterDescription constant_filter_description(*filter_column);
+        if (constant_filter_description.always_true)
+        {
+            passed_rows += chunk.num_rows;
+            removeFilterIfNeed(chunk.columns);
+            return;
+        }
+        if (constant_filter_description.always_false)
+        {
+            chunk.clear(); // "Will finish at next prepare call"
+            return;
+        }
+        if (filter_column->getDataType() != CHGPU_U8)
+            throw Exception(CHGPU_ERR_BAD_ARGUMENTS, "Illegal type of column for filter. Must be UInt8 or Nullable(UInt8) or Const variants of them.");
+        uint64_t num_filtered_rows = 0;
+        check(chgpu_count_bytes_in_filter(filter_column->context()->get(), filter_column->handle(), &num_filtered_rows)); // :192-216
+        if (num_filtered_rows == 0)
+        {
+            chunk.clear(); // :221-226
+            return;
+        }
+        if (num_filtered_rows != chunk.num_rows)
+        {
+            // :238-252 -- constant columns are cut, the others filtered (in one call: one count + scan for the whole chunk)
+            Columns to_filter;
+            std::vector<size_t> where;
+            for (size_t i = 0; i < chunk.columns.size(); ++i)
+            {
+                if (i == filter_arg_position && remove_filter_column)
+                    continue;
+                if (chunk.columns[i]->isConst())
+                    chunk.columns[i] = chunk.columns[i]->cutConst(num_filtered_rows);
+                else
+                {
+                    to_filter.push_back(chunk.columns[i]);
+                    where.push_back(i);
+                }
+            }
+            filterColumns(to_filter, *filter_column, static_cast<ssize_t>(num_filtered_rows));
+            for (size_t k = 0; k < where.size(); ++k)
+                chunk.columns[where[k]] = to_filter[k];
+            chunk.num_rows = num_filtered_rows;
+        }
+        passed_rows += num_filtered_rows;
+        removeFilterIfNeed(chunk.columns);
+    }
+
     void transform(Chunk & chunk) override
     {
+        if (has_filter_column)
+        {
+            transformWithFilterColumn(chunk);
+            return;
+        }
         const auto & arg = *chunk.columns.at(filter_arg_position);
         auto mask = predicate.executeImpl(arg); // :146-147
         uint64_t num_filtered_rows = 0;
@@ -395,7 +498,9 @@ protected:
 
 private:
     size_t filter_arg_position;
-    FunctionComparisonConst predicate;
+    FunctionComparisonConst predicate{CHGPU_NE, uint8_t(0)};
+    bool has_filter_column = false;
+    bool remove_filter_column = false;
 };
 
 /// ActionsDAG (src/Interpreters/ActionsDAG.h): INPUT / COLUMN (constant) / FUNCTION nodes under the reference's function
@@ -714,27 +819,97 @@ private:
     chgpu_agg * h = nullptr;
 };
 
-/// AggregatingTransform (AggregatingTransform.cpp:640-840): consume() per chunk, then generate the result once.
+/// ManyAggregatedData (AggregatingTransform.h:74-100): one AggregatedDataVariants per pipeline stream, shared by the streams'
+/// AggregatingTransforms; the stream that finishes LAST merges them (num_finished, AggregatingTransform.cpp:728-744).
+struct ManyAggregatedData
+{
+    std::vector<std::shared_ptr<GpuAggregator>> variants;
+    std::atomic<uint32_t> num_finished{0};
+    explicit ManyAggregatedData(std::vector<std::shared_ptr<GpuAggregator>> variants_) : variants(std::move(variants_)) {}
+};
+using ManyAggregatedDataPtr = std::shared_ptr<ManyAggregatedData>;
+
+/// AggregatingTransform (AggregatingTransform.cpp:523-840): consume() per chunk on its own stream's variant; when the input ends, work()
+/// runs initGenerate: every stream but the last only reports in, the last one folds all variants into the first
+/// (Aggregator::mergeDataImpl: insert-or-merge, chgpu_agg_merge) and becomes the generating transform.
 class GpuAggregatingTransform : public IProcessor
 {
 public:
+    /// one stream, one variant (nothing to merge)
     GpuAggregatingTransform(std::shared_ptr<GpuAggregator> aggregator_, std::optional<size_t> key_position_)
-        : aggregator(std::move(aggregator_)), key_position(key_position_) {}
+        : many_data(std::make_shared<ManyAggregatedData>(std::vector<std::shared_ptr<GpuAggregator>>{std::move(aggregator_)})), current_variant(0),
+          key_position(key_position_) {}
+    /// stream `current_variant_` of `many_data_->variants.size()` streams
+    GpuAggregatingTransform(ManyAggregatedDataPtr many_data_, size_t current_variant_, std::optional<size_t> key_position_)
+        : many_data(std::move(many_data_)), current_variant(current_variant_), key_position(key_position_) {}
     std::string getName() const override { return "GpuAggregatingTransform"; }
     void consume(Chunk chunk)
     {
         if (chunk.num_rows == 0)
             return;
         src_rows += chunk.num_rows;
-        aggregator->executeOnBlock(chunk.columns, 0, chunk.num_rows, key_position); // :664-693
+        many_data->variants.at(current_variant)->executeOnBlock(chunk.columns, 0, chunk.num_rows, key_position); // :664-693
     }
-    void work() override {}
-    Chunk generate() { return aggregator->convertToBlock(); } // initGenerate :695 (single variant: nothing to merge)
+    /// the input port is finished: initGenerate (:695-744)
+    void work() override
+    {
+        if (is_generate_initialized)
+            return;
+        is_generate_initialized = true;
+        if (many_data->num_finished.fetch_add(1) + 1 < many_data->variants.size())
+            return; // not the last stream: its variant stays in many_data for the one that is
+        auto & variants = many_data->variants;
+        for (size_t i = 1; i < variants.size(); ++i) // mergeDataImpl into the first (prepareVariantsToMerge keeps the largest first; sizes need a read-back each)
+            variants[0]->merge(*variants[i]);
+        is_last = true;
+    }
+    /// true on exactly one of the streams' transforms after every stream's work(): the one that generates
+    bool isGenerating() const { return is_last; }
+    Chunk generate()
+    {
+        if (!is_generate_initialized)
+            work();
+        if (!is_last)
+            return Chunk{};
+        return many_data->variants[0]->convertToBlock();
+    }
     uint64_t src_rows = 0;
 
 private:
-    std::shared_ptr<GpuAggregator> aggregator;
+    ManyAggregatedDataPtr many_data;
+    size_t current_variant;
     std::optional<size_t> key_position;
+    bool is_generate_initialized = false;
+    bool is_last = false;
+};
+
+/// FilterTransform + AggregatingTransform without key, fused: `SELECT sum(val), count() WHERE pred <op> constant` in one pass over the
+/// stripe (chgpu_filter_sum: FilterTransform.cpp:136-256 -> Aggregator::executeWithoutKeyImpl, Aggregator.cpp:1276-1321) -- no mask, no
+/// filtered column.  Integer sums (wrap-around, SumSimple's UInt64 / Int64 state).
+class GpuFilterSumTransform : public IProcessor
+{
+public:
+    GpuFilterSumTransform(size_t pred_position_, FunctionComparisonConst predicate_, size_t value_position_)
+        : pred_position(pred_position_), predicate(std::move(predicate_)), value_position(value_position_) {}
+    std::string getName() const override { return "GpuFilterSumTransform"; }
+    void consume(const Chunk & chunk)
+    {
+        if (chunk.num_rows == 0)
+            return;
+        const auto & pred = *chunk.columns.at(pred_position);
+        uint64_t s = 0, c = 0;
+        check(chgpu_filter_sum(pred.context()->get(), pred.handle(), predicate.op, predicate.scalar_type, predicate.scalar, chunk.columns.at(value_position)->handle(), &s, &c));
+        sum += s;
+        count += c;
+        src_rows += chunk.num_rows;
+    }
+    void work() override {}
+    uint64_t sum = 0, count = 0, src_rows = 0;
+
+private:
+    size_t pred_position;
+    FunctionComparisonConst predicate;
+    size_t value_position;
 };
 
 /// IJoin (IJoin.h:80-142) for HashJoin key64.

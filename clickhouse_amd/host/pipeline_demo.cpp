@@ -29,8 +29,103 @@ static constexpr size_t DEFAULT_BLOCK_SIZE = 65409; // src/Core/Defines.h:31-32
         }                                                                    \
     } while (0)
 
+// pipeline_demo --bench-host-blocks <rows> [streams] [stripe_rows]: `SELECT sum(a), count() WHERE a < 214748365` over Int64 rows that START
+// IN HOST MEMORY as Blocks of 65 409 rows -- every pipeline stream (thread, own Context) glues its Blocks into pinned stripes, uploads them
+// asynchronously and runs the fused filter + sum on each stripe.  Prints one JSON line: the PCIe-inclusive rows/s.
+static int bench_host_blocks(size_t n, int streams, size_t stripe_rows)
+{
+    std::vector<int64_t> a(n);
+    uint64_t x = 88172645463325252ull;
+    for (size_t i = 0; i < n; ++i)
+    {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        a[i] = static_cast<int64_t>(x & 0x7FFFFFFF);
+    }
+    const int64_t thr = 214748365;
+    uint64_t want_sum = 0, want_cnt = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (a[i] < thr)
+        {
+            want_sum += static_cast<uint64_t>(a[i]);
+            ++want_cnt;
+        }
+    double best = 0;
+    for (int rep = 0; rep < 3; ++rep)
+    {
+        std::vector<uint64_t> sums(streams, 0), cnts(streams, 0);
+        std::atomic<int> bad{0};
+        std::vector<std::thread> pool;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int t = 0; t < streams; ++t)
+            pool.emplace_back([&, t] {
+                try
+                {
+                    auto ctx = std::make_shared<Context>(0);
+                    StripeBuilder<int64_t> sb(ctx, stripe_rows);
+                    GpuFilterSumTransform fs(0, FunctionComparisonConst(CHGPU_LT, thr), 0);
+                    const size_t n_blocks = (n + DEFAULT_BLOCK_SIZE - 1) / DEFAULT_BLOCK_SIZE;
+                    auto run_stripe = [&] {
+                        Chunk c;
+                        c.num_rows = sb.rows();
+                        c.columns = {sb.flush()};
+                        fs.consume(c);
+                    };
+                    for (size_t bi = n_blocks * t / streams; bi < n_blocks * (t + 1) / streams; ++bi)
+                    {
+                        const size_t b = bi * DEFAULT_BLOCK_SIZE, rows = std::min(DEFAULT_BLOCK_SIZE, n - b);
+                        size_t done = 0;
+                        while (done < rows)
+                        {
+                            done += sb.appendBlock(a.data() + b + done, rows - done);
+                            if (sb.room() == 0)
+                                run_stripe();
+                        }
+                    }
+                    if (sb.rows())
+                        run_stripe();
+                    sums[t] = fs.sum;
+                    cnts[t] = fs.count;
+                }
+                catch (...)
+                {
+                    ++bad;
+                }
+            });
+        for (auto & th : pool)
+            th.join();
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        uint64_t s = 0, c = 0;
+        for (int t = 0; t < streams; ++t)
+        {
+            s += sums[t];
+            c += cnts[t];
+        }
+        if (bad || s != want_sum || c != want_cnt)
+        {
+            std::fprintf(stderr, "bench-host-blocks: wrong result\n");
+            return 1;
+        }
+        best = std::max(best, double(n) / secs);
+    }
+    std::printf("{\"rows\": %zu, \"streams\": %d, \"stripe_rows\": %zu, \"block_rows\": %zu, \"rows_per_s_pcie_inclusive\": %.6g, \"host_GBps\": %.4g}\n", n, streams,
+                stripe_rows, size_t(DEFAULT_BLOCK_SIZE), best, best * 8 / 1e9);
+    return 0;
+}
+
 int main(int argc, char ** argv)
 {
+    if (argc > 2 && std::string(argv[1]) == "--bench-host-blocks")
+    {
+        try
+        {
+            return bench_host_blocks(std::strtoull(argv[2], nullptr, 10), argc > 3 ? std::atoi(argv[3]) : 4, argc > 4 ? std::strtoull(argv[4], nullptr, 10) : (size_t(8) << 20));
+        }
+        catch (const Exception & e)
+        {
+            std::fprintf(stderr, "chgpu::Exception %d: %s\n", e.code(), e.what());
+            return 1;
+        }
+    }
     const size_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 2000003;
     try
     {
@@ -312,6 +407,107 @@ int main(int argc, char ** argv)
             for (auto & th : pool)
                 th.join();
             REQUIRE(bad == 0);
+        }
+
+        // ---- many streams -> one result: every pipeline stream aggregates into its own variant on its own Context; the stream that
+        //      finishes last merges them (ManyAggregatedData, AggregatingTransform.cpp:728-744 -> Aggregator::mergeDataImpl) ----
+        {
+            constexpr int STREAMS = 4;
+            std::vector<ContextPtr> tctx;
+            std::vector<std::shared_ptr<GpuAggregator>> variants;
+            for (int t = 0; t < STREAMS; ++t)
+            {
+                tctx.push_back(std::make_shared<Context>(0));
+                variants.push_back(std::make_shared<GpuAggregator>(tctx.back(), CHGPU_U32, std::vector<AggregateDescription>{{CHGPU_AGG_SUM, CHGPU_I64, 0}, {CHGPU_AGG_COUNT, CHGPU_U64, 0}}));
+            }
+            auto many = std::make_shared<ManyAggregatedData>(variants);
+            std::vector<std::unique_ptr<GpuAggregatingTransform>> transforms;
+            for (int t = 0; t < STREAMS; ++t)
+                transforms.push_back(std::make_unique<GpuAggregatingTransform>(many, t, 1));
+            std::atomic<int> bad{0};
+            std::vector<std::thread> pool;
+            for (int t = 0; t < STREAMS; ++t)
+                pool.emplace_back([&, t] {
+                    try
+                    {
+                        const size_t lo = n * t / STREAMS, hi = n * (t + 1) / STREAMS;
+                        for (size_t b = lo; b < hi; b += 300000) // the stream's input arrives chunk by chunk
+                        {
+                            const size_t rows = std::min<size_t>(300000, hi - b);
+                            Chunk part;
+                            part.columns = {ColumnVector::fromHost<int64_t>(tctx[t], a.data() + b, rows), ColumnVector::fromHost<uint32_t>(tctx[t], k.data() + b, rows)};
+                            part.num_rows = rows;
+                            transforms[t]->consume(std::move(part));
+                        }
+                        transforms[t]->work(); // input finished: the last stream to arrive here merges
+                    }
+                    catch (...)
+                    {
+                        ++bad;
+                    }
+                });
+            for (auto & th : pool)
+                th.join();
+            REQUIRE(bad == 0);
+            int generating = 0;
+            for (auto & tr : transforms)
+                if (tr->isGenerating())
+                {
+                    ++generating;
+                    Chunk r = tr->generate();
+                    REQUIRE(r.num_rows == want.size());
+                    auto gk = r.columns[0]->getData<uint32_t>();
+                    auto gs = r.columns[1]->getData<int64_t>();
+                    auto gc = r.columns[2]->getData<uint64_t>();
+                    for (size_t g = 0; g < gk.size(); ++g)
+                    {
+                        const auto & w = want.at(gk[g]);
+                        REQUIRE(static_cast<uint64_t>(gs[g]) == w.first && gc[g] == w.second);
+                    }
+                }
+            REQUIRE(generating == 1);
+        }
+
+        // ---- constant filter columns: ConstantFilterDescription (FilterDescription.cpp:20-48, FilterTransform.cpp:153-176, :248-249) ----
+        {
+            const uint8_t one = 1, zero = 0;
+            auto c1 = ColumnVector::createConst(ColumnVector::fromHost<uint8_t>(ctx, &one, 1), n);
+            auto c0 = ColumnVector::createConst(ColumnVector::fromHost<uint8_t>(ctx, &zero, 1), n);
+            REQUIRE(ConstantFilterDescription(*c1).always_true && !ConstantFilterDescription(*c1).always_false);
+            REQUIRE(ConstantFilterDescription(*c0).always_false && !ConstantFilterDescription(*stripe.columns[0]).always_true);
+            Chunk in;
+            in.columns = {stripe.columns[0], c1};
+            in.num_rows = n;
+            GpuFilterTransform keep_all(1, true); // WHERE 1: columns untouched, the filter column removed
+            keep_all.setInput(in);
+            keep_all.work();
+            REQUIRE(keep_all.hasOutput());
+            Chunk out_all = keep_all.pullOutput();
+            REQUIRE(out_all.num_rows == n && out_all.columns.size() == 1 && out_all.columns[0].get() == stripe.columns[0].get());
+            in.columns = {stripe.columns[0], c0};
+            GpuFilterTransform keep_none(1, true); // WHERE 0: the chunk is dropped
+            keep_none.setInput(in);
+            keep_none.work();
+            REQUIRE(!keep_none.hasOutput());
+            // an ordinary filter column next to a constant column: the constant is cut, not filtered
+            if (want_cnt != 0 && want_cnt != n) // (a chunk in which every or no row passes never reaches IColumn::filter)
+            {
+            auto mask = FunctionComparisonConst(CHGPU_LT, thr).executeImpl(*stripe.columns[0]);
+            const int64_t seven = 7;
+            in.columns = {stripe.columns[0], mask, ColumnVector::createConst(ColumnVector::fromHost<int64_t>(ctx, &seven, 1), n)};
+            GpuFilterTransform some(1, false);
+            some.setInput(in);
+            some.work();
+            REQUIRE(some.hasOutput());
+            Chunk out_some = some.pullOutput();
+            REQUIRE(out_some.num_rows == want_cnt && out_some.columns.size() == 3);
+            REQUIRE(out_some.columns[0]->size() == want_cnt && out_some.columns[1]->size() == want_cnt);
+            REQUIRE(out_some.columns[2]->isConst() && out_some.columns[2]->size() == want_cnt && out_some.columns[2]->getDataColumnPtr()->getData<int64_t>()[0] == 7);
+            uint64_t s2 = 0;
+            for (auto v : out_some.columns[0]->getData<int64_t>())
+                s2 += static_cast<uint64_t>(v);
+            REQUIRE(s2 == want_sum);
+            }
         }
 
         // ---- FULL JOIN: the LEFT probe + used flags, then getNonJoinedBlocks ------------------------------------------------

@@ -141,13 +141,10 @@ def _q41_group_by(ch, ctx, year, nation, rev, cost, group_by=None):
     if group_by is not None:
         keys, (s_rev, s_cost, cnt) = group_by(key, [rev, cost])
         return _decode_groups(keys, s_rev, s_cost, cnt)
-    agg = ch.Aggregator(np.uint64, [(ch.AGG_SUM, np.uint32), (ch.AGG_SUM, np.uint32), (ch.AGG_COUNT, None)], ctx=ctx)
+    agg = ch.Aggregator(np.uint64, Q41_AGGS(ch), ctx=ctx)
     agg.execute_on_block(key, [rev, cost, None])
-    keys_c, (s_rev, s_cost, cnt) = agg.finalize_columns()
-    yy = ch.unpack_fixed_key(keys_c, 0, np.uint32).numpy()
-    nn = ch.unpack_fixed_key(keys_c, 4, np.uint8).numpy()
-    s_rev, s_cost, cnt = s_rev.numpy(), s_cost.numpy(), cnt.numpy()
-    return {(int(y), int(n)): (int(a) - int(b), int(c)) for y, n, a, b, c in zip(yy, nn, s_rev, s_cost, cnt)}
+    keys, (s_rev, s_cost, cnt) = agg.convert_to_block()   # 35 rows: the packed keys are taken apart on the host
+    return _decode_groups(keys, s_rev, s_cost, cnt)
 
 
 def q41_cpu(O, dims, lo, block_rows=65409, threads=1, make_agg=None):
