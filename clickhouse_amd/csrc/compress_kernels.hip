@@ -56,6 +56,8 @@ __global__ __launch_bounds__(256) void k_lz4_decode(const u8 * __restrict__ src,
         const u8 * in = src + uni64(job.src_off);
         u8 * out = (uni(job.post) ? dst_stage : dst_out) + uni64(job.dst_off);
         const u32 isz = uni(job.src_size), osz = uni(job.dst_size);
+        if (uni(job.method) == 0x93u || uni(job.method) == 0x94u)
+            continue; // T64 / DoubleDelta frames: k_t64_decode / k_double_delta_decode
         if (uni(job.method) == 0x02u)
         {
             if (isz != osz)
@@ -394,6 +396,256 @@ __global__ __launch_bounds__(256) void k_delta_decode(const u8 * __restrict__ st
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// CODEC(T64) (src/Compression/CompressionCodecT64.cpp:538-677): payload = [cookie: type magic | variant << 7][min 8 B][max 8 B] and, per 64
+// values, num_bits UInt64 of a transposed matrix -- num_bits = the bits in which min and max differ; the 'byte' variant stores whole bytes
+// of the values as 64-byte planes and bit-transposes only the last partial byte, the 'bit' variant bit-transposes everything.  A block of
+// 64 values is exactly one wavefront: lane = value; a byte plane is one coalesced 64-byte load, a bit row is one 8-byte word the whole
+// wave reads (its bit `lane` belongs to this lane).  Upper bits come from min (or max, for the non-negative values of a signed range that
+// crosses zero: restoreUpperBits).  One workgroup per frame, its four waves take the frame's blocks in turn.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 t64_bits_u(u64 mn, u64 mx) { const u64 x = mn ^ mx; return x ? 64u - (u32)__builtin_clzll(x) : 0u; }
+__device__ __forceinline__ u32 t64_bits_s(i64 mn, i64 mx)
+{
+    if (mn < 0 && mx >= 0)
+        return (mn + mx >= 0) ? t64_bits_u(0, (u64)mx) + 1 : t64_bits_u(0, (u64)~mn) + 1;
+    return t64_bits_u((u64)mn, (u64)mx);
+}
+
+__global__ __launch_bounds__(256) void k_t64_decode(const u8 * __restrict__ src, u8 * __restrict__ dst_out, const FrameJob * __restrict__ jobs, u32 n_jobs, u32 * __restrict__ err)
+{
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u32 j = blockIdx.x; j < n_jobs; j += gridDim.x)
+    {
+        const FrameJob job = jobs[j];
+        if (uni(job.method) != 0x93u)
+            continue;
+        const u8 * in = src + uni64(job.src_off);
+        u8 * out = dst_out + uni64(job.dst_off);
+        const u32 isz = uni(job.src_size), osz = uni(job.dst_size);
+        bool bad = isz < 17;
+        u32 width = 0, sgn = 0, full = 0, num_bits = 0;
+        u64 mn = 0, mx = 0;
+        if (!bad)
+        {
+            const u32 cookie = in[0], magic = cookie & 0x7Fu;
+            full = cookie >> 7;
+            switch (magic) // MagicNumber -> base type (CompressionCodecT64.cpp:75-160)
+            {
+                case 1: width = 1; break;
+                case 17: case 6: width = 1; sgn = 1; break;
+                case 2: case 13: width = 2; break;
+                case 7: case 18: width = 2; sgn = 1; break;
+                case 3: case 14: case 21: width = 4; break;
+                case 8: case 19: case 22: width = 4; sgn = 1; break;
+                case 4: width = 8; break;
+                case 9: case 15: case 20: width = 8; sgn = 1; break;
+                default: bad = true; break;
+            }
+            __builtin_memcpy(&mn, in + 1, 8);
+            __builtin_memcpy(&mx, in + 9, 8);
+        }
+        u64 n = 0, num_full = 0;
+        u32 tail = 0;
+        if (!bad)
+        {
+            bad = osz % width != 0;
+            n = osz / width;
+            num_bits = sgn ? t64_bits_s((i64)mn, (i64)mx) : t64_bits_u(mn, mx);
+            if (!bad && num_bits)
+            {
+                const u32 body = isz - 17, shift = 8 * num_bits;
+                bad = body == 0 || body % shift != 0;
+                num_full = body / shift;
+                tail = (u32)(n % 64);
+                if (tail && num_full)
+                    --num_full;
+                bad = bad || num_full * 64 + tail != n;
+            }
+        }
+        if (__builtin_amdgcn_readfirstlane((int)bad))
+        {
+            if (threadIdx.x == 0)
+                atomicOr(err, 8u);
+            continue;
+        }
+        const u64 M = width == 8 ? ~0ull : ((1ull << (8 * width)) - 1);
+        if (!num_bits)
+        {
+            for (u64 i = threadIdx.x; i < n; i += 256)
+                __builtin_memcpy(out + i * width, &mn, width); // every value equals min
+            continue;
+        }
+        u64 upper_min = 0, upper_max = 0, sign_bit = 0;
+        if (num_bits < 64)
+            upper_min = (mn >> num_bits << num_bits) & M;
+        if (sgn && (i64)mn < 0 && (i64)mx >= 0 && num_bits < 64)
+        {
+            sign_bit = (1ull << (num_bits - 1)) & M;
+            upper_max = (mx >> num_bits << num_bits) & M;
+        }
+        const u32 full_bytes = num_bits / 8, part_bits = num_bits % 8;
+        const u64 blocks = num_full + (tail ? 1 : 0);
+        const u8 * body = in + 17;
+        for (u64 b = wave; b < blocks; b += 4)
+        {
+            const u8 * blk = body + b * 8 * (u64)num_bits;
+            const u32 cnt = b == num_full ? tail : 64u;
+            u64 v = 0;
+            u32 first_row = 0;
+            if (!full)
+            {
+                for (u32 k = 0; k < full_bytes; ++k)
+                    v |= (u64)blk[64 * k + lane] << (8 * k);
+                first_row = 8 * full_bytes;
+            }
+            const u32 n_rows = full ? num_bits : part_bits;
+            for (u32 r = 0; r < n_rows; ++r)
+            {
+                u64 row;
+                __builtin_memcpy(&row, blk + 8 * (u64)(first_row + r), 8); // the same address in every lane: one broadcast load
+                v |= ((row >> lane) & 1ull) << (first_row + r);
+            }
+            if (sign_bit)
+                v |= (v & sign_bit) ? upper_min : upper_max;
+            else
+                v |= upper_min;
+            if (lane < cnt)
+                __builtin_memcpy(out + (b * 64 + lane) * width, &v, width);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CODEC(DoubleDelta) (src/Compression/CompressionCodecDoubleDelta.cpp:367-447): [width][bytes_to_skip][skipped][items u32][first value]
+// [first delta] and a bit stream of prefix-coded double deltas (0 | 10 s x6 | 110 s x8 | 1110 s x11 | 11110 s x31 | 11111 s x63, big-endian
+// bit order, BitHelpers.h).  A value's position in the stream depends on every code before it and its value on the two values before it:
+// the frame is decoded front to back, here by ONE LANE PER FRAME -- the parallelism is across frames (a column file of N rows has
+// N / 8192 ... N / 131072 of them).  Functional first: the rate is reported in profiles/, not tuned.
+// ---------------------------------------------------------------------------------------------
+struct DdReader
+{
+    const u8 * cur;
+    const u8 * end;
+    u64 buf;
+    u32 bits;
+    __device__ __forceinline__ void fill()
+    {
+        while (bits <= 56 && cur < end)
+        {
+            buf |= (u64)*cur++ << (56 - bits);
+            bits += 8;
+        }
+    }
+    __device__ __forceinline__ u64 read32(u32 n) // n <= 32
+    {
+        if (n == 0)
+            return 0;
+        if (bits < n)
+            fill();
+        const u64 v = buf >> (64 - n);
+        buf <<= n;
+        bits = bits >= n ? bits - n : 0;
+        return v;
+    }
+    __device__ __forceinline__ u64 read(u32 n) { return n > 32 ? (read32(n - 32) << 32) | read32(32) : read32(n); }
+    __device__ __forceinline__ bool eof()
+    {
+        return bits == 0 && cur >= end;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_double_delta_decode(const u8 * __restrict__ src, u8 * __restrict__ dst_out, const FrameJob * __restrict__ jobs, u32 n_jobs, u32 * __restrict__ err)
+{
+    const u32 j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= n_jobs)
+        return;
+    const FrameJob job = jobs[j];
+    if (job.method != 0x94u)
+        return;
+    const u8 * in = src + job.src_off;
+    u8 * out = dst_out + job.dst_off;
+    const u32 isz = job.src_size, osz = job.dst_size;
+    if (isz < 2)
+    {
+        atomicOr(err, 16u);
+        return;
+    }
+    const u32 width = in[0], skip = in[1];
+    if (!(width == 1 || width == 2 || width == 4 || width == 8) || skip >= width || skip > osz || 2 + skip > isz)
+    {
+        atomicOr(err, 16u);
+        return;
+    }
+    for (u32 k = 0; k < skip; ++k)
+        out[k] = in[2 + k];
+    const u8 * s = in + 2 + skip, * s_end = in + isz;
+    u8 * d = out + skip, * d_end = out + osz;
+    if (s + 4 > s_end)
+        return;
+    u32 items;
+    __builtin_memcpy(&items, s, 4);
+    s += 4;
+    const u64 M = width == 8 ? ~0ull : ((1ull << (8 * width)) - 1);
+    if (s + width > s_end || items < 1)
+        return;
+    u64 prev_value = 0, prev_delta = 0;
+    __builtin_memcpy(&prev_value, s, width);
+    if (d + width > d_end)
+    {
+        atomicOr(err, 16u);
+        return;
+    }
+    __builtin_memcpy(d, &prev_value, width);
+    s += width;
+    d += width;
+    if (s + width > s_end || items < 2)
+        return;
+    __builtin_memcpy(&prev_delta, s, width);
+    prev_value = (prev_value + prev_delta) & M;
+    if (d + width > d_end)
+    {
+        atomicOr(err, 16u);
+        return;
+    }
+    __builtin_memcpy(d, &prev_value, width);
+    s += width;
+    d += width;
+    DdReader r{s, s_end, 0, 0};
+    for (u32 read = 2; read < items && !r.eof(); ++read)
+    {
+        if (r.bits < 8)
+            r.fill();
+        const u32 top = (u32)(r.buf >> 59); // the five bits peekByte() >> 3 looks at (WRITE_SPEC_LUT)
+        u32 pbits, dbits;
+        if (top < 16) { pbits = 1; dbits = 0; }
+        else if (top < 24) { pbits = 2; dbits = 7; }
+        else if (top < 28) { pbits = 3; dbits = 9; }
+        else if (top < 30) { pbits = 4; dbits = 12; }
+        else if (top == 30) { pbits = 5; dbits = 32; }
+        else { pbits = 5; dbits = 64; }
+        (void)r.read32(pbits);
+        u64 dd = 0;
+        if (dbits)
+        {
+            const u64 sign = r.read32(1);
+            dd = (r.read(dbits - 1) + 1) & M;
+            if (sign)
+                dd = (0 - dd) & M;
+        }
+        const u64 delta = (dd + prev_delta) & M, cur = (prev_value + delta) & M;
+        if (d + width > d_end)
+        {
+            atomicOr(err, 16u);
+            return;
+        }
+        __builtin_memcpy(d, &cur, width);
+        d += width;
+        prev_delta = (cur - prev_value) & M;
+        prev_value = cur;
+    }
+}
+
 /* Decompress n_frames frames of `compressed_u8` into one new UInt8 column of sum(decompressed_sizes) bytes.  Host arrays describe the
    frames: payload offset / size inside compressed_u8 and method byte of the (last applied) general-purpose stage, its output size
    (stage_sizes; NULL = decompressed_sizes) and, for CODEC(Delta, LZ4), post_methods[f] = 0x92 (NULL / 0 = single stage).
@@ -408,12 +660,17 @@ extern "C" int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compre
     CHGPU_REQUIRE(n_frames == 0 || (payload_offsets && payload_sizes && decompressed_sizes && methods), CHGPU_ERR_BAD_ARGUMENTS, "NULL frame arrays");
     std::vector<FrameJob> jobs(n_frames);
     u64 total = 0, stage_total = 0;
+    u32 n_t64 = 0, n_dd = 0;
     for (u32 f = 0; f < n_frames; ++f)
     {
-        CHGPU_REQUIRE(methods[f] == 0x82 || methods[f] == 0x02, CHGPU_ERR_NOT_IMPLEMENTED, "compression method 0x%02x: CPU path", methods[f]);
+        CHGPU_REQUIRE(methods[f] == 0x82 || methods[f] == 0x02 || methods[f] == 0x93 || methods[f] == 0x94, CHGPU_ERR_NOT_IMPLEMENTED,
+                      "compression method 0x%02x: CPU path", methods[f]);
+        n_t64 += methods[f] == 0x93;
+        n_dd += methods[f] == 0x94;
         CHGPU_REQUIRE(payload_offsets[f] + payload_sizes[f] <= compressed_u8->rows, CHGPU_ERR_BAD_ARGUMENTS, "frame %u lies outside the compressed buffer", f);
         const u32 post = post_methods ? post_methods[f] : 0;
         CHGPU_REQUIRE(post == 0 || post == 0x92, CHGPU_ERR_NOT_IMPLEMENTED, "codec 0x%02x in front of the general-purpose stage: CPU path", post);
+        CHGPU_REQUIRE(post == 0 || methods[f] == 0x82, CHGPU_ERR_NOT_IMPLEMENTED, "a Delta stage behind method 0x%02x: CPU path", methods[f]);
         CHGPU_REQUIRE(post == 0 || stage_sizes, CHGPU_ERR_BAD_ARGUMENTS, "stage_sizes is NULL");
         FrameJob jb{};
         jb.src_off = payload_offsets[f];
@@ -464,6 +721,18 @@ extern "C" int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compre
             hipLaunchKernelGGL(k_lz4_decode, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)compressed_u8->data, (u8 *)res->data, (u8 *)stage, (const FrameJob *)jd,
                                n_frames, err);
             ctx->counters[6] += 1;
+            if (n_t64)
+            {
+                hipLaunchKernelGGL(k_t64_decode, dim3(n_frames < 4096 ? n_frames : 4096), dim3(256), 0, ctx->stream, (const u8 *)compressed_u8->data, (u8 *)res->data, (const FrameJob *)jd,
+                                   n_frames, err);
+                ctx->counters[6] += 1;
+            }
+            if (n_dd)
+            {
+                hipLaunchKernelGGL(k_double_delta_decode, dim3((n_frames + 63) / 64), dim3(64), 0, ctx->stream, (const u8 *)compressed_u8->data, (u8 *)res->data, (const FrameJob *)jd,
+                                   n_frames, err);
+                ctx->counters[6] += 1;
+            }
             if (stage_total)
             {
                 hipLaunchKernelGGL(k_delta_decode, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)stage, (u8 *)res->data, (const FrameJob *)jd, n_frames, err);

@@ -21,6 +21,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 METHOD_NONE, METHOD_LZ4, METHOD_DELTA, METHOD_MULTIPLE = 0x02, 0x82, 0x92, 0x91
+METHOD_T64, METHOD_DOUBLE_DELTA = 0x93, 0x94  # CompressionInfo.h:40-51
 DELTA_LZ4 = "delta+lz4"  # CODEC(Delta(w), LZ4)
 HEADER = 9
 CHECKSUM = 16
@@ -34,10 +35,14 @@ def lib():
         if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "ch_compress.c")):
             subprocess.check_call(["make", "-C", _HERE, "libchcompress.so"])
         L = C.CDLL(so)
-        for name in ("cho_lz4_decompress", "cho_delta_decode"):
+        for name in ("cho_lz4_decompress", "cho_delta_decode", "cho_double_delta_decode", "cho_t64_decode"):
             fn = getattr(L, name)
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.cho_double_delta_encode.restype = C.c_long
+        L.cho_double_delta_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_size_t]
+        L.cho_t64_encode.restype = C.c_long
+        L.cho_t64_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_int, C.c_uint, C.c_int, C.c_void_p, C.c_size_t]
         L.cho_city_hash128.restype = None
         L.cho_city_hash128.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
         _lib = L
@@ -56,6 +61,50 @@ def delta_decode(payload: bytes, dst_size: int) -> bytes:
     src = np.frombuffer(payload, dtype=np.uint8)
     dst = np.zeros(dst_size, dtype=np.uint8)
     if lib().cho_delta_decode(src.ctypes.data, src.shape[0], dst.ctypes.data, dst_size) != 0:
+        raise ValueError("CANNOT_DECOMPRESS")
+    return dst.tobytes()
+
+
+def double_delta_decode(payload: bytes, dst_size: int) -> bytes:
+    """CompressionCodecDoubleDelta::doDecompressData over the codec payload ([width][bytes_to_skip] ...)"""
+    src = np.frombuffer(payload, dtype=np.uint8)
+    dst = np.zeros(dst_size, dtype=np.uint8)
+    if lib().cho_double_delta_decode(src.ctypes.data, src.shape[0], dst.ctypes.data, dst_size) != 0:
+        raise ValueError("CANNOT_DECOMPRESS")
+    return dst.tobytes()
+
+
+def double_delta_encode(raw: bytes, width: int) -> bytes:
+    """CompressionCodecDoubleDelta::doCompressData -> the codec payload"""
+    src = np.frombuffer(raw, dtype=np.uint8)
+    cap = 2 + width + 4 + 2 * width + (len(raw) // width) * 9 + 64
+    dst = np.zeros(cap, dtype=np.uint8)
+    n = lib().cho_double_delta_encode(src.ctypes.data, src.shape[0], width, dst.ctypes.data, cap)
+    if n < 0:
+        raise ValueError("CANNOT_COMPRESS")
+    return dst[:n].tobytes()
+
+
+T64_MAGIC = {"uint8": 1, "uint16": 2, "uint32": 3, "uint64": 4, "int8": 6, "int16": 7, "int32": 8, "int64": 9}  # CompressionCodecT64.cpp:75-94
+
+
+def t64_encode(values: np.ndarray, variant_bit: bool = False) -> bytes:
+    """CompressionCodecT64::doCompressData of a numeric array -> the codec payload ([cookie][min][max][transposed blocks])"""
+    values = np.ascontiguousarray(values)
+    raw = values.view(np.uint8).reshape(-1)
+    cap = 17 + (values.shape[0] + 64) * 8 + 1024
+    dst = np.zeros(cap, dtype=np.uint8)
+    n = lib().cho_t64_encode(raw.ctypes.data, raw.shape[0], values.dtype.itemsize, int(values.dtype.kind == "i"), T64_MAGIC[values.dtype.name],
+                             int(variant_bit), dst.ctypes.data, cap)
+    if n < 0:
+        raise ValueError("CANNOT_COMPRESS")
+    return dst[:n].tobytes()
+
+
+def t64_decode(payload: bytes, dst_size: int) -> bytes:
+    src = np.frombuffer(payload, dtype=np.uint8)
+    dst = np.zeros(dst_size, dtype=np.uint8)
+    if lib().cho_t64_decode(src.ctypes.data, src.shape[0], dst.ctypes.data, dst_size) != 0:
         raise ValueError("CANNOT_DECOMPRESS")
     return dst.tobytes()
 
@@ -84,6 +133,18 @@ def delta_encode(raw: bytes, width: int) -> bytes:
     x = np.frombuffer(raw[skip:], dtype={1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[width])
     d = np.diff(np.concatenate((np.zeros(1, dtype=x.dtype), x))) if x.size else x
     return bytes([width, skip]) + raw[:skip] + d.astype(x.dtype).tobytes()
+
+
+def write_codec_frames(values: np.ndarray, method: int, block_rows: int = 8192, t64_bit: bool = False) -> bytes:
+    """a column file whose frames are single applications of DoubleDelta / T64 (CODEC(DoubleDelta), CODEC(T64)): one frame per block_rows values"""
+    values = np.ascontiguousarray(values)
+    out = bytearray()
+    for lo in range(0, values.shape[0], block_rows):
+        chunk = values[lo:lo + block_rows]
+        raw = chunk.tobytes()
+        payload = double_delta_encode(raw, values.dtype.itemsize) if method == METHOD_DOUBLE_DELTA else t64_encode(chunk, t64_bit)
+        out += _framed(_stage(method, payload, len(raw)))
+    return bytes(out)
 
 
 def write_frames(raw: bytes, block_size: int = 65536, method=METHOD_LZ4, delta_width: int = 8) -> bytes:
@@ -131,6 +192,10 @@ def read_frames(buf: bytes) -> bytes:
             out += payload
         elif method == METHOD_DELTA:
             out += delta_decode(payload, dsize)
+        elif method == METHOD_DOUBLE_DELTA:
+            out += double_delta_decode(payload, dsize)
+        elif method == METHOD_T64:
+            out += t64_decode(payload, dsize)
         elif method == METHOD_MULTIPLE:
             out += _multiple_decode(payload, dsize)
         else:

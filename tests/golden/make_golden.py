@@ -85,6 +85,7 @@ def main():
         json.dump(dict(source="src/Common/HashTable/Hash.h compiled in place (oracle/ref_hash_wrapper.cpp)", kat=kat), f, indent=1)
     print("wrote", os.path.join(HERE, "sql_reference_rows.json"), "and hash_kat.json")
     make_cmp_kat(ref_root)
+    make_codec_kat(ref_root)
     make_mod_kat(ref_root)
     make_sort_kat(ref_root)
     make_string_kat(ref_root)
@@ -203,6 +204,33 @@ def make_cmp_kat(ref_root):
         json.dump(dict(source="tests/queries/0_stateless/00411_long_accurate_number_comparison_float.{sql,reference}",
                        order="i=f i!=f i<f i<=f i>f i>=f f=i f!=i f<i f<=i f>i f>=i", cases=cases), f)
     print("wrote expr_cmp_kat.json:", len(cases), "cases")
+
+
+def make_codec_kat(ref_root):
+    """DoubleDelta's compatibility vectors: the (sequence, frame bytes) pairs of src/Compression/tests/gtest_compressionCodec.cpp:1171-1209
+    (the sequences are restated by tests/test_compression.py::dd_compat_sequence; only the expected BYTES are taken from the file) and the
+    two worked examples of the codec's own documentation comment (CompressionCodecDoubleDelta.cpp:73-118)."""
+    import re
+    path = os.path.join(ref_root, "src/Compression/tests/gtest_compressionCodec.cpp")
+    text = open(path).read()
+    a = text.index("INSTANTIATE_TEST_SUITE_P(DoubleDelta,")
+    b = text.index("template <typename ValueType>", a)
+    block = text[a:b]
+    vectors = []
+    for m in re.finditer(r'DDCompatibilityTestSequence<(\w+)>\(\),\s*BIN_STR\("((?:[^"\\]|\\.)*)"\)', block):
+        raw = m.group(2)
+        data = bytes(int(h, 16) for h in re.findall(r"\\x([0-9a-fA-F]{2})", raw))
+        assert len(re.findall(r"\\x[0-9a-fA-F]{2}", raw)) * 4 == len(raw), "only \\xNN escapes expected"
+        vectors.append(dict(type=m.group(1), frame_hex=data.hex()))
+    assert [v["type"] for v in vectors] == ["Int8", "UInt8", "Int16", "UInt16", "Int32", "UInt32", "Int64", "UInt64"]
+    doc = [dict(type="UInt8", values=list(range(1, 11)), payload_hex="0a0000000101" + "00"),
+           dict(type="Int16", values=[-10, 10, -20, 20, -40, 40], payload_hex="06000000f6ff1400b8e22eb1e458")]
+    with open(os.path.join(HERE, "codec_kat.json"), "w") as f:
+        json.dump(dict(source="src/Compression/tests/gtest_compressionCodec.cpp:1171-1209 (frames: method byte 0x94, compressed size, "
+                              "decompressed size, codec payload) and the worked examples in CompressionCodecDoubleDelta.cpp:73-118 "
+                              "(payload after [width][bytes_to_skip])",
+                       double_delta_frames=vectors, double_delta_doc_examples=doc), f, indent=1)
+    print("wrote codec_kat.json:", len(vectors), "frames")
 
 
 if __name__ == "__main__":

@@ -293,3 +293,148 @@ def test_gpu_decodes_synthetic_sequences():
         assert len(frames) == n_frames
         out = CC.decompress_frames(ctx, ctx.upload(np.frombuffer(buf, dtype=np.uint8)), frames).numpy().tobytes()
         assert out == raw, n_frames
+
+
+# ---- DoubleDelta / T64 (round 3) ---------------------------------------------------------------------------------------------------
+NP_OF_NAME = {"Int8": np.int8, "UInt8": np.uint8, "Int16": np.int16, "UInt16": np.uint16, "Int32": np.int32, "UInt32": np.uint32, "Int64": np.int64, "UInt64": np.uint64}
+
+
+def dd_compat_sequence(dtype):
+    """DDCompatibilityTestSequence<T> (src/Compression/tests/gtest_compressionCodec.cpp:1139-1166) restated: three times 42, then for every
+    corner point p of the encoding whose magnitude fits T the six values a generator of double deltas p-4 .. p+1 yields, starting afresh
+    (previous value and delta 0) at every corner point -- the lambda is passed by value.  Arithmetic in Int64, cast to T by truncation."""
+    info = np.iinfo(dtype)
+    vals = [42, 42, 42]
+    for p in (-63, 64, -255, 256, -2047, 2048, -2**31, 2**31 - 1):
+        if abs(p) > info.max:
+            break
+        prev = prev_delta = 0
+        for dd in range(p - 4, p + 2):
+            cur = dd + prev + prev_delta
+            prev, prev_delta = cur, dd + prev_delta
+            vals.append(cur)
+    return np.array([v & 0xFFFFFFFFFFFFFFFF for v in vals], dtype=np.uint64).astype(dtype)   # static_cast<T>: modular
+
+
+def _codec_kat():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "codec_kat.json")))
+
+
+def test_oracle_double_delta_pinned_by_reference_compatibility_vectors():
+    """both directions against the reference's own (sequence, bytes) pairs: decode(bytes) == sequence and encode(sequence) == bytes"""
+    kat = _codec_kat()
+    for v in kat["double_delta_frames"]:
+        dt = NP_OF_NAME[v["type"]]
+        frame = bytes.fromhex(v["frame_hex"])
+        method, csize, dsize = struct.unpack_from("<BII", frame, 0)
+        assert method == OC.METHOD_DOUBLE_DELTA and csize == len(frame)
+        seq = dd_compat_sequence(dt)
+        assert dsize == seq.nbytes, (v["type"], dsize, seq.nbytes)
+        assert OC.double_delta_decode(frame[9:], dsize) == seq.tobytes(), v["type"]
+        assert OC.double_delta_encode(seq.tobytes(), seq.dtype.itemsize) == frame[9:], v["type"]
+    for ex in kat["double_delta_doc_examples"]:
+        seq = np.array(ex["values"], dtype=NP_OF_NAME[ex["type"]])
+        w = seq.dtype.itemsize
+        payload = bytes([w, 0]) + bytes.fromhex(ex["payload_hex"])
+        assert OC.double_delta_encode(seq.tobytes(), w) == payload
+        assert OC.double_delta_decode(payload, seq.nbytes) == seq.tobytes()
+
+
+def t64_scenarios():
+    """the value ranges the reference's T64 tests insert and read back (tests/queries/0_stateless/00870_t64_codec.sql, 00871_t64_codec_signed.sql,
+    00872_t64_bit_codec.sql): runs of 1, 2, 4 rows, then blocks that straddle every power of two 2^8 .. 2^56 with 10 / 11 / 64 / 65 ... rows,
+    for every width; the signed test mirrors them around zero.  The tests assert `column == T64 column` for every row."""
+    out = []
+    for dt in (np.uint8, np.uint16, np.uint32, np.uint64, np.int8, np.int16, np.int32, np.int64):
+        signed = np.dtype(dt).kind == "i"
+        seqs = [np.arange(1), np.arange(2), np.full(4, 42), np.arange(2**8), np.arange(2**9)]
+        for e, counts in ((16, (10, 11, 64, 65)), (24, (10, 11, 128, 129)), (32, (10, 20, 256, 257)), (40, (10, 20, 512, 513)), (48, (10, 20, 1024, 1025)),
+                          (56, (10, 20, 2048, 2049))):
+            for c in counts:
+                seqs.append(2**e - 10 + np.arange(c, dtype=np.int64))
+                seqs.append(2**e - 64 + np.arange(c, dtype=np.int64))
+            seqs.append(2**e - 1 + np.arange(counts[-1], dtype=np.int64))
+        for s_ in seqs:
+            s_ = np.asarray(s_, dtype=np.int64)
+            out.append(s_.astype(np.uint64).astype(dt))               # toUInt / toInt of the reference: truncation
+            if signed:
+                out.append((-s_).astype(np.uint64).astype(dt))
+                out.append((s_ - s_.shape[0] // 2).astype(np.uint64).astype(dt))   # a block that crosses zero
+    return out
+
+
+def test_oracle_t64_round_trips_the_reference_test_ranges():
+    for seq in t64_scenarios():
+        for bit in (False, True):
+            payload = OC.t64_encode(seq, bit)
+            assert OC.t64_decode(payload, seq.nbytes) == seq.tobytes(), (seq.dtype, seq[:4], bit)
+    # a payload whose size is not a whole number of transposed blocks, and an unknown type cookie, are refused
+    p = OC.t64_encode(np.arange(100, dtype=np.uint32))
+    with pytest.raises(ValueError):
+        OC.t64_decode(p[:-3], 400)
+    with pytest.raises(ValueError):
+        OC.t64_decode(bytes([5]) + p[1:], 400)
+
+
+@pytest.mark.gpu
+def test_gpu_double_delta_frames_pinned_by_reference_vectors_and_equal_to_the_oracle():
+    import clickhouse_amd as ch
+    ctx = ch.Context(0)
+    kat = _codec_kat()
+    for v in kat["double_delta_frames"]:
+        dt = NP_OF_NAME[v["type"]]
+        frame = bytes.fromhex(v["frame_hex"])
+        lo, hi = OC.city_hash128(frame)
+        col = ch.compression.read_column_file(ctx, struct.pack("<QQ", lo, hi) + frame, dt)
+        assert np.array_equal(col.numpy(), dd_compat_sequence(dt)), v["type"]
+    rng = np.random.Generator(np.random.PCG64(5))
+    for dt in (np.uint8, np.int16, np.uint32, np.int64, np.uint64):
+        info = np.iinfo(dt)
+        n = 100_003
+        cases = [np.cumsum(rng.integers(0, 50, size=n)).astype(np.uint64).astype(dt),                       # near-constant stride: 1-9 bit codes
+                 rng.integers(info.min, info.max, size=n, dtype=np.int64 if info.min < 0 else np.uint64).astype(dt) if dt != np.uint64
+                 else rng.integers(0, 2**64, size=n, dtype=np.uint64),                                      # every double delta at full width
+                 np.full(n, 7).astype(dt), np.arange(3).astype(dt), np.zeros(0, dtype=dt), np.array([info.max, info.min, info.max], dtype=dt)]
+        for seq in cases:
+            buf = OC.write_codec_frames(seq, OC.METHOD_DOUBLE_DELTA, block_rows=8192)
+            assert OC.read_frames(buf) == seq.tobytes()
+            if seq.shape[0] == 0:
+                continue
+            got = ch.compression.read_column_file(ctx, buf, dt).numpy()
+            assert np.array_equal(got, seq), (dt, seq[:5])
+
+
+@pytest.mark.gpu
+def test_gpu_t64_frames_round_trip_the_reference_test_ranges():
+    import clickhouse_amd as ch
+    ctx = ch.Context(0)
+    rng = np.random.Generator(np.random.PCG64(6))
+    extra = [rng.integers(1000, 5000, size=100_001).astype(np.uint32), rng.integers(-300, 300, size=70_000).astype(np.int64),
+             rng.integers(0, 2**64, size=9_999, dtype=np.uint64), np.full(12345, -5, dtype=np.int16)]
+    for seq in t64_scenarios() + extra:
+        for bit in (False, True):
+            buf = OC.write_codec_frames(seq, OC.METHOD_T64, block_rows=4096 + 37, t64_bit=bit)
+            assert OC.read_frames(buf) == seq.tobytes()
+            got = ch.compression.read_column_file(ctx, buf, seq.dtype.type).numpy()
+            assert np.array_equal(got, seq), (seq.dtype, seq[:4], bit)
+
+
+@pytest.mark.gpu
+def test_gpu_malformed_codec_frames_are_errors_not_faults():
+    import clickhouse_amd as ch
+    ctx = ch.Context(0)
+    seq = np.arange(1000, dtype=np.uint32) * 3
+    for method in (OC.METHOD_T64, OC.METHOD_DOUBLE_DELTA):
+        good = OC.write_codec_frames(seq, method, block_rows=1000)
+        frame = bytearray(good[16:])
+        for pos, val in ((9, 0x7f), (9, 3), (10, 0xff)):       # the cookie / width byte, bytes_to_skip
+            bad = bytearray(frame)
+            bad[pos] = val
+            lo, hi = OC.city_hash128(bytes(bad))
+            try:
+                got = ch.compression.read_column_file(ctx, struct.pack("<QQ", lo, hi) + bytes(bad), np.uint32).numpy()
+                assert got.shape[0] == 1000   # a changed byte that still parses must not fault either
+            except ch.ChgpuError as e:
+                assert e.code in (ch._capi.ERR_BAD_ARGUMENTS, ch._capi.ERR_NOT_IMPLEMENTED)
