@@ -63,12 +63,12 @@ class Aggregator:
 
     @property
     def n_words(self):
-        return sum(2 if k == K.AGG_AVG else 1 for k, _ in self.aggs)
+        return sum(2 if k == K.AGG_AVG else 1 for k, _ in self.aggs)   # (min / max: one order-key word)
 
     def result_dtypes(self):
         out = []
         for kind, t in self.aggs:
-            out.append(np.uint64 if kind == K.AGG_COUNT else np.float64 if kind == K.AGG_AVG else sum_result_dtype(t))
+            out.append(np.uint64 if kind == K.AGG_COUNT else np.float64 if kind == K.AGG_AVG else NP_OF[t] if kind in (K.AGG_MIN, K.AGG_MAX) else sum_result_dtype(t))
         return out
 
     def finalize_columns(self):
@@ -168,28 +168,14 @@ class NullableKeyAggregator:
 
 
 def group_by_min_max(ctx: Context, keys: Column, values: Column):
-    """SELECT key, min(value), max(value) GROUP BY key for integer keys and integer values, composed from the ordered-output pieces:
-    ORDER BY key, value (two stable radix sorts), group boundaries = rows whose key differs from the previous row's (a generated
-    comparison over two shifted views of the sorted key column), min = the first and max = the last value of every run.  The hash
-    aggregator's own state set is count / sum / avg; this route costs two sorts (~25 ms per 1e8 Int64 rows) and is exact.
-    Float values are not taken: AggregateFunctionMin keeps a NaN that arrives first (order-dependent).
+    """SELECT key, min(value), max(value) GROUP BY key ORDER BY key: min / max states in the hash aggregator (CHGPU_AGG_MIN / _MAX, round 3 --
+    rounds 1-2 took a detour over two stable sorts), the groups then ordered by key.
     -> (keys Column, min Column, max Column), one row per group, ascending by key."""
-    from .columns import filter_to_indices, sort_permutation
-    from .expression import ActionsDAG
-    if values.dtype.kind == "f":
-        raise K.ChgpuError(K.ERR_NOT_IMPLEMENTED, "min / max of a Float column: CPU path")
-    n = keys.size()
-    if n == 0:
+    from .columns import sort_permutation
+    if keys.size() == 0:
         return ctx.alloc(keys.dtype, 0), ctx.alloc(values.dtype, 0), ctx.alloc(values.dtype, 0)
-    perm = sort_permutation(keys, sort_permutation(values))
-    sk, sv = keys.index(perm), values.index(perm)
-    if n == 1:
-        return sk, sv, sv
-    d = ActionsDAG()
-    d.add_function("notEquals", d.add_input(0, keys.dtype), d.add_input(1, keys.dtype))
-    starts_after_first = d.compile().execute(ctx, [sk.cut(1, n - 1), sk.cut(0, n - 1)], [2])[0]  # row i+1 opens a run when key[i+1] != key[i]
-    opens = filter_to_indices(starts_after_first).numpy() + np.uint64(1)
-    first = np.concatenate([np.zeros(1, dtype=np.uint64), opens])
-    last = np.concatenate([opens - np.uint64(1), np.array([n - 1], dtype=np.uint64)])
-    fi, la = ctx.upload(first), ctx.upload(last)
-    return sk.index(fi), sv.index(fi), sv.index(la)
+    agg = Aggregator(keys.dtype, [(K.AGG_MIN, values.dtype), (K.AGG_MAX, values.dtype)], ctx=ctx)
+    agg.execute_on_block(keys, [values, values])
+    gk, (mn, mx) = agg.finalize_columns()
+    perm = sort_permutation(gk)
+    return gk.index(perm), mn.index(perm), mx.index(perm)

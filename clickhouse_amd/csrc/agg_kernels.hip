@@ -97,6 +97,7 @@ struct chgpu_agg
     size_t table_class = 0;
     u64 n_groups = 0; // host copy, refreshed after every call
     bool hint_probed = false; // the cardinality of a hint-less aggregation was sampled on its first large block
+    bool has_extremum = false; // some function is min / max: rows take the DIRECT kernel (the LDS-staged plans only know how to add)
     u64 host_words[AGG_MAX_WORDS]; // without_key states live on the host (8 B each)
 };
 
@@ -132,8 +133,16 @@ __device__ __forceinline__ u64 load_arg_bits(const void * p, int type, u64 i)
     }
 }
 
-__device__ __forceinline__ void global_add_word(u64 * p, u64 bits, bool is_f64)
+// op: 0 = wrap-around integer add, 1 = Float64 add, 2 = unsigned max (min / max states: order keys, see agg_order_key)
+__device__ __forceinline__ void global_add_word(u64 * p, u64 bits, int op)
 {
+    if (op == 2)
+    {
+        if (bits) // (0 is the identity: nothing to do)
+            __hip_atomic_fetch_max((unsigned long long *)p, (unsigned long long)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const bool is_f64 = op == 1;
     if (is_f64)
         __hip_atomic_fetch_add((double *)p, __longlong_as_double((long long)bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
@@ -196,6 +205,32 @@ __device__ __forceinline__ u64 table_emplace(const AggTable & t, u64 key, bool s
     return slot;
 }
 
+// min / max states (AggregateFunctionsMinMax.cpp, SingleValueDataFixed<T>::setIfSmaller / setIfGreater, SingleValueData.cpp:219-262): the
+// state word holds an ORDER KEY -- the value mapped to an unsigned 64-bit integer that sorts like the value (unsigned: itself; signed: sign
+// bit flipped; floats: the IEEE total-order fold, Float32 after its exact widening) -- for max, and its complement for min, combined with
+// an unsigned atomic max.  A freshly zeroed cell is then the identity of both, exactly like the sums' zero: the rehash, the merges and the
+// exports move min / max words with no special case but the combining operation.  (A group only exists because a row created it, so
+// `has()` is always true for it.)  NaNs take their total-order place -- above +inf / below -inf by sign -- where the reference's answer
+// depends on which row came first (`NaN < x` is false either way).
+__device__ __host__ __forceinline__ u64 agg_order_key(u64 bits, int type)
+{
+    switch (type)
+    {
+        case CHGPU_I64: case CHGPU_I32: case CHGPU_I16: case CHGPU_I8: return bits ^ 0x8000000000000000ull; // (already sign-extended)
+        case CHGPU_F64: case CHGPU_F32: return (bits >> 63) ? ~bits : bits ^ 0x8000000000000000ull;
+        default: return bits;
+    }
+}
+__device__ __host__ __forceinline__ u64 agg_order_key_inverse(u64 key, int type)
+{
+    switch (type)
+    {
+        case CHGPU_I64: case CHGPU_I32: case CHGPU_I16: case CHGPU_I8: return key ^ 0x8000000000000000ull;
+        case CHGPU_F64: case CHGPU_F32: return (key >> 63) ? key ^ 0x8000000000000000ull : ~key;
+        default: return key;
+    }
+}
+
 // add row i's contribution of every aggregate to the cell `slot` (IAggregateFunction::add per function)
 __device__ __forceinline__ void add_row_global(const AggTable & t, const AggDesc & d, u64 slot, u64 i)
 {
@@ -206,6 +241,11 @@ __device__ __forceinline__ void add_row_global(const AggTable & t, const AggDesc
         u64 * w = t.words + (u64)a.word * stride + slot;
         if (a.kind == CHGPU_AGG_COUNT)
             global_add_word(w, 1, false);
+        else if (a.kind == CHGPU_AGG_MIN || a.kind == CHGPU_AGG_MAX)
+        {
+            const u64 k = agg_order_key(load_arg_bits(a.ptr, a.arg_type, i), a.arg_type);
+            global_add_word(w, a.kind == CHGPU_AGG_MAX ? k : ~k, 2);
+        }
         else
         {
             global_add_word(w, load_arg_bits(a.ptr, a.arg_type, i), a.arg_type == CHGPU_F64 || a.arg_type == CHGPU_F32);
@@ -1506,7 +1546,8 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_tuples(AggTable t, u32 n_wo
                     failed = true;
                 else
                     for (u32 w = 0; w < n_words; ++w)
-                        global_add_word(t.words + (u64)w * gstride + slot, src_words[(u64)w * src_stride + i], (word_is_f64 >> w) & 1);
+                        global_add_word(t.words + (u64)w * gstride + slot, src_words[(u64)w * src_stride + i],
+                                        (int)((word_is_f64 >> w) & 1) | (int)(((word_is_f64 >> (16 + w)) & 1) << 1)); // upper half of the mask: max words
             }
         }
         const u64 b = __ballot(failed);
@@ -1665,10 +1706,16 @@ extern "C" int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, 
     {
         const int kind = agg_kinds[j];
         const int at = (kind == CHGPU_AGG_COUNT || !arg_types) ? CHGPU_U64 : arg_types[j];
-        if (kind != CHGPU_AGG_COUNT && kind != CHGPU_AGG_SUM && kind != CHGPU_AGG_AVG)
+        const bool extremum = kind == CHGPU_AGG_MIN || kind == CHGPU_AGG_MAX;
+        if (kind != CHGPU_AGG_COUNT && kind != CHGPU_AGG_SUM && kind != CHGPU_AGG_AVG && !extremum)
         {
             delete a;
             return chgpu_set_error(CHGPU_ERR_NOT_IMPLEMENTED, "aggregate function kind %d has no device state: CPU path", kind);
+        }
+        if (extremum && key_type < 0)
+        {
+            delete a;
+            return chgpu_set_error(CHGPU_ERR_NOT_IMPLEMENTED, "min / max without key: chgpu_expr_filter_minmax_node");
         }
         if (kind != CHGPU_AGG_COUNT && !chgpu_type_size(at))
         {
@@ -1678,7 +1725,12 @@ extern "C" int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, 
         a->kinds[j] = kind;
         a->arg_types[j] = at;
         a->word_off[j] = w;
-        if (kind != CHGPU_AGG_COUNT && chgpu_type_is_float(at))
+        if (extremum)
+        {
+            a->word_is_f64 |= 1u << (16 + w); // upper half of the mask: the word combines by unsigned max (order keys), never by an add
+            a->has_extremum = true;
+        }
+        else if (kind != CHGPU_AGG_COUNT && chgpu_type_is_float(at))
             a->word_is_f64 |= 1u << w;
         w += kind == CHGPU_AGG_AVG ? 2 : 1;
     }
@@ -2560,7 +2612,7 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
     if (filter)
     {
         const bool partitioned = a->size_hint > lds_groups && n >= (4u << 20) && !chgpu_opt(ctx, "agg_no_partition", 0);
-        const bool will_range = !partitioned && a->size_hint <= 65536 && n < (1ull << 32) && !chgpu_opt(ctx, "tune_agg_no_ranged", 0);
+        const bool will_range = !partitioned && a->size_hint <= 65536 && n < (1ull << 32) && !chgpu_opt(ctx, "tune_agg_no_ranged", 0) && !a->has_extremum;
         if (!will_range)
             return agg_add_block_materialised(a, key_col, arg_cols, row_begin, row_end, filter);
         // The aggregation kernel is issue-bound: it spends nearly the same time on a masked-out row as on a kept one, while
@@ -2587,6 +2639,18 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
     void * scratch = nullptr;
     CHGPU_TRY(chgpu_scratch(ctx, n_words64 * sizeof(u64) + 256, &scratch));
     u64 * pending = (u64 *)scratch;
+
+    if (a->has_extremum)
+    {
+        // min / max states: one emplace + one atomic per state word and row (the LDS-staged and partitioned plans carry additive words only)
+        CHGPU_TRY(agg_ensure_table(a));
+        hipLaunchKernelGGL(k_agg_rows_direct<AGG_MODE_ALL>, dim3(chgpu_grid_for(ctx, n, AGG_THREADS, 8)), dim3(AGG_THREADS), 0, ctx->stream, a->t, d, key_col->data, a->key_type,
+                           row_begin, n, pending);
+        ctx->counters[6] += 1;
+        ctx->counters[5] += n;
+        CHGPU_HIP(hipGetLastError());
+        return agg_finish_rounds(a, d, key_col->data, a->key_type, row_begin, n, pending);
+    }
 
     // PARTITIONED strategy: large promised cardinality and enough rows to amortise two extra passes
     {
@@ -3147,6 +3211,24 @@ extern "C" int chgpu_agg_export_states_two_level(chgpu_agg * a, chgpu_col ** key
     return CHGPU_OK;
 }
 
+// min / max state words (order keys; complemented for min) -> values of the argument's type
+__global__ __launch_bounds__(256) void k_extremum_decode(const u64 * __restrict__ words, u64 n, int type, int is_min, void * __restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        const u64 bits = agg_order_key_inverse(is_min ? ~words[i] : words[i], type);
+        switch (type)
+        {
+            case CHGPU_I64: case CHGPU_U64: case CHGPU_F64: ((u64 *)out)[i] = bits; break;
+            case CHGPU_U32: case CHGPU_I32: ((u32 *)out)[i] = (u32)bits; break;
+            case CHGPU_U16: case CHGPU_I16: ((u16 *)out)[i] = (u16)bits; break;
+            case CHGPU_U8: case CHGPU_I8: ((u8 *)out)[i] = (u8)bits; break;
+            case CHGPU_F32: ((float *)out)[i] = (float)__longlong_as_double((long long)bits); break; // the widening was exact: so is this
+            default: break;
+        }
+    }
+}
+
 extern "C" int chgpu_agg_finalize(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** res_cols, uint64_t * groups)
 {
     ChgpuDeviceGuard _dev_guard(a ? a->ctx : nullptr);
@@ -3170,6 +3252,21 @@ extern "C" int chgpu_agg_finalize(chgpu_agg * a, chgpu_col ** keys_out, chgpu_co
             words[w]->type = chgpu_sum_result_type(a->arg_types[j]); // SumSimple: Int64 / UInt64 / Float64
             res_cols[j] = words[w];
             words[w] = nullptr;
+        }
+        else if (a->kinds[j] == CHGPU_AGG_MIN || a->kinds[j] == CHGPU_AGG_MAX)
+        {
+            // insertResultInto: the value itself, in the argument's type (AggregateFunctionsMinMax.cpp)
+            chgpu_col * r = nullptr;
+            rc = chgpu_col_new(ctx, a->arg_types[j], n, &r);
+            if (rc != CHGPU_OK)
+                break;
+            if (n)
+            {
+                hipLaunchKernelGGL(k_extremum_decode, dim3(chgpu_grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, (const u64 *)words[w]->data, n, a->arg_types[j],
+                                   a->kinds[j] == CHGPU_AGG_MIN ? 1 : 0, r->data);
+                ctx->counters[6] += 1;
+            }
+            res_cols[j] = r;
         }
         else
         {

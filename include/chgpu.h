@@ -65,7 +65,11 @@ enum
 enum { CHGPU_EQ = 0, CHGPU_NE = 1, CHGPU_LT = 2, CHGPU_GT = 3, CHGPU_LE = 4, CHGPU_GE = 5 };
 
 /* ---- aggregate functions with POD states the device can hold (src/AggregateFunctions/) ---- */
-enum { CHGPU_AGG_COUNT = 0, CHGPU_AGG_SUM = 1, CHGPU_AGG_AVG = 2 };
+enum { CHGPU_AGG_COUNT = 0, CHGPU_AGG_SUM = 1, CHGPU_AGG_AVG = 2,
+       /* min / max over a numeric argument, result in the argument's type (AggregateFunctionsMinMax.cpp, SingleValueDataFixed: SingleValueData.cpp:
+          219-262); with a GROUP BY key only (without key: chgpu_expr_filter_minmax_node).  The 8-byte state word is an order key: merge /
+          export / import as for the sums, but never through the wire serialisation of chgpu_agg_serialize_states. */
+       CHGPU_AGG_MIN = 3, CHGPU_AGG_MAX = 4 };
 
 /* ---- JoinKind / JoinStrictness subset (src/Core/Joins.h) ---- */
 enum { CHGPU_JOIN_INNER = 0, CHGPU_JOIN_LEFT = 1, CHGPU_JOIN_RIGHT = 2, CHGPU_JOIN_FULL = 3 }; /* RIGHT / FULL: strictness ALL only */

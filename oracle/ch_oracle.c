@@ -1093,7 +1093,45 @@ struct cho_agg
     int n_arenas;
 };
 
-static size_t state_size(int kind) { return kind == CHO_AGG_AVG ? 16 : 8; }
+/* min / max: SingleValueDataFixed<T> {has_value, value} (src/AggregateFunctions/SingleValueData.h) -- here 8 bytes of flag + the value widened
+   to 8 bytes (integers sign- / zero-extended, Float32 widened to Float64: both order-preserving and exactly reversible) */
+static size_t state_size(int kind) { return (kind == CHO_AGG_AVG || kind == CHO_AGG_MIN || kind == CHO_AGG_MAX) ? 16 : 8; }
+
+static int is_signed_type(int t) { return t == CHO_I64 || t == CHO_I32 || t == CHO_I16 || t == CHO_I8; }
+static int is_float_type(int t) { return t == CHO_F64 || t == CHO_F32; }
+static uint64_t load_widened(int t, const void * arg, size_t i)
+{
+    switch (t)
+    {
+        case CHO_I64: return (uint64_t)((const int64_t *)arg)[i];
+        case CHO_U64: return ((const uint64_t *)arg)[i];
+        case CHO_U32: return ((const uint32_t *)arg)[i];
+        case CHO_I32: return (uint64_t)(int64_t)((const int32_t *)arg)[i];
+        case CHO_U16: return ((const uint16_t *)arg)[i];
+        case CHO_I16: return (uint64_t)(int64_t)((const int16_t *)arg)[i];
+        case CHO_U8: return ((const uint8_t *)arg)[i];
+        case CHO_I8: return (uint64_t)(int64_t)((const int8_t *)arg)[i];
+        case CHO_F64: return ((const uint64_t *)arg)[i];
+        case CHO_F32: { double d = (double)((const float *)arg)[i]; uint64_t b; memcpy(&b, &d, 8); return b; }
+        default: return 0;
+    }
+}
+/* `to < value` / `to > value` in the argument's own type (SingleValueDataFixed<T>::setIfSmaller / setIfGreater, SingleValueData.cpp:219-240) */
+static int widened_less(int t, uint64_t x, uint64_t y)
+{
+    if (is_float_type(t)) { double a, b; memcpy(&a, &x, 8); memcpy(&b, &y, 8); return a < b; }
+    if (is_signed_type(t)) return (int64_t)x < (int64_t)y;
+    return x < y;
+}
+static void extremum_update(int kind, int t, char * st, uint64_t v)
+{
+    uint64_t * has = (uint64_t *)st, * val = (uint64_t *)(st + 8);
+    if (!*has || (kind == CHO_AGG_MIN ? widened_less(t, v, *val) : widened_less(t, *val, v)))
+    {
+        *has = 1;
+        *val = v;
+    }
+}
 
 cho_agg * cho_agg_create(int key_type, int n_aggs, const int * kinds, const int * arg_types, uint64_t two_level_threshold)
 {
@@ -1148,6 +1186,10 @@ static inline void agg_add_row(const cho_agg * a, int j, char * place, const voi
         case CHO_AGG_COUNT:
             ++*(uint64_t *)st;
             break;
+        case CHO_AGG_MIN:
+        case CHO_AGG_MAX:
+            extremum_update(a->kinds[j], a->arg_types[j], st, load_widened(a->arg_types[j], arg, i));
+            break;
         case CHO_AGG_AVG:
             ++*(uint64_t *)(st + 8); /* denominator */
             /* numerator accumulates like sum */
@@ -1179,6 +1221,13 @@ static void agg_merge_states(const cho_agg * a, char * dst, const char * src)
     {
         char * d = dst + a->offsets[j];
         const char * s = src + a->offsets[j];
+        if (a->kinds[j] == CHO_AGG_MIN || a->kinds[j] == CHO_AGG_MAX)
+        {
+            /* setIfSmaller(const SingleValueDataFixed &) / setIfGreater (SingleValueData.cpp:243-262): `to.has() && (!has() || to.value < value)` */
+            if (*(const uint64_t *)s)
+                extremum_update(a->kinds[j], a->arg_types[j], d, *(const uint64_t *)(s + 8));
+            continue;
+        }
         int is_f = (a->kinds[j] != CHO_AGG_COUNT) && sum_result_type(a->arg_types[j]) == CHO_F64;
         if (is_f)
             *(double *)d += *(const double *)s;
@@ -1351,6 +1400,8 @@ static void agg_emit_row(const cho_agg * a, uint64_t key, const char * place, si
             double r = cho_avg_divide(sum_result_type(a->arg_types[j]), st, *(const uint64_t *)(st + 8));
             memcpy(o, &r, 8);
         }
+        else if (a->kinds[j] == CHO_AGG_MIN || a->kinds[j] == CHO_AGG_MAX)
+            memcpy(o, st + 8, 8); /* the widened value (a state without value inserts the default 0) */
         else
             memcpy(o, st, 8); /* insertResultInto: sum / count raw 8 bytes */
     }

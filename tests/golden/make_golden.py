@@ -61,6 +61,13 @@ def main():
     # round(avg(log(2)*number), 6) GROUP BY number % 5 over numbers(1e7): lines 7..11 of the .reference
     out["01300_avg_group_by_mod5"] = dict(source="tests/queries/0_stateless/01300_group_by_other_keys.reference",
                                           rows=rows_of(ref_root, "01300_group_by_other_keys", 6, 11))
+    # min / max states per group (round 3): max(log(2) * number) GROUP BY number % 2, number % 3 -- and the integer forms of 01321
+    out["01300_max_group_by_mod2_mod3"] = dict(source="tests/queries/0_stateless/01300_group_by_other_keys.reference",
+                                               rows=rows_of(ref_root, "01300_group_by_other_keys", 0, 6))
+    out["01321_min_max_group_by_mod2_mod3"] = dict(source="tests/queries/0_stateless/01321_aggregate_functions_of_group_by_keys.reference",
+                                                   rows=rows_of(ref_root, "01321_aggregate_functions_of_group_by_keys", 0, 6))
+    out["01321_max_product_group_by_mod7_mod5"] = dict(source="tests/queries/0_stateless/01321_aggregate_functions_of_group_by_keys.reference",
+                                                       rows=rows_of(ref_root, "01321_aggregate_functions_of_group_by_keys", 12, 47))
 
     with open(os.path.join(HERE, "sql_reference_rows.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -7,7 +7,7 @@ reference's .reference files so they can be diffed against tests/golden/sql_refe
 import numpy as np
 
 I64, U32, U64, F64, U8, I32 = 0, 1, 2, 3, 4, 5
-AGG_COUNT, AGG_SUM, AGG_AVG = 0, 1, 2
+AGG_COUNT, AGG_SUM, AGG_AVG, AGG_MIN, AGG_MAX = 0, 1, 2, 3, 4
 JOIN_INNER, JOIN_LEFT = 0, 1
 STRICT_ANY, STRICT_ALL, STRICT_SEMI, STRICT_ANTI = 0, 1, 2, 3
 
@@ -160,6 +160,44 @@ def q01091(engine):
         a.execute_on_block(None, [n[b:b + bs]])
     _, (s,) = a.convert_to_block()
     return [[str(int(s[0]))]]
+
+
+def q01300_max(engine, rows=10000000, block=65505):
+    # round(max(log(2) * number), 6) FROM numbers(1e7) GROUP BY number % 2, number % 3, (number % 2 + number % 3) % 2  ORDER BY k
+    # (the third key is a function of the first two: six groups; the keys are packed the way keys16 would be)
+    n = numbers(rows)
+    val = np.log(2.0) * n.astype(np.float64)
+    key = ((n % 2) | ((n % 3) << np.uint64(8))).astype(np.uint32)
+    a = engine.Aggregator(np.uint32, [(AGG_MAX, np.float64)])
+    for b in range(0, rows, block):
+        a.execute_on_block(key[b:b + block], [val[b:b + block]])
+    _, (mx,) = a.convert_to_block()
+    return sorted(round(float(x), 6) for x in mx)
+
+
+def q01321_min_max(engine, rows=10000000, block=65409):
+    # SELECT min(number % 2) AS a, max(number % 3) AS b FROM numbers(1e7) GROUP BY number % 2, number % 3 ORDER BY a, b
+    n = numbers(rows)
+    k2, k3 = (n % 2).astype(np.uint8), (n % 3).astype(np.uint8)
+    key = (k2.astype(np.uint32) | (k3.astype(np.uint32) << 8))
+    a = engine.Aggregator(np.uint32, [(AGG_MIN, np.uint8), (AGG_MAX, np.uint8)])
+    for b in range(0, rows, block):
+        a.execute_on_block(key[b:b + block], [k2[b:b + block], k3[b:b + block]])
+    _, (mn, mx) = a.convert_to_block()
+    return sorted([str(int(x)), str(int(y))] for x, y in zip(mn, mx))
+
+
+def q01321_max_product(engine, rows=10000000, block=65409):
+    # SELECT max((number % 5) * (number % 7)) AS a FROM numbers(1e7) GROUP BY number % 7, number % 5 ORDER BY a
+    n = numbers(rows)
+    k5, k7 = (n % 5), (n % 7)
+    prod = (k5 * k7).astype(np.uint16)   # UInt8 * UInt8 -> UInt16 (NumberTraits)
+    key = (k7 | (k5 << np.uint64(8))).astype(np.uint32)
+    a = engine.Aggregator(np.uint32, [(AGG_MAX, np.uint16)])
+    for b in range(0, rows, block):
+        a.execute_on_block(key[b:b + block], [prod[b:b + block]])
+    _, (mx,) = a.convert_to_block()
+    return sorted(int(x) for x in mx)
 
 
 def q01300(engine, rows=10000000, block=65505):

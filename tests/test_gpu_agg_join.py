@@ -681,3 +681,81 @@ def test_00974_full_outer_join_reference_rows(ch, ctx):
     rows.sort(key=lambda t: t[2])  # ORDER BY q1.cnt2
     fmt = [(str(np.datetime64("1970-01-01") + np.timedelta64(d, "D")), str(a), str(b2)) for d, a, b2 in rows]
     assert fmt == want
+
+
+# ---- round 3: min / max states in the hash aggregator (AggregateFunctionsMinMax.cpp, SingleValueDataFixed) ----------------------------------
+def test_min_max_reference_rows_on_gpu(engine, golden):
+    """the reference's own expected rows: Float64 max per group (01300) and integer min / max per group (01321): bit-exact, no tolerance --
+    an extremum is one of the inputs"""
+    assert S.q01300_max(engine) == sorted(float(r[0]) for r in golden["rows"]["01300_max_group_by_mod2_mod3"]["rows"])
+    assert S.q01321_min_max(engine) == sorted(golden["rows"]["01321_min_max_group_by_mod2_mod3"]["rows"])
+    assert S.q01321_max_product(engine) == sorted(int(r[0]) for r in golden["rows"]["01321_max_product_group_by_mod7_mod5"]["rows"])
+
+
+@pytest.mark.parametrize("dt", [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64, np.float32, np.float64])
+def test_min_max_states_match_oracle_every_type_with_growth_and_merge(ch, ctx, oracle_mod, dt):
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(int(np.dtype(dt).itemsize) * 7 + (np.dtype(dt).kind == "f")))
+    n, groups = 300_000, 150_000                      # more groups than the initial table's max fill would take without growing? no: growth is
+    keys = rng.integers(0, groups, size=n, dtype=np.uint64)   # exercised by the second block below (size_hint = 0, 4 Mi cells) -- merges rehash
+    keys[:7] = 0                                       # the zero key lives out of line
+    if np.dtype(dt).kind == "f":
+        vals = ((rng.random(n) - 0.5) * 10.0 ** rng.integers(-30, 30, size=n)).astype(dt)
+        vals[::1000] = dt(0.0)
+        vals[5::1000] = dt(-0.0)
+        vals[7::5000] = np.inf
+        vals[9::5000] = -np.inf
+    else:
+        info = np.iinfo(dt)
+        vals = rng.integers(info.min, info.max, size=n, dtype=np.int64 if info.min < 0 else np.uint64, endpoint=True).astype(dt)
+        vals[3::1000] = info.min
+        vals[4::1000] = info.max
+    aggs = [(ch.AGG_MIN, dt), (ch.AGG_MAX, dt), (ch.AGG_COUNT, None), (ch.AGG_SUM, np.uint64)]
+    ones = np.ones(n, dtype=np.uint64)
+    A, B = ch.Aggregator(np.uint64, aggs, ctx=ctx), ch.Aggregator(np.uint64, aggs, ctx=ctx)
+    OA, OB = O.Aggregator(np.uint64, aggs), O.Aggregator(np.uint64, aggs)
+    h = n // 2
+    for g_, o_, lo, hi in ((A, OA, 0, h), (B, OB, h, n)):
+        for b in range(lo, hi, 65409):
+            e = min(hi, b + 65409)
+            g_.execute_on_block(keys[b:e], [vals[b:e], vals[b:e], None, ones[b:e]])
+            o_.execute_on_block(keys[b:e], [vals[b:e], vals[b:e], None, ones[b:e]])
+    A.merge(B)                                          # mergeDataImpl: min of mins, max of maxes
+    OA.merge(OB)
+    gk, (gmn, gmx, gc, gs) = A.convert_to_block()
+    ok, (omn, omx, oc, os_) = OA.convert_to_block()
+    i, j = np.argsort(gk), np.argsort(ok)
+    assert np.array_equal(gk[i], ok[j]) and np.array_equal(gc[i], oc[j]) and np.array_equal(gs[i], os_[j])
+    assert gmn.dtype == np.dtype(dt) and gmx.dtype == np.dtype(dt)
+    # bit-exact: an extremum is one of the inputs (-0.0 / +0.0 compare equal: either may stand for the group, so compare by value there)
+    assert np.array_equal(gmn[i], omn[j]) and np.array_equal(gmx[i], omx[j])
+    # partial states travel like the sums': export, then merge into a fresh aggregator (the sharded GROUP BY's route)
+    k2, words, rows = A.export_state_columns()
+    Cg = ch.Aggregator(np.uint64, aggs, ctx=ctx)
+    Cg.merge_states(k2, words, rows)
+    Cg.merge_states(k2, words, rows)                    # twice: min / max are idempotent, counts and sums double
+    ck, (cmn, cmx, cc, cs) = Cg.convert_to_block()
+    q = np.argsort(ck)
+    assert np.array_equal(ck[q], gk[i]) and np.array_equal(cmn[q], gmn[i]) and np.array_equal(cmx[q], gmx[i]) and np.array_equal(cc[q], 2 * gc[i])
+
+
+def test_min_max_with_where_mask_and_table_growth(ch, ctx, oracle_mod):
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(99))
+    n = 6_000_000                                        # 3 M distinct keys: beyond the 2 Mi max fill of the initial table -> grow + rehash of max words
+    keys = rng.integers(0, 3_000_000, size=n, dtype=np.uint64).astype(np.uint32)
+    vals = rng.integers(-2**40, 2**40, size=n, dtype=np.int64)
+    mask = (rng.random(n) < 0.7).astype(np.uint8)
+    aggs = [(ch.AGG_MAX, np.int64), (ch.AGG_MIN, np.int64)]
+    A = ch.Aggregator(np.uint32, aggs, ctx=ctx)
+    A.execute_on_block(keys, [vals, vals], filter=mask)
+    OA = O.Aggregator(np.uint32, aggs)
+    m = mask.astype(bool)
+    OA.execute_on_block(keys[m], [vals[m], vals[m]])
+    gk, (gmx, gmn) = A.convert_to_block()
+    ok, (omx, omn) = OA.convert_to_block()
+    i, j = np.argsort(gk), np.argsort(ok)
+    assert np.array_equal(gk[i], ok[j]) and np.array_equal(gmx[i], omx[j]) and np.array_equal(gmn[i], omn[j])
+    with pytest.raises(ch.ChgpuError) as e:              # without key: the generated kernel route (chgpu_expr_filter_minmax_node)
+        ch.Aggregator(None, [(ch.AGG_MIN, np.int64)], ctx=ctx)
+    assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED

@@ -128,3 +128,14 @@ def test_keys_fixed_pack_and_group_by_two_keys(oracle_mod, golden):
     probe = np.concatenate([keys[:10], np.full((1, 32), 9, dtype=np.uint8)])
     got = m.batch(probe, False)
     assert np.array_equal(got[:10], ids[:10]) and got[10] == 2**64 - 1 and len(m) == uniq.shape[0]
+
+
+# ---- round 3: min / max states per group, pinned by the reference's rows of 01300 (Float64 max) and 01321 (integer min / max) ----------------
+def test_01300_max_float64_group_by(oracle_mod, golden):
+    want = sorted(float(r[0]) for r in golden["rows"]["01300_max_group_by_mod2_mod3"]["rows"])
+    assert S.q01300_max(oracle_mod) == want
+
+
+def test_01321_min_max_group_by(oracle_mod, golden):
+    assert S.q01321_min_max(oracle_mod) == sorted(golden["rows"]["01321_min_max_group_by_mod2_mod3"]["rows"])
+    assert S.q01321_max_product(oracle_mod) == sorted(int(r[0]) for r in golden["rows"]["01321_max_product_group_by_mod7_mod5"]["rows"])

@@ -218,7 +218,8 @@ def test_gpu_sort_nan_order_reference_blocks():
 @pytest.mark.gpu
 @pytest.mark.parametrize("key_dtype,val_dtype,groups", [(np.uint32, np.int64, 1000), (np.int64, np.int32, 50_000), (np.uint16, np.uint8, 7), (np.uint64, np.uint64, 1)])
 def test_gpu_group_by_min_max_through_ordered_output(key_dtype, val_dtype, groups):
-    """GROUP BY key -> min(value), max(value) composed from ORDER BY key, value + run boundaries; numpy minimum.at / maximum.at beside it"""
+    """GROUP BY key -> min(value), max(value) ORDER BY key: min / max states of the hash aggregator, the groups sorted afterwards; numpy
+    minimum.at / maximum.at beside it (tests/test_gpu_agg_join.py holds the oracle and reference-row comparisons)"""
     import clickhouse_amd as ch
     ctx = ch.Context()
     rng = np.random.Generator(np.random.PCG64(groups))
@@ -233,5 +234,9 @@ def test_gpu_group_by_min_max_through_ordered_output(key_dtype, val_dtype, group
     np.minimum.at(wmin, inv, v)
     np.maximum.at(wmax, inv, v)
     assert np.array_equal(gk.numpy(), uk) and np.array_equal(gmin.numpy(), wmin) and np.array_equal(gmax.numpy(), wmax)
-    with pytest.raises(ch.ChgpuError):
-        ch.group_by_min_max(ctx, ctx.upload(k), ctx.upload(v.astype(np.float64)))
+    vf = v.astype(np.float64) * 0.5
+    gk, gmin, gmax = ch.group_by_min_max(ctx, ctx.upload(k), ctx.upload(vf))
+    fmin, fmax = np.full(uk.shape[0], np.inf), np.full(uk.shape[0], -np.inf)
+    np.minimum.at(fmin, inv, vf)
+    np.maximum.at(fmax, inv, vf)
+    assert np.array_equal(gk.numpy(), uk) and np.array_equal(gmin.numpy(), fmin) and np.array_equal(gmax.numpy(), fmax)
