@@ -510,7 +510,7 @@ def config_c2_from_host_blocks(args, ctx, ch, torch, np, dev, stream, with_cpu, 
     rows = min(args.rows, 400_000_000)
     best = None
     for streams in (4, 8):
-        p = subprocess.run([exe, "--bench-host-blocks", str(rows), str(streams)], capture_output=True, text=True, timeout=600)
+        p = subprocess.run([exe, "--bench-host-blocks", str(rows), str(streams), str(2 << 20)], capture_output=True, text=True, timeout=600)
         if p.returncode != 0:
             raise RuntimeError(f"pipeline_demo --bench-host-blocks failed: {p.stderr[-300:]}")
         r = json.loads(p.stdout.strip().splitlines()[-1])
