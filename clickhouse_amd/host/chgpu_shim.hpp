@@ -1048,12 +1048,98 @@ public:
         block = std::move(res);
     }
 
+    chgpu_join * handle() const { return h; }
+    const Columns & rightPayload()
+    {
+        if (right_payload.empty() && !right_blocks.empty())
+            onBuildPhaseFinish();
+        return right_payload;
+    }
+    size_t rightBlocks() const { return right_blocks.size(); }
+    int getKind() const { return kind; }
+    int getStrictness() const { return strictness; }
+
 private:
     ContextPtr ctx;
     int kind, strictness;
     chgpu_join * h = nullptr;
     std::vector<Chunk> right_blocks; // data->blocks (HashJoin.cpp:656-658)
     Columns right_payload;           // the same columns glued end to end for the device gather
+};
+
+/// A chain of JoiningTransforms whose joins are all of the filter form (LEFT SEMI / LEFT ANTI / ALL over unique build keys): what
+/// N x (joinBlock -> joinRightColumns -> block.filter(filter) over every left column -> AddedColumns gather; HashJoinMethodsImpl.h:68-202)
+/// produce, computed before any left column is copied (chgpu_join_probe_chain): one sweep over the left KEY columns answers which rows
+/// survive every join, then only the survivors are gathered -- their left columns once (IColumn::index), every join's right payload by the
+/// matched build row (fillFromBlocksAndRowNumbers).  Output layout = the per-join chain's: [left columns..., payload of join 0..., payload
+/// of join 1 ...].  Joins the entry does not take (INNER ANY, RIGHT / FULL, ALL over duplicate keys) make it throw NOT_IMPLEMENTED: the
+/// caller keeps its JoiningTransform chain.
+struct JoinChainStep
+{
+    std::shared_ptr<GpuHashJoin> join;
+    size_t left_key_position;
+};
+
+inline void joinBlockChain(const std::vector<JoinChainStep> & steps, Chunk & block)
+{
+    if (steps.empty())
+        return;
+    const size_t n = steps.size();
+    std::vector<chgpu_join *> joins;
+    std::vector<const chgpu_col *> keys;
+    std::vector<int> want(n, 0);
+    for (size_t s = 0; s < n; ++s)
+    {
+        joins.push_back(steps[s].join->handle());
+        keys.push_back(block.columns.at(steps[s].left_key_position)->handle());
+        want[s] = steps[s].join->rightPayload().empty() ? 0 : 1;
+    }
+    std::vector<const chgpu_col *> carry;
+    for (auto & c : block.columns)
+        carry.push_back(c->handle());
+    std::vector<chgpu_col *> rowids(n, nullptr), carried(carry.size(), nullptr);
+    uint64_t kept = 0;
+    check(chgpu_join_probe_chain(static_cast<uint32_t>(n), joins.data(), keys.data(), nullptr, want.data(), static_cast<uint32_t>(carry.size()), carry.data(), nullptr,
+                                 rowids.data(), carried.data(), nullptr, &kept));
+    const ContextPtr & ctx = block.columns.at(0)->context();
+    Chunk res;
+    res.num_rows = kept;
+    for (auto * c : carried)
+        res.columns.push_back(std::make_shared<ColumnVector>(ctx, c));
+    for (size_t s = 0; s < n; ++s)
+    {
+        if (!rowids[s])
+            continue;
+        ColumnPtr ids = std::make_shared<ColumnVector>(ctx, rowids[s]);
+        if (steps[s].join->rightBlocks() > 1)
+        {
+            chgpu_col * flat = nullptr;
+            check(chgpu_join_flatten_rowids(steps[s].join->handle(), ids->handle(), &flat));
+            ids = std::make_shared<ColumnVector>(ctx, flat);
+        }
+        for (auto & payload : steps[s].join->rightPayload())
+            res.columns.push_back(payload->index(*ids, 0, /*default_for_missing*/ true));
+    }
+    block = std::move(res);
+}
+
+/// the same as ONE processor standing where the chain of JoiningTransforms stood
+class GpuJoinChainTransform : public ISimpleTransform
+{
+public:
+    explicit GpuJoinChainTransform(std::vector<JoinChainStep> steps_) : steps(std::move(steps_)) {}
+    std::string getName() const override { return "GpuJoinChainTransform"; }
+
+protected:
+    void transform(Chunk & chunk) override
+    {
+        joinBlockChain(steps, chunk);
+        if (chunk.num_rows == 0)
+            chunk.clear(); // (an empty chunk is not forwarded: ISimpleTransform.cpp:101-107)
+    }
+
+private:
+    std::vector<JoinChainStep> steps;
 };
 
 /// FillingRightJoinSideTransform + JoiningTransform (JoiningTransform.cpp:176-260, 347-357)

@@ -517,6 +517,98 @@ int main(int argc, char ** argv)
             }
         }
 
+        // ---- a star join (SSB Q4.1's shape in small): fact rows through two semi joins and two payload joins, once as the chain of
+        //      JoiningTransforms (one joinBlock + block.filter per join) and once as ONE GpuJoinChainTransform (late materialisation);
+        //      both feed the same GROUP BY and must agree row for row -------------------------------------------------------------
+        {
+            const size_t fact_rows = std::max<size_t>(n, 1500000), D1 = 20000, D2 = 30000, D3 = 300000, D4 = 400;
+            std::vector<uint32_t> f1(fact_rows), f2(fact_rows), f3(fact_rows), f4(fact_rows), rev(fact_rows);
+            uint64_t y = 0x9E3779B97F4A7C15ull;
+            auto next = [&] { y ^= y << 13; y ^= y >> 7; y ^= y << 17; return y; };
+            for (size_t i = 0; i < fact_rows; ++i)
+            {
+                f1[i] = 1 + next() % D1; f2[i] = 1 + next() % D2; f3[i] = 1 + next() % D3; f4[i] = 19920101 + next() % D4; rev[i] = next() % 1000000;
+            }
+            auto dim_keys = [&](size_t domain, uint32_t base, uint32_t keep_of, uint32_t keep) {
+                std::vector<uint32_t> kk;
+                for (uint32_t v = 0; v < domain; ++v)
+                    if ((v * 2654435761u >> 7) % keep_of < keep)
+                        kk.push_back(base + v);
+                return kk;
+            };
+            const auto k1 = dim_keys(D1, 1, 5, 1), k2 = dim_keys(D2, 1, 5, 2), k3 = dim_keys(D3, 1, 5, 1), k4 = dim_keys(D4, 19920101, 1, 1);
+            std::vector<uint8_t> nation(k3.size());
+            std::vector<uint32_t> year(k4.size());
+            for (size_t i = 0; i < k3.size(); ++i) nation[i] = static_cast<uint8_t>(k3[i] % 25);
+            for (size_t i = 0; i < k4.size(); ++i) year[i] = 1992 + static_cast<uint32_t>(i / 366);
+            // (addBlockToJoin keeps every column of the right Block as the right payload, the key included)
+            auto build = [&](int kind, int strictness, const std::vector<uint32_t> & kk, ColumnPtr payload) {
+                auto j = std::make_shared<GpuHashJoin>(ctx, CHGPU_U32, kind, strictness);
+                Chunk b;
+                b.columns = {ColumnVector::fromHost<uint32_t>(ctx, kk.data(), kk.size())};
+                if (payload)
+                    b.columns.push_back(payload);
+                b.num_rows = kk.size();
+                j->addBlockToJoin(b, 0);
+                j->onBuildPhaseFinish();
+                return j;
+            };
+            Chunk fact;
+            fact.columns = {ColumnVector::fromHost<uint32_t>(ctx, f1.data(), fact_rows), ColumnVector::fromHost<uint32_t>(ctx, f2.data(), fact_rows),
+                            ColumnVector::fromHost<uint32_t>(ctx, f3.data(), fact_rows), ColumnVector::fromHost<uint32_t>(ctx, f4.data(), fact_rows),
+                            ColumnVector::fromHost<uint32_t>(ctx, rev.data(), fact_rows)};
+            fact.num_rows = fact_rows;
+            auto run = [&](bool chain) {
+                auto j1 = build(CHGPU_JOIN_LEFT, CHGPU_STRICT_SEMI, k1, nullptr);
+                auto j2 = build(CHGPU_JOIN_LEFT, CHGPU_STRICT_SEMI, k2, nullptr);
+                auto j3 = build(CHGPU_JOIN_INNER, CHGPU_STRICT_ALL, k3, ColumnVector::fromHost<uint8_t>(ctx, nation.data(), nation.size()));
+                auto j4 = build(CHGPU_JOIN_INNER, CHGPU_STRICT_ALL, k4, ColumnVector::fromHost<uint32_t>(ctx, year.data(), year.size()));
+                Chunk c = fact;
+                if (chain)
+                {
+                    GpuJoinChainTransform t({{j1, 0}, {j2, 1}, {j3, 2}, {j4, 3}});
+                    t.setInput(c);
+                    t.work();
+                    c = t.hasOutput() ? t.pullOutput() : Chunk{};
+                }
+                else
+                {
+                    std::shared_ptr<Chunk> rest;
+                    j1->joinBlock(c, 0, rest);
+                    j2->joinBlock(c, 1, rest);
+                    j3->joinBlock(c, 2, rest);
+                    j4->joinBlock(c, 3, rest);
+                }
+                return c;
+            };
+            Chunk a_chain = run(true), a_each = run(false);
+            REQUIRE(a_chain.num_rows == a_each.num_rows && a_chain.num_rows > 0);
+            REQUIRE(a_chain.columns.size() == a_each.columns.size());
+            // SEMI joins built through addBlockToJoin carry their key column as payload too; every column must agree
+            for (size_t c = 0; c < a_chain.columns.size(); ++c)
+            {
+                REQUIRE(a_chain.columns[c]->getDataType() == a_each.columns[c]->getDataType());
+                if (a_chain.columns[c]->getDataType() == CHGPU_U32)
+                    REQUIRE(a_chain.columns[c]->getData<uint32_t>() == a_each.columns[c]->getData<uint32_t>());
+                else
+                    REQUIRE(a_chain.columns[c]->getData<uint8_t>() == a_each.columns[c]->getData<uint8_t>());
+            }
+            // and against the host: the rows whose four keys are all present
+            auto has = [](const std::vector<uint32_t> & kk, uint32_t v) { return std::binary_search(kk.begin(), kk.end(), v); };
+            uint64_t want_rows = 0, want_rev = 0;
+            for (size_t i = 0; i < fact_rows; ++i)
+                if (has(k1, f1[i]) && has(k2, f2[i]) && has(k3, f3[i]) && has(k4, f4[i]))
+                {
+                    ++want_rows;
+                    want_rev += rev[i];
+                }
+            REQUIRE(a_chain.num_rows == want_rows);
+            uint64_t got_rev = 0;
+            for (auto v : a_chain.columns[4]->getData<uint32_t>())
+                got_rev += v;
+            REQUIRE(got_rev == want_rev);
+        }
+
         // ---- FULL JOIN: the LEFT probe + used flags, then getNonJoinedBlocks ------------------------------------------------
         {
             auto full = std::make_shared<GpuHashJoin>(ctx, CHGPU_U64, CHGPU_JOIN_FULL, CHGPU_STRICT_ALL);
