@@ -12,6 +12,6 @@ from .expression import ActionsDAG, ExpressionActions
 from .lowcardinality import ColumnString, ColumnLowCardinality, LowCardinalityAggregator, LowCardinalityDictionary, PackedKeysAggregator
 from .hashjoin import HashJoin, join_probe_chain
 from .merging import AggregatedBlock, MergingAggregatedMemoryEfficientTransform
-from .keysfixed import KeyDict, KeysFixedAggregator, KeysFixedHashJoin
+from .keysfixed import KeyDict, KeysFixedAggregator, KeysFixedHashJoin, ColumnFixedString, FixedStringAggregator
 
 __all__ = [n for n in dir() if not n.startswith("_")]

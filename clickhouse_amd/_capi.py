@@ -111,6 +111,8 @@ SIGNATURES = {
     "chgpu_native_walk_block": (_i, [_vp, _u64, _u64, _u32, _vp, C.POINTER(_u32), _pu64, C.POINTER(C.c_int32), C.POINTER(_i), _pu64]),
     "chgpu_agg_serialize_states": (_i, [_vp, _i, _vp, _vp, _pp, _pp]),
     "chgpu_agg_deserialize_states": (_i, [_vp, _i, _vp, _u32, _pu64, _pu64, _pp, _pp]),
+    "chgpu_fixed_string_word": (_i, [_vp, _vp, _u32, _u32, _pp]),
+    "chgpu_fixed_string_from_words": (_i, [_vp, _u32, _pp, _u32, _pp]),
     "chgpu_keydict_create": (_i, [_vp, _u32, _u64, _pp]),
     "chgpu_keydict_encode": (_i, [_vp, _u32, _pp, _u64, _u64, _i, _pp]),
     "chgpu_keydict_size": (_i, [_vp, _pu64]),

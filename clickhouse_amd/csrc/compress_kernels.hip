@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void k_lz4_decode(const u8 * __restrict__ src,
         const u8 * in = src + uni64(job.src_off);
         u8 * out = (uni(job.post) ? dst_stage : dst_out) + uni64(job.dst_off);
         const u32 isz = uni(job.src_size), osz = uni(job.dst_size);
-        if (uni(job.method) == 0x93u || uni(job.method) == 0x94u)
-            continue; // T64 / DoubleDelta frames: k_t64_decode / k_double_delta_decode
+        if (uni(job.method) == 0x93u || uni(job.method) == 0x94u || uni(job.method) == 0x95u)
+            continue; // T64 / DoubleDelta / Gorilla frames: k_t64_decode / k_double_delta_decode / k_gorilla_decode
         if (uni(job.method) == 0x02u)
         {
             if (isz != osz)
@@ -646,6 +646,85 @@ __global__ __launch_bounds__(64) void k_double_delta_decode(const u8 * __restric
     }
 }
 
+// CODEC(Gorilla) (src/Compression/CompressionCodecGorilla.cpp:268-330): [width][bytes_to_skip][skipped][items u32][first value] and a bit
+// stream of XOR differences -- 0: the value repeats | 10: the meaningful bits, inside the previous window of leading / trailing zeros |
+// 11: leading zeros (W - 1 bits), length (W bits), the meaningful bits; W = 4 / 5 / 6 / 7 for 1 / 2 / 4 / 8-byte values.  Like DoubleDelta
+// a front-to-back code: one lane per frame.
+__global__ __launch_bounds__(64) void k_gorilla_decode(const u8 * __restrict__ src, u8 * __restrict__ dst_out, const FrameJob * __restrict__ jobs, u32 n_jobs, u32 * __restrict__ err)
+{
+    const u32 j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= n_jobs)
+        return;
+    const FrameJob job = jobs[j];
+    if (job.method != 0x95u)
+        return;
+    const u8 * in = src + job.src_off;
+    u8 * out = dst_out + job.dst_off;
+    const u32 isz = job.src_size, osz = job.dst_size;
+    if (isz < 2)
+    {
+        atomicOr(err, 32u);
+        return;
+    }
+    const u32 width = in[0], skip = in[1];
+    if (!(width == 1 || width == 2 || width == 4 || width == 8) || skip >= width || skip > osz || 2 + skip > isz)
+    {
+        atomicOr(err, 32u);
+        return;
+    }
+    for (u32 k = 0; k < skip; ++k)
+        out[k] = in[2 + k];
+    const u32 X = 8 * width, DBL = width == 1 ? 4u : width == 2 ? 5u : width == 4 ? 6u : 7u, LZL = DBL - 1;
+    const u8 * s = in + 2 + skip, * s_end = in + isz;
+    u8 * d = out + skip;
+    if (s + 4 > s_end)
+        return;
+    u32 items;
+    __builtin_memcpy(&items, s, 4);
+    s += 4;
+    if (s + width > s_end || items < 1)
+        return;
+    if ((u64)items * width > osz - skip)
+    {
+        atomicOr(err, 32u);
+        return;
+    }
+    const u64 M = width == 8 ? ~0ull : ((1ull << X) - 1);
+    u64 prev = 0;
+    __builtin_memcpy(&prev, s, width);
+    __builtin_memcpy(d, &prev, width);
+    s += width;
+    d += width;
+    DdReader r{s, s_end, 0, 0};
+    u32 p_lz = 0, p_db = 0, p_tz = 0;
+    for (u32 read = 1; read < items && !r.eof(); ++read)
+    {
+        u64 cur = prev;
+        u32 lz = p_lz, db = p_db, tz = p_tz;
+        if (r.read32(1) == 1)
+        {
+            if (r.read32(1) == 1)
+            {
+                lz = (u32)r.read32(LZL);
+                db = (u32)r.read32(DBL);
+                tz = (X - lz - db) & 0xFFu; // (UInt8 arithmetic in the reference: a corrupted length wraps there too)
+            }
+            if (lz == 0 && db == 0 && tz == 0)
+            {
+                atomicOr(err, 32u);
+                return;
+            }
+            u64 x = db > 64 ? 0 : (db == 64 ? ((r.read32(32) << 32) | r.read32(32)) : r.read(db));
+            x = tz >= 64 ? 0 : x << tz;
+            cur = (prev ^ x) & M;
+        }
+        __builtin_memcpy(d, &cur, width);
+        d += width;
+        p_lz = lz, p_db = db, p_tz = tz;
+        prev = cur;
+    }
+}
+
 /* Decompress n_frames frames of `compressed_u8` into one new UInt8 column of sum(decompressed_sizes) bytes.  Host arrays describe the
    frames: payload offset / size inside compressed_u8 and method byte of the (last applied) general-purpose stage, its output size
    (stage_sizes; NULL = decompressed_sizes) and, for CODEC(Delta, LZ4), post_methods[f] = 0x92 (NULL / 0 = single stage).
@@ -660,13 +739,14 @@ extern "C" int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compre
     CHGPU_REQUIRE(n_frames == 0 || (payload_offsets && payload_sizes && decompressed_sizes && methods), CHGPU_ERR_BAD_ARGUMENTS, "NULL frame arrays");
     std::vector<FrameJob> jobs(n_frames);
     u64 total = 0, stage_total = 0;
-    u32 n_t64 = 0, n_dd = 0;
+    u32 n_t64 = 0, n_dd = 0, n_gor = 0;
     for (u32 f = 0; f < n_frames; ++f)
     {
-        CHGPU_REQUIRE(methods[f] == 0x82 || methods[f] == 0x02 || methods[f] == 0x93 || methods[f] == 0x94, CHGPU_ERR_NOT_IMPLEMENTED,
+        CHGPU_REQUIRE(methods[f] == 0x82 || methods[f] == 0x02 || methods[f] == 0x93 || methods[f] == 0x94 || methods[f] == 0x95, CHGPU_ERR_NOT_IMPLEMENTED,
                       "compression method 0x%02x: CPU path", methods[f]);
         n_t64 += methods[f] == 0x93;
         n_dd += methods[f] == 0x94;
+        n_gor += methods[f] == 0x95;
         CHGPU_REQUIRE(payload_offsets[f] + payload_sizes[f] <= compressed_u8->rows, CHGPU_ERR_BAD_ARGUMENTS, "frame %u lies outside the compressed buffer", f);
         const u32 post = post_methods ? post_methods[f] : 0;
         CHGPU_REQUIRE(post == 0 || post == 0x92, CHGPU_ERR_NOT_IMPLEMENTED, "codec 0x%02x in front of the general-purpose stage: CPU path", post);
@@ -731,6 +811,12 @@ extern "C" int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compre
             {
                 hipLaunchKernelGGL(k_double_delta_decode, dim3((n_frames + 63) / 64), dim3(64), 0, ctx->stream, (const u8 *)compressed_u8->data, (u8 *)res->data, (const FrameJob *)jd,
                                    n_frames, err);
+                ctx->counters[6] += 1;
+            }
+            if (n_gor)
+            {
+                hipLaunchKernelGGL(k_gorilla_decode, dim3((n_frames + 63) / 64), dim3(64), 0, ctx->stream, (const u8 *)compressed_u8->data, (u8 *)res->data, (const FrameJob *)jd, n_frames,
+                                   err);
                 ctx->counters[6] += 1;
             }
             if (stage_total)

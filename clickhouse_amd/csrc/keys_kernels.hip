@@ -236,3 +236,91 @@ extern "C" int chgpu_lc_remap(chgpu_ctx * ctx, const chgpu_col * indexes, const 
     *out_u32 = res;
     return CHGPU_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// FixedString(N) keys (ColumnFixedString: rows x N bytes, src/Columns/ColumnFixedString.h; AggregatedDataVariants::key_fixed_string,
+// AggregatedDataVariants.h:65-66,91-92 / HashJoin's key_fixed_string).  A FixedString value is N raw bytes, padding zeros included, so
+// it IS a fixed-width key: its 8-byte words (little endian, zero padded past N) go where the other fixed keys go -- one UInt64 key for
+// N <= 8 (key64), keys128 / keys256 through the key dictionary for N <= 32.  Two values are equal iff their words are.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fixed_string_word(const u8 * __restrict__ chars, u64 rows, u32 n, u32 word, u64 * __restrict__ out)
+{
+    const u32 lo = word * 8, cnt = n - lo < 8 ? n - lo : 8;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < rows; i += (u64)gridDim.x * 256)
+    {
+        const u8 * p = chars + i * n + lo;
+        u64 v = 0;
+        for (u32 b = 0; b < cnt; ++b)
+            v |= (u64)p[b] << (8 * b);
+        out[i] = v;
+    }
+}
+
+struct FsWords
+{
+    const u64 * w[4];
+};
+__global__ __launch_bounds__(256) void k_fixed_string_from_words(FsWords words, u64 rows, u32 n, u8 * __restrict__ chars)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < rows; i += (u64)gridDim.x * 256)
+        for (u32 b = 0; b < n; ++b)
+            chars[i * n + b] = (u8)(words.w[b >> 3][i] >> (8 * (b & 7)));
+}
+
+extern "C" int chgpu_fixed_string_word(chgpu_ctx * ctx, const chgpu_col * chars_u8, uint32_t n, uint32_t word_index, chgpu_col ** out_u64)
+{
+    ChgpuDeviceGuard _dev_guard(ctx);
+    CHGPU_REQUIRE(ctx && chars_u8 && out_u64, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(chars_u8->type == CHGPU_U8, CHGPU_ERR_BAD_ARGUMENTS, "FixedString chars are a UInt8 column");
+    CHGPU_REQUIRE(n >= 1 && n <= 32, CHGPU_ERR_NOT_IMPLEMENTED, "FixedString(%u) key: beyond keys256, CPU path", n);
+    CHGPU_REQUIRE(chars_u8->rows % n == 0, CHGPU_ERR_SIZES_MISMATCH, "FixedString chars (%llu bytes) are not a multiple of N = %u", (unsigned long long)chars_u8->rows, n);
+    CHGPU_REQUIRE(word_index * 8 < n, CHGPU_ERR_BAD_ARGUMENTS, "word %u lies beyond FixedString(%u)", word_index, n);
+    const u64 rows = chars_u8->rows / n;
+    chgpu_col * out = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U64, rows, &out));
+    if (rows)
+    {
+        hipLaunchKernelGGL(k_fixed_string_word, dim3(chgpu_grid_for(ctx, rows, 256, 8)), dim3(256), 0, ctx->stream, (const u8 *)chars_u8->data, rows, n, word_index, (u64 *)out->data);
+        ctx->counters[6] += 1;
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+        {
+            chgpu_col_free(out);
+            return chgpu_set_error(CHGPU_ERR_DEVICE, "fixed_string_word: %s", hipGetErrorString(e));
+        }
+    }
+    *out_u64 = out;
+    return CHGPU_OK;
+}
+
+extern "C" int chgpu_fixed_string_from_words(chgpu_ctx * ctx, uint32_t n_words, const chgpu_col * const * words_u64, uint32_t n, chgpu_col ** chars_u8)
+{
+    ChgpuDeviceGuard _dev_guard(ctx);
+    CHGPU_REQUIRE(ctx && words_u64 && chars_u8, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    CHGPU_REQUIRE(n >= 1 && n <= 32 && n_words == (n + 7) / 8, CHGPU_ERR_BAD_ARGUMENTS, "FixedString(%u) takes %u words, %u given", n, (n + 7) / 8, n_words);
+    FsWords fw{};
+    u64 rows = 0;
+    for (u32 w = 0; w < n_words; ++w)
+    {
+        CHGPU_REQUIRE(words_u64[w] && chgpu_type_size(words_u64[w]->type) == 8, CHGPU_ERR_BAD_ARGUMENTS, "word column %u must be 8 bytes wide", w);
+        CHGPU_REQUIRE(w == 0 || words_u64[w]->rows == rows, CHGPU_ERR_SIZES_MISMATCH, "word columns differ in length");
+        rows = words_u64[w]->rows;
+        fw.w[w] = (const u64 *)words_u64[w]->data;
+    }
+    chgpu_col * out = nullptr;
+    CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U8, rows * n, &out));
+    if (rows)
+    {
+        hipLaunchKernelGGL(k_fixed_string_from_words, dim3(chgpu_grid_for(ctx, rows, 256, 8)), dim3(256), 0, ctx->stream, fw, rows, n, (u8 *)out->data);
+        ctx->counters[6] += 1;
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+        {
+            chgpu_col_free(out);
+            return chgpu_set_error(CHGPU_ERR_DEVICE, "fixed_string_from_words: %s", hipGetErrorString(e));
+        }
+    }
+    *chars_u8 = out;
+    return CHGPU_OK;
+}

@@ -121,3 +121,72 @@ class KeysFixedHashJoin:
 
     def probe_count_sum(self, key_cols, payload=None):
         return self.join.probe_count_sum(self.dict.encode(key_cols, False), payload)
+
+
+class ColumnFixedString:
+    """ColumnFixedString (src/Columns/ColumnFixedString.h): `chars` = rows x n raw bytes in HBM."""
+
+    def __init__(self, chars: Column, n: int):
+        assert chars.size() % n == 0
+        self.chars, self.n, self.ctx = chars, n, chars.ctx
+
+    @classmethod
+    def from_numpy(cls, ctx: Context, values: np.ndarray):
+        """values: an array of dtype 'S<n>' (numpy pads with zero bytes exactly like FixedString)"""
+        values = np.ascontiguousarray(values)
+        assert values.dtype.kind == "S"
+        return cls(ctx.upload(values.view(np.uint8).reshape(-1)), values.dtype.itemsize)
+
+    def size(self):
+        return self.chars.size() // self.n
+
+    @property
+    def n_words(self):
+        return (self.n + 7) // 8
+
+    def words(self):
+        """the value's 8-byte words as UInt64 Columns (chgpu_fixed_string_word)"""
+        out = []
+        for w in range(self.n_words):
+            h = C.c_void_p()
+            K.check(K.lib().chgpu_fixed_string_word(self.ctx._live(), self.chars._h, self.n, w, C.byref(h)))
+            out.append(Column(self.ctx, h))
+        return out
+
+    @classmethod
+    def from_words(cls, ctx: Context, words, n: int):
+        ptrs = (C.c_void_p * len(words))(*[w._h for w in words])
+        h = C.c_void_p()
+        K.check(K.lib().chgpu_fixed_string_from_words(ctx._live(), len(words), ptrs, n, C.byref(h)))
+        return cls(Column(ctx, h), n)
+
+    def numpy(self):
+        return self.chars.numpy().view(f"S{self.n}")
+
+
+class FixedStringAggregator:
+    """GROUP BY one FixedString(N) key (AggregatedDataVariants::key_fixed_string): N <= 8 -> the UInt64 aggregator over the value's single
+    word, N <= 32 -> keys128 / keys256 over its words."""
+
+    def __init__(self, n: int, aggs, size_hint: int = 0, ctx: Context | None = None):
+        self.ctx = ctx if ctx is not None else Context(0)
+        self.n = n
+        if n > 32:
+            raise K.ChgpuError(K.ERR_NOT_IMPLEMENTED, f"FixedString({n}) key: beyond keys256, CPU path")
+        self.wide = n > 8
+        self.inner = (KeysFixedAggregator([np.uint64] * ((n + 7) // 8), aggs, size_hint, self.ctx) if self.wide
+                      else Aggregator(np.uint64, aggs, size_hint=size_hint, ctx=self.ctx))
+
+    def execute_on_block(self, key: ColumnFixedString, args):
+        assert key.n == self.n
+        words = key.words()
+        self.inner.execute_on_block(words if self.wide else words[0], args)
+
+    def __len__(self):
+        return len(self.inner)
+
+    def convert_to_block(self):
+        """-> (keys as an 'S<n>' ndarray, [result ndarrays])"""
+        keys, res = self.inner.finalize_columns()
+        words = keys if self.wide else [keys]
+        return ColumnFixedString.from_words(self.ctx, words, self.n).numpy(), [r.numpy() for r in res]

@@ -377,6 +377,12 @@ int chgpu_partition_by_hash(chgpu_ctx * ctx, const chgpu_col * keys, uint32_t nu
    inverse used when the key column(s) of the result block are produced (insertKeyIntoColumns). */
 int chgpu_pack_fixed_keys(chgpu_ctx * ctx, uint32_t n_cols, const chgpu_col * const * cols, chgpu_col ** packed_u64);
 int chgpu_unpack_fixed_key(chgpu_ctx * ctx, const chgpu_col * packed_u64, uint32_t byte_offset, int type, chgpu_col ** out);
+/* FixedString(N) keys (ColumnFixedString: rows x N raw bytes, src/Columns/ColumnFixedString.h; AggregatedDataVariants::key_fixed_string,
+   AggregatedDataVariants.h:65-66,91-92; HashJoin key_fixed_string).  A value is N bytes, padding zeros included: a fixed-width key.  Word w =
+   bytes [8w, 8w + 8) of every value as one UInt64 (little endian, zero padded past N): N <= 8 -> the ordinary UInt64 key (key64), N <= 32 ->
+   keys128 / keys256 (chgpu_keydict_*).  chgpu_fixed_string_from_words is insertKeyIntoColumns: words -> chars.  N > 32 -> NOT_IMPLEMENTED. */
+int chgpu_fixed_string_word(chgpu_ctx * ctx, const chgpu_col * chars_u8, uint32_t n, uint32_t word_index, chgpu_col ** out_u64);
+int chgpu_fixed_string_from_words(chgpu_ctx * ctx, uint32_t n_words, const chgpu_col * const * words_u64, uint32_t n, chgpu_col ** chars_u8);
 /* a15 keys128 / keys256: several fixed-width key columns that pack into more than 8 bytes (AggregatedDataVariants.h:70-71,83-84:
    HashMap<UInt128 / UInt256, ...>; HashMethodKeysFixed, src/Common/ColumnsHashing/HashMethod.h:236-410; packFixed,
    AggregationCommon.h:91-158; the same maps under HashJoin, HashJoin.h:267-358).  A chgpu_keydict is a device-resident, exact dictionary

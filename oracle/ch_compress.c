@@ -590,3 +590,104 @@ int cho_t64_decode(const uint8_t * src, size_t src_size, uint8_t * dst, size_t d
     }
     return 0;
 }
+
+/* ---- Gorilla (src/Compression/CompressionCodecGorilla.cpp:196-330): [width][bytes_to_skip][skipped][items u32][first value] and a bit
+ * stream of XOR differences: 0 = same value | 10 + the meaningful bits inside the PREVIOUS window of leading / trailing zeros | 11 +
+ * leading zeros (W - 1 bits) + length (W bits) + the meaningful bits, W = 4 / 5 / 6 / 7 for 1 / 2 / 4 / 8-byte values.  Pinned by the worked
+ * example in the codec's documentation comment (:58-104, tests/golden/codec_kat.json); the reference ships no compatibility vectors. ---- */
+static unsigned gorilla_len_bits(unsigned width) { return width == 1 ? 4 : width == 2 ? 5 : width == 4 ? 6 : 7; }
+
+long cho_gorilla_encode(const uint8_t * src, size_t src_size, unsigned width, uint8_t * dst, size_t dst_cap)
+{
+    if (!(width == 1 || width == 2 || width == 4 || width == 8)) return -1;
+    const unsigned skip = (unsigned)(src_size % width), X = 8 * width, DBL = gorilla_len_bits(width), LZL = DBL - 1;
+    if (dst_cap < 2 + skip + 4 + (size_t)width + 16) return -1;
+    dst[0] = (uint8_t)width;
+    dst[1] = (uint8_t)skip;
+    memcpy(dst + 2, src, skip);
+    uint8_t * d = dst + 2 + skip;
+    const uint8_t * s = src + skip, * s_end = src + src_size;
+    const uint32_t items = (uint32_t)((src_size - skip) / width);
+    memcpy(d, &items, 4);
+    d += 4;
+    uint64_t prev = 0;
+    unsigned p_lz = 0, p_db = 0, p_tz = 0;
+    if (s < s_end) { prev = dd_load(s, width); dd_store(d, width, prev); s += width; d += width; }
+    cho_bitw w = {d, dst + dst_cap, 0, 0, 0};
+    for (; s < s_end; s += width)
+    {
+        const uint64_t cur = dd_load(s, width), x = cur ^ prev;
+        if (x == 0)
+            bw_write(&w, 1, 0);
+        else
+        {
+            const unsigned lz = (unsigned)__builtin_clzll(x) - (64 - X), tz = (unsigned)__builtin_ctzll(x), db = X - lz - tz;
+            if (p_db != 0 && p_lz <= lz && p_tz <= tz)
+            {
+                bw_write(&w, 2, 2);
+                bw_write(&w, p_db, x >> p_tz);
+            }
+            else
+            {
+                bw_write(&w, 2, 3);
+                bw_write(&w, LZL, lz);
+                bw_write(&w, DBL, db);
+                bw_write(&w, db, x >> tz);
+                p_lz = lz; p_db = db; p_tz = tz;
+            }
+        }
+        prev = cur;
+    }
+    bw_finish(&w);
+    if (w.overflow) return -1;
+    return (long)(w.cur - dst);
+}
+
+int cho_gorilla_decode(const uint8_t * src, size_t src_size, uint8_t * dst, size_t dst_size)
+{
+    if (src_size < 2) return -1;
+    const unsigned width = src[0], skip = src[1];
+    if (!(width == 1 || width == 2 || width == 4 || width == 8)) return -1;
+    if (skip > dst_size || 2 + (size_t)skip > src_size) return -1;
+    memcpy(dst, src + 2, skip);
+    const unsigned X = 8 * width, DBL = gorilla_len_bits(width), LZL = DBL - 1;
+    const uint8_t * s = src + 2 + skip, * s_end = src + src_size;
+    uint8_t * d = dst + skip;
+    const size_t room = dst_size - skip;
+    if (s + 4 > s_end) return 0;
+    uint32_t items;
+    memcpy(&items, s, 4);
+    s += 4;
+    if (s + width > s_end || items < 1) return 0;
+    if ((uint64_t)items * width > room) return -1;
+    uint64_t prev = dd_load(s, width);
+    dd_store(d, width, prev);
+    s += width; d += width;
+    cho_bitr r = {s, s_end, 0, 0};
+    unsigned p_lz = 0, p_db = 0, p_tz = 0;
+    const uint64_t M = dd_mask(width);
+    for (uint32_t read = 1; read < items && !br_eof(&r); ++read)
+    {
+        uint64_t cur = prev;
+        unsigned lz = p_lz, db = p_db, tz = p_tz;
+        if (br_read(&r, 1) == 1)
+        {
+            if (br_read(&r, 1) == 1)
+            {
+                lz = (unsigned)br_read(&r, LZL);
+                db = (unsigned)br_read(&r, DBL);
+                tz = X - lz - db; /* (UInt8 arithmetic in the reference: a corrupted length wraps there too) */
+                tz &= 0xFF;
+            }
+            if (lz == 0 && db == 0 && tz == 0) return -1;
+            uint64_t x = db > 64 ? 0 : br_read(&r, db);
+            x = tz >= 64 ? 0 : x << tz;
+            cur = (prev ^ x) & M;
+        }
+        dd_store(d, width, cur);
+        d += width;
+        p_lz = lz; p_db = db; p_tz = tz;
+        prev = cur;
+    }
+    return 0;
+}

@@ -21,7 +21,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 METHOD_NONE, METHOD_LZ4, METHOD_DELTA, METHOD_MULTIPLE = 0x02, 0x82, 0x92, 0x91
-METHOD_T64, METHOD_DOUBLE_DELTA = 0x93, 0x94  # CompressionInfo.h:40-51
+METHOD_T64, METHOD_DOUBLE_DELTA, METHOD_GORILLA = 0x93, 0x94, 0x95  # CompressionInfo.h:40-51
 DELTA_LZ4 = "delta+lz4"  # CODEC(Delta(w), LZ4)
 HEADER = 9
 CHECKSUM = 16
@@ -35,12 +35,14 @@ def lib():
         if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "ch_compress.c")):
             subprocess.check_call(["make", "-C", _HERE, "libchcompress.so"])
         L = C.CDLL(so)
-        for name in ("cho_lz4_decompress", "cho_delta_decode", "cho_double_delta_decode", "cho_t64_decode"):
+        for name in ("cho_lz4_decompress", "cho_delta_decode", "cho_double_delta_decode", "cho_t64_decode", "cho_gorilla_decode"):
             fn = getattr(L, name)
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.cho_double_delta_encode.restype = C.c_long
         L.cho_double_delta_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_size_t]
+        L.cho_gorilla_encode.restype = C.c_long
+        L.cho_gorilla_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_size_t]
         L.cho_t64_encode.restype = C.c_long
         L.cho_t64_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_int, C.c_uint, C.c_int, C.c_void_p, C.c_size_t]
         L.cho_city_hash128.restype = None
@@ -80,6 +82,25 @@ def double_delta_encode(raw: bytes, width: int) -> bytes:
     cap = 2 + width + 4 + 2 * width + (len(raw) // width) * 9 + 64
     dst = np.zeros(cap, dtype=np.uint8)
     n = lib().cho_double_delta_encode(src.ctypes.data, src.shape[0], width, dst.ctypes.data, cap)
+    if n < 0:
+        raise ValueError("CANNOT_COMPRESS")
+    return dst[:n].tobytes()
+
+
+def gorilla_decode(payload: bytes, dst_size: int) -> bytes:
+    src = np.frombuffer(payload, dtype=np.uint8)
+    dst = np.zeros(dst_size, dtype=np.uint8)
+    if lib().cho_gorilla_decode(src.ctypes.data, src.shape[0], dst.ctypes.data, dst_size) != 0:
+        raise ValueError("CANNOT_DECOMPRESS")
+    return dst.tobytes()
+
+
+def gorilla_encode(raw: bytes, width: int) -> bytes:
+    """CompressionCodecGorilla::doCompressData -> the codec payload"""
+    src = np.frombuffer(raw, dtype=np.uint8)
+    cap = 2 + width + 4 + width + (len(raw) // width) * (2 + 13 + 8 * width) // 8 + 64
+    dst = np.zeros(cap, dtype=np.uint8)
+    n = lib().cho_gorilla_encode(src.ctypes.data, src.shape[0], width, dst.ctypes.data, cap)
     if n < 0:
         raise ValueError("CANNOT_COMPRESS")
     return dst[:n].tobytes()
@@ -142,7 +163,8 @@ def write_codec_frames(values: np.ndarray, method: int, block_rows: int = 8192, 
     for lo in range(0, values.shape[0], block_rows):
         chunk = values[lo:lo + block_rows]
         raw = chunk.tobytes()
-        payload = double_delta_encode(raw, values.dtype.itemsize) if method == METHOD_DOUBLE_DELTA else t64_encode(chunk, t64_bit)
+        payload = (double_delta_encode(raw, values.dtype.itemsize) if method == METHOD_DOUBLE_DELTA else gorilla_encode(raw, values.dtype.itemsize)
+                   if method == METHOD_GORILLA else t64_encode(chunk, t64_bit))
         out += _framed(_stage(method, payload, len(raw)))
     return bytes(out)
 
@@ -196,6 +218,8 @@ def read_frames(buf: bytes) -> bytes:
             out += double_delta_decode(payload, dsize)
         elif method == METHOD_T64:
             out += t64_decode(payload, dsize)
+        elif method == METHOD_GORILLA:
+            out += gorilla_decode(payload, dsize)
         elif method == METHOD_MULTIPLE:
             out += _multiple_decode(payload, dsize)
         else:

@@ -232,8 +232,10 @@ def make_codec_kat(ref_root):
     assert [v["type"] for v in vectors] == ["Int8", "UInt8", "Int16", "UInt16", "Int32", "UInt32", "Int64", "UInt64"]
     doc = [dict(type="UInt8", values=list(range(1, 11)), payload_hex="0a0000000101" + "00"),
            dict(type="Int16", values=[-10, 10, -20, 20, -40, 40], payload_hex="06000000f6ff1400b8e22eb1e458")]
+    gorilla_doc = [dict(type="Float32", values=[0.1, 0.1, 0.11, 0.2, 0.1], payload_hex="05000000cdcccc3d6a5ad8b63ccd75b16c77000000")]
     with open(os.path.join(HERE, "codec_kat.json"), "w") as f:
-        json.dump(dict(source="src/Compression/tests/gtest_compressionCodec.cpp:1171-1209 (frames: method byte 0x94, compressed size, "
+        json.dump(dict(gorilla_doc_examples=gorilla_doc, gorilla_source="the worked example in src/Compression/CompressionCodecGorilla.cpp:58-104 (payload after "
+                       "[width][bytes_to_skip])", source="src/Compression/tests/gtest_compressionCodec.cpp:1171-1209 (frames: method byte 0x94, compressed size, "
                               "decompressed size, codec payload) and the worked examples in CompressionCodecDoubleDelta.cpp:73-118 "
                               "(payload after [width][bytes_to_skip])",
                        double_delta_frames=vectors, double_delta_doc_examples=doc), f, indent=1)

@@ -438,3 +438,45 @@ def test_gpu_malformed_codec_frames_are_errors_not_faults():
                 assert got.shape[0] == 1000   # a changed byte that still parses must not fault either
             except ch.ChgpuError as e:
                 assert e.code in (ch._capi.ERR_BAD_ARGUMENTS, ch._capi.ERR_NOT_IMPLEMENTED)
+
+
+def test_oracle_gorilla_pinned_by_the_reference_worked_example_and_round_trips():
+    kat = _codec_kat()
+    for ex in kat["gorilla_doc_examples"]:
+        seq = np.array(ex["values"], dtype=np.float32)
+        payload = bytes([4, 0]) + bytes.fromhex(ex["payload_hex"])
+        assert OC.gorilla_encode(seq.tobytes(), 4) == payload
+        assert OC.gorilla_decode(payload, seq.nbytes) == seq.tobytes()
+    rng = np.random.Generator(np.random.PCG64(8))
+    for dt in (np.float32, np.float64, np.uint8, np.uint16, np.uint32, np.uint64):
+        for seq in _gorilla_cases(rng, dt):
+            assert OC.gorilla_decode(OC.gorilla_encode(seq.tobytes(), seq.dtype.itemsize), seq.nbytes) == seq.tobytes()
+
+
+def _gorilla_cases(rng, dt):
+    n = 50_001
+    if np.dtype(dt).kind == "f":
+        return [np.cumsum(rng.random(n)).astype(dt), (rng.random(n) * 1e-3 + 20.0).astype(dt), np.full(n, 1.5).astype(dt),
+                rng.standard_normal(n).astype(dt) * dt(1e30), np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0], dtype=dt)]
+    info = np.iinfo(dt)
+    return [rng.integers(0, 200, size=n).astype(dt), rng.integers(0, info.max, size=n, dtype=np.uint64, endpoint=True).astype(dt), np.array([info.max, 0, info.max, 1], dtype=dt)]
+
+
+@pytest.mark.gpu
+def test_gpu_gorilla_frames_equal_the_oracle_and_the_reference_example():
+    import clickhouse_amd as ch
+    ctx = ch.Context(0)
+    kat = _codec_kat()
+    ex = kat["gorilla_doc_examples"][0]
+    seq = np.array(ex["values"], dtype=np.float32)
+    frame = struct.pack("<BII", OC.METHOD_GORILLA, 9 + 2 + len(bytes.fromhex(ex["payload_hex"])), seq.nbytes) + bytes([4, 0]) + bytes.fromhex(ex["payload_hex"])
+    lo, hi = OC.city_hash128(frame)
+    got = ch.compression.read_column_file(ctx, struct.pack("<QQ", lo, hi) + frame, np.float32).numpy()
+    assert got.tobytes() == seq.tobytes()
+    rng = np.random.Generator(np.random.PCG64(9))
+    for dt in (np.float32, np.float64, np.uint8, np.uint16, np.uint32, np.uint64):
+        for seq in _gorilla_cases(rng, dt):
+            buf = OC.write_codec_frames(seq, OC.METHOD_GORILLA, block_rows=4096)
+            assert OC.read_frames(buf) == seq.tobytes()
+            got = ch.compression.read_column_file(ctx, buf, dt).numpy()
+            assert got.tobytes() == seq.tobytes(), (dt, seq[:4])

@@ -643,3 +643,61 @@ def test_merging_aggregated_transform_over_two_level_exports_and_wire_bytes(ch, 
     assert np.array_equal(keys[o], wk[wo])
     assert np.array_equal(cols[1][o], wr[1][wo]) and np.array_equal(cols[2][o], wr[2][wo])
     assert np.allclose(cols[0][o], wr[0][wo], rtol=1e-12, atol=0)
+
+
+# ---- round 3: FixedString(N) keys (AggregatedDataVariants::key_fixed_string) ---------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 7, 8, 9, 16, 17, 32])
+def test_fixed_string_group_by_matches_oracle(ch, ctx, oracle_mod, n):
+    """GROUP BY one FixedString(N): the value's words are the fixed keys (one UInt64 key for N <= 8, keys128 / keys256 beyond); the oracle groups
+    the same words (Aggregator key64 / its keys128-256 restatement) and both must return every distinct byte string once"""
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(n))
+    rows, distinct = 120_000, 3_000
+    pool = rng.integers(0, 256, size=(distinct, n), dtype=np.uint8)
+    pool[0] = 0                                              # the all-zero value: the zero key of key64 (00134_aggregation_by_fixed_string_of_size_1_2_4_8)
+    pool[1, n // 2:] = 0                                     # trailing zero padding belongs to the value
+    vals = pool[rng.integers(0, distinct, size=rows)]
+    arg = rng.integers(-1000, 1000, size=rows).astype(np.int64)
+    aggs = [(ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)]
+    G = ch.FixedStringAggregator(n, aggs, ctx=ctx)
+    key = ch.ColumnFixedString.from_numpy(ctx, np.ascontiguousarray(vals).view(f"S{n}").reshape(-1))
+    G.execute_on_block(key, [arg, None])
+    gk, (gs, gc) = G.convert_to_block()
+    nw = (n + 7) // 8
+    padded = np.zeros((rows, nw * 8), dtype=np.uint8)
+    padded[:, :n] = vals
+    words = [np.ascontiguousarray(padded[:, 8 * w:8 * w + 8]).view(np.uint64).reshape(-1) for w in range(nw)]
+    if nw == 1:
+        R = O.Aggregator(np.uint64, aggs)
+        R.execute_on_block(words[0], [arg, None])
+        ok, (os_, oc) = R.convert_to_block()
+        okeys = ok.view(np.uint8).reshape(-1, 8)[:, :n]
+    else:
+        R = O.KeysFixedAggregator([np.uint64] * nw, aggs)
+        R.execute_on_block(words, [arg, None])
+        oks, (os_, oc) = R.convert_to_block()
+        okeys = np.concatenate([k.view(np.uint8).reshape(-1, 8) for k in oks], axis=1)[:, :n]
+    got = {bytes(k.ljust(n, b"\0")): (int(s), int(c)) for k, s, c in zip(gk.tolist(), gs, gc)}
+    want = {bytes(k.tobytes()): (int(s), int(c)) for k, s, c in zip(okeys, os_, oc)}
+    assert got == want and len(got) == np.unique(vals, axis=0).shape[0]
+    assert gk.dtype == np.dtype(f"S{n}")
+
+
+def test_fixed_string_reference_rows_00134_and_00128(ch, ctx):
+    """00134: GROUP BY materialize(toFixedString('', N)) over one row -> one group of N zero bytes, N = 1..9.
+    00128: GROUP BY number, FixedString(3) '   ' over 100000 rows -> 100000 groups; ORDER BY n DESC LIMIT 10 starts at 99999."""
+    for n in range(1, 10):
+        G = ch.FixedStringAggregator(n, [(ch.AGG_COUNT, None)], ctx=ctx)
+        G.execute_on_block(ch.ColumnFixedString.from_numpy(ctx, np.zeros(1, dtype=f"S{n}")), [None])
+        gk, (gc,) = G.convert_to_block()
+        assert gk.tolist() == [b""] and gk.view(np.uint8).tolist() == [0] * n and gc.tolist() == [1]     # numpy prints S-values without their padding
+    numbers = np.arange(100_000, dtype=np.uint64)
+    k = np.full(100_000, b"   ", dtype="S3")
+    A = ch.KeysFixedAggregator([np.uint64, np.uint64], [(ch.AGG_COUNT, None)], ctx=ctx)          # keys128: number + the FixedString's word
+    A.execute_on_block([numbers, ch.ColumnFixedString.from_numpy(ctx, k).words()[0]], [None])
+    (kn, kw), (cnt,) = A.convert_to_block()
+    assert kn.shape[0] == 100_000 and (cnt == 1).all() and (kw == int.from_bytes(b"   ", "little")).all()
+    assert sorted(kn.tolist(), reverse=True)[:5] == [99999, 99998, 99997, 99996, 99995]
+    with pytest.raises(ch.ChgpuError) as e:
+        ch.FixedStringAggregator(33, [(ch.AGG_COUNT, None)], ctx=ctx)
+    assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED
