@@ -727,10 +727,11 @@ def config_c5(args, ctx, ch, torch, np, dev, stream, with_cpu):
            "roofline": {"bound": "hbm", "algorithmic_bytes": algo, "achieved": algo / (wall_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
     try:  # the last committed PMC collection of the plan on its own (tools/gpu_pmc_c5.sh), quoted only for the same workload
-        ts = json.load(open(os.path.join(REPO, "profiles", "r02_traffic_ssb.json")))
+        ts = json.load(open(os.path.join(REPO, "profiles", "traffic_ssb.json")))
         if ts.get("algorithmic_bytes") == algo:
             out["roofline"]["traffic"] = ts.get("C5_hbm_bytes_per_run")
-            out["roofline"]["traffic_source"] = "profiles/r02_traffic_ssb.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --only-c5`, tools/gpu_pmc_c5.sh"
+            out["roofline"]["traffic_source"] = (f"profiles/{ts.get('tag', '')}_traffic_ssb.json (= profiles/traffic_ssb.json): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                 "passes of `bench.py --only-c5`, tools/gpu_pmc_c5.sh")
     except Exception:
         pass
     if with_cpu:

@@ -5,7 +5,7 @@
 #   pmc_write_<tag>/  rocprofv3 --pmc WRITE_SIZE   (own pass)
 # Counters are never combined with trace domains other than --kernel-trace (node-stability rule of this pool).
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

@@ -1,6 +1,6 @@
 # HBM traffic of the SSB plan (C5) on its own: FETCH_SIZE and WRITE_SIZE passes of `bench.py --only-c5` (separate runs, --kernel-trace only),
-# summed over the plan's kernels and divided by the number of plan runs.  Run on the GPU box:  gpurun -- 'bash tools/gpu_pmc_c5.sh r02'
-TAG=${1:-r02}
+# summed over the plan's kernels and divided by the number of plan runs.  Run on the GPU box:  gpurun -- 'bash tools/gpu_pmc_c5.sh r03'
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
