@@ -71,6 +71,12 @@ struct AggDesc
     u32 n_words;
     AggArg a[AGG_MAX_AGGS];
     u32 word_is_f64; // bit w set: state word w is Float64
+    // deterministic Float64 sums (see Fx128): bit w set = word w is the LOW half of a 128-bit fixed-point sum whose high half is word
+    // fx_hi[w] (one of the words appended behind the regular ones); values are multiples of 2^fx_base
+    u32 word_fx;
+    u32 word_fx_hi; // the high halves (never updated on their own)
+    unsigned char fx_hi[AGG_MAX_WORDS];
+    int fx_base;
 };
 
 struct AggTable
@@ -98,6 +104,18 @@ struct chgpu_agg
     u64 n_groups = 0; // host copy, refreshed after every call
     bool hint_probed = false; // the cardinality of a hint-less aggregation was sampled on its first large block
     bool has_extremum = false; // some function is min / max: rows take the DIRECT kernel (the LDS-staged plans only know how to add)
+    // deterministic Float64 sums (option deterministic_float_sums, the default): sum / avg over a float argument keep a 128-bit fixed-point
+    // state {word, fx_hi[word]} in units of 2^fx_base instead of a double.  n_words counts the appended high halves too; the first
+    // n_pub_words are the words the C ABI shows (state columns, wire format): exports fold a pair back into its Float64 column.
+    u32 n_pub_words = 0;
+    u32 word_fx = 0, word_fx_hi = 0;
+    unsigned char fx_hi[AGG_MAX_WORDS] = {0};
+    // window invariant: every state is a sum of at most fx_rows values, each below 2^(127 - fx_log_cap) units of 2^fx_base
+    int fx_base = 0;
+    bool fx_base_set = false;
+    u64 fx_rows = 0;
+    int fx_log_cap = 30;
+    int fx_emin = 4096; // smallest (unbiased) exponent among the non-zero values added so far
     u64 host_words[AGG_MAX_WORDS]; // without_key states live on the host (8 B each)
 };
 
@@ -147,6 +165,114 @@ __device__ __forceinline__ void global_add_word(u64 * p, u64 bits, int op)
         __hip_atomic_fetch_add((double *)p, __longlong_as_double((long long)bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
         __hip_atomic_fetch_add((unsigned long long *)p, (unsigned long long)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- deterministic Float64 sums -------------------------------------------------------------------------------------------------
+// A double atomicAdd makes a group's sum depend on the order the hardware happened to serve the rows in (the reference is deterministic
+// for a fixed block split: AggregateFunctionSum.h:72-101 adds in row order).  Integer addition is associative, so the state of sum /
+// avg over a float argument is a two's complement 128-bit integer in units of 2^base instead: every row contributes trunc(x * 2^-base),
+// whatever the order, the plan or the number of workgroups.  base = (largest exponent seen) - 96: the window holds 2^30 rows of the
+// largest magnitude and keeps every bit of values down to 2^-44 of it (2^-20 relative precision down to 2^-76 of it) -- the host widens
+// the window (an arithmetic shift of every state) when a block brings a larger exponent or the row count outgrows the head room.
+// The two halves are separate words: low += x.lo returns the old value, and the adder that sees the wrap carries into the high word --
+// each wrap is seen by exactly one adder, so the pair ends at the exact sum.
+struct Fx128
+{
+    u64 lo, hi;
+};
+__device__ __host__ __forceinline__ Fx128 fx_from_double(u64 bits, int base)
+{
+    const u32 e = (u32)(bits >> 52) & 0x7ffu;
+    u64 m = bits & 0xFFFFFFFFFFFFFull;
+    if (e)
+        m |= 1ull << 52;
+    const int sh = (int)(e ? e : 1u) - 1075 - base; // x = m * 2^(e - 1075)
+    Fx128 r;
+    if (sh >= 64)
+        r.lo = 0, r.hi = sh < 128 ? m << (sh - 64) : 0; // (sh + 53 <= 97 by the choice of base)
+    else if (sh > 0)
+        r.lo = m << sh, r.hi = m >> (64 - sh);
+    else if (sh > -64)
+        r.lo = m >> -sh, r.hi = 0;
+    else
+        r.lo = 0, r.hi = 0;
+    if (bits >> 63)
+    {
+        r.lo = ~r.lo + 1;
+        r.hi = ~r.hi + (r.lo == 0 ? 1 : 0);
+    }
+    return r;
+}
+// the pair as the nearest double (ties to even): the only rounding of the whole sum
+__device__ __host__ __forceinline__ double fx_to_double(u64 lo, u64 hi, int base)
+{
+    const bool neg = (hi >> 63) != 0;
+    if (neg)
+    {
+        lo = ~lo + 1;
+        hi = ~hi + (lo == 0 ? 1 : 0);
+    }
+    if ((lo | hi) == 0)
+        return 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int top = hi ? 127 - __clzll((long long)hi) : 63 - __clzll((long long)lo);
+#else
+    const int top = hi ? 127 - __builtin_clzll(hi) : 63 - __builtin_clzll(lo);
+#endif
+    u64 m;
+    int sh = top - 52; // bits dropped
+    if (sh <= 0)
+        m = lo, sh = 0; // (top <= 52: the magnitude is exact in a double)
+    else
+    {
+        // m = magnitude >> sh, rem = the dropped bits against one half
+        u64 rem_hi, rem_lo; // dropped bits, left-aligned in 128 bits
+        if (sh < 64)
+        {
+            m = (lo >> sh) | (hi << (64 - sh));
+            rem_hi = lo << (64 - sh);
+            rem_lo = 0;
+        }
+        else if (sh == 64)
+        {
+            m = hi;
+            rem_hi = lo;
+            rem_lo = 0;
+        }
+        else
+        {
+            m = hi >> (sh - 64);
+            rem_hi = (hi << (128 - sh)) | (lo >> (sh - 64));
+            rem_lo = lo << (128 - sh);
+        }
+        const u64 half = 1ull << 63;
+        if (rem_hi > half || (rem_hi == half && (rem_lo != 0 || (m & 1))))
+            ++m; // (2^53 is a double too)
+    }
+    const double v = ldexp((double)m, sh + base);
+    return neg ? -v : v;
+}
+__device__ __forceinline__ void global_add_fx(u64 * lo, u64 * hi, Fx128 x)
+{
+    u64 h = x.hi;
+    if (x.lo)
+    {
+        const u64 old = __hip_atomic_fetch_add((unsigned long long *)lo, (unsigned long long)x.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h += (old + x.lo < old) ? 1 : 0;
+    }
+    if (h)
+        __hip_atomic_fetch_add((unsigned long long *)hi, (unsigned long long)h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lds_add_fx(u64 * lo, u64 * hi, Fx128 x)
+{
+    u64 h = x.hi;
+    if (x.lo)
+    {
+        const u64 old = atomicAdd((unsigned long long *)lo, (unsigned long long)x.lo);
+        h += (old + x.lo < old) ? 1 : 0;
+    }
+    if (h)
+        atomicAdd((unsigned long long *)hi, (unsigned long long)h);
 }
 
 // Find-or-claim the cell of `key` (emplace).  Returns the slot, or ~0 when the row must wait for a bigger table.
@@ -248,7 +374,10 @@ __device__ __forceinline__ void add_row_global(const AggTable & t, const AggDesc
         }
         else
         {
-            global_add_word(w, load_arg_bits(a.ptr, a.arg_type, i), a.arg_type == CHGPU_F64 || a.arg_type == CHGPU_F32);
+            if ((d.word_fx >> a.word) & 1)
+                global_add_fx(w, t.words + (u64)d.fx_hi[a.word] * stride + slot, fx_from_double(load_arg_bits(a.ptr, a.arg_type, i), d.fx_base));
+            else
+                global_add_word(w, load_arg_bits(a.ptr, a.arg_type, i), a.arg_type == CHGPU_F64 || a.arg_type == CHGPU_F32);
             if (a.kind == CHGPU_AGG_AVG)
                 global_add_word(w + stride, 1, false); // denominator
         }
@@ -268,7 +397,10 @@ __device__ __forceinline__ void add_vals_global(const AggTable & t, const AggDes
             global_add_word(w, cnt, false);
         else
         {
-            global_add_word(w, a.pre == 0 ? bits0 : bits1, a.arg_type == CHGPU_F64 || a.arg_type == CHGPU_F32);
+            if ((d.word_fx >> a.word) & 1)
+                global_add_fx(w, t.words + (u64)d.fx_hi[a.word] * stride + slot, fx_from_double(a.pre == 0 ? bits0 : bits1, d.fx_base));
+            else
+                global_add_word(w, a.pre == 0 ? bits0 : bits1, a.arg_type == CHGPU_F64 || a.arg_type == CHGPU_F32);
             if (a.kind == CHGPU_AGG_AVG)
                 global_add_word(w + stride, cnt, false); // denominator
         }
@@ -335,7 +467,8 @@ __global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, co
     // per function and row group also drains the wave's LDS queue through lgkmcnt(0) -- see k_agg_part_lds
     const void * a_ptr[AGG_MAX_AGGS];
     int a_kind[AGG_MAX_AGGS], a_type[AGG_MAX_AGGS];
-    u32 a_word[AGG_MAX_AGGS];
+    u32 a_word[AGG_MAX_AGGS], a_hi[AGG_MAX_AGGS]; // a_hi: the high word of a fixed-point sum (0 = an ordinary state word)
+    const int fx_base = d.fx_base;
 #pragma unroll
     for (u32 j = 0; j < AGG_MAX_AGGS; ++j)
     {
@@ -344,6 +477,7 @@ __global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, co
         a_kind[j] = on ? d.a[j].kind : -1;
         a_type[j] = on ? d.a[j].arg_type : 0;
         a_word[j] = on ? d.a[j].word : 0;
+        a_hi[j] = (on && d.a[j].kind != CHGPU_AGG_COUNT && ((d.word_fx >> d.a[j].word) & 1)) ? d.fx_hi[d.a[j].word] : 0;
     }
     const u64 wave0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u64 n_waves = ((u64)gridDim.x * blockDim.x) >> 6;
@@ -419,7 +553,9 @@ __global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, co
                             u64 bits;
                             if (j < PRE) bits = argv[q][j < PRE ? j : 0];
                             else bits = load_arg_bits(a_ptr[j], a_type[j], i);
-                            if (a_type[j] == CHGPU_F64 || a_type[j] == CHGPU_F32)
+                            if (a_hi[j])
+                                lds_add_fx(w, lwords + a_hi[j] * lstride + ls, fx_from_double(bits, fx_base));
+                            else if (a_type[j] == CHGPU_F64 || a_type[j] == CHGPU_F32)
                                 atomicAdd((double *)w, __longlong_as_double((long long)bits));
                             else
                                 atomicAdd((unsigned long long *)w, (unsigned long long)bits);
@@ -462,7 +598,17 @@ __global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, co
         }
         for (u32 w = 0; w < d.n_words; ++w)
         {
+            if ((d.word_fx_hi >> w) & 1)
+                continue; // flushed with its low half
             const u64 bits = lwords[w * lstride + s];
+            if ((d.word_fx >> w) & 1)
+            {
+                const u32 wh = d.fx_hi[w];
+                const u64 hb = lwords[wh * lstride + s];
+                if (bits | hb)
+                    global_add_fx(t.words + (u64)w * gstride + slot, t.words + (u64)wh * gstride + slot, Fx128{bits, hb});
+                continue;
+            }
             const bool f = (d.word_is_f64 >> w) & 1;
             if (f ? (__longlong_as_double((long long)bits) != 0.0 || bits != 0) : (bits != 0))
                 global_add_word(t.words + (u64)w * gstride + slot, bits, f);
@@ -816,16 +962,25 @@ __device__ __forceinline__ u64 part_extend(u64 raw, int ex)
     }
 }
 
-// does any state word of the compile-time update code use operation a or b?
+// does any state word of the compile-time update code use operation a or b?  (7: the low half of a fixed-point sum of argument word 0 --
+// it counts as a user of that word with 1 and 3; 9: the high half, updated together with its low half)
 __host__ __device__ constexpr bool gbp_ops_use(u32 ops, u32 a, u32 b)
 {
     for (u32 w = 0; w < 8; ++w)
     {
         const u32 op = (ops >> (4 * w)) & 15u;
-        if (op == a || op == b)
+        if (op == a || op == b || (op == 7 && (a == 1 || b == 1 || a == 3 || b == 3)))
             return true;
     }
     return false;
+}
+// index of the (first) state word with operation `code`
+__host__ __device__ constexpr u32 gbp_ops_find(u32 ops, u32 code)
+{
+    for (u32 w = 0; w < 8; ++w)
+        if (((ops >> (4 * w)) & 15u) == code)
+            return w;
+    return 0;
 }
 
 struct PartLds
@@ -871,15 +1026,16 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
     // s_waitcnt lgkmcnt(0) also drains every LDS operation the wave has in flight -- the pass was issue-bound at ~170
     // clocks per 64 rows while the LDS itself can take this mix at 8.5 lanes/clock (tools/lds_bench.hip).
     //   op: 0 none, 1 add u64 (integer sum), 2 add f64, 3 count as u32, 4 count as u64
-    u32 a_off[AGG_MAX_AGGS], a_off2[AGG_MAX_AGGS];
+    u32 a_off[AGG_MAX_AGGS], a_off2[AGG_MAX_AGGS], a_off3[AGG_MAX_AGGS];
     int a_op[AGG_MAX_AGGS], a_op2[AGG_MAX_AGGS], a_src[AGG_MAX_AGGS];
+    const int fx_base = d.fx_base;
     // what to do with the zero-extended load of argument word 0 / 1: 0 nothing, 1/2/3 sign-extend from 8/16/32 bits (Int8/16/32
     // columns), 4 Float32 -> Float64 bits
     int ex0 = 0, ex1 = 0;
 #pragma unroll
     for (u32 j = 0; j < AGG_MAX_AGGS; ++j)
     {
-        a_off[j] = a_off2[j] = 0;
+        a_off[j] = a_off2[j] = a_off3[j] = 0;
         a_op[j] = a_op2[j] = a_src[j] = 0;
         if (OPS == 0 && j < d.n_aggs)
         {
@@ -890,6 +1046,11 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
             else
             {
                 a_op[j] = (d.a[j].arg_type == CHGPU_F64 || d.a[j].arg_type == CHGPU_F32) ? 2 : 1;
+                if ((d.word_fx >> w) & 1)
+                {
+                    a_op[j] = 5; // 128-bit fixed-point sum: the low half at a_off, the high half at a_off3
+                    a_off3[j] = L.off(d.fx_hi[w]);
+                }
                 a_src[j] = (int)d.a[j].pre;
                 const int ex = d.a[j].arg_type == CHGPU_I8 ? 1 : d.a[j].arg_type == CHGPU_I16 ? 2 : d.a[j].arg_type == CHGPU_I32 ? 3 : d.a[j].arg_type == CHGPU_F32 ? 4 : 0;
                 (d.a[j].pre == 0 ? ex0 : ex1) = ex;
@@ -1039,6 +1200,10 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                                 unsigned char * wp = lds_raw + w_off[w];
                                 if (op == 1 || op == 2)
                                     atomicAdd((unsigned long long *)wp + ls, (unsigned long long)(op == 1 ? b0 : b1));
+                                else if (op == 7)
+                                    lds_add_fx((u64 *)wp + ls, (u64 *)(lds_raw + w_off[gbp_ops_find(OPS, 9)]) + ls, fx_from_double(b0, fx_base));
+                                else if (op == 9)
+                                    continue;
                                 else if (op == 3 || op == 4)
                                     atomicAdd((double *)wp + ls, __longlong_as_double((long long)(op == 3 ? b0 : b1)));
                                 else if (op == 5)
@@ -1061,6 +1226,8 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                                 atomicAdd((double *)w + ls, __longlong_as_double((long long)bits));
                             else if (a_op[j] == 3)
                                 atomicAdd((unsigned int *)w + ls, 1u);
+                            else if (a_op[j] == 5)
+                                lds_add_fx((u64 *)w + ls, (u64 *)(lds_raw + a_off3[j]) + ls, fx_from_double(bits, fx_base));
                             else
                                 atomicAdd((unsigned long long *)w + ls, 1ull);
                             if (a_op2[j] == 3)
@@ -1117,8 +1284,18 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
             }
             for (u32 w = 0; w < d.n_words; ++w)
             {
+                if ((d.word_fx_hi >> w) & 1)
+                    continue; // flushed with its low half
                 const unsigned char * wp = lds_raw + L.off(w);
                 const u64 bits = ((cnt32 >> w) & 1) ? (u64)((const u32 *)wp)[s] : ((const u64 *)wp)[s];
+                if ((d.word_fx >> w) & 1)
+                {
+                    const u32 wh = d.fx_hi[w];
+                    const u64 hb = ((const u64 *)(lds_raw + L.off(wh)))[s];
+                    if (bits | hb)
+                        global_add_fx(t.words + (u64)w * gstride + slot, t.words + (u64)wh * gstride + slot, Fx128{bits, hb});
+                    continue;
+                }
                 if (bits != 0)
                     global_add_word(t.words + (u64)w * gstride + slot, bits, (d.word_is_f64 >> w) & 1);
             }
@@ -1354,6 +1531,10 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
                     unsigned char * wp = lds_raw + w_off[w];
                     if (op == 1)
                         atomicAdd((unsigned long long *)wp + ls, (unsigned long long)b0);
+                    else if (op == 7)
+                        lds_add_fx((u64 *)wp + ls, (u64 *)(lds_raw + w_off[gbp_ops_find(OPS, 9)]) + ls, fx_from_double(b0, d.fx_base));
+                    else if (op == 9)
+                        continue;
                     else if (op == 3)
                         atomicAdd((double *)wp + ls, __longlong_as_double((long long)b0));
                     else if (op == 5)
@@ -1492,8 +1673,18 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
             }
             for (u32 w = 0; w < d.n_words; ++w)
             {
+                if ((d.word_fx_hi >> w) & 1)
+                    continue; // flushed with its low half
                 const unsigned char * wp = lds_raw + L.off(w);
                 const u64 bits = ((cnt32 >> w) & 1) ? (u64)((const u32 *)wp)[s] : ((const u64 *)wp)[s];
+                if ((d.word_fx >> w) & 1)
+                {
+                    const u32 wh = d.fx_hi[w];
+                    const u64 hb = ((const u64 *)(lds_raw + L.off(wh)))[s];
+                    if (bits | hb)
+                        global_add_fx(t.words + (u64)w * gstride + slot, t.words + (u64)wh * gstride + slot, Fx128{bits, hb});
+                    continue;
+                }
                 if (bits != 0)
                     global_add_word(t.words + (u64)w * gstride + slot, bits, (d.word_is_f64 >> w) & 1);
             }
@@ -1505,8 +1696,13 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
 // Merge (key, state words) tuples into the table: mergeToViaEmplace, also the rehash of a grown table.
 // src_words[w] + i*1 ; src keys are u64; key==0 entries are skipped when skip_zero_keys (table arrays: empty cells),
 // zero_slot_index: index in the source arrays of the out-of-line zero key (or ~0).
+struct AggFxWords
+{
+    u32 word_fx, word_fx_hi;
+    unsigned char fx_hi[AGG_MAX_WORDS];
+};
 template <int MODE>
-__global__ __launch_bounds__(AGG_THREADS) void k_agg_tuples(AggTable t, u32 n_words, u32 word_is_f64, const u64 * __restrict__ src_keys,
+__global__ __launch_bounds__(AGG_THREADS) void k_agg_tuples(AggTable t, u32 n_words, u32 word_is_f64, AggFxWords fx, const u64 * __restrict__ src_keys,
                                                             const u64 * __restrict__ src_words, u64 src_stride, u64 n, int skip_zero_keys,
                                                             u64 zero_slot_index, int soft_limit, u64 * __restrict__ pending)
 {
@@ -1546,8 +1742,19 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_tuples(AggTable t, u32 n_wo
                     failed = true;
                 else
                     for (u32 w = 0; w < n_words; ++w)
+                    {
+                        if ((fx.word_fx_hi >> w) & 1)
+                            continue; // merged with its low half
+                        if ((fx.word_fx >> w) & 1)
+                        {
+                            const u32 wh = fx.fx_hi[w];
+                            global_add_fx(t.words + (u64)w * gstride + slot, t.words + (u64)wh * gstride + slot,
+                                          Fx128{src_words[(u64)w * src_stride + i], src_words[(u64)wh * src_stride + i]});
+                            continue;
+                        }
                         global_add_word(t.words + (u64)w * gstride + slot, src_words[(u64)w * src_stride + i],
                                         (int)((word_is_f64 >> w) & 1) | (int)(((word_is_f64 >> (16 + w)) & 1) << 1)); // upper half of the mask: max words
+                    }
             }
         }
         const u64 b = __ballot(failed);
@@ -1614,6 +1821,15 @@ static u64 pow2_ceil(u64 x)
     return p;
 }
 
+static AggFxWords agg_fx_words(const chgpu_agg * a)
+{
+    AggFxWords f;
+    f.word_fx = a->word_fx;
+    f.word_fx_hi = a->word_fx_hi;
+    memcpy(f.fx_hi, a->fx_hi, sizeof(f.fx_hi));
+    return f;
+}
+
 static int agg_alloc_table(chgpu_agg * a, u64 capacity, AggTable * t, void ** mem, size_t * mem_class)
 {
     const size_t cells = capacity + 1;
@@ -1662,7 +1878,7 @@ static int agg_grow(chgpu_agg * a, u64 min_groups, bool has_zero)
     // old cells [0, capacity) plus the out-of-line zero cell when it is set; no soft limit: the new table fits them all
     const u64 n = a->t.capacity + (has_zero ? 1 : 0);
     const u32 grid = chgpu_grid_for(a->ctx, n, AGG_THREADS, 8);
-    hipLaunchKernelGGL(k_agg_tuples<AGG_MODE_ALL>, dim3(grid), dim3(AGG_THREADS), 0, a->ctx->stream, nt, a->n_words, a->word_is_f64,
+    hipLaunchKernelGGL(k_agg_tuples<AGG_MODE_ALL>, dim3(grid), dim3(AGG_THREADS), 0, a->ctx->stream, nt, a->n_words, a->word_is_f64, agg_fx_words(a),
                        a->t.keys, a->t.words, a->t.capacity + 1, n, 1, has_zero ? a->t.capacity : ~0ull, 0, (u64 *)nullptr);
     a->ctx->counters[6] += 1;
     a->ctx->counters[7] += 1;
@@ -1734,6 +1950,25 @@ extern "C" int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, 
             a->word_is_f64 |= 1u << w;
         w += kind == CHGPU_AGG_AVG ? 2 : 1;
     }
+    a->n_pub_words = w;
+    if (key_type >= 0 && chgpu_opt(ctx, "deterministic_float_sums", 1))
+    {
+        u32 n_fx = 0;
+        for (u32 j = 0; j < n_aggs; ++j)
+            n_fx += ((a->word_is_f64 >> a->word_off[j]) & 1) ? 1 : 0;
+        if (w + n_fx <= AGG_MAX_WORDS) // (more words than the masks hold: such an aggregation keeps its double states)
+            for (u32 j = 0; j < n_aggs; ++j)
+            {
+                const u32 lo = a->word_off[j];
+                if (!((a->word_is_f64 >> lo) & 1))
+                    continue;
+                a->word_is_f64 &= ~(1u << lo); // the low half combines by an integer add
+                a->word_fx |= 1u << lo;
+                a->word_fx_hi |= 1u << w;
+                a->fx_hi[lo] = (unsigned char)w;
+                ++w;
+            }
+    }
     a->n_words = w;
     memset(a->host_words, 0, sizeof(a->host_words));
     chgpu_ctx_retain(ctx);
@@ -1759,6 +1994,10 @@ static void agg_fill_desc(const chgpu_agg * a, const chgpu_col * const * arg_col
     d->n_aggs = a->n_aggs;
     d->n_words = a->n_words;
     d->word_is_f64 = a->word_is_f64;
+    d->word_fx = a->word_fx;
+    d->word_fx_hi = a->word_fx_hi;
+    memcpy(d->fx_hi, a->fx_hi, sizeof(d->fx_hi));
+    d->fx_base = a->fx_base;
     for (u32 j = 0; j < a->n_aggs; ++j)
     {
         d->a[j].ptr = (arg_cols && arg_cols[j]) ? arg_cols[j]->data : nullptr;
@@ -1770,6 +2009,201 @@ static void agg_fill_desc(const chgpu_agg * a, const chgpu_col * const * arg_col
 }
 
 static int agg_finish_rounds(chgpu_agg * a, const AggDesc & d, const void * keys, int key_type, u64 row_begin, u64 n, u64 * pending);
+
+// ---- the fixed-point window of the deterministic Float64 sums (see Fx128) ----
+// Over the non-zero finite values (as doubles; a subnormal counts as exponent 1): out[0] = largest biased exponent (0 = no such value),
+// out[2] = 2047 - smallest biased exponent; out[1] = 1 when some value is NaN / +-inf
+__global__ __launch_bounds__(256) void k_fx_exp_stats(const void * __restrict__ p, int type, u64 row_begin, u64 n, u32 * __restrict__ out)
+{
+    u32 emax = 0, emin_c = 0, bad = 0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        const u64 bits = load_arg_bits(p, type, row_begin + i);
+        u32 e = (u32)(bits >> 52) & 0x7ffu;
+        if (e == 0x7ffu)
+            bad = 1;
+        else if (bits << 1)
+        {
+            e = e ? e : 1u;
+            emax = e > emax ? e : emax;
+            emin_c = 2047u - e > emin_c ? 2047u - e : emin_c;
+        }
+    }
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1)
+    {
+        const u32 o = (u32)__shfl_xor((int)emax, dlt, WAVE), q = (u32)__shfl_xor((int)emin_c, dlt, WAVE);
+        emax = o > emax ? o : emax;
+        emin_c = q > emin_c ? q : emin_c;
+    }
+    const u64 anybad = __ballot(bad != 0);
+    if ((threadIdx.x & 63) == 0)
+    {
+        if (emax)
+        {
+            atomicMax(&out[0], emax);
+            atomicMax(&out[2], emin_c);
+        }
+        if (anybad)
+            out[1] = 1;
+    }
+}
+// every state of one pair shifted right by sh bits (arithmetic: floor), the window's unit growing from 2^base to 2^(base + sh)
+__global__ __launch_bounds__(256) void k_fx_shift(u64 * __restrict__ lo, u64 * __restrict__ hi, u64 cells, int sh)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < cells; i += (u64)gridDim.x * 256)
+    {
+        const u64 l = lo[i], h = hi[i];
+        if ((l | h) == 0)
+            continue;
+        u64 nl, nh;
+        if (sh >= 128)
+            nl = nh = (u64)((i64)h >> 63);
+        else if (sh >= 64)
+            nl = (u64)((i64)h >> (sh - 64 < 63 ? sh - 64 : 63)), nh = (u64)((i64)h >> 63);
+        else
+            nl = (l >> sh) | (h << (64 - sh)), nh = (u64)((i64)h >> sh);
+        lo[i] = nl;
+        hi[i] = nh;
+    }
+}
+// out[i] = the pair as a double (out may be lo itself); hi is cleared when clear_hi
+__global__ __launch_bounds__(256) void k_fx_to_double(u64 * __restrict__ lo, u64 * __restrict__ hi, u64 n, int base, int clear_hi)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        const double v = fx_to_double(lo[i], hi[i], base);
+        lo[i] = (u64)__double_as_longlong(v);
+        if (clear_hi)
+            hi[i] = 0;
+    }
+}
+__global__ __launch_bounds__(256) void k_fx_from_double(const u64 * __restrict__ src, u64 n, int base, u64 * __restrict__ lo, u64 * __restrict__ hi)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    {
+        const Fx128 x = fx_from_double(src[i], base);
+        lo[i] = x.lo;
+        hi[i] = x.hi;
+    }
+}
+
+static int agg_fx_shift(chgpu_agg * a, int sh)
+{
+    if (sh <= 0 || !a->table_mem)
+        return CHGPU_OK;
+    const u64 cells = a->t.capacity + 1;
+    for (u32 w = 0; w < a->n_pub_words; ++w)
+        if ((a->word_fx >> w) & 1)
+        {
+            hipLaunchKernelGGL(k_fx_shift, dim3(chgpu_grid_for(a->ctx, cells, 256, 8)), dim3(256), 0, a->ctx->stream, a->t.words + (u64)w * cells,
+                               a->t.words + (u64)a->fx_hi[w] * cells, cells, sh);
+            a->ctx->counters[6] += 1;
+        }
+    CHGPU_HIP(hipGetLastError());
+    return CHGPU_OK;
+}
+// Moves the window to (base, log_cap); never narrows it.
+static int agg_fx_set_window(chgpu_agg * a, int base, int log_cap)
+{
+    if (!a->fx_base_set)
+    {
+        a->fx_base = base;
+        a->fx_log_cap = log_cap;
+        a->fx_base_set = true;
+        return CHGPU_OK;
+    }
+    if (base > a->fx_base)
+        CHGPU_TRY(agg_fx_shift(a, base - a->fx_base));
+    a->fx_base = base > a->fx_base ? base : a->fx_base;
+    a->fx_log_cap = log_cap > a->fx_log_cap ? log_cap : a->fx_log_cap;
+    return CHGPU_OK;
+}
+// The aggregation goes back to double states (a NaN or an infinity cannot be a fixed-point value: from here on its sums behave like the
+// reference's, poisoned groups included); every pair becomes the double it stands for.
+static int agg_fx_to_plain(chgpu_agg * a)
+{
+    if (!a->word_fx)
+        return CHGPU_OK;
+    if (a->table_mem)
+    {
+        const u64 cells = a->t.capacity + 1;
+        for (u32 w = 0; w < a->n_pub_words; ++w)
+            if ((a->word_fx >> w) & 1)
+            {
+                hipLaunchKernelGGL(k_fx_to_double, dim3(chgpu_grid_for(a->ctx, cells, 256, 8)), dim3(256), 0, a->ctx->stream, a->t.words + (u64)w * cells,
+                                   a->t.words + (u64)a->fx_hi[w] * cells, cells, a->fx_base, 1);
+                a->ctx->counters[6] += 1;
+            }
+        CHGPU_HIP(hipGetLastError());
+    }
+    a->word_is_f64 |= a->word_fx;
+    a->word_fx = 0; // (word_fx_hi stays: the spare words keep being skipped; they hold zeros)
+    return CHGPU_OK;
+}
+// exponent statistics of `n` values of one column: *emax_biased = 0 when every value is zero (then *emin_biased is 2047)
+static int agg_fx_stats(chgpu_ctx * ctx, const void * data, int type, u64 row_begin, u64 n, u32 * emax_biased, u32 * emin_biased, bool * nonfinite)
+{
+    void * scratch = nullptr;
+    CHGPU_TRY(chgpu_scratch(ctx, 256, &scratch));
+    CHGPU_HIP(hipMemsetAsync(scratch, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(k_fx_exp_stats, dim3(chgpu_grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, data, type, row_begin, n, (u32 *)scratch);
+    ctx->counters[6] += 1;
+    CHGPU_HIP(hipGetLastError());
+    u32 r[4];
+    CHGPU_TRY(chgpu_read_back(ctx, scratch, r, 16));
+    *emax_biased = r[0];
+    *emin_biased = 2047u - r[2];
+    *nonfinite = r[1] != 0;
+    return CHGPU_OK;
+}
+// Every value must keep at least this many significant bits in the window; an input whose magnitudes spread further (2^(97 - 24) = 1e22
+// between the largest and the smallest non-zero value, less 8 bits per widening for more than 2^30 rows) goes back to double states.
+static constexpr int FX_MIN_BITS = 24;
+// Makes room for `n` more values whose biased exponents span [emin, emax] (emax 0 = all of them zero).
+static int agg_fx_admit(chgpu_agg * a, u32 emax_biased, u32 emin_biased, u64 n)
+{
+    if (emax_biased == 0)
+    {
+        a->fx_rows += n; // zeros fit any window
+        return CHGPU_OK;
+    }
+    int log_cap = a->fx_base_set ? a->fx_log_cap : 30;
+    const u64 rows = a->fx_rows + n;
+    while (log_cap < 62 && rows > (1ull << log_cap))
+        log_cap += 8;
+    const int e_unb = (int)emax_biased - 1023;                        // every |x| < 2^(e_unb + 1)
+    int base = e_unb + 1 - 127 + log_cap;                             // ... = 2^(127 - log_cap) units
+    if (a->fx_base_set && a->fx_base + (log_cap - a->fx_log_cap) > base)
+        base = a->fx_base + (log_cap - a->fx_log_cap);                // the states already there keep the invariant
+    const int emin = (int)emin_biased - 1023 < a->fx_emin ? (int)emin_biased - 1023 : a->fx_emin;
+    if (emin + 1 - FX_MIN_BITS < base) // the smallest value ever added would keep fewer than FX_MIN_BITS bits
+        return agg_fx_to_plain(a);
+    CHGPU_TRY(agg_fx_set_window(a, base, log_cap));
+    a->fx_emin = emin;
+    a->fx_rows = rows;
+    return CHGPU_OK;
+}
+// before a block's rows are added: look at the float arguments of the fixed-point sums
+static int agg_fx_prepare_block(chgpu_agg * a, const chgpu_col * const * arg_cols, u64 row_begin, u64 n)
+{
+    if (!a->word_fx || n == 0)
+        return CHGPU_OK;
+    u32 emax = 0, emin = 2047;
+    for (u32 j = 0; j < a->n_aggs; ++j)
+    {
+        if (a->kinds[j] == CHGPU_AGG_COUNT || !((a->word_fx >> a->word_off[j]) & 1))
+            continue;
+        u32 e = 0, em = 2047;
+        bool bad = false;
+        CHGPU_TRY(agg_fx_stats(a->ctx, arg_cols[j]->data, a->arg_types[j], row_begin, n, &e, &em, &bad));
+        if (bad)
+            return agg_fx_to_plain(a);
+        emax = e > emax ? e : emax;
+        emin = em < emin ? em : emin;
+    }
+    return agg_fx_admit(a, emax, emin, n);
+}
 
 // Compact LDS cell of the partition-aggregate kernel for this aggregator's shape (see PartLds): bytes per cell and which
 // state words are 32-bit counts.
@@ -1961,6 +2395,8 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
             else
             {
                 word_op[w] = d.a[j].arg_type == CHGPU_F64 ? 3 : 1;
+                if ((a->word_fx >> w) & 1)
+                    word_op[w] = 7, word_op[a->fx_hi[w]] = 9;
                 if (d.a[j].kind == CHGPU_AGG_AVG)
                     word_op[w + 1] = ((cnt32 >> (w + 1)) & 1) ? 5 : 6;
             }
@@ -1973,7 +2409,7 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
         if (!ok)
             ops = 0;
     }
-    if (ops != 0x51 && ops != 0x15 && ops != 0x1 && ops != 0x53 && ops != 0x3 && ops != 0x61 && ops != 0x16)
+    if (ops != 0x51 && ops != 0x15 && ops != 0x1 && ops != 0x53 && ops != 0x3 && ops != 0x61 && ops != 0x16 && ops != 0x97 && ops != 0x957 && ops != 0x967)
         return CHGPU_ERR_NOT_IMPLEMENTED;
     const u32 G = (u32)ctx->num_cus;
     const u64 rows_per_wg = ((n + G - 1) / G + TILE - 1) / TILE * TILE;
@@ -2036,6 +2472,9 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
         case 0x53: GB_TILES(KT_, 0x53, TILE_, AOS_); break;   \
         case 0x3: GB_TILES(KT_, 0x3, TILE_, AOS_); break;     \
         case 0x61: GB_TILES(KT_, 0x61, TILE_, AOS_); break;   \
+        case 0x97: GB_TILES(KT_, 0x97, TILE_, AOS_); break;   \
+        case 0x957: GB_TILES(KT_, 0x957, TILE_, AOS_); break; \
+        case 0x967: GB_TILES(KT_, 0x967, TILE_, AOS_); break; \
         default: GB_TILES(KT_, 0x16, TILE_, AOS_); break;     \
     }
         if (aos && key32)
@@ -2400,6 +2839,11 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
                     const bool f = d.a[j].arg_type == CHGPU_F64;
                     ok = ok && d.a[j].pre < 2;
                     word_op[w] = (f ? 3 : 1) + d.a[j].pre;
+                    if ((a->word_fx >> w) & 1)
+                    {
+                        ok = ok && d.a[j].pre == 0; // (a fixed-point sum of the second argument word: generic kernel)
+                        word_op[w] = 7, word_op[a->fx_hi[w]] = 9;
+                    }
                     if (d.a[j].kind == CHGPU_AGG_AVG)
                         word_op[w + 1] = ((cnt32 >> (w + 1)) & 1) ? 5 : 6;
                 }
@@ -2432,6 +2876,8 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
         case 0x3: GB_AGG(KT_, 0x3); break;   /* sum(Float64) */   \
         case 0x21: GB_AGG(KT_, 0x21); break; /* sum, sum */       \
         case 0x521: GB_AGG(KT_, 0x521); break; /* sum, sum, count */ \
+        case 0x97: GB_AGG(KT_, 0x97); break; /* sum(Float64) as a fixed-point pair */ \
+        case 0x957: GB_AGG(KT_, 0x957); break; /* the same + count: avg(Float64) */ \
         default: GB_AGG(KT_, 0); break;                      \
     }
         if (key32)
@@ -2632,6 +3078,7 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
                 return agg_add_block_materialised(a, key_col, arg_cols, row_begin, row_end, filter);
         }
     }
+    CHGPU_TRY(agg_fx_prepare_block(a, arg_cols, row_begin, n)); // (may widen the fixed-point window: before the descriptor is filled)
     AggDesc d;
     agg_fill_desc(a, arg_cols, &d);
 
@@ -2891,7 +3338,7 @@ static int agg_merge_tuples(chgpu_agg * a, const u64 * src_keys, const u64 * src
     CHGPU_TRY(chgpu_scratch(ctx, n_words64 * sizeof(u64) + 256, &scratch));
     u64 * pending = (u64 *)scratch;
     const u32 grid = chgpu_grid_for(ctx, n, AGG_THREADS, 8);
-    hipLaunchKernelGGL(k_agg_tuples<AGG_MODE_ALL>, dim3(grid), dim3(AGG_THREADS), 0, ctx->stream, a->t, a->n_words, a->word_is_f64,
+    hipLaunchKernelGGL(k_agg_tuples<AGG_MODE_ALL>, dim3(grid), dim3(AGG_THREADS), 0, ctx->stream, a->t, a->n_words, a->word_is_f64, agg_fx_words(a),
                        src_keys, src_words, src_stride, n, skip_zero_keys, zero_slot_index, 1, pending);
     ctx->counters[6] += 1;
     CHGPU_HIP(hipGetLastError());
@@ -2902,7 +3349,7 @@ static int agg_merge_tuples(chgpu_agg * a, const u64 * src_keys, const u64 * src
         if (!c.overflow)
             return CHGPU_OK;
         CHGPU_TRY(agg_grow(a, c.n_groups, c.has_zero != 0));
-        hipLaunchKernelGGL(k_agg_tuples<AGG_MODE_PENDING>, dim3(grid), dim3(AGG_THREADS), 0, ctx->stream, a->t, a->n_words, a->word_is_f64,
+        hipLaunchKernelGGL(k_agg_tuples<AGG_MODE_PENDING>, dim3(grid), dim3(AGG_THREADS), 0, ctx->stream, a->t, a->n_words, a->word_is_f64, agg_fx_words(a),
                            src_keys, src_words, src_stride, n, skip_zero_keys, zero_slot_index, 1, pending);
         ctx->counters[6] += 1;
         CHGPU_HIP(hipGetLastError());
@@ -2949,6 +3396,51 @@ extern "C" int chgpu_agg_merge(chgpu_agg * dst, const chgpu_agg * src)
     }
     if (!src->table_mem)
         return CHGPU_OK;
+    CHGPU_REQUIRE(dst->n_words == src->n_words, CHGPU_ERR_BAD_ARGUMENTS, "cannot merge aggregations created under different deterministic_float_sums settings");
+    if (dst->word_fx || src->word_fx)
+    {
+        // fixed-point sums: both sides to ONE window first (the source's states are re-expressed in place: same values, possibly a coarser
+        // unit -- the reference's merge consumes its source too), or both back to doubles when one of them met a NaN / infinity
+        chgpu_agg * s = const_cast<chgpu_agg *>(src);
+        if (!dst->word_fx || !s->word_fx)
+        {
+            CHGPU_TRY(agg_fx_to_plain(dst));
+            CHGPU_TRY(agg_fx_to_plain(s));
+        }
+        else if (s->fx_base_set)
+        {
+            if (!dst->fx_base_set)
+            {
+                CHGPU_TRY(agg_fx_set_window(dst, s->fx_base, s->fx_log_cap));
+                dst->fx_rows += s->fx_rows;
+                dst->fx_emin = s->fx_emin;
+            }
+            else
+            {
+                int log_cap = dst->fx_log_cap > s->fx_log_cap ? dst->fx_log_cap : s->fx_log_cap;
+                const u64 rows = dst->fx_rows + s->fx_rows;
+                while (log_cap < 62 && rows > (1ull << log_cap))
+                    log_cap += 8;
+                const int bd = dst->fx_base + (log_cap - dst->fx_log_cap), bs = s->fx_base + (log_cap - s->fx_log_cap);
+                const int base = bd > bs ? bd : bs;
+                const int emin = dst->fx_emin < s->fx_emin ? dst->fx_emin : s->fx_emin;
+                if (emin + 1 - FX_MIN_BITS < base)
+                {
+                    CHGPU_TRY(agg_fx_to_plain(dst));
+                    CHGPU_TRY(agg_fx_to_plain(s));
+                }
+                else
+                {
+                    CHGPU_TRY(agg_fx_set_window(dst, base, log_cap));
+                    CHGPU_TRY(agg_fx_set_window(s, base, log_cap));
+                    dst->fx_emin = emin;
+                    dst->fx_rows = rows;
+                }
+            }
+        }
+        if (src->ctx != dst->ctx)
+            CHGPU_HIP(hipStreamSynchronize(src->ctx->stream)); // (the re-expression ran on the source's stream)
+    }
     // the source's zero cell participates only when it is set
     AggCtrl sc;
     CHGPU_TRY(chgpu_read_back(dst->ctx, src->t.ctrl, &sc, sizeof(sc)));
@@ -2961,7 +3453,7 @@ extern "C" int chgpu_agg_merge_states(chgpu_agg * dst, const chgpu_col * key_col
     ChgpuDeviceGuard _dev_guard(dst ? dst->ctx : nullptr);
     CHGPU_REQUIRE(dst && state_cols, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     chgpu_ctx * ctx = dst->ctx;
-    for (u32 w = 0; w < dst->n_words; ++w)
+    for (u32 w = 0; w < dst->n_pub_words; ++w)
     {
         CHGPU_REQUIRE(state_cols[w], CHGPU_ERR_BAD_ARGUMENTS, "state column %u is NULL", w);
         CHGPU_REQUIRE(chgpu_type_size(state_cols[w]->type) == 8, CHGPU_ERR_BAD_ARGUMENTS, "state column %u must be 8 bytes wide", w);
@@ -2993,6 +3485,24 @@ extern "C" int chgpu_agg_merge_states(chgpu_agg * dst, const chgpu_col * key_col
     CHGPU_REQUIRE(key_col->type == dst->key_type, CHGPU_ERR_BAD_ARGUMENTS, "key column type mismatch");
     if (rows == 0)
         return CHGPU_OK;
+    // Float64 sum states arriving for fixed-point sums: each is one value for the window (or the end of the fixed-point mode)
+    if (dst->word_fx)
+    {
+        u32 emax = 0, emin = 2047;
+        bool bad = false;
+        for (u32 w = 0; w < dst->n_pub_words && !bad; ++w)
+            if ((dst->word_fx >> w) & 1)
+            {
+                u32 e = 0, em = 2047;
+                CHGPU_TRY(agg_fx_stats(ctx, state_cols[w]->data, CHGPU_F64, 0, rows, &e, &em, &bad));
+                emax = e > emax ? e : emax;
+                emin = em < emin ? em : emin;
+            }
+        if (bad)
+            CHGPU_TRY(agg_fx_to_plain(dst));
+        else
+            CHGPU_TRY(agg_fx_admit(dst, emax, emin, rows));
+    }
     // stage into one SoA buffer [keys u64][words...] so the tuple kernel sees a single stride
     chgpu_col * stage = nullptr;
     CHGPU_TRY(chgpu_col_new(ctx, CHGPU_U64, rows * (1 + dst->n_words), &stage));
@@ -3011,8 +3521,17 @@ extern "C" int chgpu_agg_merge_states(chgpu_agg * dst, const chgpu_col * key_col
                 break;
             }
         }
-        for (u32 w = 0; w < dst->n_words && rc == CHGPU_OK; ++w)
+        for (u32 w = 0; w < dst->n_pub_words && rc == CHGPU_OK; ++w)
+        {
+            if ((dst->word_fx >> w) & 1)
+            {
+                hipLaunchKernelGGL(k_fx_from_double, dim3(grid), dim3(256), 0, ctx->stream, (const u64 *)state_cols[w]->data, (u64)rows, dst->fx_base,
+                                   sk + (u64)(w + 1) * rows, sk + (u64)(dst->fx_hi[w] + 1) * rows);
+                ctx->counters[6] += 1;
+                continue;
+            }
             rc = hipMemcpyAsync(sk + (u64)(w + 1) * rows, state_cols[w]->data, rows * 8, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? CHGPU_OK : CHGPU_ERR_DEVICE;
+        }
     }
     if (rc == CHGPU_OK)
         rc = agg_merge_tuples(dst, sk, sk + rows, rows, rows, 0, ~0ull);
@@ -3069,8 +3588,8 @@ static int agg_export(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** word_co
     {
         if (keys_out)
             CHGPU_TRY(chgpu_col_new(ctx, a->key_type, 0, keys_out));
-        for (u32 w = 0; w < a->n_words; ++w)
-            CHGPU_TRY(chgpu_col_new(ctx, ((a->word_is_f64 >> w) & 1) ? CHGPU_F64 : CHGPU_U64, 0, &word_cols[w]));
+        for (u32 w = 0; w < a->n_pub_words; ++w)
+            CHGPU_TRY(chgpu_col_new(ctx, (((a->word_is_f64 | a->word_fx) >> w) & 1) ? CHGPU_F64 : CHGPU_U64, 0, &word_cols[w]));
         *groups = 0;
         return CHGPU_OK;
     }
@@ -3117,6 +3636,26 @@ static int agg_export(chgpu_agg * a, chgpu_col ** keys_out, chgpu_col ** word_co
             word_cols[w] = nullptr;
         }
     };
+    if (rc == CHGPU_OK)
+    {
+        // the fixed-point sums leave as the doubles they stand for (one rounding per group); the spare high words stay inside
+        for (u32 w = 0; w < a->n_pub_words; ++w)
+            if ((a->word_fx >> w) & 1)
+            {
+                if (n_out)
+                {
+                    hipLaunchKernelGGL(k_fx_to_double, dim3(chgpu_grid_for(ctx, n_out, 256, 8)), dim3(256), 0, ctx->stream, (u64 *)word_cols[w]->data,
+                                       (u64 *)word_cols[a->fx_hi[w]]->data, n_out, a->fx_base, 0);
+                    ctx->counters[6] += 1;
+                }
+                word_cols[w]->type = CHGPU_F64;
+            }
+        for (u32 w = a->n_pub_words; w < a->n_words; ++w)
+        {
+            chgpu_col_free(word_cols[w]); // pooled: reuse is stream-ordered behind the conversion
+            word_cols[w] = nullptr;
+        }
+    }
     if (rc != CHGPU_OK)
     {
         chgpu_col_free(k64);
@@ -3179,7 +3718,7 @@ extern "C" int chgpu_agg_export_states_two_level(chgpu_agg * a, chgpu_col ** key
     chgpu_col * words[AGG_MAX_WORDS] = {nullptr};
     u64 n = 0;
     CHGPU_TRY(agg_export(a, &keys, words, &n));
-    const u32 nw = a->n_words;
+    const u32 nw = a->n_pub_words;
     chgpu_col * sorted[AGG_MAX_WORDS + 1] = {nullptr};
     int rc = CHGPU_OK;
     // <= 8 columns per partition call; the key column rides in the first
@@ -3283,7 +3822,7 @@ extern "C" int chgpu_agg_finalize(chgpu_agg * a, chgpu_col ** keys_out, chgpu_co
             res_cols[j] = r;
         }
     }
-    for (u32 w = 0; w < a->n_words; ++w)
+    for (u32 w = 0; w < a->n_pub_words; ++w)
         if (words[w])
             chgpu_col_free(words[w]); // pooled: reuse is stream-ordered behind k_avg_divide
     *groups = n;

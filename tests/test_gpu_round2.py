@@ -404,7 +404,7 @@ def test_groupby_tile_sorted_plan_widens_narrow_arguments(ch, ctx, arg_dtype):
 def test_groupby_tile_sorted_plan_edge_cases(ch, ctx, key_dtype, case):
     """The two-pass plan (k_rp_tilesort + k_agg_tiles_lds) where its special paths run: LDS tables that overflow because the hint was
     far too small (rows left pending for the finish rounds), runs far longer than a wave (a key with half of all rows), the zero key,
-    a row count that ends in the middle of a tile and of a 16-byte pair, Float64 sums (within 1e-9 relative: atomics reorder the adds)."""
+    a row count that ends in the middle of a tile and of a 16-byte pair, Float64 sums (bit-equal from run to run)."""
     rng = np.random.Generator(np.random.PCG64(77))
     n = 7_340_033
     if case == "more_groups_than_promised":
@@ -434,6 +434,11 @@ def test_groupby_tile_sorted_plan_edge_cases(ch, ctx, key_dtype, case):
     if case == "f64_sum":
         want = np.bincount(inv, weights=v, minlength=uk.shape[0])
         assert np.allclose(gs[order], want, rtol=1e-9, atol=1e-6)
+        # a second run gives the same bits: the sums are kept in fixed point (tests/test_gpu_float_sums.py), no atomic adds doubles
+        B = ch.Aggregator(key_dtype, aggs, size_hint=hint, ctx=ctx)
+        B.execute_on_block(ctx.upload(k), [ctx.upload(v), None])
+        gk2, (gs2, _) = B.convert_to_block()
+        assert np.array_equal(gs[order].view(np.uint64), gs2[np.argsort(gk2)].view(np.uint64))
     else:
         want = np.zeros(uk.shape[0], dtype=np.uint64)
         np.add.at(want, inv, v.astype(np.uint64))
