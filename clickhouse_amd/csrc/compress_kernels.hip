@@ -22,14 +22,58 @@ struct FrameJob
     u32 src_size; // payload bytes
     u32 dst_size; // decompressed bytes
     u32 method;   // 0x82 LZ4, 0x02 NONE
-    u32 post;     // 0: dst is the output buffer; 0x92: dst is the stage buffer and a Delta stage follows (CODEC(Delta, LZ4))
-    u64 out_off;  // post != 0: where the Delta stage writes in the output buffer
+    u32 post;     // 0: dst is the output buffer; 0x92 .. 0x95: dst is the stage buffer and a Delta / T64 / DoubleDelta / Gorilla stage follows
+                  // (CODEC(Delta, LZ4), CODEC(DoubleDelta, ZSTD), ...: the general-purpose stage's output is that codec's block, header first)
+    u64 out_off;  // post != 0: where the codec stage writes in the output buffer
     u32 out_size; // post != 0: final decompressed size
     u32 pad;
 };
 
 __device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 uni64(u64 v) { return ((u64)uni((u32)(v >> 32)) << 32) | uni((u32)v); }
+
+// Where codec M of a frame reads and writes.  stage == nullptr: the frames that ARE an application of M (CODEC(T64) alone).  Otherwise the
+// frames whose general-purpose stage left M's block in the stage buffer (CompressionCodecMultiple.cpp:68-130: every stage carries its own
+// 9-byte header -- method, compressed size incl. the header, decompressed size -- which must agree with what the outer frame promised).
+struct CodecIo
+{
+    const u8 * in;
+    u8 * out;
+    u32 isz, osz;
+    bool take, bad;
+};
+__device__ __forceinline__ CodecIo codec_io(const FrameJob & job, u32 M, const u8 * src, const u8 * stage, u8 * dst_out)
+{
+    CodecIo io{nullptr, nullptr, 0, 0, false, false};
+    if (!stage)
+    {
+        if (job.method != M)
+            return io;
+        io.take = true;
+        io.in = src + job.src_off;
+        io.out = dst_out + job.dst_off;
+        io.isz = job.src_size;
+        io.osz = job.dst_size;
+        return io;
+    }
+    if (job.post != M)
+        return io;
+    io.take = true;
+    const u8 * h = stage + job.dst_off;
+    const u32 ssz = job.dst_size;
+    if (ssz < 9)
+    {
+        io.bad = true;
+        return io;
+    }
+    const u32 csize = (u32)h[1] | ((u32)h[2] << 8) | ((u32)h[3] << 16) | ((u32)h[4] << 24), dsize = (u32)h[5] | ((u32)h[6] << 8) | ((u32)h[7] << 16) | ((u32)h[8] << 24);
+    io.bad = h[0] != M || csize != ssz || dsize != job.out_size;
+    io.in = h + 9;
+    io.isz = ssz - 9;
+    io.out = dst_out + job.out_off;
+    io.osz = job.out_size;
+    return io;
+}
 
 // Per wave: a window of the compressed input and a ring of the most recent output live in LDS, so the serial part of the format --
 // token, length bytes, offset -- and the short-distance matches that dominate column data (zero bytes 8 back, the previous value 8
@@ -412,18 +456,20 @@ __device__ __forceinline__ u32 t64_bits_s(i64 mn, i64 mx)
     return t64_bits_u((u64)mn, (u64)mx);
 }
 
-__global__ __launch_bounds__(256) void k_t64_decode(const u8 * __restrict__ src, u8 * __restrict__ dst_out, const FrameJob * __restrict__ jobs, u32 n_jobs, u32 * __restrict__ err)
+__global__ __launch_bounds__(256) void k_t64_decode(const u8 * __restrict__ src, const u8 * __restrict__ stage, u8 * __restrict__ dst_out, const FrameJob * __restrict__ jobs, u32 n_jobs,
+                                                    u32 * __restrict__ err)
 {
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (u32 j = blockIdx.x; j < n_jobs; j += gridDim.x)
     {
         const FrameJob job = jobs[j];
-        if (uni(job.method) != 0x93u)
+        const CodecIo io = codec_io(job, 0x93u, src, stage, dst_out);
+        if (!uni(io.take))
             continue;
-        const u8 * in = src + uni64(job.src_off);
-        u8 * out = dst_out + uni64(job.dst_off);
-        const u32 isz = uni(job.src_size), osz = uni(job.dst_size);
-        bool bad = isz < 17;
+        const u8 * in = (const u8 *)uni64((u64)io.in);
+        u8 * out = (u8 *)uni64((u64)io.out);
+        const u32 isz = uni(io.isz), osz = uni(io.osz);
+        bool bad = uni(io.bad) || isz < 17;
         u32 width = 0, sgn = 0, full = 0, num_bits = 0;
         u64 mn = 0, mx = 0;
         if (!bad)
@@ -555,18 +601,20 @@ struct DdReader
     }
 };
 
-__global__ __launch_bounds__(64) void k_double_delta_decode(const u8 * __restrict__ src, u8 * __restrict__ dst_out, const FrameJob * __restrict__ jobs, u32 n_jobs, u32 * __restrict__ err)
+__global__ __launch_bounds__(64) void k_double_delta_decode(const u8 * __restrict__ src, const u8 * __restrict__ stage, u8 * __restrict__ dst_out, const FrameJob * __restrict__ jobs,
+                                                            u32 n_jobs, u32 * __restrict__ err)
 {
     const u32 j = blockIdx.x * 64 + threadIdx.x;
     if (j >= n_jobs)
         return;
     const FrameJob job = jobs[j];
-    if (job.method != 0x94u)
+    const CodecIo io = codec_io(job, 0x94u, src, stage, dst_out);
+    if (!io.take)
         return;
-    const u8 * in = src + job.src_off;
-    u8 * out = dst_out + job.dst_off;
-    const u32 isz = job.src_size, osz = job.dst_size;
-    if (isz < 2)
+    const u8 * in = io.in;
+    u8 * out = io.out;
+    const u32 isz = io.isz, osz = io.osz;
+    if (io.bad || isz < 2)
     {
         atomicOr(err, 16u);
         return;
@@ -650,18 +698,20 @@ __global__ __launch_bounds__(64) void k_double_delta_decode(const u8 * __restric
 // stream of XOR differences -- 0: the value repeats | 10: the meaningful bits, inside the previous window of leading / trailing zeros |
 // 11: leading zeros (W - 1 bits), length (W bits), the meaningful bits; W = 4 / 5 / 6 / 7 for 1 / 2 / 4 / 8-byte values.  Like DoubleDelta
 // a front-to-back code: one lane per frame.
-__global__ __launch_bounds__(64) void k_gorilla_decode(const u8 * __restrict__ src, u8 * __restrict__ dst_out, const FrameJob * __restrict__ jobs, u32 n_jobs, u32 * __restrict__ err)
+__global__ __launch_bounds__(64) void k_gorilla_decode(const u8 * __restrict__ src, const u8 * __restrict__ stage, u8 * __restrict__ dst_out, const FrameJob * __restrict__ jobs, u32 n_jobs,
+                                                       u32 * __restrict__ err)
 {
     const u32 j = blockIdx.x * 64 + threadIdx.x;
     if (j >= n_jobs)
         return;
     const FrameJob job = jobs[j];
-    if (job.method != 0x95u)
+    const CodecIo io = codec_io(job, 0x95u, src, stage, dst_out);
+    if (!io.take)
         return;
-    const u8 * in = src + job.src_off;
-    u8 * out = dst_out + job.dst_off;
-    const u32 isz = job.src_size, osz = job.dst_size;
-    if (isz < 2)
+    const u8 * in = io.in;
+    u8 * out = io.out;
+    const u32 isz = io.isz, osz = io.osz;
+    if (io.bad || isz < 2)
     {
         atomicOr(err, 32u);
         return;
@@ -739,7 +789,7 @@ extern "C" int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compre
     CHGPU_REQUIRE(n_frames == 0 || (payload_offsets && payload_sizes && decompressed_sizes && methods), CHGPU_ERR_BAD_ARGUMENTS, "NULL frame arrays");
     std::vector<FrameJob> jobs(n_frames);
     u64 total = 0, stage_total = 0;
-    u32 n_t64 = 0, n_dd = 0, n_gor = 0;
+    u32 n_t64 = 0, n_dd = 0, n_gor = 0, p_delta = 0, p_t64 = 0, p_dd = 0, p_gor = 0;
     for (u32 f = 0; f < n_frames; ++f)
     {
         CHGPU_REQUIRE(methods[f] == 0x82 || methods[f] == 0x02 || methods[f] == 0x93 || methods[f] == 0x94 || methods[f] == 0x95, CHGPU_ERR_NOT_IMPLEMENTED,
@@ -749,9 +799,13 @@ extern "C" int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compre
         n_gor += methods[f] == 0x95;
         CHGPU_REQUIRE(payload_offsets[f] + payload_sizes[f] <= compressed_u8->rows, CHGPU_ERR_BAD_ARGUMENTS, "frame %u lies outside the compressed buffer", f);
         const u32 post = post_methods ? post_methods[f] : 0;
-        CHGPU_REQUIRE(post == 0 || post == 0x92, CHGPU_ERR_NOT_IMPLEMENTED, "codec 0x%02x in front of the general-purpose stage: CPU path", post);
-        CHGPU_REQUIRE(post == 0 || methods[f] == 0x82, CHGPU_ERR_NOT_IMPLEMENTED, "a Delta stage behind method 0x%02x: CPU path", methods[f]);
+        CHGPU_REQUIRE(post == 0 || (post >= 0x92 && post <= 0x95), CHGPU_ERR_NOT_IMPLEMENTED, "codec 0x%02x in front of the general-purpose stage: CPU path", post);
+        CHGPU_REQUIRE(post == 0 || methods[f] == 0x82 || methods[f] == 0x02, CHGPU_ERR_NOT_IMPLEMENTED, "a codec stage behind method 0x%02x: CPU path", methods[f]);
         CHGPU_REQUIRE(post == 0 || stage_sizes, CHGPU_ERR_BAD_ARGUMENTS, "stage_sizes is NULL");
+        p_delta += post == 0x92;
+        p_t64 += post == 0x93;
+        p_dd += post == 0x94;
+        p_gor += post == 0x95;
         FrameJob jb{};
         jb.src_off = payload_offsets[f];
         jb.src_size = payload_sizes[f];
@@ -803,25 +857,44 @@ extern "C" int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compre
             ctx->counters[6] += 1;
             if (n_t64)
             {
-                hipLaunchKernelGGL(k_t64_decode, dim3(n_frames < 4096 ? n_frames : 4096), dim3(256), 0, ctx->stream, (const u8 *)compressed_u8->data, (u8 *)res->data, (const FrameJob *)jd,
-                                   n_frames, err);
+                hipLaunchKernelGGL(k_t64_decode, dim3(n_frames < 4096 ? n_frames : 4096), dim3(256), 0, ctx->stream, (const u8 *)compressed_u8->data, (const u8 *)nullptr, (u8 *)res->data,
+                                   (const FrameJob *)jd, n_frames, err);
                 ctx->counters[6] += 1;
             }
             if (n_dd)
             {
-                hipLaunchKernelGGL(k_double_delta_decode, dim3((n_frames + 63) / 64), dim3(64), 0, ctx->stream, (const u8 *)compressed_u8->data, (u8 *)res->data, (const FrameJob *)jd,
-                                   n_frames, err);
+                hipLaunchKernelGGL(k_double_delta_decode, dim3((n_frames + 63) / 64), dim3(64), 0, ctx->stream, (const u8 *)compressed_u8->data, (const u8 *)nullptr, (u8 *)res->data,
+                                   (const FrameJob *)jd, n_frames, err);
                 ctx->counters[6] += 1;
             }
             if (n_gor)
             {
-                hipLaunchKernelGGL(k_gorilla_decode, dim3((n_frames + 63) / 64), dim3(64), 0, ctx->stream, (const u8 *)compressed_u8->data, (u8 *)res->data, (const FrameJob *)jd, n_frames,
-                                   err);
+                hipLaunchKernelGGL(k_gorilla_decode, dim3((n_frames + 63) / 64), dim3(64), 0, ctx->stream, (const u8 *)compressed_u8->data, (const u8 *)nullptr, (u8 *)res->data,
+                                   (const FrameJob *)jd, n_frames, err);
                 ctx->counters[6] += 1;
             }
-            if (stage_total)
+            // the codec stages behind a general-purpose stage read its output in the stage buffer
+            if (p_delta)
             {
                 hipLaunchKernelGGL(k_delta_decode, dim3(grid), dim3(256), 0, ctx->stream, (const u8 *)stage, (u8 *)res->data, (const FrameJob *)jd, n_frames, err);
+                ctx->counters[6] += 1;
+            }
+            if (p_t64)
+            {
+                hipLaunchKernelGGL(k_t64_decode, dim3(n_frames < 4096 ? n_frames : 4096), dim3(256), 0, ctx->stream, (const u8 *)compressed_u8->data, (const u8 *)stage, (u8 *)res->data,
+                                   (const FrameJob *)jd, n_frames, err);
+                ctx->counters[6] += 1;
+            }
+            if (p_dd)
+            {
+                hipLaunchKernelGGL(k_double_delta_decode, dim3((n_frames + 63) / 64), dim3(64), 0, ctx->stream, (const u8 *)compressed_u8->data, (const u8 *)stage, (u8 *)res->data,
+                                   (const FrameJob *)jd, n_frames, err);
+                ctx->counters[6] += 1;
+            }
+            if (p_gor)
+            {
+                hipLaunchKernelGGL(k_gorilla_decode, dim3((n_frames + 63) / 64), dim3(64), 0, ctx->stream, (const u8 *)compressed_u8->data, (const u8 *)stage, (u8 *)res->data,
+                                   (const FrameJob *)jd, n_frames, err);
                 ctx->counters[6] += 1;
             }
             e = hipGetLastError();

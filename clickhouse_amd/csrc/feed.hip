@@ -12,6 +12,7 @@
 // CityHash128 below is written from the algorithm as Google published it (cityhash 1.0.2: the version ClickHouse froze, because its
 // checksums are on disk), not taken from the reference's contrib/ copy; oracle/ref_city_wrapper.cpp compiles that copy in place to pin it.
 #include "chgpu_internal.h"
+#include <dlfcn.h>
 
 #include <string>
 #include <utility>
@@ -211,13 +212,15 @@ extern "C" int chgpu_compressed_walk_frames(const uint8_t * file, uint64_t size,
         u64 off = pos + CKSUM + HDR;
         u32 sz = csize - (u32)HDR, stage = dsize;
         u8 post = 0;
-        // CODEC(Delta, LZ4): Multiple (0x91) = [n methods][method bytes][the last stage's own header + payload] (CompressionCodecMultiple.cpp:68-130)
-        if (method == 0x91 && sz >= 3 + HDR && file[off] == 2 && file[off + 1] == 0x92 && file[off + 2] == 0x82)
+        // CODEC(Delta, LZ4), CODEC(DoubleDelta, ZSTD), CODEC(T64, LZ4), CODEC(Gorilla, LZ4) ...: Multiple (0x91) = [n methods][method bytes][the
+        // last stage's own header + payload] (CompressionCodecMultiple.cpp:68-130); the pairs {a column codec, a general-purpose codec}
+        if (method == 0x91 && sz >= 3 + HDR && file[off] == 2 && file[off + 1] >= 0x92 && file[off + 1] <= 0x95 && (file[off + 2] == 0x82 || file[off + 2] == 0x90 || file[off + 2] == 0x02))
         {
+            const u8 codec = file[off + 1], general = file[off + 2];
             const u32 c2 = rd_u32(file + off + 3 + 1), d2 = rd_u32(file + off + 3 + 5);
-            CHGPU_REQUIRE(file[off + 3] == 0x82 && c2 >= HDR && 3 + (u64)c2 <= sz && d2 <= MAX_COMPRESSED_SIZE, CHGPU_ERR_BAD_ARGUMENTS,
+            CHGPU_REQUIRE(file[off + 3] == general && c2 >= HDR && 3 + (u64)c2 <= sz && d2 <= MAX_COMPRESSED_SIZE, CHGPU_ERR_BAD_ARGUMENTS,
                           "Cannot decompress: bad stage header in codec Multiple");
-            method = 0x82, post = 0x92, stage = d2;
+            method = general, post = codec, stage = d2;
             off += 3 + HDR, sz = c2 - (u32)HDR;
         }
         if (n < capacity)
@@ -236,6 +239,33 @@ extern "C" int chgpu_compressed_walk_frames(const uint8_t * file, uint64_t size,
     return CHGPU_OK;
 }
 
+namespace
+{
+struct ZstdLib
+{
+    size_t (*decompress)(void *, size_t, const void *, size_t);
+    unsigned (*is_error)(size_t);
+    const char * (*error_name)(size_t);
+};
+// libzstd of the host (the reference links the same library: contrib/zstd), loaded once; nullptr when the host has none
+const ZstdLib * zstd_lib()
+{
+    static ZstdLib lib;
+    static const bool ok = [] {
+        void * h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h)
+            h = dlopen("libzstd.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h)
+            return false;
+        lib.decompress = (size_t(*)(void *, size_t, const void *, size_t))dlsym(h, "ZSTD_decompress");
+        lib.is_error = (unsigned (*)(size_t))dlsym(h, "ZSTD_isError");
+        lib.error_name = (const char * (*)(size_t))dlsym(h, "ZSTD_getErrorName");
+        return lib.decompress && lib.is_error && lib.error_name;
+    }();
+    return ok ? &lib : nullptr;
+}
+} // namespace
+
 extern "C" int chgpu_read_compressed_column(chgpu_ctx * ctx, const uint8_t * file, uint64_t size, int type, int verify_checksums, chgpu_col ** out)
 {
     CHGPU_REQUIRE(ctx && (file || size == 0) && out, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
@@ -253,6 +283,44 @@ extern "C" int chgpu_read_compressed_column(chgpu_ctx * ctx, const uint8_t * fil
         total += dsizes[f];
     CHGPU_REQUIRE(total % es == 0, CHGPU_ERR_SIZES_MISMATCH, "Cannot read all data: %llu decompressed bytes are not a multiple of the element size %zu",
                   (unsigned long long)total, es);
+    // ZSTD (0x90, CompressionCodecZSTD.cpp:60-66: the payload is one zstd frame) is undone on the HOST by the library the reference links --
+    // libzstd, loaded on first use -- into an image of the file in which those frames are stored ones (method NONE); what crosses PCIe is
+    // then the decompressed bytes of these frames and the compressed bytes of all others.  A column codec behind it (CODEC(DoubleDelta,
+    // ZSTD)) still runs on the device.
+    std::vector<u8> image;
+    bool any_zstd = false;
+    for (u32 f = 0; f < n; ++f)
+        any_zstd = any_zstd || methods[f] == 0x90;
+    if (any_zstd)
+    {
+        const ZstdLib * z = zstd_lib();
+        CHGPU_REQUIRE(z, CHGPU_ERR_NOT_IMPLEMENTED, "compression method 0x90 (ZSTD) needs libzstd.so.1 on the host: CPU path");
+        u64 image_bytes = 0;
+        for (u32 f = 0; f < n; ++f)
+            image_bytes += methods[f] == 0x90 ? stages[f] : sizes[f];
+        image.resize(image_bytes ? image_bytes : 1);
+        u64 at = 0;
+        for (u32 f = 0; f < n; ++f)
+        {
+            if (methods[f] == 0x90)
+            {
+                const size_t got = z->decompress(image.data() + at, stages[f], file + offs[f], sizes[f]);
+                CHGPU_REQUIRE(!z->is_error(got) && got == stages[f], CHGPU_ERR_BAD_ARGUMENTS, "Cannot decompress ZSTD-encoded data: %s (CANNOT_DECOMPRESS)",
+                              z->is_error(got) ? z->error_name(got) : "wrong decompressed size");
+                methods[f] = 0x02;
+                offs[f] = at;
+                sizes[f] = stages[f];
+            }
+            else
+            {
+                memcpy(image.data() + at, file + offs[f], sizes[f]);
+                offs[f] = at;
+            }
+            at += sizes[f];
+        }
+        file = image.data();
+        size = image_bytes;
+    }
     chgpu_col * compressed = nullptr;
     CHGPU_TRY(chgpu_col_upload(ctx, CHGPU_U8, file, size, &compressed));
     chgpu_col * raw = nullptr;

@@ -22,6 +22,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 METHOD_NONE, METHOD_LZ4, METHOD_DELTA, METHOD_MULTIPLE = 0x02, 0x82, 0x92, 0x91
 METHOD_T64, METHOD_DOUBLE_DELTA, METHOD_GORILLA = 0x93, 0x94, 0x95  # CompressionInfo.h:40-51
+METHOD_ZSTD = 0x90
 DELTA_LZ4 = "delta+lz4"  # CODEC(Delta(w), LZ4)
 HEADER = 9
 CHECKSUM = 16
@@ -169,6 +170,59 @@ def write_codec_frames(values: np.ndarray, method: int, block_rows: int = 8192, 
     return bytes(out)
 
 
+def zstd_compress(raw: bytes, level: int = 1) -> bytes:
+    """CompressionCodecZSTD::doCompressData (CompressionCodecZSTD.cpp:40-57): the payload is one zstd frame (libzstd through pyarrow here)"""
+    import pyarrow as pa
+    return pa.Codec("zstd", compression_level=level).compress(raw, asbytes=True)
+
+
+def zstd_decompress(payload: bytes, dst_size: int) -> bytes:
+    """CompressionCodecZSTD::doDecompressData (:60-66): ZSTD_decompress into a buffer of the size the frame header promises"""
+    import pyarrow as pa
+    out = pa.decompress(payload, decompressed_size=dst_size, codec="zstd", asbytes=True)
+    if len(out) != dst_size:
+        raise ValueError("CANNOT_DECOMPRESS: wrong decompressed size")
+    return out
+
+
+def _codec_encode(chunk: np.ndarray, method: int, t64_bit: bool = False) -> bytes:
+    raw = chunk.tobytes()
+    w = chunk.dtype.itemsize
+    if method == METHOD_DOUBLE_DELTA:
+        return double_delta_encode(raw, w)
+    if method == METHOD_GORILLA:
+        return gorilla_encode(raw, w)
+    if method == METHOD_T64:
+        return t64_encode(chunk, t64_bit)
+    if method == METHOD_DELTA:
+        return delta_encode(raw, w)
+    raise NotImplementedError(hex(method))
+
+
+def _general_encode(raw: bytes, method: int) -> bytes:
+    import pyarrow as pa
+    if method == METHOD_LZ4:
+        return pa.compress(raw, codec="lz4_raw", asbytes=True)
+    if method == METHOD_ZSTD:
+        return zstd_compress(raw)
+    if method == METHOD_NONE:
+        return raw
+    raise NotImplementedError(hex(method))
+
+
+def write_multiple_frames(values: np.ndarray, codec: int, general: int, block_rows: int = 8192, t64_bit: bool = False) -> bytes:
+    """CODEC(<column codec>, <general-purpose codec>) -- e.g. CODEC(DoubleDelta, ZSTD), CODEC(T64, LZ4): a Multiple frame per block_rows
+    values (CompressionCodecMultiple.cpp:40-66: the method list, then the stages applied in order, each with its own 9-byte header)"""
+    values = np.ascontiguousarray(values)
+    out = bytearray()
+    for lo in range(0, values.shape[0], block_rows):
+        chunk = values[lo:lo + block_rows]
+        st1 = _stage(codec, _codec_encode(chunk, codec, t64_bit), chunk.nbytes)
+        st2 = _stage(general, _general_encode(st1, general), len(st1))
+        out += _framed(_stage(METHOD_MULTIPLE, bytes([2, codec, general]) + st2, chunk.nbytes))
+    return bytes(out)
+
+
 def write_frames(raw: bytes, block_size: int = 65536, method=METHOD_LZ4, delta_width: int = 8) -> bytes:
     """CompressedWriteBuffer: one frame per `block_size` bytes of input, each with its CityHash128 checksum.
     method DELTA_LZ4 = CODEC(Delta(delta_width), LZ4): a Multiple frame (CompressionCodecMultiple.cpp:40-66) -- the method list, then
@@ -182,7 +236,7 @@ def write_frames(raw: bytes, block_size: int = 65536, method=METHOD_LZ4, delta_w
             st2 = _stage(METHOD_LZ4, pa.compress(st1, codec="lz4_raw", asbytes=True), len(st1))
             out += _framed(_stage(METHOD_MULTIPLE, bytes([2, METHOD_DELTA, METHOD_LZ4]) + st2, len(chunk)))
             continue
-        payload = pa.compress(chunk, codec="lz4_raw", asbytes=True) if method == METHOD_LZ4 else chunk
+        payload = _general_encode(chunk, method)
         out += _framed(_stage(method, payload, len(chunk)))
     return bytes(out)
 
@@ -222,6 +276,8 @@ def read_frames(buf: bytes) -> bytes:
             out += gorilla_decode(payload, dsize)
         elif method == METHOD_MULTIPLE:
             out += _multiple_decode(payload, dsize)
+        elif method == METHOD_ZSTD:
+            out += zstd_decompress(payload, dsize)
         else:
             raise NotImplementedError(hex(method))
     return bytes(out)
@@ -236,6 +292,14 @@ def _decode_stage(buf: bytes) -> bytes:
         return delta_decode(payload, dsize)
     if method == METHOD_NONE:
         return payload
+    if method == METHOD_ZSTD:
+        return zstd_decompress(payload, dsize)
+    if method == METHOD_DOUBLE_DELTA:
+        return double_delta_decode(payload, dsize)
+    if method == METHOD_GORILLA:
+        return gorilla_decode(payload, dsize)
+    if method == METHOD_T64:
+        return t64_decode(payload, dsize)
     raise NotImplementedError(hex(method))
 
 

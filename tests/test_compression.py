@@ -480,3 +480,76 @@ def test_gpu_gorilla_frames_equal_the_oracle_and_the_reference_example():
             assert OC.read_frames(buf) == seq.tobytes()
             got = ch.compression.read_column_file(ctx, buf, dt).numpy()
             assert got.tobytes() == seq.tobytes(), (dt, seq[:4])
+
+
+# ---- round 3: ZSTD and the usual pairs CODEC(<column codec>, <general-purpose codec>) ------------------------------------------------------
+_PAIR_CODECS = ["DELTA", "T64", "DOUBLE_DELTA", "GORILLA"]
+_PAIR_GENERALS = ["LZ4", "ZSTD", "NONE"]
+
+
+def _pair_values(rng, dt, n):
+    if np.dtype(dt).kind == "f":
+        return (np.cumsum(rng.normal(size=n)) * 3.5).astype(dt)
+    info = np.iinfo(dt)
+    walk = np.cumsum(rng.integers(-3, 40, size=n))
+    return (walk % (int(info.max) - int(info.min) + 1) + int(info.min)).astype(dt) if np.dtype(dt).itemsize < 8 else walk.astype(dt)
+
+
+def test_oracle_multiple_frames_round_trip():
+    """Multiple{codec, general} as CompressionCodecMultiple lays it out (every stage with its own header), and plain ZSTD frames; the
+    codecs of gtest_compressionCodec.cpp:805-812 ("DoubleDelta, ZSTD", "Gorilla, ZSTD", ...)"""
+    rng = np.random.Generator(np.random.PCG64(12))
+    for codec in _PAIR_CODECS:
+        for general in _PAIR_GENERALS:
+            v = _pair_values(rng, np.int64 if codec != "GORILLA" else np.float64, 20_001)
+            buf = OC.write_multiple_frames(v, getattr(OC, "METHOD_" + codec), getattr(OC, "METHOD_" + general), block_rows=4096)
+            assert OC.read_frames(buf) == v.tobytes()
+            assert buf[16] == OC.METHOD_MULTIPLE and buf[25:28] == bytes([2, getattr(OC, "METHOD_" + codec), getattr(OC, "METHOD_" + general)])
+    raw = _pair_values(rng, np.uint32, 50_000).tobytes()
+    assert OC.read_frames(OC.write_frames(raw, 65536, OC.METHOD_ZSTD)) == raw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("general", _PAIR_GENERALS)
+@pytest.mark.parametrize("codec", _PAIR_CODECS)
+def test_gpu_codec_pairs_decode_to_the_original_column(codec, general):
+    """the column codec runs on the device behind the general-purpose stage (LZ4 decoded on the device; ZSTD undone on the host by libzstd,
+    the library the reference links -- CompressionCodecZSTD.cpp:60-66 -- before the bytes cross PCIe)"""
+    import clickhouse_amd as ch
+    ctx = ch.Context(0)
+    rng = np.random.Generator(np.random.PCG64(13))
+    dts = (np.float64, np.float32, np.uint32) if codec == "GORILLA" else (np.int64, np.uint32, np.int16, np.uint8) if codec != "T64" else (np.int64, np.uint32, np.int16, np.int8)
+    for dt in dts:
+        for n in (1, 4097, 30_000):
+            v = _pair_values(rng, dt, n)
+            buf = OC.write_multiple_frames(v, getattr(OC, "METHOD_" + codec), getattr(OC, "METHOD_" + general), block_rows=4096)
+            assert OC.read_frames(buf) == v.tobytes()
+            got = ch.compression.read_column_file(ctx, buf, dt).numpy()
+            assert got.tobytes() == v.tobytes(), (codec, general, dt, n)
+
+
+@pytest.mark.gpu
+def test_gpu_zstd_frames_and_mixed_files():
+    import clickhouse_amd as ch
+    ctx = ch.Context(0)
+    rng = np.random.Generator(np.random.PCG64(14))
+    v = _pair_values(rng, np.int64, 200_000)
+    raw = v.tobytes()
+    z = OC.write_frames(raw, 65536, OC.METHOD_ZSTD)
+    assert ch.compression.read_column_file(ctx, z, np.int64).numpy().tobytes() == raw
+    # a file whose parts were written under different codecs (ALTER ... MODIFY CODEC leaves such files): frames are independent
+    mixed = OC.write_frames(raw[:400_000], 65536, OC.METHOD_LZ4) + OC.write_frames(raw[400_000:800_000], 65536, OC.METHOD_ZSTD) + \
+        OC.write_multiple_frames(v[100_000:150_000], OC.METHOD_DOUBLE_DELTA, OC.METHOD_ZSTD) + OC.write_frames(raw[1_200_000:], 1 << 20, OC.METHOD_NONE)
+    assert ch.compression.read_column_file(ctx, mixed, np.int64).numpy().tobytes() == raw
+    # a damaged zstd payload is CANNOT_DECOMPRESS, and so is a stage header that disagrees with the outer frame
+    bad = bytearray(OC.write_frames(raw[:65536], 65536, OC.METHOD_ZSTD))
+    bad[16 + 9 + 6] ^= 0xFF
+    with pytest.raises(ch.ChgpuError) as e:
+        ch.compression.read_column_file(ctx, bytes(bad), np.int64, verify_checksums=False)
+    assert e.value.code == ch._capi.ERR_BAD_ARGUMENTS
+    m = bytearray(OC.write_multiple_frames(v[:4096], OC.METHOD_T64, OC.METHOD_NONE))
+    inner = 16 + 9 + 3 + 9                                           # outer checksum + header, method list, the NONE stage's header: T64's own header
+    m[inner + 5] ^= 0x01                                             # ... whose decompressed size no longer matches
+    with pytest.raises(ch.ChgpuError) as e:
+        ch.compression.read_column_file(ctx, bytes(m), np.int64, verify_checksums=False)
+    assert e.value.code == ch._capi.ERR_BAD_ARGUMENTS
