@@ -109,6 +109,7 @@ SIGNATURES = {
     "chgpu_read_compressed_column": (_i, [_vp, _vp, _u64, _i, _i, _pp]),
     "chgpu_city_hash128": (_i, [_vp, _u64, _pu64]),
     "chgpu_native_walk_block": (_i, [_vp, _u64, _u64, _u32, _vp, C.POINTER(_u32), _pu64, C.POINTER(C.c_int32), C.POINTER(_i), _pu64]),
+    "chgpu_native_read_strings": (_i, [_vp, _vp, _u64, _u64, _pp, _pp]),
     "chgpu_agg_serialize_states": (_i, [_vp, _i, _vp, _vp, _pp, _pp]),
     "chgpu_agg_deserialize_states": (_i, [_vp, _i, _vp, _u32, _pu64, _pu64, _pp, _pp]),
     "chgpu_fixed_string_word": (_i, [_vp, _vp, _u32, _u32, _pp]),

@@ -75,17 +75,59 @@ def city_hash128(data: bytes):
 
 
 class NativeColumn:
-    def __init__(self, name, type_name, dtype, offset, nbytes):
-        self.name, self.type_name, self.dtype, self.offset, self.nbytes = name, type_name, dtype, offset, nbytes
+    """one column of a Native block in HBM.  kind "numeric": `values`; "fixed_string": `values` = rows x N bytes (UInt8) and `fixed_n`;
+    "string": `offsets`, `chars` (ColumnString); "lc_string": `indexes` (UInt8/16/32/64) + the dictionary `offsets`, `chars` (key 0 is NULL when
+    `nullable`).  `null_map`: the UInt8 map of a Nullable column (None otherwise)."""
+
+    def __init__(self, name, type_name, kind):
+        self.name, self.type_name, self.kind = name, type_name, kind
+        self.values = self.offsets = self.chars = self.indexes = self.null_map = None
+        self.fixed_n, self.nullable, self.num_keys = 0, False, 0
+
+    def strings(self):
+        """the values as a list of bytes (None for NULL): host-side, for tests and small results"""
+        if self.kind == "numeric":
+            raise TypeError("numeric column")
+        if self.kind == "fixed_string":
+            raw = self.values.numpy().tobytes()
+            vals = [raw[i:i + self.fixed_n] for i in range(0, len(raw), self.fixed_n)]
+        else:
+            offs = self.offsets.numpy() if self.offsets.size() else np.zeros(0, dtype=np.uint64)
+            chars = self.chars.numpy().tobytes() if self.chars.size() else b""
+            keys = [chars[(int(offs[i - 1]) if i else 0):int(offs[i]) - 1] for i in range(offs.shape[0])]
+            if self.kind == "string":
+                vals = keys
+            else:
+                if self.nullable and keys:
+                    keys[0] = None
+                vals = [keys[int(i)] for i in self.indexes.numpy()]
+        if self.null_map is not None:
+            nm = self.null_map.numpy()
+            vals = [None if nm[i] else v for i, v in enumerate(vals)]
+        return vals
 
 
 class _NativeColumnStruct(C.Structure):
-    _fields_ = [("name", C.c_char * 64), ("type_name", C.c_char * 32), ("type", C.c_int32), ("data_offset", C.c_uint64), ("data_bytes", C.c_uint64)]
+    _fields_ = [("name", C.c_char * 64), ("type_name", C.c_char * 64), ("type", C.c_int32), ("kind", C.c_int32), ("fixed_n", C.c_uint32), ("is_nullable", C.c_int32),
+                ("data_offset", C.c_uint64), ("data_bytes", C.c_uint64), ("null_map_offset", C.c_uint64), ("chars_bytes", C.c_uint64),
+                ("lc_num_keys", C.c_uint64), ("lc_keys_offset", C.c_uint64), ("lc_keys_bytes", C.c_uint64), ("lc_keys_chars_bytes", C.c_uint64)]
 
 
-def read_native_block(ctx: Context, buf, pos: int = 0, server_revision: int = 0):
-    """NativeReader::read for one block of plain numeric columns: -> (dict(rows, bucket_num, is_overflows, next_pos), [(name, Column)])
-    The header walk is chgpu_native_walk_block; every column's values go to HBM as they lie in the buffer."""
+NATIVE_KINDS = {0: "numeric", 1: "string", 2: "fixed_string", 3: "lc_string"}
+
+
+def _read_strings(ctx: Context, view: bytes, offset: int, nbytes: int, rows: int):
+    arr = (C.c_uint8 * max(1, nbytes)).from_buffer_copy(view[offset:offset + nbytes] or b"\0")
+    oh, ch_ = C.c_void_p(), C.c_void_p()
+    K.check(K.lib().chgpu_native_read_strings(ctx._live(), arr, nbytes, rows, C.byref(oh), C.byref(ch_)))
+    return Column(ctx, oh), Column(ctx, ch_)
+
+
+def read_native_block(ctx: Context, buf, pos: int = 0, server_revision: int = 0, described: bool = False):
+    """NativeReader::read for one block: -> (dict(rows, bucket_num, is_overflows, next_pos), [(name, Column)]) for blocks of plain numeric
+    columns, or with described=True [(name, NativeColumn)] for every type the walk carries (numbers, String, FixedString(N), Nullable of
+    them, LowCardinality(String)).  The header walk is chgpu_native_walk_block; the values go to HBM as they lie in the buffer, Strings
+    through chgpu_native_read_strings."""
     from .columns import NP_OF
     raw = bytes(buf)
     view = raw[pos:]
@@ -96,8 +138,23 @@ def read_native_block(ctx: Context, buf, pos: int = 0, server_revision: int = 0)
     cols = (_NativeColumnStruct * max(1, ncols.value))()
     K.check(K.lib().chgpu_native_walk_block(arr, len(view), server_revision, ncols.value, cols, C.byref(ncols), C.byref(nrows), C.byref(bucket), C.byref(over), C.byref(used)))
     out = []
+    rows = int(nrows.value)
     for c in range(ncols.value):
-        dt = np.dtype(NP_OF[cols[c].type])
-        data = np.frombuffer(view, dtype=dt, count=nrows.value, offset=cols[c].data_offset)
-        out.append((cols[c].name.decode(), ctx.upload(data)))
-    return dict(rows=int(nrows.value), bucket_num=int(bucket.value), is_overflows=bool(over.value), next_pos=pos + int(used.value)), out
+        d = cols[c]
+        nc = NativeColumn(d.name.decode(), d.type_name.decode(), NATIVE_KINDS[d.kind])
+        nc.nullable, nc.fixed_n, nc.num_keys = bool(d.is_nullable), int(d.fixed_n), int(d.lc_num_keys)
+        if nc.kind == "numeric":
+            nc.values = ctx.upload(np.frombuffer(view, dtype=np.dtype(NP_OF[d.type]), count=rows, offset=d.data_offset))
+        elif nc.kind == "fixed_string":
+            nc.values = ctx.upload(np.frombuffer(view, dtype=np.uint8, count=rows * nc.fixed_n, offset=d.data_offset))
+        elif nc.kind == "string":
+            nc.offsets, nc.chars = _read_strings(ctx, view, d.data_offset, d.data_bytes, rows)
+        else:
+            nc.offsets, nc.chars = _read_strings(ctx, view, d.lc_keys_offset, d.lc_keys_bytes, nc.num_keys)
+            nc.indexes = ctx.upload(np.frombuffer(view, dtype=np.dtype(NP_OF[d.type]), count=rows, offset=d.data_offset))
+        if nc.nullable and nc.kind != "lc_string" and rows:
+            nc.null_map = ctx.upload(np.frombuffer(view, dtype=np.uint8, count=rows, offset=d.null_map_offset))
+        if not described and (nc.kind != "numeric" or nc.nullable):
+            raise K.ChgpuError(K.ERR_NOT_IMPLEMENTED, f"column {nc.name} has type {nc.type_name}: read_native_block(described=True)")
+        out.append((nc.name, nc if described else nc.values))
+    return dict(rows=rows, bucket_num=int(bucket.value), is_overflows=bool(over.value), next_pos=pos + int(used.value)), out

@@ -435,22 +435,119 @@ extern "C" int chgpu_native_walk_block(const uint8_t * data, uint64_t size, uint
             CHGPU_REQUIRE(r.ok, CHGPU_ERR_BAD_ARGUMENTS, "Cannot read all data: truncated column header");
             CHGPU_REQUIRE(!has_custom, CHGPU_ERR_NOT_IMPLEMENTED, "column %s has a custom (sparse) serialization: CPU path", name.c_str());
         }
-        const int tag = native_type_tag(type);
-        CHGPU_REQUIRE(tag >= 0, CHGPU_ERR_NOT_IMPLEMENTED, "column %s has type %s: only plain numeric columns are read on this path (CPU path)", name.c_str(), type.c_str());
-        const u64 nbytes = rows * chgpu_type_size(tag);
-        CHGPU_REQUIRE(nbytes <= (u64)(r.end - r.p), CHGPU_ERR_BAD_ARGUMENTS, "Cannot read all data in NativeReader. Rows expected: %llu (CANNOT_READ_ALL_DATA)",
-                      (unsigned long long)rows);
-        if (c < capacity)
+        chgpu_native_column o;
+        memset(&o, 0, sizeof(o));
+        snprintf(o.name, sizeof(o.name), "%s", name.c_str());
+        snprintf(o.type_name, sizeof(o.type_name), "%s", type.c_str());
+        // the type name, outside in: LowCardinality(...) and Nullable(...) wrap String / FixedString(N) / a number
+        std::string inner = type;
+        bool lc = false;
+        auto unwrap = [&](const char * prefix) {
+            const size_t n = strlen(prefix);
+            if (inner.size() > n + 1 && inner.compare(0, n, prefix) == 0 && inner.back() == ')')
+            {
+                inner = inner.substr(n, inner.size() - n - 1);
+                return true;
+            }
+            return false;
+        };
+        lc = unwrap("LowCardinality(");
+        o.is_nullable = unwrap("Nullable(") ? 1 : 0;
+        int tag = native_type_tag(inner);
+        if (inner == "String")
+            o.kind = CHGPU_NATIVE_STRING, tag = CHGPU_U8;
+        else if (unwrap("FixedString("))
         {
-            chgpu_native_column & o = columns[c];
-            memset(&o, 0, sizeof(o));
-            snprintf(o.name, sizeof(o.name), "%s", name.c_str());
-            snprintf(o.type_name, sizeof(o.type_name), "%s", type.c_str());
-            o.type = tag;
-            o.data_offset = (u64)(r.p - data);
-            o.data_bytes = nbytes;
+            char * endp = nullptr;
+            const unsigned long long fn = strtoull(inner.c_str(), &endp, 10);
+            CHGPU_REQUIRE(endp && *endp == 0 && fn >= 1 && fn <= 0xFFFFFFull, CHGPU_ERR_BAD_ARGUMENTS, "column %s: bad type %s", name.c_str(), type.c_str());
+            o.kind = CHGPU_NATIVE_FIXED_STRING, o.fixed_n = (u32)fn, tag = CHGPU_U8;
         }
-        r.p += nbytes;
+        CHGPU_REQUIRE(tag >= 0, CHGPU_ERR_NOT_IMPLEMENTED, "column %s has type %s: numbers, String, FixedString and their Nullable / LowCardinality(String) forms are read on this path (CPU path)",
+                      name.c_str(), type.c_str());
+        CHGPU_REQUIRE(!lc || o.kind == CHGPU_NATIVE_STRING, CHGPU_ERR_NOT_IMPLEMENTED, "column %s has type %s: LowCardinality of String only (CPU path)", name.c_str(), type.c_str());
+        const char * short_msg = "Cannot read all data in NativeReader. Rows expected: %llu (CANNOT_READ_ALL_DATA)";
+        // SerializationString::deserializeBinaryBulk: (VarUInt length, bytes) per value -- the walk finds the end and counts the bytes
+        auto walk_strings = [&](u64 n_values, u64 * chars_bytes) -> bool {
+            u64 total = 0;
+            for (u64 i = 0; i < n_values; ++i)
+            {
+                const u64 len = r.varuint();
+                if (!r.ok || len > (u64)(r.end - r.p))
+                    return false;
+                r.p += len;
+                total += len;
+            }
+            *chars_bytes = total;
+            return true;
+        };
+        if (rows) // (NativeReader.cpp:240-245: no rows, nothing to read -- not even the state prefix)
+        {
+            if (lc)
+            {
+                // SerializationLowCardinality: the state prefix (keys version), then [index type + flags][additional keys][rows][indexes]
+                // (SerializationLowCardinality.cpp:84-164, :560-700; the byte layout 02010_lc_native.python writes by hand)
+                u64 version = 0, itype = 0, num_keys = 0, num_rows = 0;
+                CHGPU_REQUIRE(r.bytes(&version, 8), CHGPU_ERR_BAD_ARGUMENTS, short_msg, (unsigned long long)rows);
+                CHGPU_REQUIRE(version == 1, CHGPU_ERR_BAD_ARGUMENTS, "Invalid version for SerializationLowCardinality key column. (INCORRECT_DATA)");
+                CHGPU_REQUIRE(r.bytes(&itype, 8), CHGPU_ERR_BAD_ARGUMENTS, short_msg, (unsigned long long)rows);
+                const u64 flags = itype & 0x700ull, width_code = itype & ~0x700ull;
+                CHGPU_REQUIRE(width_code <= 3, CHGPU_ERR_BAD_ARGUMENTS, "Invalid type for SerializationLowCardinality index column. (INCORRECT_DATA)");
+                CHGPU_REQUIRE(!(flags & 0x100), CHGPU_ERR_BAD_ARGUMENTS, "LowCardinality indexes serialization type for Native format cannot use global dictionary (INCORRECT_DATA)");
+                CHGPU_REQUIRE(flags & 0x200, CHGPU_ERR_BAD_ARGUMENTS, "No additional keys found. (INCORRECT_DATA)");
+                CHGPU_REQUIRE(r.bytes(&num_keys, 8), CHGPU_ERR_BAD_ARGUMENTS, short_msg, (unsigned long long)rows);
+                o.kind = CHGPU_NATIVE_LC_STRING;
+                o.lc_num_keys = num_keys;
+                o.lc_keys_offset = (u64)(r.p - data);
+                CHGPU_REQUIRE(num_keys <= (u64)(r.end - r.p) && walk_strings(num_keys, &o.lc_keys_chars_bytes), CHGPU_ERR_BAD_ARGUMENTS, short_msg, (unsigned long long)rows);
+                o.lc_keys_bytes = (u64)(r.p - data) - o.lc_keys_offset;
+                CHGPU_REQUIRE(r.bytes(&num_rows, 8), CHGPU_ERR_BAD_ARGUMENTS, short_msg, (unsigned long long)rows);
+                CHGPU_REQUIRE(num_rows == rows, CHGPU_ERR_BAD_ARGUMENTS, "Cannot read all data in NativeReader. Rows read: %llu. Rows expected: %llu (CANNOT_READ_ALL_DATA)",
+                              (unsigned long long)num_rows, (unsigned long long)rows);
+                static const int index_tags[4] = {CHGPU_U8, CHGPU_U16, CHGPU_U32, CHGPU_U64};
+                tag = index_tags[width_code];
+                const u64 w = 1ull << width_code, nbytes = rows * w;
+                CHGPU_REQUIRE(nbytes <= (u64)(r.end - r.p), CHGPU_ERR_BAD_ARGUMENTS, short_msg, (unsigned long long)rows);
+                // ColumnLowCardinality::Index::checkSizeOfType / insertRangeFromDictionaryEncodedColumn (ColumnLowCardinality.cpp:240-252)
+                for (u64 i = 0; i < rows; ++i)
+                {
+                    u64 ix = 0;
+                    memcpy(&ix, r.p + i * w, w);
+                    CHGPU_REQUIRE(ix < num_keys, CHGPU_ERR_BAD_ARGUMENTS, "Index for LowCardinality is out of range. Dictionary size is %llu, but found index with value %llu (INCORRECT_DATA)",
+                                  (unsigned long long)num_keys, (unsigned long long)ix);
+                }
+                o.data_offset = (u64)(r.p - data);
+                o.data_bytes = nbytes;
+                r.p += nbytes;
+            }
+            else
+            {
+                if (o.is_nullable) // SerializationNullable: the null map (one byte per row), then the nested column
+                {
+                    CHGPU_REQUIRE(rows <= (u64)(r.end - r.p), CHGPU_ERR_BAD_ARGUMENTS, short_msg, (unsigned long long)rows);
+                    o.null_map_offset = (u64)(r.p - data);
+                    r.p += rows;
+                }
+                o.data_offset = (u64)(r.p - data);
+                if (o.kind == CHGPU_NATIVE_STRING)
+                {
+                    CHGPU_REQUIRE(walk_strings(rows, &o.chars_bytes), CHGPU_ERR_BAD_ARGUMENTS, short_msg, (unsigned long long)rows);
+                    o.data_bytes = (u64)(r.p - data) - o.data_offset;
+                }
+                else
+                {
+                    const u64 nbytes = rows * (o.kind == CHGPU_NATIVE_FIXED_STRING ? (u64)o.fixed_n : (u64)chgpu_type_size(tag));
+                    CHGPU_REQUIRE(nbytes <= (u64)(r.end - r.p), CHGPU_ERR_BAD_ARGUMENTS, short_msg, (unsigned long long)rows);
+                    o.data_bytes = nbytes;
+                    r.p += nbytes;
+                }
+            }
+        }
+        else if (lc)
+            o.kind = CHGPU_NATIVE_LC_STRING, tag = CHGPU_U8;
+        o.type = tag;
+        if (c < capacity)
+            columns[c] = o;
     }
     *n_columns = (u32)cols;
     *n_rows = rows;
@@ -459,6 +556,40 @@ extern "C" int chgpu_native_walk_block(const uint8_t * data, uint64_t size, uint
     if (is_overflows)
         *is_overflows = overflows;
     *bytes_consumed = (u64)(r.p - data);
+    return CHGPU_OK;
+}
+
+/* SerializationString::deserializeBinaryBulk (src/DataTypes/Serializations/SerializationString.cpp): `rows` values, each a VarUInt length and
+   that many bytes, in host memory -> a ColumnString in HBM (chars: every value followed by a zero byte; offsets[i] = end of value i incl. the
+   zero).  The lengths form a chain only the host can follow; it lays the bytes out once and the two buffers cross PCIe. */
+extern "C" int chgpu_native_read_strings(chgpu_ctx * ctx, const uint8_t * serialized, uint64_t bytes, uint64_t rows, chgpu_col ** offsets_u64, chgpu_col ** chars_u8)
+{
+    CHGPU_REQUIRE(ctx && (serialized || bytes == 0) && offsets_u64 && chars_u8, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    ChgpuDeviceGuard guard(ctx);
+    Reader r{serialized, serialized + bytes};
+    std::vector<u64> offs(rows ? rows : 1);
+    std::vector<u8> chars;
+    chars.reserve(bytes + rows + 8);
+    for (u64 i = 0; i < rows; ++i)
+    {
+        const u64 len = r.varuint();
+        CHGPU_REQUIRE(r.ok && len <= (u64)(r.end - r.p), CHGPU_ERR_BAD_ARGUMENTS, "Cannot read all data: truncated String value %llu (CANNOT_READ_ALL_DATA)", (unsigned long long)i);
+        chars.insert(chars.end(), r.p, r.p + len);
+        chars.push_back(0);
+        r.p += len;
+        offs[i] = chars.size();
+    }
+    chgpu_col * o = nullptr;
+    CHGPU_TRY(chgpu_col_upload(ctx, CHGPU_U64, offs.data(), rows, &o));
+    chgpu_col * ch = nullptr;
+    const int rc = chgpu_col_upload(ctx, CHGPU_U8, chars.data(), chars.size(), &ch);
+    if (rc != CHGPU_OK)
+    {
+        chgpu_col_free(o);
+        return rc;
+    }
+    *offsets_u64 = o;
+    *chars_u8 = ch;
     return CHGPU_OK;
 }
 

@@ -163,19 +163,45 @@ int chgpu_read_compressed_column(chgpu_ctx * ctx, const uint8_t * file, uint64_t
 int chgpu_city_hash128(const void * data, uint64_t size, uint64_t out_low_high[2]);
 /* Native format (src/Formats/NativeReader.cpp:113-260): the header walk of ONE block in host memory.  [BlockInfo when server_revision > 0:
    (field, value)* 0 with field 1 = is_overflows, 2 = bucket_num (src/Core/BlockInfo.cpp:38-62)] columns, rows (VarUInt), then per column
-   name, type name (strings), [a custom-serialization flag byte from revision 54454 on] and the values.  Plain numeric columns are described
-   (where their rows x sizeof(T) little-endian bytes lie: upload them with chgpu_col_upload / chgpu_col_upload_async); any other type
-   answers CHGPU_ERR_NOT_IMPLEMENTED.  *bytes_consumed = where the next block starts. */
+   name, type name (strings), [a custom-serialization flag byte from revision 54454 on] and the values.  The walk describes where every
+   column's parts lie; the caller moves them to HBM:
+     numbers (kind NUMERIC): rows x sizeof(T) little-endian bytes at data_offset (chgpu_col_upload / chgpu_col_upload_async);
+     FixedString(N) (FIXED_STRING): rows x N bytes at data_offset, a UInt8 column for chgpu_fixed_string_word;
+     String (STRING): (VarUInt length, bytes) per value in [data_offset, +data_bytes), chars_bytes of them value bytes -> chgpu_native_read_strings;
+     Nullable(T) of these: is_nullable = 1 and the null map's rows bytes at null_map_offset, in front of the nested values
+       (SerializationNullable; chgpu_filter_description_nullable / NullableKeyAggregator take the map);
+     LowCardinality(String) and LowCardinality(Nullable(String)) (LC_STRING): SerializationLowCardinality.cpp:84-164,:560-700 -- keys version
+       (must be 1), index type + flags (a global dictionary is refused, additional keys are required: the reference's messages), lc_num_keys
+       keys serialized as Strings in [lc_keys_offset, +lc_keys_bytes) (chgpu_native_read_strings; is_nullable: key 0 stands for NULL), then
+       rows indexes of `type` (UInt8/16/32/64) at data_offset, each checked against lc_num_keys ("Index for LowCardinality is out of
+       range", ColumnLowCardinality.cpp:240-252).  Indexes + dictionary are a ColumnLowCardinality for chgpu_lc_remap / GROUP BY / joins.
+   Any other type answers CHGPU_ERR_NOT_IMPLEMENTED.  *bytes_consumed = where the next block starts.
+   Parity pin: tests/golden/native_lc_blocks.json = the bytes and messages of tests/queries/0_stateless/02010_lc_native.{python,reference}. */
+enum
+{
+    CHGPU_NATIVE_NUMERIC = 0,
+    CHGPU_NATIVE_STRING = 1,
+    CHGPU_NATIVE_FIXED_STRING = 2,
+    CHGPU_NATIVE_LC_STRING = 3
+};
 typedef struct chgpu_native_column
 {
     char name[64];
-    char type_name[32];
-    int32_t type;         /* CHGPU_* element type */
+    char type_name[64];
+    int32_t type;         /* CHGPU_* element type: the values' (NUMERIC), UInt8 (STRING / FIXED_STRING), the indexes' (LC_STRING) */
+    int32_t kind;         /* CHGPU_NATIVE_* */
+    uint32_t fixed_n;     /* FixedString(N) */
+    int32_t is_nullable;
     uint64_t data_offset; /* byte offset of the column's values inside `data` */
     uint64_t data_bytes;
+    uint64_t null_map_offset;
+    uint64_t chars_bytes; /* STRING: sum of the value lengths */
+    uint64_t lc_num_keys, lc_keys_offset, lc_keys_bytes, lc_keys_chars_bytes;
 } chgpu_native_column;
 int chgpu_native_walk_block(const uint8_t * data, uint64_t size, uint64_t server_revision, uint32_t capacity, chgpu_native_column * columns, uint32_t * n_columns,
                             uint64_t * n_rows, int32_t * bucket_num, int * is_overflows, uint64_t * bytes_consumed);
+/* `rows` serialized String values (SerializationString::deserializeBinaryBulk) in host memory -> a ColumnString in HBM */
+int chgpu_native_read_strings(chgpu_ctx * ctx, const uint8_t * serialized, uint64_t bytes, uint64_t rows, chgpu_col ** offsets_u64, chgpu_col ** chars_u8);
 int chgpu_decompress_frames(chgpu_ctx * ctx, const chgpu_col * compressed_u8, uint32_t n_frames, const uint64_t * payload_offsets,
                             const uint32_t * payload_sizes, const uint32_t * decompressed_sizes, const uint8_t * methods,
                             const uint8_t * post_methods, const uint32_t * stage_sizes, chgpu_col ** out_u8);

@@ -242,5 +242,50 @@ def make_codec_kat(ref_root):
     print("wrote codec_kat.json:", len(vectors), "frames")
 
 
+def make_native_lc_blocks(ref_root):
+    """tests/queries/0_stateless/02010_lc_native.python sends four hand-written Native blocks with one LowCardinality(String) column over
+    the wire (:198-375: the bytes after the packet type and the external table name are a Native block at revision 54449 -- BlockInfo,
+    dimensions, name, type, then the LowCardinality serialization); 02010_lc_native.reference holds what the server answers.  The byte
+    fields below restate the script's literals (version, index type + flags, keys, indexes); the expected messages are read from the
+    .reference file."""
+    ref = open(os.path.join(ref_root, "tests/queries/0_stateless/02010_lc_native.reference")).read().splitlines()
+    answers = [ln.split(":", 1)[1].strip() for ln in ref if ln.startswith("code 117:")]
+    assert len(answers) == 3
+
+    def varuint(x):
+        out = bytearray()
+        while x >= 0x80:
+            out.append((x & 0x7F) | 0x80)
+            x >>= 7
+        out.append(x)
+        return bytes(out)
+
+    def string(b):
+        return varuint(len(b)) + b
+
+    def block(index_type_bytes, index_bytes):
+        ba = bytearray()
+        ba += varuint(1) + bytes([0]) + varuint(2) + bytes([0] * 4) + varuint(0)               # serializeBlockInfo :148-153: is_overflows 0, bucket_num bytes 0
+        ba += varuint(1) + varuint(1)                                                           # one column, one row
+        ba += string(b"x") + string(b"LowCardinality(String)")
+        ba += bytes([1] + [0] * 7)                                                              # SharedDictionariesWithAdditionalKeys
+        ba += bytes(index_type_bytes + [0] * 6)
+        ba += bytes([1] + [0] * 7) + string(b"hello")                                           # one key
+        ba += bytes([1] + [0] * 7) + bytes(index_bytes)                                         # one index
+        return bytes(ba).hex()
+
+    cases = [
+        dict(name="valid", source_lines="198-233", block_hex=block([3, 2], [0] * 8), values=["hello"], error=None),
+        dict(name="index_overflow", source_lines="236-270", block_hex=block([3, 2], [0] * 7 + [1]), values=None, error=answers[0]),
+        dict(name="global_dictionary", source_lines="273-307", block_hex=block([3, 3], [0] * 8), values=None, error=answers[1]),
+        dict(name="no_additional_keys", source_lines="310-344", block_hex=block([3, 0], [0] * 8), values=None, error=answers[2]),
+    ]
+    out = dict(source="tests/queries/0_stateless/02010_lc_native.python + .reference", server_revision=54449, cases=cases)
+    with open(os.path.join(HERE, "native_lc_blocks.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote native_lc_blocks.json:", len(cases), "cases")
+
+
 if __name__ == "__main__":
     main()
+    make_native_lc_blocks(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")

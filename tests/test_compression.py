@@ -1,6 +1,8 @@
 """compressed frames (LZ4 / NONE) decoded in HBM.  Compressor = Apache Arrow's liblz4 (independent of both
 decoders); CPU: the C restatement returns the original bytes; GPU: the wave-per-frame decoder does, for real column data and for
 adversarial streams (long overlapping matches, 255-run length bytes, incompressible data), and rejects malformed frames."""
+import json
+import os
 import struct
 
 import numpy as np
@@ -216,7 +218,7 @@ def test_native_block_header_walk():
         assert raw[cols[1].data_offset:cols[1].data_offset + 4000] == b.tobytes()
     rc = K.lib().chgpu_native_walk_block(arr_t, 30, 54454, 2, cols, C.byref(ncols), C.byref(nrows), C.byref(bucket), C.byref(over), C.byref(used))
     assert rc == K.ERR_BAD_ARGUMENTS                                                                   # truncated
-    s = bytes(varuint(1) + varuint(3) + string("s") + string("String") + b"\x01a\x01b\x01c")
+    s = bytes(varuint(1) + varuint(3) + string("s") + string("Array(UInt8)") + b"\x01\x02\x03abc")
     arr_s = (C.c_uint8 * len(s)).from_buffer_copy(s)
     assert K.lib().chgpu_native_walk_block(arr_s, len(s), 0, 2, cols, C.byref(ncols), C.byref(nrows), None, None, C.byref(used)) == K.ERR_NOT_IMPLEMENTED
 
@@ -553,3 +555,143 @@ def test_gpu_zstd_frames_and_mixed_files():
     with pytest.raises(ch.ChgpuError) as e:
         ch.compression.read_column_file(ctx, bytes(m), np.int64, verify_checksums=False)
     assert e.value.code == ch._capi.ERR_BAD_ARGUMENTS
+
+
+# ---- round 3: Native blocks with String / FixedString / Nullable / LowCardinality(String) columns ------------------------------------------
+def _varuint(x):
+    out = bytearray()
+    while x >= 0x80:
+        out.append((x & 0x7F) | 0x80)
+        x >>= 7
+    out.append(x)
+    return bytes(out)
+
+
+def _nstring(b):
+    return _varuint(len(b)) + b
+
+
+def _walk(raw, rev, capacity=8):
+    import ctypes as C
+    import clickhouse_amd as ch
+    from clickhouse_amd import compression as CC
+    K = ch._capi
+    arr = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+    cols = (CC._NativeColumnStruct * capacity)()
+    ncols, nrows, used = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+    bucket, over = C.c_int32(-1), C.c_int(0)
+    K.check(K.lib().chgpu_native_walk_block(arr, len(raw), rev, capacity, cols, C.byref(ncols), C.byref(nrows), C.byref(bucket), C.byref(over), C.byref(used)))
+    return cols, ncols.value, nrows.value, used.value
+
+
+def test_native_lowcardinality_blocks_pinned_by_the_reference_test():
+    """the four hand-written LowCardinality(String) blocks of 02010_lc_native.python: the valid one is described, the three malformed ones
+    are refused with the message 02010_lc_native.reference records"""
+    import clickhouse_amd as ch
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "native_lc_blocks.json")))
+    for case in kat["cases"]:
+        raw = bytes.fromhex(case["block_hex"])
+        if case["error"] is None:
+            cols, ncols, nrows, used = _walk(raw, kat["server_revision"])
+            d = cols[0]
+            assert (ncols, nrows, used) == (1, 1, len(raw)) and (d.name, d.type_name, d.kind, d.type, d.lc_num_keys) == (b"x", b"LowCardinality(String)", 3, ch._capi.U64, 1)
+            assert raw[d.lc_keys_offset:d.lc_keys_offset + d.lc_keys_bytes] == b"\x05hello" and raw[d.data_offset:d.data_offset + d.data_bytes] == bytes(8)
+        else:
+            with pytest.raises(ch.ChgpuError) as e:
+                _walk(raw, kat["server_revision"])
+            assert e.value.code == ch._capi.ERR_BAD_ARGUMENTS and case["error"] in str(e.value), (case["name"], str(e.value))
+
+
+def _native_block(rev, rows, columns):
+    """NativeWriter::write restated: [BlockInfo] columns rows, then per column name, type, [custom-serialization flag], values"""
+    blk = bytearray()
+    if rev > 0:
+        blk += _varuint(1) + bytes([0]) + _varuint(2) + (-1).to_bytes(4, "little", signed=True) + _varuint(0)
+    blk += _varuint(len(columns)) + _varuint(rows)
+    for name, tname, payload in columns:
+        blk += _nstring(name.encode()) + _nstring(tname.encode())
+        if rev >= 54454:
+            blk += bytes([0])
+        blk += payload
+    return bytes(blk)
+
+
+def _lc_payload(keys, indexes, index_dtype):
+    code = {1: 0, 2: 1, 4: 2, 8: 3}[np.dtype(index_dtype).itemsize]
+    return (1).to_bytes(8, "little") + (code | 0x200).to_bytes(8, "little") + len(keys).to_bytes(8, "little") + b"".join(_nstring(k) for k in keys) + \
+        len(indexes).to_bytes(8, "little") + np.asarray(indexes, dtype=index_dtype).tobytes()
+
+
+def _mixed_block(rng, rows, rev):
+    words = [b"", b"a", b"hello", b"x" * 200, "żółw".encode(), b"with\0zero", b"tail "]
+    s_vals = [words[i] for i in rng.integers(0, len(words), size=rows)]
+    ns_vals = [None if rng.random() < 0.2 else words[i] for i in rng.integers(0, len(words), size=rows)]
+    nums = rng.integers(0, 2**63, size=rows, dtype=np.uint64)
+    ni = rng.integers(-100, 100, size=rows).astype(np.int32)
+    ni_null = (rng.random(rows) < 0.3).astype(np.uint8)
+    fs = rng.integers(0, 256, size=(rows, 3), dtype=np.uint8)
+    keys = [b"", b"DE", b"FR", b"a longer dictionary value"]            # (the dictionary of a Native block starts with the default value)
+    lc_ix = rng.integers(0, len(keys), size=rows)
+    nkeys = [b"", b"", b"red", b"green"]                                  # LowCardinality(Nullable(String)): key 0 = NULL, key 1 = the default ''
+    nlc_ix = rng.integers(0, len(nkeys), size=rows)
+    cols = [
+        ("n", "UInt64", nums.tobytes()),
+        ("s", "String", b"".join(_nstring(v) for v in s_vals)),
+        ("ni", "Nullable(Int32)", ni_null.tobytes() + ni.tobytes()),
+        ("fs", "FixedString(3)", fs.tobytes()),
+        ("lc", "LowCardinality(String)", _lc_payload(keys, lc_ix, np.uint8) if rows else b""),
+        ("ns", "Nullable(String)", bytes(1 if v is None else 0 for v in ns_vals) + b"".join(_nstring(v or b"") for v in ns_vals)),
+        ("nlc", "LowCardinality(Nullable(String))", _lc_payload(nkeys, nlc_ix, np.uint16) if rows else b""),
+    ]
+    want = dict(n=nums, s=s_vals, ni=[None if ni_null[i] else int(ni[i]) for i in range(rows)], fs=[fs[i].tobytes() for i in range(rows)],
+                lc=[keys[i] for i in lc_ix], ns=ns_vals, nlc=[None if i == 0 else nkeys[i] for i in nlc_ix])
+    return _native_block(rev, rows, cols), want
+
+
+def test_native_walk_describes_non_numeric_columns():
+    rng = np.random.Generator(np.random.PCG64(21))
+    for rev in (0, 54454):
+        for rows in (0, 1, 500):
+            raw, _ = _mixed_block(rng, rows, rev)
+            cols, ncols, nrows, used = _walk(raw + b"next", rev)
+            assert (ncols, nrows, used) == (7, rows, len(raw))
+            assert [cols[c].kind for c in range(7)] == [0, 1, 0, 2, 3, 1, 3] and [cols[c].is_nullable for c in range(7)] == [0, 0, 1, 0, 0, 1, 1]
+            assert cols[3].fixed_n == 3 and cols[3].data_bytes == 3 * rows and cols[0].data_bytes == 8 * rows
+            if rows:
+                assert cols[2].data_offset == cols[2].null_map_offset + rows and cols[4].lc_num_keys == 4 and cols[6].lc_num_keys == 4
+            # every truncation of the block is CANNOT_READ_ALL_DATA, never a read past the end
+            import clickhouse_amd as ch
+            for cut in sorted(set(int(x) for x in rng.integers(1, len(raw), size=12))) if rows else []:
+                with pytest.raises(ch.ChgpuError) as e:
+                    _walk(raw[:cut], rev)
+                assert e.value.code == ch._capi.ERR_BAD_ARGUMENTS
+
+
+@pytest.mark.gpu
+def test_gpu_native_block_with_strings_and_lowcardinality():
+    import clickhouse_amd as ch
+    from clickhouse_amd import compression as CC
+    ctx = ch.Context(0)
+    rng = np.random.Generator(np.random.PCG64(22))
+    for rows in (0, 1, 3000):
+        raw, want = _mixed_block(rng, rows, 54454)
+        info, cols = CC.read_native_block(ctx, raw + raw, 0, 54454, described=True)
+        assert info["rows"] == rows and info["next_pos"] == len(raw)
+        got = dict(cols)
+        assert np.array_equal(got["n"].values.numpy() if rows else np.zeros(0, dtype=np.uint64), want["n"])
+        if not rows:
+            continue
+        assert got["s"].strings() == want["s"] and got["fs"].strings() == want["fs"] and got["lc"].strings() == want["lc"]
+        assert got["ns"].strings() == want["ns"] and got["nlc"].strings() == want["nlc"]
+        nm = got["ni"].null_map.numpy()
+        assert [None if nm[i] else int(v) for i, v in enumerate(got["ni"].values.numpy())] == want["ni"]
+        # the LowCardinality column is a key column as it stands: GROUP BY its indexes, name the groups through the dictionary
+        A = ch.Aggregator(np.uint8, [(ch.AGG_COUNT, None)], ctx=ctx)
+        A.execute_on_block(got["lc"].indexes, [None])
+        gk, (gc,) = A.convert_to_block()
+        keys = [b"", b"DE", b"FR", b"a longer dictionary value"]
+        assert {keys[int(k)]: int(c) for k, c in zip(gk, gc)} == {k: want["lc"].count(k) for k in set(want["lc"])}
+        # the String column goes through the device dictionary encoder: same groups as the host's
+        from clickhouse_amd.lowcardinality import ColumnString
+        lc = ColumnString(got["s"].offsets, got["s"].chars).dictionary_encode()
+        assert sorted(lc.dictionary) == sorted(set(want["s"])) and [lc.dictionary[int(i)] for i in lc.indexes.numpy()] == want["s"]
