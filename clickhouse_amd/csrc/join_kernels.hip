@@ -131,7 +131,9 @@ struct chgpu_join
 static inline int jf_left_kind(const chgpu_join * j) { return (j->kind == CHGPU_JOIN_LEFT || j->kind == CHGPU_JOIN_FULL) ? CHGPU_JOIN_LEFT : CHGPU_JOIN_INNER; }
 static inline bool jf_track_used(const chgpu_join * j) { return j->kind == CHGPU_JOIN_RIGHT || j->kind == CHGPU_JOIN_FULL; }
 
-static inline bool jf_need_replication(const chgpu_join * j) { return j->strictness == CHGPU_STRICT_ALL; } // JoinFeatures.h:29
+// RIGHT ANY / RIGHT SEMI: the first left row to find a key takes ALL the right rows of that key, so the left row is replicated (JoinFeatures.h:28)
+static inline bool jf_right_once(const chgpu_join * j) { return j->kind == CHGPU_JOIN_RIGHT && (j->strictness == CHGPU_STRICT_ANY || j->strictness == CHGPU_STRICT_SEMI); }
+static inline bool jf_need_replication(const chgpu_join * j) { return j->strictness == CHGPU_STRICT_ALL || jf_right_once(j); } // JoinFeatures.h:28
 static inline bool jf_need_filter(const chgpu_join * j)
 {
     return !jf_need_replication(j)
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(JT) void k_fill_u64(u64 * p, u64 n, u64 v)
         p[i] = v;
 }
 
-enum { PV_ALL_INNER, PV_ALL_LEFT, PV_ANY_LEFT, PV_SEMI_LEFT, PV_ANTI_LEFT, PV_ANY_INNER };
+enum { PV_ALL_INNER, PV_ALL_LEFT, PV_ANY_LEFT, PV_SEMI_LEFT, PV_ANTI_LEFT, PV_ANY_INNER, PV_ONCE_RIGHT, PV_ANTI_RIGHT };
 
 // probe pass 0 (INNER ANY only): every matching left row bids for its right cell with its sequence number
 template <bool PF>
@@ -481,6 +483,8 @@ __global__ __launch_bounds__(JT) void k_join_probe_count(JoinTable t, int varian
             case PV_SEMI_LEFT: c = found ? 1 : 0; f = found; break;
             case PV_ANTI_LEFT: c = found ? 0 : 1; f = !found; break;              // :515-519, :535-536
             case PV_ANY_INNER: c = (found && t.used_by[slot] == seq_base + i) ? 1 : 0; f = (u8)c; break; // setUsedOnce, :498-510
+            case PV_ONCE_RIGHT: c = (found && t.used_by[slot] == seq_base + i) ? rows_here : 0; break;     // RIGHT ANY / SEMI: setUsedOnce + addFoundRowAll, :487-497
+            case PV_ANTI_RIGHT: c = 0; f = 0; break;                              // RIGHT ANTI: found rows only set the flags (:515-519), nothing is emitted
         }
         counts[i] = c;
         val_of_left[i] = v;
@@ -819,6 +823,39 @@ __global__ __launch_bounds__(JT) void k_join_mark_used(const u64 * __restrict__ 
     }
 }
 
+// RIGHT ANTI: a probe emits nothing; the left row that won a key's bid (the first to find it, over all blocks) marks every right row of
+// that key as used -- once per key, however many left rows find it (used_flags.setUsed(find_result), HashJoinMethodsImpl.h:515-519)
+__global__ __launch_bounds__(JT) void k_join_mark_used_keys(JoinTable t, const u32 * __restrict__ slot_of_left, const u64 * __restrict__ val_of_left, u64 n, u64 seq_base,
+                                                            const u64 * __restrict__ block_base, u64 n_blocks, u64 total_rows, u8 * __restrict__ used)
+{
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+    {
+        const u32 slot = slot_of_left[i];
+        if (slot == NO_SLOT || t.used_by[slot] != seq_base + i)
+            continue;
+        const u64 v = val_of_left[i];
+        auto mark = [&](u64 r) {
+            const u64 b = r >> 32;
+            if (b < n_blocks)
+            {
+                const u64 f = block_base[b] + (r & 0xFFFFFFFFull);
+                if (f < total_rows)
+                    used[f] = 1;
+            }
+        };
+        if (!(v & JV_MULTI))
+        {
+            mark(v);
+            continue;
+        }
+        const u64 c0 = (v >> 40) & JV_CNT_SAT;
+        const u32 c = c0 < JV_CNT_SAT ? (u32)c0 : t.cnt[slot];
+        const u64 * run = t.rowids + (v & JV_START_MASK);
+        for (u32 k = 0; k < c; ++k)
+            mark(run[k]);
+    }
+}
+
 // NotJoinedHash (src/Interpreters/HashJoin/HashJoin.cpp:1280-1420): the build rows no probe row ever matched -- rows whose key was
 // NULL or whose ON mask was 0 included (they were never inserted, so they are never used) -- as (block << 32 | row) ids
 __global__ __launch_bounds__(JT) void k_join_unused_flags(const u8 * __restrict__ used, u64 n, u32 * __restrict__ flag)
@@ -864,11 +901,11 @@ extern "C" int chgpu_join_create(chgpu_ctx * ctx, int key_type, int kind, int st
     CHGPU_REQUIRE(chgpu_type_is_int(key_type),
                   CHGPU_ERR_NOT_IMPLEMENTED, "join key type %d: CPU path", key_type);
     CHGPU_REQUIRE(kind >= CHGPU_JOIN_INNER && kind <= CHGPU_JOIN_FULL, CHGPU_ERR_NOT_IMPLEMENTED, "join kind %d: CPU path", kind);
-    CHGPU_REQUIRE((kind != CHGPU_JOIN_RIGHT && kind != CHGPU_JOIN_FULL) || strictness == CHGPU_STRICT_ALL, CHGPU_ERR_NOT_IMPLEMENTED,
-                  "RIGHT / FULL joins are carried for strictness ALL only (RIGHT ANY / SEMI / ANTI use per-key flags, joinDispatch.h:30-68): CPU path");
+    CHGPU_REQUIRE(kind != CHGPU_JOIN_FULL || strictness == CHGPU_STRICT_ALL, CHGPU_ERR_NOT_IMPLEMENTED,
+                  "FULL joins are carried for strictness ALL only (FULL ANY is a TODO in the reference too, HashJoinMethodsImpl.h:511-514): CPU path");
     CHGPU_REQUIRE(strictness >= CHGPU_STRICT_ANY && strictness <= CHGPU_STRICT_ANTI, CHGPU_ERR_NOT_IMPLEMENTED, "join strictness %d: CPU path", strictness);
-    CHGPU_REQUIRE(!((strictness == CHGPU_STRICT_SEMI || strictness == CHGPU_STRICT_ANTI) && kind != CHGPU_JOIN_LEFT), CHGPU_ERR_NOT_IMPLEMENTED,
-                  "only SEMI LEFT / ANTI LEFT are valid here (joinDispatch.h:52-64)");
+    CHGPU_REQUIRE(!((strictness == CHGPU_STRICT_SEMI || strictness == CHGPU_STRICT_ANTI) && kind != CHGPU_JOIN_LEFT && kind != CHGPU_JOIN_RIGHT), CHGPU_ERR_NOT_IMPLEMENTED,
+                  "only SEMI / ANTI LEFT and RIGHT are valid (joinDispatch.h:52-64)");
     chgpu_join * j = new chgpu_join();
     j->ctx = ctx;
     j->key_type = key_type;
@@ -1234,8 +1271,10 @@ static int join_build_table(chgpu_join * j)
         return CHGPU_OK;
     j->build_closed = true;
     chgpu_ctx * ctx = j->ctx;
-    const bool maps_all = j->strictness == CHGPU_STRICT_ALL;
-    const bool flagged = j->kind == CHGPU_JOIN_INNER && j->strictness == CHGPU_STRICT_ANY;
+    // joinDispatch.h:30-68: MapsAll for every ALL join and for every RIGHT join (RIGHT ANY / SEMI / ANTI keep all rows of a key); a cell
+    // remembers the left row that consumed it for INNER ANY and for RIGHT ANY / SEMI / ANTI (setUsedOnce / the per-key flag)
+    const bool maps_all = j->strictness == CHGPU_STRICT_ALL || j->kind == CHGPU_JOIN_RIGHT;
+    const bool flagged = (j->kind == CHGPU_JOIN_INNER && j->strictness == CHGPU_STRICT_ANY) || (j->kind == CHGPU_JOIN_RIGHT && j->strictness != CHGPU_STRICT_ALL);
     // load factor in (0.175, 0.35]: a probe then resolves at its home cell nearly always (1.1 cells per hit, 1.3 per miss, against 1.75 / 3.6
     // at 0.6).  Measured at C4: build 1.00 -> 0.90 ms (fewer retried claims), probe 3.40 -> 2.26 ms region-partitioned, 4.83 -> 3.39 ms
     // one-pass.  The table is immutable after the build and 288 GB of HBM make the doubled footprint (512 MB of cells for 1e7 rows) cheap.
@@ -1416,7 +1455,7 @@ extern "C" int chgpu_join_non_joined_rows(chgpu_join * j, chgpu_col ** right_row
     if (!j->finished)
         CHGPU_TRY(join_build_table(j));
     chgpu_ctx * ctx = j->ctx;
-    const u64 n = j->total_rows;
+    const u64 n = j->strictness == CHGPU_STRICT_SEMI ? 0 : j->total_rows; // JoinCommon::hasNonJoinedBlocks (JoinUtils.cpp:634-638): none for SEMI
     chgpu_col * out = nullptr;
     u64 total = 0;
     if (n)
@@ -1522,13 +1561,15 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
     const bool need_filter = jf_need_filter(j), need_repl = jf_need_replication(j);
     CHGPU_REQUIRE(!need_filter || filter_out, CHGPU_ERR_BAD_ARGUMENTS, "this join variant produces a filter: filter_u8 must not be NULL");
     CHGPU_REQUIRE(!need_repl || offsets_out, CHGPU_ERR_BAD_ARGUMENTS, "this join variant produces offsets_to_replicate: offsets_u64 must not be NULL");
-    CHGPU_REQUIRE(right_rowid_out || (need_filter && !need_repl && (j->strictness == CHGPU_STRICT_SEMI || j->strictness == CHGPU_STRICT_ANTI)),
+    CHGPU_REQUIRE(right_rowid_out || (need_filter && !need_repl && j->kind == CHGPU_JOIN_LEFT && (j->strictness == CHGPU_STRICT_SEMI || j->strictness == CHGPU_STRICT_ANTI)),
                   CHGPU_ERR_BAD_ARGUMENTS, "right_rowid_u64 may only be NULL for LEFT SEMI / LEFT ANTI (filter-only probe)");
     if (filter_out) *filter_out = nullptr;
     if (offsets_out) *offsets_out = nullptr;
     if (right_rowid_out) *right_rowid_out = nullptr;
     int variant;
     if (j->strictness == CHGPU_STRICT_ALL) variant = jf_left_kind(j) == CHGPU_JOIN_LEFT ? PV_ALL_LEFT : PV_ALL_INNER;
+    else if (jf_right_once(j)) variant = PV_ONCE_RIGHT;
+    else if (j->kind == CHGPU_JOIN_RIGHT) variant = PV_ANTI_RIGHT;
     else if (j->strictness == CHGPU_STRICT_SEMI) variant = PV_SEMI_LEFT;
     else if (j->strictness == CHGPU_STRICT_ANTI) variant = PV_ANTI_LEFT;
     else variant = jf_left_kind(j) == CHGPU_JOIN_LEFT ? PV_ANY_LEFT : PV_ANY_INNER;
@@ -1647,14 +1688,21 @@ extern "C" int chgpu_join_probe(chgpu_join * j, const chgpu_col * key_col, const
     const void * kp = key_col->data;
     const u8 * nm = null_map ? (const u8 *)null_map->data : nullptr;
     const u64 seq_base = j->left_seq;
-    if (variant == PV_ANY_INNER)
+    const bool bids = variant == PV_ANY_INNER || variant == PV_ONCE_RIGHT || variant == PV_ANTI_RIGHT;
+    if (bids)
     {
         hipLaunchKernelGGL(j->t.pf ? k_join_probe_bid<true> : k_join_probe_bid<false>, dim3(grid), dim3(JT), 0, ctx->stream, j->t, kp, j->key_type, nm, n, seq_base, slot_of_left);
         ctx->counters[6] += 1;
     }
     hipLaunchKernelGGL(j->t.pf ? k_join_probe_count<true> : k_join_probe_count<false>, dim3(grid), dim3(JT), 0, ctx->stream, j->t, variant, kp, j->key_type, nm, n, seq_base,
-                       variant == PV_ANY_INNER ? 1 : 0, slot_of_left, val_of_left, counts, filter ? (u8 *)filter->data : nullptr);
+                       bids ? 1 : 0, slot_of_left, val_of_left, counts, filter ? (u8 *)filter->data : nullptr);
     ctx->counters[6] += 1;
+    if (variant == PV_ANTI_RIGHT)
+    {
+        hipLaunchKernelGGL(k_join_mark_used_keys, dim3(grid), dim3(JT), 0, ctx->stream, j->t, (const u32 *)slot_of_left, (const u64 *)val_of_left, n, seq_base,
+                           (const u64 *)j->block_base_dev, (u64)j->blocks.size(), j->total_rows, j->used);
+        ctx->counters[6] += 1;
+    }
     if ((rc = chgpu_scan_inclusive_u32_u64(ctx, counts, (u64 *)offsets->data, n, total_dev, tmp, tmp_b)) != CHGPU_OK)
         return fail(rc);
     hipLaunchKernelGGL(k_join_cut, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)offsets->data, n, (u64)max_joined_block_rows, j->t.ctrl);

@@ -32,8 +32,8 @@ class HashJoin:
             pass
 
     @property
-    def need_replication(self):  # JoinFeatures.h:29
-        return self.strictness == K.STRICT_ALL
+    def need_replication(self):  # JoinFeatures.h:28: is_all_join || (is_any_join && right) || (is_semi_join && right)
+        return self.strictness == K.STRICT_ALL or (self.kind == K.JOIN_RIGHT and self.strictness in (K.STRICT_ANY, K.STRICT_SEMI))
 
     @property
     def need_filter(self):  # JoinFeatures.h:32

@@ -960,10 +960,14 @@ public:
         check(chgpu_join_total_rows(h, &r, nullptr));
         return r;
     }
-    bool needReplication() const { return strictness == CHGPU_STRICT_ALL; }
+    /// JoinFeatures.h:28,31
+    bool needReplication() const
+    {
+        return strictness == CHGPU_STRICT_ALL || (kind == CHGPU_JOIN_RIGHT && (strictness == CHGPU_STRICT_ANY || strictness == CHGPU_STRICT_SEMI));
+    }
     bool needFilter() const
     {
-        return !needReplication() && (kind == CHGPU_JOIN_INNER || strictness == CHGPU_STRICT_SEMI || strictness == CHGPU_STRICT_ANTI);
+        return !needReplication() && (kind == CHGPU_JOIN_INNER || kind == CHGPU_JOIN_RIGHT || strictness == CHGPU_STRICT_SEMI || strictness == CHGPU_STRICT_ANTI);
     }
 
     /// getNonJoinedBlocks (IJoin.h:133-134; NotJoinedBlocks::nextImpl, src/Interpreters/NotJoinedBlocks.cpp) for RIGHT / FULL joins, after

@@ -848,7 +848,7 @@ int main(int argc, char ** argv)
         bool fell_back = false;
         try
         {
-            GpuHashJoin right_join(ctx, CHGPU_U64, CHGPU_JOIN_RIGHT, CHGPU_STRICT_ANY); // RIGHT ANY uses per-key flags: not carried
+            GpuHashJoin full_any(ctx, CHGPU_U64, CHGPU_JOIN_FULL, CHGPU_STRICT_ANY); // FULL ANY: a TODO in the reference too (HashJoinMethodsImpl.h:511-514)
         }
         catch (const Exception & e)
         {

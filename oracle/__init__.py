@@ -642,6 +642,33 @@ def hash_to_selector(keys: np.ndarray, num_shards: int) -> np.ndarray:
     return out
 
 
+def right_once_pairs(build_blocks, probe_key_batches, anti: bool = False):
+    """RIGHT ANY / RIGHT SEMI (and the flags of RIGHT ANTI) restated from joinRightColumns (HashJoinMethodsImpl.h:487-497, :515-519): the map
+    is MapsAll (joinDispatch.h:37,53,61: every inserted right row is kept) with ONE flag per key; left rows are taken in order, over all
+    probed blocks, and the first one to find a key sets its flag (setUsedOnce) and is joined with ALL right rows of that key
+    (addFoundRowAll); every later left row with the same key adds nothing.  RIGHT ANTI emits nothing and only sets the flag.
+    -> ([per batch: sorted [(left_row, block, row)]], sorted [(block, row)] of the right rows under a flag that was set)"""
+    rows_of = {}
+    for b, (keys, nm, jm) in enumerate(build_blocks):
+        for r in range(keys.shape[0]):
+            if (nm is not None and nm[r]) or (jm is not None and not jm[r]):
+                continue
+            rows_of.setdefault(int(keys[r]), []).append((b, r))
+    used, out = set(), []
+    for keys, nm in probe_key_batches:
+        pairs = []
+        for i in range(keys.shape[0]):
+            if nm is not None and nm[i]:
+                continue
+            k = int(keys[i])
+            if k in rows_of and k not in used:
+                used.add(k)
+                if not anti:
+                    pairs += [(i, b, r) for b, r in rows_of[k]]
+        out.append(sorted(pairs))
+    return out, sorted(br for k in used for br in rows_of[k])
+
+
 def non_joined_rows(build_blocks, probe_key_batches):
     """RIGHT / FULL join with strictness ALL: the build rows NotJoinedHash emits after the probe phase (HashJoin.cpp:1280-1420) are
     those whose JoinUsedFlags bit was never set (JoinUsedFlags.h; set in addFoundRowAll for every matching right row).  With ALL

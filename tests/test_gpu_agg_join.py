@@ -247,7 +247,7 @@ def test_join_empty_sides_and_errors(ch, engine):
         j.add_block(np.array([6], dtype=np.uint64))                         # addBlockToJoin after the build phase finished
     assert e.value.code == ch._capi.ERR_LOGICAL
     with pytest.raises(ch.ChgpuError) as e:
-        ch.HashJoin(ch.JOIN_RIGHT, ch.STRICT_SEMI)                          # RIGHT SEMI: explicit CPU fallback signal
+        ch.HashJoin(ch.JOIN_FULL, ch.STRICT_SEMI)                           # FULL SEMI is not a join (joinDispatch.h:52-56): explicit CPU fallback signal
     assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED
 
 
@@ -632,9 +632,62 @@ def test_right_and_full_join_all_with_non_joined_rows(ch, ctx, oracle_mod, kind_
     assert len(got) + len({(b, r) for b, r in zip(gb.tolist(), gr.tolist()) if b >= 0}) <= g.total_rows
 
 
+@pytest.mark.parametrize("strict_name", ["ANY", "SEMI", "ANTI"])
+def test_right_any_semi_anti_joins(ch, ctx, oracle_mod, strict_name):
+    """RIGHT ANY / SEMI / ANTI (joinDispatch.h:37,53,61: MapsAll with one flag per key): the first left row to find a key -- over all probed
+    blocks -- is joined with every right row of it, later ones add nothing; RIGHT ANTI emits nothing.  getNonJoinedBlocks: the right rows
+    whose key no left row found for ANY / ANTI, none for SEMI (JoinCommon::hasNonJoinedBlocks).  Checked against the oracle's restatement
+    of joinRightColumns, triple by triple, with duplicate build keys, NULLs, ON masks, the zero key and a max_joined_block_rows cut."""
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(len(strict_name) + 40))
+    strict = getattr(ch, "STRICT_" + strict_name)
+    g = ch.HashJoin(ch.JOIN_RIGHT, strict, ctx=ctx)
+    build = []
+    for b in range(4):
+        n = [5000, 1, 0, 7001][b]
+        keys = rng.integers(0, 3000, size=n).astype(np.uint64)       # ~4 right rows per key
+        keys[: min(n, 3)] = 0
+        nm = (rng.random(n) < 0.05).astype(np.uint8) if b % 2 == 0 else None
+        jm = (rng.random(n) < 0.9).astype(np.uint8) if b == 3 else None
+        g.add_block(keys, nm, jm)
+        build.append((keys, nm, jm))
+    probes, got = [], []
+    for batch in range(3):
+        n = [4000, 0, 2500][batch]
+        left = rng.integers(0, 2000, size=n).astype(np.uint64)       # keys 2000..2999 of the build side are never probed
+        lnm = (rng.random(n) < 0.1).astype(np.uint8) if batch == 0 else None
+        if batch == 2:
+            # the early stop of need_replication joins: the tail comes back unprocessed and is resubmitted (HashJoinMethodsImpl.h:434-444)
+            pairs, pos = [], 0
+            while pos < n:
+                gl, gb, gr, gc = g.joined_pairs(left[pos:], lnm[pos:] if lnm is not None else None, max_joined_block_rows=300 if strict_name != "ANTI" else 0)
+                assert gc > 0
+                pairs += [(int(l) + pos, int(b), int(r)) for l, b, r in zip(gl, gb, gr)]
+                pos += gc
+        else:
+            gl, gb, gr, gc = g.joined_pairs(left, lnm)
+            assert gc == n
+            pairs = list(zip(gl.tolist(), gb.tolist(), gr.tolist()))
+        got.append(sorted(pairs))
+        probes.append((left, lnm))
+    want, flagged = O.right_once_pairs(build, probes, anti=strict_name == "ANTI")
+    assert got == want
+    if strict_name == "ANTI":
+        assert all(len(p) == 0 for p in got)
+    nb, nr = g.non_joined_rows()
+    non_joined = list(zip(nb.tolist(), nr.tolist()))
+    assert non_joined == sorted(non_joined)
+    if strict_name == "SEMI":
+        assert non_joined == []
+    else:
+        assert non_joined == O.non_joined_rows(build, probes)
+        total = sum(k.shape[0] for k, _, _ in build)
+        assert len(non_joined) + len(flagged) == total and not (set(non_joined) & set(flagged))
+
+
 def test_right_join_restrictions_and_empty_cases(ch, ctx):
     with pytest.raises(ch.ChgpuError) as ei:
-        ch.HashJoin(ch.JOIN_RIGHT, ch.STRICT_ANY, ctx=ctx)
+        ch.HashJoin(ch.JOIN_FULL, ch.STRICT_ANY, ctx=ctx)              # a TODO in the reference too (HashJoinMethodsImpl.h:511-514)
     assert ei.value.code == ch._capi.ERR_NOT_IMPLEMENTED
     j = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, ctx=ctx)
     j.add_block(np.array([1, 2], dtype=np.uint64))
