@@ -17,7 +17,7 @@ OK = 0
 ERR_SIZES_MISMATCH, ERR_NOT_IMPLEMENTED, ERR_OOM, ERR_LOGICAL, ERR_BAD_ARGUMENTS, ERR_DEVICE, ERR_TOO_MANY_ROWS = -1, -2, -3, -4, -5, -6, -7
 I64, U32, U64, F64, U8, I32, U16, I16, I8, F32 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 EQ, NE, LT, GT, LE, GE = 0, 1, 2, 3, 4, 5
-AGG_COUNT, AGG_SUM, AGG_AVG, AGG_MIN, AGG_MAX = 0, 1, 2, 3, 4
+AGG_COUNT, AGG_SUM, AGG_AVG, AGG_MIN, AGG_MAX, AGG_ANY = 0, 1, 2, 3, 4, 5
 JOIN_INNER, JOIN_LEFT, JOIN_RIGHT, JOIN_FULL = 0, 1, 2, 3
 STRICT_ANY, STRICT_ALL, STRICT_SEMI, STRICT_ANTI = 0, 1, 2, 3
 N_COUNTERS = 8

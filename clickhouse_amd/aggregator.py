@@ -63,12 +63,12 @@ class Aggregator:
 
     @property
     def n_words(self):
-        return sum(2 if k == K.AGG_AVG else 1 for k, _ in self.aggs)   # (min / max: one order-key word)
+        return sum(2 if k in (K.AGG_AVG, K.AGG_ANY) else 1 for k, _ in self.aggs)   # (min / max: one order-key word; any: claim + value)
 
     def result_dtypes(self):
         out = []
         for kind, t in self.aggs:
-            out.append(np.uint64 if kind == K.AGG_COUNT else np.float64 if kind == K.AGG_AVG else NP_OF[t] if kind in (K.AGG_MIN, K.AGG_MAX) else sum_result_dtype(t))
+            out.append(np.uint64 if kind == K.AGG_COUNT else np.float64 if kind == K.AGG_AVG else NP_OF[t] if kind in (K.AGG_MIN, K.AGG_MAX, K.AGG_ANY) else sum_result_dtype(t))
         return out
 
     def finalize_columns(self):

@@ -77,6 +77,7 @@ struct AggDesc
     u32 word_fx_hi; // the high halves (never updated on their own)
     unsigned char fx_hi[AGG_MAX_WORDS];
     int fx_base;
+    u64 row_seq; // any(): row i of the argument columns is the (row_seq + i)-th row this aggregation has seen (modulo 2^64)
 };
 
 struct AggTable
@@ -103,7 +104,11 @@ struct chgpu_agg
     size_t table_class = 0;
     u64 n_groups = 0; // host copy, refreshed after every call
     bool hint_probed = false; // the cardinality of a hint-less aggregation was sampled on its first large block
-    bool has_extremum = false; // some function is min / max: rows take the DIRECT kernel (the LDS-staged plans only know how to add)
+    bool has_extremum = false; // some function is min / max / any: rows take the DIRECT kernel (the LDS-staged plans only know how to add)
+    // any(): {claim, value} words.  claim = ~(ordinal of the row that set the value) under an unsigned max: the EARLIEST row of the group
+    // wins whatever order the hardware serves the rows in; the value is stored by a second pass from the winner's row (k_agg_any_resolve)
+    u32 word_any = 0; // bit w: word w is a claim, word w + 1 its value
+    u64 any_seq = 0;  // rows seen so far
     // deterministic Float64 sums (option deterministic_float_sums, the default): sum / avg over a float argument keep a 128-bit fixed-point
     // state {word, fx_hi[word]} in units of 2^fx_base instead of a double.  n_words counts the appended high halves too; the first
     // n_pub_words are the words the C ABI shows (state columns, wire format): exports fold a pair back into its Float64 column.
@@ -372,6 +377,8 @@ __device__ __forceinline__ void add_row_global(const AggTable & t, const AggDesc
             const u64 k = agg_order_key(load_arg_bits(a.ptr, a.arg_type, i), a.arg_type);
             global_add_word(w, a.kind == CHGPU_AGG_MAX ? k : ~k, 2);
         }
+        else if (a.kind == CHGPU_AGG_ANY)
+            global_add_word(w, ~(d.row_seq + i), 2); // the claim of the earliest row; its value follows in k_agg_any_resolve
         else
         {
             if ((d.word_fx >> a.word) & 1)
@@ -1698,7 +1705,7 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
 // zero_slot_index: index in the source arrays of the out-of-line zero key (or ~0).
 struct AggFxWords
 {
-    u32 word_fx, word_fx_hi;
+    u32 word_fx, word_fx_hi, word_any;
     unsigned char fx_hi[AGG_MAX_WORDS];
 };
 template <int MODE>
@@ -1745,6 +1752,15 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_tuples(AggTable t, u32 n_wo
                     {
                         if ((fx.word_fx_hi >> w) & 1)
                             continue; // merged with its low half
+                        if ((fx.word_any >> w) & 1)
+                        {
+                            // any(): changeFirstTime (SingleValueData.cpp) -- a state that has a value keeps it; {claim, value} move together
+                            const u64 claim = src_words[(u64)w * src_stride + i];
+                            if (claim && atomicCAS((unsigned long long *)(t.words + (u64)w * gstride + slot), 0ull, (unsigned long long)claim) == 0ull)
+                                t.words[(u64)(w + 1) * gstride + slot] = src_words[(u64)(w + 1) * src_stride + i];
+                            ++w;
+                            continue;
+                        }
                         if ((fx.word_fx >> w) & 1)
                         {
                             const u32 wh = fx.fx_hi[w];
@@ -1826,6 +1842,7 @@ static AggFxWords agg_fx_words(const chgpu_agg * a)
     AggFxWords f;
     f.word_fx = a->word_fx;
     f.word_fx_hi = a->word_fx_hi;
+    f.word_any = a->word_any;
     memcpy(f.fx_hi, a->fx_hi, sizeof(f.fx_hi));
     return f;
 }
@@ -1922,7 +1939,8 @@ extern "C" int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, 
     {
         const int kind = agg_kinds[j];
         const int at = (kind == CHGPU_AGG_COUNT || !arg_types) ? CHGPU_U64 : arg_types[j];
-        const bool extremum = kind == CHGPU_AGG_MIN || kind == CHGPU_AGG_MAX;
+        const bool any_value = kind == CHGPU_AGG_ANY;
+        const bool extremum = kind == CHGPU_AGG_MIN || kind == CHGPU_AGG_MAX || any_value;
         if (kind != CHGPU_AGG_COUNT && kind != CHGPU_AGG_SUM && kind != CHGPU_AGG_AVG && !extremum)
         {
             delete a;
@@ -1931,7 +1949,7 @@ extern "C" int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, 
         if (extremum && key_type < 0)
         {
             delete a;
-            return chgpu_set_error(CHGPU_ERR_NOT_IMPLEMENTED, "min / max without key: chgpu_expr_filter_minmax_node");
+            return chgpu_set_error(CHGPU_ERR_NOT_IMPLEMENTED, "min / max / any without key: chgpu_expr_filter_minmax_node (any: the first row of the block)");
         }
         if (kind != CHGPU_AGG_COUNT && !chgpu_type_size(at))
         {
@@ -1945,10 +1963,17 @@ extern "C" int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, 
         {
             a->word_is_f64 |= 1u << (16 + w); // upper half of the mask: the word combines by unsigned max (order keys), never by an add
             a->has_extremum = true;
+            if (any_value)
+                a->word_any |= 1u << w;
         }
         else if (kind != CHGPU_AGG_COUNT && chgpu_type_is_float(at))
             a->word_is_f64 |= 1u << w;
-        w += kind == CHGPU_AGG_AVG ? 2 : 1;
+        w += (kind == CHGPU_AGG_AVG || any_value) ? 2 : 1;
+    }
+    if (w > AGG_MAX_WORDS)
+    {
+        delete a;
+        return chgpu_set_error(CHGPU_ERR_NOT_IMPLEMENTED, "more than %u state words: CPU path", AGG_MAX_WORDS);
     }
     a->n_pub_words = w;
     if (key_type >= 0 && chgpu_opt(ctx, "deterministic_float_sums", 1))
@@ -1998,6 +2023,7 @@ static void agg_fill_desc(const chgpu_agg * a, const chgpu_col * const * arg_col
     d->word_fx_hi = a->word_fx_hi;
     memcpy(d->fx_hi, a->fx_hi, sizeof(d->fx_hi));
     d->fx_base = a->fx_base;
+    d->row_seq = 0;
     for (u32 j = 0; j < a->n_aggs; ++j)
     {
         d->a[j].ptr = (arg_cols && arg_cols[j]) ? arg_cols[j]->data : nullptr;
@@ -2009,6 +2035,36 @@ static void agg_fill_desc(const chgpu_agg * a, const chgpu_col * const * arg_col
 }
 
 static int agg_finish_rounds(chgpu_agg * a, const AggDesc & d, const void * keys, int key_type, u64 row_begin, u64 n, u64 * pending);
+
+// any(): the second pass of a block.  Every group's claim word now names the earliest of its rows (all blocks so far); the row a claim
+// names stores its value.  Claims set by earlier blocks name rows of those blocks: no row of this block matches them, the value stays.
+__global__ __launch_bounds__(AGG_THREADS) void k_agg_any_resolve(AggTable t, AggDesc d, const void * __restrict__ keys, int key_type, u64 row_begin, u64 n)
+{
+    const u64 stride = t.capacity + 1, mask = t.capacity - 1;
+    for (u64 r = (u64)blockIdx.x * AGG_THREADS + threadIdx.x; r < n; r += (u64)gridDim.x * AGG_THREADS)
+    {
+        const u64 i = row_begin + r;
+        const u64 key = load_key_zext(keys, key_type, i);
+        u64 slot = t.capacity; // the zero key's cell
+        if (key != 0)
+        {
+            slot = dev_intHash64(key) & mask;
+            for (u64 step = 0; step < t.capacity; ++step)
+            {
+                const u64 k = t.keys[slot];
+                if (k == key || k == 0)
+                    break;
+                slot = (slot + 1) & mask;
+            }
+            if (t.keys[slot] != key)
+                continue; // (every row of the block was placed before this pass: not reached)
+        }
+        const u64 claim = ~(d.row_seq + i);
+        for (u32 j = 0; j < d.n_aggs; ++j)
+            if (d.a[j].kind == CHGPU_AGG_ANY && t.words[(u64)d.a[j].word * stride + slot] == claim)
+                t.words[(u64)(d.a[j].word + 1) * stride + slot] = load_arg_bits(d.a[j].ptr, d.a[j].arg_type, i);
+    }
+}
 
 // ---- the fixed-point window of the deterministic Float64 sums (see Fx128) ----
 // Over the non-zero finite values (as doubles; a subnormal counts as exponent 1): out[0] = largest biased exponent (0 = no such value),
@@ -3089,14 +3145,23 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
 
     if (a->has_extremum)
     {
-        // min / max states: one emplace + one atomic per state word and row (the LDS-staged and partitioned plans carry additive words only)
+        // min / max / any states: one emplace + one atomic per state word and row (the LDS-staged and partitioned plans carry additive words only)
         CHGPU_TRY(agg_ensure_table(a));
+        d.row_seq = a->any_seq - row_begin; // row i of the columns is the (any_seq + i - row_begin)-th row of the aggregation
         hipLaunchKernelGGL(k_agg_rows_direct<AGG_MODE_ALL>, dim3(chgpu_grid_for(ctx, n, AGG_THREADS, 8)), dim3(AGG_THREADS), 0, ctx->stream, a->t, d, key_col->data, a->key_type,
                            row_begin, n, pending);
         ctx->counters[6] += 1;
         ctx->counters[5] += n;
         CHGPU_HIP(hipGetLastError());
-        return agg_finish_rounds(a, d, key_col->data, a->key_type, row_begin, n, pending);
+        CHGPU_TRY(agg_finish_rounds(a, d, key_col->data, a->key_type, row_begin, n, pending));
+        if (a->word_any)
+        {
+            hipLaunchKernelGGL(k_agg_any_resolve, dim3(chgpu_grid_for(ctx, n, AGG_THREADS, 8)), dim3(AGG_THREADS), 0, ctx->stream, a->t, d, key_col->data, a->key_type, row_begin, n);
+            ctx->counters[6] += 1;
+            CHGPU_HIP(hipGetLastError());
+            a->any_seq += n;
+        }
+        return CHGPU_OK;
     }
 
     // PARTITIONED strategy: large promised cardinality and enough rows to amortise two extra passes
@@ -3755,7 +3820,7 @@ __global__ __launch_bounds__(256) void k_extremum_decode(const u64 * __restrict_
 {
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
     {
-        const u64 bits = agg_order_key_inverse(is_min ? ~words[i] : words[i], type);
+        const u64 bits = is_min == 2 ? words[i] : agg_order_key_inverse(is_min ? ~words[i] : words[i], type);
         switch (type)
         {
             case CHGPU_I64: case CHGPU_U64: case CHGPU_F64: ((u64 *)out)[i] = bits; break;
@@ -3792,7 +3857,7 @@ extern "C" int chgpu_agg_finalize(chgpu_agg * a, chgpu_col ** keys_out, chgpu_co
             res_cols[j] = words[w];
             words[w] = nullptr;
         }
-        else if (a->kinds[j] == CHGPU_AGG_MIN || a->kinds[j] == CHGPU_AGG_MAX)
+        else if (a->kinds[j] == CHGPU_AGG_MIN || a->kinds[j] == CHGPU_AGG_MAX || a->kinds[j] == CHGPU_AGG_ANY)
         {
             // insertResultInto: the value itself, in the argument's type (AggregateFunctionsMinMax.cpp)
             chgpu_col * r = nullptr;
@@ -3801,8 +3866,10 @@ extern "C" int chgpu_agg_finalize(chgpu_agg * a, chgpu_col ** keys_out, chgpu_co
                 break;
             if (n)
             {
-                hipLaunchKernelGGL(k_extremum_decode, dim3(chgpu_grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, (const u64 *)words[w]->data, n, a->arg_types[j],
-                                   a->kinds[j] == CHGPU_AGG_MIN ? 1 : 0, r->data);
+                // (any: the value word, as loaded -- no order key to undo)
+                hipLaunchKernelGGL(k_extremum_decode, dim3(chgpu_grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream,
+                                   (const u64 *)words[a->kinds[j] == CHGPU_AGG_ANY ? w + 1 : w]->data, n, a->arg_types[j],
+                                   a->kinds[j] == CHGPU_AGG_MIN ? 1 : a->kinds[j] == CHGPU_AGG_ANY ? 2 : 0, r->data);
                 ctx->counters[6] += 1;
             }
             res_cols[j] = r;

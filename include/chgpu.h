@@ -69,7 +69,11 @@ enum { CHGPU_AGG_COUNT = 0, CHGPU_AGG_SUM = 1, CHGPU_AGG_AVG = 2,
        /* min / max over a numeric argument, result in the argument's type (AggregateFunctionsMinMax.cpp, SingleValueDataFixed: SingleValueData.cpp:
           219-262); with a GROUP BY key only (without key: chgpu_expr_filter_minmax_node).  The 8-byte state word is an order key: merge /
           export / import as for the sums, but never through the wire serialisation of chgpu_agg_serialize_states. */
-       CHGPU_AGG_MIN = 3, CHGPU_AGG_MAX = 4 };
+       CHGPU_AGG_MIN = 3, CHGPU_AGG_MAX = 4,
+       /* any(x): the value of the group's FIRST row in the order the blocks were added (AggregateFunctionAny.cpp: setIfFirst; merges keep the
+          state that already has a value -- changeFirstTime).  Two 8-byte state words {claim, value}: the claim names the earliest row, so the
+          result does not depend on the order the hardware serves the rows in.  With a GROUP BY key only. */
+       CHGPU_AGG_ANY = 5 };
 
 /* ---- JoinKind / JoinStrictness subset (src/Core/Joins.h) ---- */
 enum { CHGPU_JOIN_INNER = 0, CHGPU_JOIN_LEFT = 1, CHGPU_JOIN_RIGHT = 2, CHGPU_JOIN_FULL = 3 }; /* RIGHT / FULL: strictness ALL only */

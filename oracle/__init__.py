@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # type tags (same numeric values as include/chgpu.h)
 I64, U32, U64, F64, U8, I32, U16, I16, I8, F32 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 EQ, NE, LT, GT, LE, GE = 0, 1, 2, 3, 4, 5
-AGG_COUNT, AGG_SUM, AGG_AVG, AGG_MIN, AGG_MAX = 0, 1, 2, 3, 4
+AGG_COUNT, AGG_SUM, AGG_AVG, AGG_MIN, AGG_MAX, AGG_ANY = 0, 1, 2, 3, 4, 5
 JOIN_INNER, JOIN_LEFT = 0, 1
 STRICT_ANY, STRICT_ALL, STRICT_SEMI, STRICT_ANTI = 0, 1, 2, 3
 DEFAULT_BLOCK_SIZE = 65409
@@ -435,7 +435,7 @@ class Aggregator:
                 out.append(np.uint64)
             elif kind == AGG_AVG:
                 out.append(np.float64)
-            elif kind in (AGG_MIN, AGG_MAX):
+            elif kind in (AGG_MIN, AGG_MAX, AGG_ANY):
                 out.append(NP_OF[t])      # the argument's own type (AggregateFunctionsMinMax.cpp)
             else:
                 out.append(sum_result_dtype(t))
@@ -445,8 +445,9 @@ class Aggregator:
         n = len(self)
         keys = np.empty(n, dtype=NP_OF[self.key_tag]) if self.key_tag >= 0 else None
         # the C side emits 8 bytes per state: min / max arrive widened (sign- / zero-extended, Float32 as Float64) and are narrowed here
-        wide = [np.float64 if (k in (AGG_MIN, AGG_MAX) and np.dtype(d).kind == "f") else np.int64 if (k in (AGG_MIN, AGG_MAX) and np.dtype(d).kind == "i")
-                else np.uint64 if k in (AGG_MIN, AGG_MAX) else d for (k, _), d in zip(self.aggs, self.result_dtypes())]
+        sv = (AGG_MIN, AGG_MAX, AGG_ANY)
+        wide = [np.float64 if (k in sv and np.dtype(d).kind == "f") else np.int64 if (k in sv and np.dtype(d).kind == "i")
+                else np.uint64 if k in sv else d for (k, _), d in zip(self.aggs, self.result_dtypes())]
         res = [np.zeros(n, dtype=d) for d in wide]
         ptrs = (C.c_void_p * max(1, len(res)))(*[r.ctypes.data for r in res])
         m = lib().cho_agg_convert_to_block(self._h, _p(keys), ptrs)

@@ -1095,7 +1095,7 @@ struct cho_agg
 
 /* min / max: SingleValueDataFixed<T> {has_value, value} (src/AggregateFunctions/SingleValueData.h) -- here 8 bytes of flag + the value widened
    to 8 bytes (integers sign- / zero-extended, Float32 widened to Float64: both order-preserving and exactly reversible) */
-static size_t state_size(int kind) { return (kind == CHO_AGG_AVG || kind == CHO_AGG_MIN || kind == CHO_AGG_MAX) ? 16 : 8; }
+static size_t state_size(int kind) { return (kind == CHO_AGG_AVG || kind == CHO_AGG_MIN || kind == CHO_AGG_MAX || kind == CHO_AGG_ANY) ? 16 : 8; }
 
 static int is_signed_type(int t) { return t == CHO_I64 || t == CHO_I32 || t == CHO_I16 || t == CHO_I8; }
 static int is_float_type(int t) { return t == CHO_F64 || t == CHO_F32; }
@@ -1126,7 +1126,9 @@ static int widened_less(int t, uint64_t x, uint64_t y)
 static void extremum_update(int kind, int t, char * st, uint64_t v)
 {
     uint64_t * has = (uint64_t *)st, * val = (uint64_t *)(st + 8);
-    if (!*has || (kind == CHO_AGG_MIN ? widened_less(t, v, *val) : widened_less(t, *val, v)))
+    /* any: SingleValueDataFixed<T>::setIfFirst / changeFirstTime (AggregateFunctionAny.cpp: add -> data().setIfFirst; SingleValueData.cpp) --
+       the first value the state is offered stays */
+    if (kind == CHO_AGG_ANY ? !*has : (!*has || (kind == CHO_AGG_MIN ? widened_less(t, v, *val) : widened_less(t, *val, v))))
     {
         *has = 1;
         *val = v;
@@ -1188,6 +1190,7 @@ static inline void agg_add_row(const cho_agg * a, int j, char * place, const voi
             break;
         case CHO_AGG_MIN:
         case CHO_AGG_MAX:
+        case CHO_AGG_ANY:
             extremum_update(a->kinds[j], a->arg_types[j], st, load_widened(a->arg_types[j], arg, i));
             break;
         case CHO_AGG_AVG:
@@ -1221,7 +1224,7 @@ static void agg_merge_states(const cho_agg * a, char * dst, const char * src)
     {
         char * d = dst + a->offsets[j];
         const char * s = src + a->offsets[j];
-        if (a->kinds[j] == CHO_AGG_MIN || a->kinds[j] == CHO_AGG_MAX)
+        if (a->kinds[j] == CHO_AGG_MIN || a->kinds[j] == CHO_AGG_MAX || a->kinds[j] == CHO_AGG_ANY)
         {
             /* setIfSmaller(const SingleValueDataFixed &) / setIfGreater (SingleValueData.cpp:243-262): `to.has() && (!has() || to.value < value)` */
             if (*(const uint64_t *)s)
@@ -1400,7 +1403,7 @@ static void agg_emit_row(const cho_agg * a, uint64_t key, const char * place, si
             double r = cho_avg_divide(sum_result_type(a->arg_types[j]), st, *(const uint64_t *)(st + 8));
             memcpy(o, &r, 8);
         }
-        else if (a->kinds[j] == CHO_AGG_MIN || a->kinds[j] == CHO_AGG_MAX)
+        else if (a->kinds[j] == CHO_AGG_MIN || a->kinds[j] == CHO_AGG_MAX || a->kinds[j] == CHO_AGG_ANY)
             memcpy(o, st + 8, 8); /* the widened value (a state without value inserts the default 0) */
         else
             memcpy(o, st, 8); /* insertResultInto: sum / count raw 8 bytes */

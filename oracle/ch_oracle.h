@@ -30,7 +30,7 @@ enum { CHO_I64 = 0, CHO_U32 = 1, CHO_U64 = 2, CHO_F64 = 3, CHO_U8 = 4, CHO_I32 =
 /* comparison ops (FunctionsComparison.h: EqualsOp..GreaterOrEqualsOp) */
 enum { CHO_EQ = 0, CHO_NE = 1, CHO_LT = 2, CHO_GT = 3, CHO_LE = 4, CHO_GE = 5 };
 /* aggregate kinds */
-enum { CHO_AGG_COUNT = 0, CHO_AGG_SUM = 1, CHO_AGG_AVG = 2, CHO_AGG_MIN = 3, CHO_AGG_MAX = 4 };
+enum { CHO_AGG_COUNT = 0, CHO_AGG_SUM = 1, CHO_AGG_AVG = 2, CHO_AGG_MIN = 3, CHO_AGG_MAX = 4, CHO_AGG_ANY = 5 };
 /* join kind / strictness (src/Core/Joins.h) */
 enum { CHO_JOIN_INNER = 0, CHO_JOIN_LEFT = 1 };
 enum { CHO_STRICT_ANY = 0, CHO_STRICT_ALL = 1, CHO_STRICT_SEMI = 2, CHO_STRICT_ANTI = 3 };

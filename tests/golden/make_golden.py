@@ -66,6 +66,10 @@ def main():
                                                rows=rows_of(ref_root, "01300_group_by_other_keys", 0, 6))
     out["01321_min_max_group_by_mod2_mod3"] = dict(source="tests/queries/0_stateless/01321_aggregate_functions_of_group_by_keys.reference",
                                                    rows=rows_of(ref_root, "01321_aggregate_functions_of_group_by_keys", 0, 6))
+    # any(number % 2), anyLast(number % 3) over the same groups (second query of the file): both arguments are constant inside a group, so
+    # the rows pin any() -- first value = last value = the group's key
+    out["01321_any_group_by_mod2_mod3"] = dict(source="tests/queries/0_stateless/01321_aggregate_functions_of_group_by_keys.reference",
+                                               rows=rows_of(ref_root, "01321_aggregate_functions_of_group_by_keys", 6, 12))
     out["01321_max_product_group_by_mod7_mod5"] = dict(source="tests/queries/0_stateless/01321_aggregate_functions_of_group_by_keys.reference",
                                                        rows=rows_of(ref_root, "01321_aggregate_functions_of_group_by_keys", 12, 47))
 

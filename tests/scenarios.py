@@ -7,7 +7,7 @@ reference's .reference files so they can be diffed against tests/golden/sql_refe
 import numpy as np
 
 I64, U32, U64, F64, U8, I32 = 0, 1, 2, 3, 4, 5
-AGG_COUNT, AGG_SUM, AGG_AVG, AGG_MIN, AGG_MAX = 0, 1, 2, 3, 4
+AGG_COUNT, AGG_SUM, AGG_AVG, AGG_MIN, AGG_MAX, AGG_ANY = 0, 1, 2, 3, 4, 5
 JOIN_INNER, JOIN_LEFT = 0, 1
 STRICT_ANY, STRICT_ALL, STRICT_SEMI, STRICT_ANTI = 0, 1, 2, 3
 
@@ -185,6 +185,19 @@ def q01321_min_max(engine, rows=10000000, block=65409):
         a.execute_on_block(key[b:b + block], [k2[b:b + block], k3[b:b + block]])
     _, (mn, mx) = a.convert_to_block()
     return sorted([str(int(x)), str(int(y))] for x, y in zip(mn, mx))
+
+
+def q01321_any(engine, rows=10000000, block=65409):
+    # SELECT any(number % 2) AS a, anyLast(number % 3) AS b FROM numbers(1e7) GROUP BY number % 2, number % 3 ORDER BY a, b
+    # (both arguments are the group's own key: first = last, so anyLast is answered by any)
+    n = numbers(rows)
+    k2, k3 = (n % 2).astype(np.uint8), (n % 3).astype(np.uint8)
+    key = (k2.astype(np.uint32) | (k3.astype(np.uint32) << 8))
+    a = engine.Aggregator(np.uint32, [(AGG_ANY, np.uint8), (AGG_ANY, np.uint8)])
+    for b in range(0, rows, block):
+        a.execute_on_block(key[b:b + block], [k2[b:b + block], k3[b:b + block]])
+    _, (x, y) = a.convert_to_block()
+    return sorted([str(int(p)), str(int(q))] for p, q in zip(x, y))
 
 
 def q01321_max_product(engine, rows=10000000, block=65409):

@@ -792,6 +792,66 @@ def test_min_max_states_match_oracle_every_type_with_growth_and_merge(ch, ctx, o
     assert np.array_equal(ck[q], gk[i]) and np.array_equal(cmn[q], gmn[i]) and np.array_equal(cmx[q], gmx[i]) and np.array_equal(cc[q], 2 * gc[i])
 
 
+def test_any_reference_rows_on_gpu(engine, golden):
+    """01321's second query -- any(number % 2), anyLast(number % 3) GROUP BY the two -- as the reference prints it"""
+    assert S.q01321_any(engine) == sorted(golden["rows"]["01321_any_group_by_mod2_mod3"]["rows"])
+
+
+@pytest.mark.parametrize("dt", [np.int8, np.uint16, np.int32, np.uint64, np.float32, np.float64])
+def test_any_is_the_first_row_of_the_group_like_the_oracle(ch, ctx, oracle_mod, dt):
+    """any(x) = the value of the group's first row over all blocks (AggregateFunctionAny.cpp: setIfFirst), whatever order the device serves
+    the rows in; merge keeps the destination's value (changeFirstTime); states travel as {claim, value} columns; a WHERE mask and a table
+    that grows in between change nothing.  Bit-exact against the oracle (single-stream row order)."""
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(int(np.dtype(dt).itemsize) + 100))
+    n, groups = 400_000, 150_000
+    keys = rng.integers(0, groups, size=n, dtype=np.uint64)
+    keys[:5] = 0
+    vals = (rng.random(n) * 200 - 100).astype(dt) if np.dtype(dt).kind == "f" else rng.integers(0, 120, size=n).astype(dt)
+    mask = (rng.random(n) < 0.7).astype(np.uint8)
+    aggs = [(ch.AGG_ANY, dt), (ch.AGG_COUNT, None), (ch.AGG_MAX, dt)]
+    A, B = ch.Aggregator(np.uint64, aggs, ctx=ctx), ch.Aggregator(np.uint64, aggs, ctx=ctx)
+    OA, OB = O.Aggregator(np.uint64, aggs), O.Aggregator(np.uint64, aggs)
+    h = n // 2
+    for g_, o_, lo, hi in ((A, OA, 0, h), (B, OB, h, n)):
+        for b in range(lo, hi, 65409):
+            e = min(hi, b + 65409)
+            g_.execute_on_block(keys[b:e], [vals[b:e], None, vals[b:e]], filter=mask[b:e])
+            kept = mask[b:e] != 0
+            o_.execute_on_block(keys[b:e][kept], [vals[b:e][kept], None, vals[b:e][kept]])
+    for agg, ora in ((A, OA), (B, OB)):
+        gk, (ga, gc, gm) = agg.convert_to_block()
+        ok, (oa, oc, om) = ora.convert_to_block()
+        i, j = np.argsort(gk), np.argsort(ok)
+        assert ga.dtype == np.dtype(dt) and np.array_equal(gk[i], ok[j]) and np.array_equal(gc[i], oc[j])
+        assert np.array_equal(ga[i].view(np.uint8), oa[j].view(np.uint8)) and np.array_equal(gm[i], om[j])
+    A.merge(B)                                          # groups only B has take B's value, the others keep A's
+    OA.merge(OB)
+    gk, (ga, gc, gm) = A.convert_to_block()
+    ok, (oa, oc, om) = OA.convert_to_block()
+    i, j = np.argsort(gk), np.argsort(ok)
+    assert np.array_equal(gk[i], ok[j]) and np.array_equal(ga[i].view(np.uint8), oa[j].view(np.uint8)) and np.array_equal(gc[i], oc[j])
+    # states: export, merge into a fresh aggregation that already holds other rows (its own values stay), and into an empty one
+    k2, words, rows = A.export_state_columns()
+    assert len(words) == 4
+    E = ch.Aggregator(np.uint64, aggs, ctx=ctx)
+    E.merge_states(k2, words, rows)
+    ek, (ea, ec, em) = E.convert_to_block()
+    q = np.argsort(ek)
+    assert np.array_equal(ek[q], gk[i]) and np.array_equal(ea[q].view(np.uint8), ga[i].view(np.uint8)) and np.array_equal(ec[q], gc[i])
+    F = ch.Aggregator(np.uint64, aggs, ctx=ctx)
+    first = np.arange(1000, dtype=np.uint64)
+    fv = np.full(1000, 7, dtype=dt)
+    F.execute_on_block(first, [fv, None, fv])
+    F.merge_states(k2, words, rows)
+    fk, (fa, fc, fm) = F.convert_to_block()
+    got = dict(zip(fk.tolist(), fa.tolist()))
+    assert all(got[k] == 7 for k in range(1000)) and all(got[int(k)] == v for k, v in zip(gk.tolist(), ga.tolist()) if k >= 1000)
+    with pytest.raises(ch.ChgpuError) as e:
+        ch.Aggregator(None, [(ch.AGG_ANY, dt)], ctx=ctx)
+    assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED
+
+
 def test_min_max_with_where_mask_and_table_growth(ch, ctx, oracle_mod):
     O = oracle_mod
     rng = np.random.Generator(np.random.PCG64(99))

@@ -139,3 +139,4 @@ def test_01300_max_float64_group_by(oracle_mod, golden):
 def test_01321_min_max_group_by(oracle_mod, golden):
     assert S.q01321_min_max(oracle_mod) == sorted(golden["rows"]["01321_min_max_group_by_mod2_mod3"]["rows"])
     assert S.q01321_max_product(oracle_mod) == sorted(int(r[0]) for r in golden["rows"]["01321_max_product_group_by_mod7_mod5"]["rows"])
+    assert S.q01321_any(oracle_mod) == sorted(golden["rows"]["01321_any_group_by_mod2_mod3"]["rows"])
