@@ -312,6 +312,8 @@ public:
     enum class Status { NeedData, PortFull, Finished, Ready };
     virtual ~IProcessor() = default;
     virtual std::string getName() const = 0;
+    /// IProcessor::prepare (IProcessor.h:170-220): what the executor may do next -- nothing here blocks or computes
+    virtual Status prepare() { return Status::Ready; }
     virtual void work() = 0;
     uint64_t elapsed_ns = 0; // IProcessor.h:359
 };
@@ -361,12 +363,93 @@ public:
     /// the consumer's side of the port: an exception travels in the data slot and surfaces on pull (Port.h: pullData rethrows)
     bool outputHasException() const { return static_cast<bool>(output_exception); }
 
+    /// ISimpleTransform::prepare (ISimpleTransform.cpp:30-74), with the two one-chunk ports this mirror has: the consumer closed the output
+    /// -> Finished; a chunk is still waiting in the output -> PortFull; a chunk is waiting in the input -> Ready (work() may run); the
+    /// producer finished -> Finished; otherwise NeedData.
+    Status prepare() override
+    {
+        if (output_closed)
+            return Status::Finished;
+        if (has_output)
+            return Status::PortFull;
+        if (has_input)
+            return Status::Ready;
+        if (input_finished)
+            return Status::Finished;
+        return Status::NeedData;
+    }
+    void finishInput() { input_finished = true; }  ///< InputPort::isFinished on the producer's side
+    void closeOutput() { output_closed = true; }   ///< OutputPort::isFinished: the consumer needs no more (LIMIT reached)
+    bool needsInput() const { return !has_input && !has_output && !input_finished && !output_closed; }
+
 protected:
     virtual void transform(Chunk & chunk) = 0;
     Chunk input, output;
-    bool has_input = false, has_output = false;
+    bool has_input = false, has_output = false, input_finished = false, output_closed = false;
     std::exception_ptr output_exception;
 };
+
+/// A linear pipeline source -> t[0] -> ... -> t[k-1] -> sink driven the way PipelineExecutor drives a graph (ExecutingGraph::updateNode,
+/// src/Processors/Executors/ExecutingGraph.cpp): every processor is asked prepare(); Ready -> work(); PortFull -> the chunk moves to the
+/// next processor's input when that one reports NeedData; NeedData at the head pulls the source; Finished propagates downstream.
+/// source(chunk) returns false when it is exhausted.
+template <typename Source, typename Sink>
+inline void executeChain(Source && source, const std::vector<ISimpleTransform *> & chain, Sink && sink)
+{
+    bool source_done = false;
+    for (;;)
+    {
+        bool progressed = false;
+        for (size_t k = chain.size(); k-- > 0;) // downstream first: ports drain before they are filled again
+        {
+            ISimpleTransform * t = chain[k];
+            switch (t->prepare())
+            {
+                case IProcessor::Status::Ready:
+                    t->work();
+                    progressed = true;
+                    break;
+                case IProcessor::Status::PortFull:
+                    if (k + 1 == chain.size())
+                    {
+                        sink(t->pullOutput());
+                        progressed = true;
+                    }
+                    else if (chain[k + 1]->needsInput())
+                    {
+                        chain[k + 1]->setInput(t->pullOutput());
+                        progressed = true;
+                    }
+                    break;
+                case IProcessor::Status::NeedData:
+                    if (k == 0)
+                    {
+                        Chunk c;
+                        if (!source_done && source(c))
+                            t->setInput(std::move(c));
+                        else
+                        {
+                            source_done = true;
+                            t->finishInput();
+                        }
+                        progressed = true;
+                    }
+                    else if (chain[k - 1]->prepare() == IProcessor::Status::Finished)
+                    {
+                        t->finishInput();
+                        progressed = true;
+                    }
+                    break;
+                case IProcessor::Status::Finished:
+                    break;
+            }
+        }
+        if (chain.empty() || chain.back()->prepare() == IProcessor::Status::Finished)
+            return;
+        if (!progressed)
+            throw Exception(CHGPU_ERR_LOGICAL, "Pipeline stuck");
+    }
+}
 
 /// FilterTransform::doTransform (FilterTransform.cpp:136-256): expression -> filter column -> filter every column.
 /// Every column of a chunk filtered by one mask: the loop `for (auto & col : columns) col = col->filter(filter, hint)` of

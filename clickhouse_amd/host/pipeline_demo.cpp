@@ -182,6 +182,28 @@ int main(int argc, char ** argv)
         REQUIRE(r0.columns[1]->getData<uint64_t>()[0] == want_cnt);
         REQUIRE(filter.passed_rows == want_cnt);
 
+        // the same plan with a second WHERE conjunct as its own transform, run the executor's way: three stripes through
+        // FilterTransform -> FilterTransform -> the aggregating sink, every step decided by prepare() (executeChain)
+        {
+            GpuFilterTransform f1(0, FunctionComparisonConst(CHGPU_LT, thr)), f2(0, FunctionComparisonConst(CHGPU_GE, int64_t(1000)));
+            auto aggx = std::make_shared<GpuAggregator>(ctx, -1, std::vector<AggregateDescription>{{CHGPU_AGG_SUM, CHGPU_I64, 0}, {CHGPU_AGG_COUNT, CHGPU_U64, 0}});
+            GpuAggregatingTransform sink_agg(aggx, std::nullopt);
+            REQUIRE(f1.prepare() == IProcessor::Status::NeedData);
+            int fed = 0;
+            executeChain([&](Chunk & c) { if (fed == 3) return false; c = stripe; ++fed; return true; }, {&f1, &f2},
+                         [&](Chunk c) { sink_agg.consume(std::move(c)); });
+            REQUIRE(f1.prepare() == IProcessor::Status::Finished && f2.prepare() == IProcessor::Status::Finished);
+            Chunk rx = sink_agg.generate();
+            uint64_t s2 = 0, c2 = 0;
+            for (size_t i = 0; i < n; ++i)
+                if (a[i] < thr && a[i] >= 1000)
+                {
+                    s2 += static_cast<uint64_t>(a[i]);
+                    ++c2;
+                }
+            REQUIRE(static_cast<uint64_t>(rx.columns[0]->getData<int64_t>()[0]) == 3 * s2 && rx.columns[1]->getData<uint64_t>()[0] == 3 * c2);
+        }
+
         // a chunk in which nothing passes is dropped, not forwarded empty (FilterTransform.cpp:221-226)
         GpuFilterTransform none(0, FunctionComparisonConst(CHGPU_LT, int64_t(0)));
         none.setInput(stripe);
