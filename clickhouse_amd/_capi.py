@@ -18,6 +18,7 @@ ERR_SIZES_MISMATCH, ERR_NOT_IMPLEMENTED, ERR_OOM, ERR_LOGICAL, ERR_BAD_ARGUMENTS
 I64, U32, U64, F64, U8, I32, U16, I16, I8, F32 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 EQ, NE, LT, GT, LE, GE = 0, 1, 2, 3, 4, 5
 AGG_COUNT, AGG_SUM, AGG_AVG, AGG_MIN, AGG_MAX, AGG_ANY = 0, 1, 2, 3, 4, 5
+ASOF_LESS, ASOF_GREATER, ASOF_LESS_OR_EQUALS, ASOF_GREATER_OR_EQUALS = 1, 2, 3, 4
 JOIN_INNER, JOIN_LEFT, JOIN_RIGHT, JOIN_FULL = 0, 1, 2, 3
 STRICT_ANY, STRICT_ALL, STRICT_SEMI, STRICT_ANTI = 0, 1, 2, 3
 N_COUNTERS = 8
@@ -110,6 +111,11 @@ SIGNATURES = {
     "chgpu_city_hash128": (_i, [_vp, _u64, _pu64]),
     "chgpu_native_walk_block": (_i, [_vp, _u64, _u64, _u32, _vp, C.POINTER(_u32), _pu64, C.POINTER(C.c_int32), C.POINTER(_i), _pu64]),
     "chgpu_native_read_strings": (_i, [_vp, _vp, _u64, _u64, _pp, _pp]),
+    "chgpu_asof_create": (_i, [_vp, _i, _i, _i, _i, _pp]),
+    "chgpu_asof_add_block": (_i, [_vp, _vp, _vp, _vp, _vp, _pu64]),
+    "chgpu_asof_total_rows": (_i, [_vp, _pu64]),
+    "chgpu_asof_probe": (_i, [_vp, _vp, _vp, _vp, _pp, _pp, _pu64]),
+    "chgpu_asof_free": (_i, [_vp]),
     "chgpu_agg_serialize_states": (_i, [_vp, _i, _vp, _vp, _pp, _pp]),
     "chgpu_agg_deserialize_states": (_i, [_vp, _i, _vp, _u32, _pu64, _pu64, _pp, _pp]),
     "chgpu_fixed_string_word": (_i, [_vp, _vp, _u32, _u32, _pp]),

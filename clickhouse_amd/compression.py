@@ -60,9 +60,13 @@ def column_from_bytes(data: Column, byte_offset: int, dtype, rows: int) -> Colum
 def read_column_file(ctx: Context, buf, dtype, verify_checksums: bool = True) -> Column:
     """a MergeTree `<column>.bin` of a numeric column (compressed frames of a plain little-endian array) -> Column in HBM
     (chgpu_read_compressed_column: frame walk + checksum verification on the host, decode on the device)"""
+    h = C.c_void_p()
+    if isinstance(buf, np.ndarray):  # the file as it lies in host memory (no copy: a column file is hundreds of megabytes)
+        view = np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
+        K.check(K.lib().chgpu_read_compressed_column(ctx._live(), C.c_void_p(view.ctypes.data), view.shape[0], TAG_OF[np.dtype(dtype)], int(verify_checksums), C.byref(h)))
+        return Column(ctx, h)
     raw = bytes(buf) if not isinstance(buf, (bytes, bytearray)) else buf
     arr = (C.c_uint8 * len(raw)).from_buffer_copy(raw) if len(raw) else None
-    h = C.c_void_p()
     K.check(K.lib().chgpu_read_compressed_column(ctx._live(), arr, len(raw), TAG_OF[np.dtype(dtype)], int(verify_checksums), C.byref(h)))
     return Column(ctx, h)
 

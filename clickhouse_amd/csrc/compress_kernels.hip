@@ -569,19 +569,91 @@ __global__ __launch_bounds__(256) void k_t64_decode(const u8 * __restrict__ src,
 // the frame is decoded front to back, here by ONE LANE PER FRAME -- the parallelism is across frames (a column file of N rows has
 // N / 8192 ... N / 131072 of them).  Functional first: the rate is reported in profiles/, not tuned.
 // ---------------------------------------------------------------------------------------------
+// one value of `width` bytes stored with ONE instruction (a memcpy of a run-time width is a byte loop)
+__device__ __forceinline__ void codec_store(u8 * d, u64 v, u32 width)
+{
+    typedef u64 u64_a1 __attribute__((aligned(1)));
+    typedef u32 u32_a1 __attribute__((aligned(1)));
+    typedef u16 u16_a1 __attribute__((aligned(1)));
+    if (width == 8)
+        *(u64_a1 *)d = v;
+    else if (width == 4)
+        *(u32_a1 *)d = (u32)v;
+    else if (width == 2)
+        *(u16_a1 *)d = (u16)v;
+    else
+        *d = (u8)v;
+}
+
 struct DdReader
 {
-    const u8 * cur;
+    // A lane is alone with its frame: every load is a full memory round trip with nothing else to hide it, so the reader keeps DEPTH
+    // 8-byte words of the stream in flight (q[0] the next to be used; a word is requested DEPTH appends before it is needed) and a
+    // 128-bit window {hi, lo} of `bits` valid bits in front of them.  Big-endian bit order (BitHelpers.h): the stream's first bit is
+    // the top bit of hi.
+    static constexpr int DEPTH = 6;
+    const u8 * cur; // the next byte not yet requested
     const u8 * end;
-    u64 buf;
+    u64 hi, lo;
     u32 bits;
-    __device__ __forceinline__ void fill()
+    u64 q[DEPTH];
+    u32 qn; // words in the queue
+    typedef u64 u64_a1 __attribute__((aligned(1)));
+    // (every index into q[] is a compile-time constant: a run-time index would move the queue to scratch memory)
+    __device__ __forceinline__ u64 request()
     {
-        while (bits <= 56 && cur < end)
+        if (cur + 8 <= end)
         {
-            buf |= (u64)*cur++ << (56 - bits);
-            bits += 8;
+            const u64 w = *(const u64_a1 *)cur; // (byte-swapped when it is used: the swap would wait for the load)
+            cur += 8;
+            ++qn;
+            return w;
         }
+        return 0;
+    }
+    __device__ __forceinline__ void init(const u8 * s, const u8 * e)
+    {
+        cur = s, end = e, hi = lo = 0, bits = 0, qn = 0;
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k)
+            q[k] = request(); // (whole words run out only at the end: the valid ones are always the first qn)
+    }
+    __device__ __forceinline__ void append(u64 w, u32 nb) // nb valid bits at the top of w behind the window (bits + nb <= 128)
+    {
+        if (bits == 0)
+            hi = w, lo = 0;
+        else if (bits < 64)
+            hi |= w >> bits, lo = w << (64 - bits);
+        else if (bits == 64)
+            lo = w;
+        else
+            lo |= w >> (bits - 64);
+        bits += nb;
+    }
+    __device__ __forceinline__ void fill() // at least 64 valid bits while the stream has them
+    {
+        if (bits > 64)
+            return;
+        if (qn)
+        {
+            append(__builtin_bswap64(q[0]), 64);
+#pragma unroll
+            for (int k = 0; k + 1 < DEPTH; ++k)
+                q[k] = q[k + 1];
+            --qn;
+            q[DEPTH - 1] = request();
+            return;
+        }
+        // the last < 8 bytes of the stream, one by one
+        u64 w = 0;
+        u32 nb = 0;
+        while (cur < end && nb < 64)
+        {
+            w |= (u64)*cur++ << (56 - nb);
+            nb += 8;
+        }
+        if (nb)
+            append(w, nb);
     }
     __device__ __forceinline__ u64 read32(u32 n) // n <= 32
     {
@@ -589,15 +661,22 @@ struct DdReader
             return 0;
         if (bits < n)
             fill();
-        const u64 v = buf >> (64 - n);
-        buf <<= n;
+        const u64 v = hi >> (64 - n);
+        hi = (hi << n) | (lo >> (64 - n));
+        lo <<= n;
         bits = bits >= n ? bits - n : 0;
         return v;
     }
     __device__ __forceinline__ u64 read(u32 n) { return n > 32 ? (read32(n - 32) << 32) | read32(32) : read32(n); }
+    __device__ __forceinline__ u32 peek5() // the next five bits (zeros past the end)
+    {
+        if (bits < 8)
+            fill();
+        return (u32)(hi >> 59);
+    }
     __device__ __forceinline__ bool eof()
     {
-        return bits == 0 && cur >= end;
+        return bits == 0 && qn == 0 && cur >= end;
     }
 };
 
@@ -659,12 +738,11 @@ __global__ __launch_bounds__(64) void k_double_delta_decode(const u8 * __restric
     __builtin_memcpy(d, &prev_value, width);
     s += width;
     d += width;
-    DdReader r{s, s_end, 0, 0};
+    DdReader r;
+    r.init(s, s_end);
     for (u32 read = 2; read < items && !r.eof(); ++read)
     {
-        if (r.bits < 8)
-            r.fill();
-        const u32 top = (u32)(r.buf >> 59); // the five bits peekByte() >> 3 looks at (WRITE_SPEC_LUT)
+        const u32 top = r.peek5(); // the five bits peekByte() >> 3 looks at (WRITE_SPEC_LUT)
         u32 pbits, dbits;
         if (top < 16) { pbits = 1; dbits = 0; }
         else if (top < 24) { pbits = 2; dbits = 7; }
@@ -687,7 +765,7 @@ __global__ __launch_bounds__(64) void k_double_delta_decode(const u8 * __restric
             atomicOr(err, 16u);
             return;
         }
-        __builtin_memcpy(d, &cur, width);
+        codec_store(d, cur, width);
         d += width;
         prev_delta = (cur - prev_value) & M;
         prev_value = cur;
@@ -745,7 +823,8 @@ __global__ __launch_bounds__(64) void k_gorilla_decode(const u8 * __restrict__ s
     __builtin_memcpy(d, &prev, width);
     s += width;
     d += width;
-    DdReader r{s, s_end, 0, 0};
+    DdReader r;
+    r.init(s, s_end);
     u32 p_lz = 0, p_db = 0, p_tz = 0;
     for (u32 read = 1; read < items && !r.eof(); ++read)
     {
@@ -768,7 +847,7 @@ __global__ __launch_bounds__(64) void k_gorilla_decode(const u8 * __restrict__ s
             x = tz >= 64 ? 0 : x << tz;
             cur = (prev ^ x) & M;
         }
-        __builtin_memcpy(d, &cur, width);
+        codec_store(d, cur, width);
         d += width;
         p_lz = lz, p_db = db, p_tz = tz;
         prev = cur;

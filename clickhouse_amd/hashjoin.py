@@ -173,3 +173,60 @@ def join_probe_chain(joins, keys, null_maps=None, right_rows=None, carry=None, w
                 right_rowid=[Column(ctx, C.c_void_p(rh[s])) if rh[s] else None for s in range(n)],
                 carry=[Column(ctx, C.c_void_p(ch_out[c])) for c in range(nc)],
                 filter=Column(ctx, fh) if want_filter else None)
+
+
+class AsofJoin:
+    """ASOF INNER / LEFT join (JoinStrictness::Asof; RowRefs.cpp SortedLookupVector, HashJoinMethodsImpl.h:462-478) over the C ABI:
+    one fixed-width integer key + one numeric asof column; `inequality` as ASOFJoinInequality with the LEFT value on the left."""
+
+    def __init__(self, kind: int, inequality: int = K.ASOF_GREATER_OR_EQUALS, key_dtype=np.uint64, asof_dtype=np.uint32, ctx: Context | None = None):
+        self.ctx = ctx if ctx is not None else Context(0)
+        self.kind, self.inequality = kind, inequality
+        self.key_dtype, self.asof_dtype = np.dtype(key_dtype), np.dtype(asof_dtype)
+        h = C.c_void_p()
+        K.check(K.lib().chgpu_asof_create(self.ctx._h, TAG_OF[self.key_dtype], TAG_OF[self.asof_dtype], kind, inequality, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            K.lib().chgpu_asof_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _col(self, x, dtype):
+        return x if isinstance(x, Column) else self.ctx.upload(np.ascontiguousarray(x, dtype=dtype))
+
+    def add_block(self, keys, asof, null_map=None, join_mask=None) -> int:
+        bi = C.c_uint64(0)
+        k, a = self._col(keys, self.key_dtype), self._col(asof, self.asof_dtype)
+        nm = self._col(null_map, np.uint8) if null_map is not None else None
+        jm = self._col(join_mask, np.uint8) if join_mask is not None else None
+        K.check(K.lib().chgpu_asof_add_block(self._h, k._h, a._h, nm._h if nm is not None else None, jm._h if jm is not None else None, C.byref(bi)))
+        return int(bi.value)
+
+    @property
+    def total_rows(self) -> int:
+        n = C.c_uint64(0)
+        K.check(K.lib().chgpu_asof_total_rows(self._h, C.byref(n)))
+        return int(n.value)
+
+    def joined_pairs(self, keys, asof, null_map=None):
+        """-> (left_row, right_block, right_row) per output row; LEFT: one per left row, (-1, -1) for the default row"""
+        k, a = self._col(keys, self.key_dtype), self._col(asof, self.asof_dtype)
+        nm = self._col(null_map, np.uint8) if null_map is not None else None
+        fh, rh = C.c_void_p(), C.c_void_p()
+        n = C.c_uint64(0)
+        K.check(K.lib().chgpu_asof_probe(self._h, k._h, a._h, nm._h if nm is not None else None, C.byref(fh), C.byref(rh), C.byref(n)))
+        filt = Column(self.ctx, fh).numpy()
+        rid = Column(self.ctx, rh).numpy()
+        left = np.nonzero(filt)[0].astype(np.int64) if self.kind == K.JOIN_INNER else np.arange(filt.shape[0], dtype=np.int64)
+        assert rid.shape[0] == left.shape[0] == n.value
+        miss = rid == NO_ROW
+        block = np.where(miss, -1, (rid >> np.uint64(32)).astype(np.int64))
+        row = np.where(miss, -1, (rid & np.uint64(0xFFFFFFFF)).astype(np.int64))
+        return left, block, row

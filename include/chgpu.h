@@ -344,6 +344,28 @@ int chgpu_expr_filter_minmax_node(chgpu_ctx * ctx, const chgpu_expr * expr, uint
 int chgpu_expr_free(chgpu_expr * expr);
 
 /* ================================================================================================
+ * ASOF joins (JoinStrictness::Asof, INNER and LEFT: joinDispatch.h:66-67).  The reference keeps, per join key, a SortedLookupVector of
+ * (asof value, row) and answers a left row with the closest right row under the join's inequality (src/Interpreters/RowRefs.cpp:40-215:
+ * insert / findAsof -> boundSearch; HashJoinMethodsImpl.h:462-478).  chgpu_asof is that map for one fixed-width integer key and one numeric
+ * asof column: chgpu_asof_add_block = addBlockToJoin (rows with a NULL key, a zero ON mask or a NaN asof value are not inserted), the
+ * first probe sorts (the vectors are immutable from then on, RowRefs.cpp:174-178).  chgpu_asof_probe = joinBlock: at most one right row
+ * per left row.  INNER: *filter_u8 marks the left rows that found one (need_filter), right_rowid_u64 holds their (block << 32 | row) ids in
+ * order, *n_out their number.  LEFT: filter_u8 may be NULL; right_rowid_u64 has one entry per left row, all-ones = the default row
+ * (add_missing).  inequality as ASOFJoinInequality (src/Core/Joins.h:78-85) with the LEFT value on the left: GREATER_OR_EQUALS (the
+ * default, `a.t >= b.t`) takes the greatest b.t <= a.t.  Right rows with equal (key, asof): the reference's choice is unspecified; here the
+ * last inserted for >= / >, the first inserted for <= / <.
+ * ============================================================================================== */
+enum { CHGPU_ASOF_LESS = 1, CHGPU_ASOF_GREATER = 2, CHGPU_ASOF_LESS_OR_EQUALS = 3, CHGPU_ASOF_GREATER_OR_EQUALS = 4 };
+typedef struct chgpu_asof chgpu_asof;
+int chgpu_asof_create(chgpu_ctx * ctx, int key_type, int asof_type, int kind, int inequality, chgpu_asof ** out);
+int chgpu_asof_add_block(chgpu_asof * join, const chgpu_col * key_col, const chgpu_col * asof_col, const chgpu_col * null_map_u8, const chgpu_col * join_mask_u8,
+                         uint64_t * block_index);
+int chgpu_asof_total_rows(chgpu_asof * join, uint64_t * rows);
+int chgpu_asof_probe(chgpu_asof * join, const chgpu_col * key_col, const chgpu_col * asof_col, const chgpu_col * null_map_u8, chgpu_col ** filter_u8,
+                     chgpu_col ** right_rowid_u64, uint64_t * n_out);
+int chgpu_asof_free(chgpu_asof * join);
+
+/* ================================================================================================
  * a22 data movement  —  IColumn::index / replicate (src/Columns/ColumnVector.cpp:1121-1143, 879-907)
  * ============================================================================================== */
 /* out[i] = col[indexes[i]], i < limit (limit 0 = all); indexes: CHGPU_U64 or CHGPU_U32.

@@ -643,6 +643,52 @@ def hash_to_selector(keys: np.ndarray, num_shards: int) -> np.ndarray:
     return out
 
 
+ASOF_LESS, ASOF_GREATER, ASOF_LESS_OR_EQUALS, ASOF_GREATER_OR_EQUALS = 1, 2, 3, 4
+
+
+def asof_pairs(build_blocks, left_keys, left_asof, inequality: int, left_null_map=None, left_join: bool = False):
+    """ASOF join restated from the reference's data structure: per key a SortedLookupVector of (asof value, row) (RowRefs.cpp:40-99 insert /
+    sort: descending for > and >=, ascending for < and <=) and findAsof -> boundSearch (:100-166): the first entry, in that order, which the
+    left value is allowed to meet -- `value >= v` (>=), `value > v` (>), `value <= v` (<=), `value < v` (<).  joinRightColumns emits that
+    row (HashJoinMethodsImpl.h:462-478); INNER drops the left rows without one, LEFT keeps them with a default row.
+    Rows with a NULL key / zero ON mask / NaN asof value are not inserted.  Equal (key, asof) right rows: the reference's pick is
+    unspecified -- build sides of the tests have none.
+    build_blocks: [(keys, asof, null_map or None, join_mask or None)] -> [(left_row, block, row)] in left-row order ((-1, -1) = default row)"""
+    import bisect
+    vec = {}
+    for b, (keys, asof, nm, jm) in enumerate(build_blocks):
+        for r in range(keys.shape[0]):
+            if (nm is not None and nm[r]) or (jm is not None and not jm[r]) or asof[r] != asof[r]:
+                continue
+            vec.setdefault(int(keys[r]), []).append((asof[r].item(), b, r))
+    for v in vec.values():
+        v.sort(key=lambda e: e[0])              # ascending here; the descending order of > / >= is walked from the other end
+    out = []
+    for i in range(left_keys.shape[0]):
+        hit = None
+        t = left_asof[i]
+        if not (left_null_map is not None and left_null_map[i]) and t == t:
+            v = vec.get(int(left_keys[i]))
+            if v:
+                vals = [e[0] for e in v]
+                t = t.item()
+                if inequality == ASOF_GREATER_OR_EQUALS:
+                    p = bisect.bisect_right(vals, t) - 1      # the greatest v <= t
+                elif inequality == ASOF_GREATER:
+                    p = bisect.bisect_left(vals, t) - 1       # the greatest v < t
+                elif inequality == ASOF_LESS_OR_EQUALS:
+                    p = bisect.bisect_left(vals, t)           # the smallest v >= t
+                else:
+                    p = bisect.bisect_right(vals, t)          # the smallest v > t
+                if 0 <= p < len(v):
+                    hit = v[p]
+        if hit is not None:
+            out.append((i, hit[1], hit[2]))
+        elif left_join:
+            out.append((i, -1, -1))
+    return out
+
+
 def right_once_pairs(build_blocks, probe_key_batches, anti: bool = False):
     """RIGHT ANY / RIGHT SEMI (and the flags of RIGHT ANTI) restated from joinRightColumns (HashJoinMethodsImpl.h:487-497, :515-519): the map
     is MapsAll (joinDispatch.h:37,53,61: every inserted right row is kept) with ONE flag per key; left rows are taken in order, over all

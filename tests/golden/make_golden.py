@@ -70,6 +70,14 @@ def main():
     # the rows pin any() -- first value = last value = the group's key
     out["01321_any_group_by_mod2_mod3"] = dict(source="tests/queries/0_stateless/01321_aggregate_functions_of_group_by_keys.reference",
                                                rows=rows_of(ref_root, "01321_aggregate_functions_of_group_by_keys", 6, 12))
+    # ASOF joins (round 3): the three queries of 00927_asof_join_noninclusive (LEFT, INNER with `A.t >= B.t`, ASOF JOIN USING), the LEFT join of
+    # 00927_asof_joins and the checksum of 00927_asof_join_long (1e7 build rows, 3e6 probe rows)
+    out["00927_asof_noninclusive"] = dict(source="tests/queries/0_stateless/00927_asof_join_noninclusive.reference",
+                                          rows=rows_of(ref_root, "00927_asof_join_noninclusive", 0, 29))
+    out["00927_asof_joins_left"] = dict(source="tests/queries/0_stateless/00927_asof_joins.reference",
+                                        rows=rows_of(ref_root, "00927_asof_joins", 0, 14))
+    out["00927_asof_join_long"] = dict(source="tests/queries/0_stateless/00927_asof_join_long.reference",
+                                       rows=rows_of(ref_root, "00927_asof_join_long", 0, 1))
     out["01321_max_product_group_by_mod7_mod5"] = dict(source="tests/queries/0_stateless/01321_aggregate_functions_of_group_by_keys.reference",
                                                        rows=rows_of(ref_root, "01321_aggregate_functions_of_group_by_keys", 12, 47))
 

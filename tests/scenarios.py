@@ -223,3 +223,65 @@ def q01300(engine, rows=10000000, block=65505):
         a.execute_on_block(key[b:b + block], [val[b:b + block]])
     _, (avg,) = a.convert_to_block()
     return sorted(float(x) for x in avg)
+
+
+# ---- ASOF joins: the inputs of the reference's 00927 tests and the rows they print ----------------------------------------------------------
+def _utc(t):
+    return "1970-01-01 00:00:%02d" % int(t)
+
+
+def _num(x):
+    x = float(x)
+    return str(int(x)) if x == int(x) else repr(x)
+
+
+def asof_noninclusive(join_pairs):
+    """00927_asof_join_noninclusive: A(k, t, a) ASOF LEFT / INNER JOIN B(k, t, b) on k, A.t >= B.t.  join_pairs(build_blocks, left_k, left_t,
+    left_join) -> [(left_row, block, row)] ((-1, -1) = default row).  -> the three result sets in the file's order, ORDER BY (A.k, A.t)"""
+    ak = np.repeat(np.array([1, 2, 3], dtype=np.uint32), 5)
+    at = np.tile(np.arange(1, 6, dtype=np.uint32), 3)
+    aa = at.astype(np.float64)
+    b_blocks = [(np.array([1, 1], dtype=np.uint32), np.array([2, 4], dtype=np.uint32), np.array([2.0, 4.0])),       # the two INSERTs into B
+                (np.array([2], dtype=np.uint32), np.array([3], dtype=np.uint32), np.array([3.0]))]
+    build = [(k, t, None, None) for k, t, _ in b_blocks]
+    out = []
+    for left_join in (True, False, False):
+        rows = []
+        for i, blk, r in join_pairs(build, ak, at, left_join):
+            bk, bt, bb = (0, 0, 0.0) if blk < 0 else (b_blocks[blk][0][r], b_blocks[blk][1][r], b_blocks[blk][2][r])
+            rows.append([str(int(ak[i])), _utc(at[i]), _num(aa[i]), _num(bb), _utc(bt), str(int(bk))])
+        out += rows                                                  # (A is already in (k, t) order)
+    return out
+
+
+def asof_joins_left(join_pairs):
+    """00927_asof_joins: tv ASOF LEFT JOIN md USING(key, t): md inserted out of time order"""
+    md = [(np.array([1, 1, 1, 1], dtype=np.uint32), np.array([20, 5, 10, 15], dtype=np.uint32), np.array([7.0, 1, 11, 5]), np.array([8.0, 2, 12, 6])),
+          (np.array([2, 2, 2, 2], dtype=np.uint32), np.array([20, 5, 10, 15], dtype=np.uint32), np.array([17.0, 11, 21, 5]), np.array([18.0, 12, 22, 6]))]
+    tk = np.repeat(np.array([1, 2], dtype=np.uint32), 7)
+    tt = np.tile(np.array([5, 6, 10, 11, 15, 16, 20], dtype=np.uint32), 2)
+    tv = np.array([1.5, 1.51, 11.5, 11.51, 5.5, 5.6, 7.5, 2.5, 2.51, 12.5, 12.51, 6.5, 5.6, 8.5])
+    rows = []
+    for i, blk, r in join_pairs([(k, t, None, None) for k, t, _, _ in md], tk, tt, True):
+        bid, ask = (0.0, 0.0) if blk < 0 else (md[blk][2][r], md[blk][3][r])
+        rows.append([str(int(tk[i])), _utc(tt[i]), _num(bid), _num(tv[i]), _num(ask)])
+    return rows
+
+
+def asof_join_long(join_pairs, keys=1000):
+    """00927_asof_join_long: tvs(k, t = 3 * number, tv = t) for 1000 keys x 10000 times; trades(k, t = 10 * number, price = t) for 1000 keys x
+    3000 times; SELECT SUM(trades.price - tvs.tv) FROM trades ASOF LEFT JOIN tvs USING(k, t)"""
+    bk = np.repeat(np.arange(keys, dtype=np.uint32), 10000)
+    bt = np.tile((np.arange(10000, dtype=np.uint32) * 3), keys)
+    lk = np.repeat(np.arange(keys, dtype=np.uint32), 3000)
+    lt = np.tile((np.arange(3000, dtype=np.uint32) * 10), keys)
+    total = 0
+    pairs = join_pairs([(bk, bt, None, None)], lk, lt, True)
+    idx = np.array([(i, r) for i, blk, r in pairs], dtype=np.int64) if not isinstance(pairs, tuple) else None
+    if idx is None:                                                  # (left rows, right rows) arrays straight from the device wrapper
+        li, ri = pairs
+    else:
+        li, ri = idx[:, 0], idx[:, 1]
+    tvv = np.where(ri >= 0, bt[np.maximum(ri, 0)].astype(np.int64), 0)
+    total = int((lt[li].astype(np.int64) - tvv).sum())
+    return [[str(total)]]

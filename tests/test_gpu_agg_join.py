@@ -872,3 +872,94 @@ def test_min_max_with_where_mask_and_table_growth(ch, ctx, oracle_mod):
     with pytest.raises(ch.ChgpuError) as e:              # without key: the generated kernel route (chgpu_expr_filter_minmax_node)
         ch.Aggregator(None, [(ch.AGG_MIN, np.int64)], ctx=ctx)
     assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED
+
+
+# ---- round 3: ASOF joins (JoinStrictness::Asof; RowRefs.cpp SortedLookupVector) ---------------------------------------------------------------
+def _gpu_asof_pairs(ch, ctx, inequality=None):
+    def jp(build, lk, lt, left):
+        j = ch.AsofJoin(ch.JOIN_LEFT if left else ch.JOIN_INNER, inequality if inequality is not None else ch.ASOF_GREATER_OR_EQUALS,
+                        key_dtype=lk.dtype, asof_dtype=lt.dtype, ctx=ctx)
+        for k, t, nm, jm in build:
+            j.add_block(k, t, nm, jm)
+        l, b, r = j.joined_pairs(lk, lt)
+        return list(zip(l.tolist(), b.tolist(), r.tolist()))
+    return jp
+
+
+def test_asof_reference_rows_on_gpu(ch, ctx, golden):
+    """the reference's own expected rows: 00927_asof_join_noninclusive (LEFT, INNER `>=`, ASOF JOIN USING), 00927_asof_joins (a build side
+    inserted out of time order) and the checksum of 00927_asof_join_long at its full size (1e7 build rows, 3e6 probe rows)"""
+    jp = _gpu_asof_pairs(ch, ctx)
+    assert S.asof_noninclusive(jp) == golden["rows"]["00927_asof_noninclusive"]["rows"]
+    assert S.asof_joins_left(jp) == golden["rows"]["00927_asof_joins_left"]["rows"]
+
+    def jp_arrays(build, lk, lt, left):
+        j = ch.AsofJoin(ch.JOIN_LEFT, ch.ASOF_GREATER_OR_EQUALS, key_dtype=lk.dtype, asof_dtype=lt.dtype, ctx=ctx)
+        for k, t, nm, jm in build:
+            j.add_block(k, t, nm, jm)
+        l, b, r = j.joined_pairs(lk, lt)
+        return l, r
+    assert S.asof_join_long(jp_arrays) == golden["rows"]["00927_asof_join_long"]["rows"]
+
+
+@pytest.mark.parametrize("asof_dt", [np.uint32, np.int64, np.float64, np.int16, np.float32])
+@pytest.mark.parametrize("ineq_name", ["LESS", "GREATER", "LESS_OR_EQUALS", "GREATER_OR_EQUALS"])
+def test_asof_matches_oracle(ch, ctx, oracle_mod, ineq_name, asof_dt):
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(len(ineq_name) * 31 + np.dtype(asof_dt).itemsize))
+    ineq = getattr(ch, "ASOF_" + ineq_name)
+    build = []
+    seen = set()
+    for b in range(3):
+        n = [4000, 0, 2500][b]
+        keys = rng.integers(0, 300, size=n).astype(np.uint64)
+        keys[: min(n, 2)] = 0
+        if np.dtype(asof_dt).kind == "f":
+            t = (rng.integers(-5000, 5000, size=n) / 8.0).astype(asof_dt)
+        else:
+            info = np.iinfo(asof_dt)
+            t = rng.integers(max(info.min, -20000), min(info.max, 20000), size=n).astype(asof_dt)
+        # no two build rows with the same (key, asof): the reference's pick among equals is unspecified
+        keep = np.ones(n, dtype=bool)
+        for i in range(n):
+            pair = (int(keys[i]), float(t[i]))
+            keep[i] = pair not in seen
+            seen.add(pair)
+        keys, t = keys[keep], t[keep]
+        n = keys.shape[0]
+        nm = (rng.random(n) < 0.05).astype(np.uint8) if b == 0 else None
+        jm = (rng.random(n) < 0.9).astype(np.uint8) if b == 2 else None
+        if np.dtype(asof_dt).kind == "f" and n:
+            t[::97] = np.nan                                             # never inserted: no comparison with NaN holds
+        build.append((keys, t, nm, jm))
+    n = 6000
+    lk = rng.integers(0, 330, size=n).astype(np.uint64)
+    lt = (rng.integers(-5200, 5200, size=n) / 8.0).astype(asof_dt) if np.dtype(asof_dt).kind == "f" else \
+        rng.integers(max(np.iinfo(asof_dt).min, -21000), min(np.iinfo(asof_dt).max, 21000), size=n).astype(asof_dt)
+    lnm = (rng.random(n) < 0.1).astype(np.uint8)
+    if np.dtype(asof_dt).kind == "f":
+        lt[::101] = np.nan
+    for left in (False, True):
+        j = ch.AsofJoin(ch.JOIN_LEFT if left else ch.JOIN_INNER, ineq, key_dtype=np.uint64, asof_dtype=asof_dt, ctx=ctx)
+        for k, t, nm, jm in build:
+            j.add_block(k, t, nm, jm)
+        l, b, r = j.joined_pairs(lk, lt, lnm)
+        got = list(zip(l.tolist(), b.tolist(), r.tolist()))
+        want = O.asof_pairs(build, lk, lt, getattr(O, "ASOF_" + ineq_name), lnm, left)
+        assert got == want
+        assert left or 0 < len(got) < n
+        with pytest.raises(ch.ChgpuError) as e:
+            j.add_block(build[0][0], build[0][1])                        # the sorted vectors are immutable after the first lookup
+        assert e.value.code == ch._capi.ERR_LOGICAL
+
+
+def test_asof_restrictions_and_empty_build(ch, ctx):
+    with pytest.raises(ch.ChgpuError) as e:
+        ch.AsofJoin(ch.JOIN_RIGHT, ctx=ctx)                              # ASOF exists for INNER and LEFT only (joinDispatch.h:66-67)
+    assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED
+    j = ch.AsofJoin(ch.JOIN_LEFT, key_dtype=np.uint32, asof_dtype=np.uint32, ctx=ctx)
+    l, b, r = j.joined_pairs(np.array([1, 2], dtype=np.uint32), np.array([5, 6], dtype=np.uint32))
+    assert l.tolist() == [0, 1] and b.tolist() == [-1, -1]
+    i = ch.AsofJoin(ch.JOIN_INNER, key_dtype=np.uint32, asof_dtype=np.uint32, ctx=ctx)
+    l, b, r = i.joined_pairs(np.array([1, 2], dtype=np.uint32), np.array([5, 6], dtype=np.uint32))
+    assert l.shape[0] == 0

@@ -140,3 +140,17 @@ def test_01321_min_max_group_by(oracle_mod, golden):
     assert S.q01321_min_max(oracle_mod) == sorted(golden["rows"]["01321_min_max_group_by_mod2_mod3"]["rows"])
     assert S.q01321_max_product(oracle_mod) == sorted(int(r[0]) for r in golden["rows"]["01321_max_product_group_by_mod7_mod5"]["rows"])
     assert S.q01321_any(oracle_mod) == sorted(golden["rows"]["01321_any_group_by_mod2_mod3"]["rows"])
+
+
+# ---- round 3: ASOF joins, pinned by the rows of the reference's 00927 tests --------------------------------------------------------------------
+def test_00927_asof_joins(oracle_mod, golden):
+    O = oracle_mod
+
+    def jp(build, lk, lt, left):
+        return O.asof_pairs(build, lk, lt, O.ASOF_GREATER_OR_EQUALS, None, left)
+    assert S.asof_noninclusive(jp) == golden["rows"]["00927_asof_noninclusive"]["rows"]
+    assert S.asof_joins_left(jp) == golden["rows"]["00927_asof_joins_left"]["rows"]
+    # 00927_asof_join_long prints 3000000 for 1000 keys (3000 per key: every trade time 10 i meets the tvs time 3 * floor(10 i / 3)); the
+    # pure-Python restatement runs 20 of the keys, the device runs all of them (tests/test_gpu_agg_join.py)
+    assert int(golden["rows"]["00927_asof_join_long"]["rows"][0][0]) == 3_000_000
+    assert S.asof_join_long(jp, keys=20) == [[str(3000 * 20)]]

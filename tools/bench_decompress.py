@@ -60,4 +60,30 @@ for name, arr, method in [(n_, a_, OC.METHOD_LZ4) for n_, a_ in cases] + [("Int6
                     "cpu_port_1thread_out_GBps": sbytes / t_port / 1e9})
         del up
         ctx.trim()
+# round 3: the column codecs (one lane per frame for the bit-stream codecs DoubleDelta / Gorilla, one wave per 64-value block for T64), alone
+# and as the second stage behind LZ4 (Multiple frames); 8192-value frames (the granule a MergeTree part writes)
+crows = min(rows, 20_000_000)
+ts = np.cumsum(rng.integers(1, 20, size=crows)).astype(np.int64)                 # timestamps: DoubleDelta's case
+gauge = (np.cumsum(rng.normal(size=crows)) * 0.25).round(2)                     # a slowly moving Float64 gauge: Gorilla's case
+small = rng.integers(0, 5000, size=crows).astype(np.int64)                     # small integers in a wide type: T64's case
+codec_cases = [("DoubleDelta, Int64 timestamps", ts, OC.METHOD_DOUBLE_DELTA, None), ("Gorilla, Float64 gauge", gauge, OC.METHOD_GORILLA, None),
+               ("T64, Int64 values < 5000", small, OC.METHOD_T64, None), ("CODEC(DoubleDelta, LZ4)", ts, OC.METHOD_DOUBLE_DELTA, OC.METHOD_LZ4),
+               ("CODEC(T64, LZ4)", small, OC.METHOD_T64, OC.METHOD_LZ4), ("CODEC(Gorilla, LZ4)", gauge, OC.METHOD_GORILLA, OC.METHOD_LZ4)]
+for name, arr, codec, general in codec_cases:
+    raw = arr.tobytes()
+    buf = OC.write_codec_frames(arr, codec, block_rows=8192) if general is None else OC.write_multiple_frames(arr, codec, general, block_rows=8192)
+    best = None
+    host = np.frombuffer(buf, dtype=np.uint8)
+    for _ in range(4):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        col = CC.read_column_file(ctx, host, arr.dtype, verify_checksums=False)   # walk + upload + decode (the upload is part of this figure)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    assert col.numpy().tobytes() == raw
+    del col
+    res.append({"case": name, "frame_values": 8192, "raw_bytes": len(raw), "compressed_bytes": len(buf), "ratio": len(raw) / len(buf),
+                "walk_upload_decode_ms": best * 1e3, "out_GBps_pcie_inclusive": len(raw) / best / 1e9})
+    ctx.trim()
 print(json.dumps({"rows": rows, "results": res}))
