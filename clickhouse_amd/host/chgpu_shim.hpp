@@ -995,6 +995,81 @@ private:
     size_t value_position;
 };
 
+/// IJoin for an ASOF join (JoinStrictness::Asof: INNER / LEFT; RowRefs.cpp SortedLookupVector, HashJoinMethodsImpl.h:462-478): equality on one
+/// fixed-width integer key, `left.asof <inequality> right.asof` on one numeric column.  The right Blocks are glued into one before they
+/// are inserted, so a right row id is the row's ordinal in the glued payload columns.
+class GpuAsofJoin
+{
+public:
+    GpuAsofJoin(ContextPtr ctx_, int key_type, int asof_type, int kind_, int inequality = CHGPU_ASOF_GREATER_OR_EQUALS) : ctx(std::move(ctx_)), kind(kind_)
+    {
+        check(chgpu_asof_create(ctx->get(), key_type, asof_type, kind, inequality, &h));
+    }
+    ~GpuAsofJoin() { chgpu_asof_free(h); }
+    GpuAsofJoin(const GpuAsofJoin &) = delete;
+
+    bool addBlockToJoin(const Chunk & block, size_t key_position_, size_t asof_position_)
+    {
+        key_position = key_position_, asof_position = asof_position_;
+        right_blocks.push_back(block);
+        return true;
+    }
+    void onBuildPhaseFinish()
+    {
+        if (built)
+            return;
+        built = true;
+        if (right_blocks.empty())
+            return;
+        for (size_t c = 0; c < right_blocks[0].columns.size(); ++c)
+        {
+            if (right_blocks.size() == 1)
+            {
+                right_payload.push_back(right_blocks[0].columns[c]);
+                continue;
+            }
+            std::vector<const chgpu_col *> parts;
+            for (auto & b : right_blocks)
+                parts.push_back(b.columns.at(c)->handle());
+            chgpu_col * cat = nullptr;
+            check(chgpu_col_concat(ctx->get(), static_cast<uint32_t>(parts.size()), parts.data(), &cat));
+            right_payload.push_back(std::make_shared<ColumnVector>(ctx, cat));
+        }
+        check(chgpu_asof_add_block(h, right_payload.at(key_position)->handle(), right_payload.at(asof_position)->handle(), nullptr, nullptr, nullptr));
+    }
+    /// joinBlock: [left columns..., right columns...]; INNER keeps the left rows that found a partner, LEFT keeps all (default right values)
+    void joinBlock(Chunk & block, size_t left_key_position, size_t left_asof_position)
+    {
+        onBuildPhaseFinish();
+        chgpu_col *filter = nullptr, *rowid = nullptr;
+        uint64_t n_out = 0;
+        check(chgpu_asof_probe(h, block.columns.at(left_key_position)->handle(), block.columns.at(left_asof_position)->handle(), nullptr, &filter, &rowid, &n_out));
+        auto filter_c = std::make_shared<ColumnVector>(ctx, filter);
+        auto rowid_c = std::make_shared<ColumnVector>(ctx, rowid);
+        Chunk res;
+        res.columns = block.columns;
+        if (kind == CHGPU_JOIN_INNER)
+            filterColumns(res.columns, *filter_c, static_cast<ssize_t>(n_out));
+        for (auto & col : right_payload)
+        {
+            chgpu_col * out = nullptr;
+            check(chgpu_index(ctx->get(), col->handle(), rowid_c->handle(), 0, /*default_for_missing*/ 1, &out));
+            res.columns.push_back(std::make_shared<ColumnVector>(ctx, out));
+        }
+        res.num_rows = n_out;
+        block = std::move(res);
+    }
+
+private:
+    ContextPtr ctx;
+    int kind;
+    chgpu_asof * h = nullptr;
+    std::vector<Chunk> right_blocks;
+    Columns right_payload;
+    size_t key_position = 0, asof_position = 0;
+    bool built = false;
+};
+
 /// IJoin (IJoin.h:80-142) for HashJoin key64.
 class GpuHashJoin
 {

@@ -866,6 +866,50 @@ int main(int argc, char ** argv)
             chgpu_agg_free(src[1]);
         }
 
+        // ---- ASOF LEFT JOIN: trades(k, t) against quotes(k, t, v) inserted as two Blocks: every trade gets the latest quote at or before it ----
+        {
+            const size_t nq = 2000, nt = 3000;
+            std::vector<uint32_t> qk(nq), qt(nq), tk(nt), tt(nt);
+            std::vector<int64_t> qv(nq);
+            for (size_t i = 0; i < nq; ++i)
+            {
+                qk[i] = static_cast<uint32_t>(i % 40);
+                qt[i] = static_cast<uint32_t>((i / 40) * 7 + 3); // per key: times 3, 10, 17, ...
+                qv[i] = static_cast<int64_t>(qk[i]) * 1000000 + qt[i];
+            }
+            for (size_t i = 0; i < nt; ++i)
+            {
+                tk[i] = static_cast<uint32_t>((i * 13) % 44); // keys 40..43 have no quotes
+                tt[i] = static_cast<uint32_t>((i * 29) % 400);
+            }
+            GpuAsofJoin asof(ctx, CHGPU_U32, CHGPU_U32, CHGPU_JOIN_LEFT);
+            for (size_t part = 0; part < 2; ++part)
+            {
+                const size_t lo = part * nq / 2, cnt = nq / 2;
+                Chunk q;
+                q.columns = {ColumnVector::fromHost<uint32_t>(ctx, qk.data() + lo, cnt), ColumnVector::fromHost<uint32_t>(ctx, qt.data() + lo, cnt),
+                             ColumnVector::fromHost<int64_t>(ctx, qv.data() + lo, cnt)};
+                q.num_rows = cnt;
+                asof.addBlockToJoin(q, 0, 1);
+            }
+            Chunk t;
+            t.columns = {ColumnVector::fromHost<uint32_t>(ctx, tk.data(), nt), ColumnVector::fromHost<uint32_t>(ctx, tt.data(), nt)};
+            t.num_rows = nt;
+            asof.joinBlock(t, 0, 1);
+            REQUIRE(t.num_rows == nt && t.columns.size() == 5);
+            auto got_v = t.columns[4]->getData<int64_t>();
+            for (size_t i = 0; i < nt; ++i)
+            {
+                int64_t want_v = 0; // the default row
+                if (tk[i] < 40 && tt[i] >= 3)
+                {
+                    const uint32_t best = (tt[i] - 3) / 7 * 7 + 3; // the greatest quote time <= the trade's
+                    want_v = static_cast<int64_t>(tk[i]) * 1000000 + (best > 49 * 7 + 3 ? 49 * 7 + 3 : best);
+                }
+                REQUIRE(got_v[i] == want_v);
+            }
+        }
+
         // unsupported surface -> NOT_IMPLEMENTED (CPU fallback signal), not a crash
         bool fell_back = false;
         try
