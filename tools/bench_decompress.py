@@ -17,13 +17,14 @@ from clickhouse_amd import compression as CC
 from oracle import compression as OC
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+codecs_only = len(sys.argv) > 2 and sys.argv[2] == "codecs"   # only the column codecs, at the full row count
 ctx = ch.Context(0)
 rng = np.random.Generator(np.random.PCG64(4))
 res = []
 cases = [("Int64 uniform in [0, 2^31) (C2's column)", rng.integers(0, 2**31, size=rows, dtype=np.int64)),
          ("Int64 ascending ids, small steps", np.cumsum(rng.integers(0, 4, size=rows)).astype(np.int64)),
          ("UInt8 discount 0..10", rng.integers(0, 11, size=rows * 4).astype(np.uint8))]
-for name, arr, method in [(n_, a_, OC.METHOD_LZ4) for n_, a_ in cases] + [("Int64 ascending ids, CODEC(Delta(8), LZ4)", cases[1][1], OC.DELTA_LZ4)]:
+for name, arr, method in ([] if codecs_only else [(n_, a_, OC.METHOD_LZ4) for n_, a_ in cases] + [("Int64 ascending ids, CODEC(Delta(8), LZ4)", cases[1][1], OC.DELTA_LZ4)]):
     raw = arr.tobytes()
     for bs in (65536, 1 << 20):
         buf = OC.write_frames(raw, bs, method)
@@ -62,13 +63,15 @@ for name, arr, method in [(n_, a_, OC.METHOD_LZ4) for n_, a_ in cases] + [("Int6
         ctx.trim()
 # round 3: the column codecs (one lane per frame for the bit-stream codecs DoubleDelta / Gorilla, one wave per 64-value block for T64), alone
 # and as the second stage behind LZ4 (Multiple frames); 8192-value frames (the granule a MergeTree part writes)
-crows = min(rows, 20_000_000)
+crows = rows if codecs_only else min(rows, 20_000_000)
 ts = np.cumsum(rng.integers(1, 20, size=crows)).astype(np.int64)                 # timestamps: DoubleDelta's case
 gauge = (np.cumsum(rng.normal(size=crows)) * 0.25).round(2)                     # a slowly moving Float64 gauge: Gorilla's case
 small = rng.integers(0, 5000, size=crows).astype(np.int64)                     # small integers in a wide type: T64's case
 codec_cases = [("DoubleDelta, Int64 timestamps", ts, OC.METHOD_DOUBLE_DELTA, None), ("Gorilla, Float64 gauge", gauge, OC.METHOD_GORILLA, None),
                ("T64, Int64 values < 5000", small, OC.METHOD_T64, None), ("CODEC(DoubleDelta, LZ4)", ts, OC.METHOD_DOUBLE_DELTA, OC.METHOD_LZ4),
                ("CODEC(T64, LZ4)", small, OC.METHOD_T64, OC.METHOD_LZ4), ("CODEC(Gorilla, LZ4)", gauge, OC.METHOD_GORILLA, OC.METHOD_LZ4)]
+if codecs_only:
+    codec_cases = codec_cases[:3]
 for name, arr, codec, general in codec_cases:
     raw = arr.tobytes()
     buf = OC.write_codec_frames(arr, codec, block_rows=8192) if general is None else OC.write_multiple_frames(arr, codec, general, block_rows=8192)
