@@ -109,6 +109,7 @@ struct chgpu_agg
     // wins whatever order the hardware serves the rows in; the value is stored by a second pass from the winner's row (k_agg_any_resolve)
     u32 word_any = 0; // bit w: word w is a claim, word w + 1 its value
     u64 any_seq = 0;  // rows seen so far
+    u64 nokey_kept = 0; // without key: rows that reached the states (0 = min / max / any have no value: insertResultInto gives the default)
     // deterministic Float64 sums (option deterministic_float_sums, the default): sum / avg over a float argument keep a 128-bit fixed-point
     // state {word, fx_hi[word]} in units of 2^fx_base instead of a double.  n_words counts the appended high halves too; the first
     // n_pub_words are the words the C ABI shows (state columns, wire format): exports fold a pair back into its Float64 column.
@@ -1946,11 +1947,6 @@ extern "C" int chgpu_agg_create(chgpu_ctx * ctx, int key_type, uint32_t n_aggs, 
             delete a;
             return chgpu_set_error(CHGPU_ERR_NOT_IMPLEMENTED, "aggregate function kind %d has no device state: CPU path", kind);
         }
-        if (extremum && key_type < 0)
-        {
-            delete a;
-            return chgpu_set_error(CHGPU_ERR_NOT_IMPLEMENTED, "min / max / any without key: chgpu_expr_filter_minmax_node (any: the first row of the block)");
-        }
         if (kind != CHGPU_AGG_COUNT && !chgpu_type_size(at))
         {
             delete a;
@@ -2035,6 +2031,45 @@ static void agg_fill_desc(const chgpu_agg * a, const chgpu_col * const * arg_col
 }
 
 static int agg_finish_rounds(chgpu_agg * a, const AggDesc & d, const void * keys, int key_type, u64 row_begin, u64 n, u64 * pending);
+
+// min / max / any WITHOUT key (executeWithoutKeyImpl, Aggregator.cpp:1276-1321: addBatchSinglePlace): one order-key maximum over the rows of
+// the block that pass `cond`; the first such row for any()
+__global__ __launch_bounds__(256) void k_nokey_extremum(const void * __restrict__ p, int type, u64 row_begin, u64 n, const u8 * __restrict__ cond, int is_min,
+                                                         unsigned long long * __restrict__ out)
+{
+    u64 best = 0;
+    for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < n; r += (u64)gridDim.x * 256)
+    {
+        const u64 i = row_begin + r;
+        if (cond && !cond[i])
+            continue;
+        const u64 k = agg_order_key(load_arg_bits(p, type, i), type);
+        const u64 v = is_min ? ~k : k;
+        best = v > best ? v : best;
+    }
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1)
+    {
+        const u64 o = ((u64)(u32)__shfl_xor((int)(u32)(best >> 32), dlt, WAVE) << 32) | (u32)__shfl_xor((int)(u32)best, dlt, WAVE);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0 && best)
+        atomicMax(out, (unsigned long long)best);
+}
+__global__ __launch_bounds__(256) void k_nokey_first_row(u64 row_begin, u64 n, const u8 * __restrict__ cond, unsigned long long * __restrict__ out)
+{
+    u64 first = ~0ull;
+    for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < n && first == ~0ull; r += (u64)gridDim.x * 256)
+        if (!cond || cond[row_begin + r])
+            first = r;
+    if (first != ~0ull)
+        atomicMin(out, (unsigned long long)first);
+}
+__global__ void k_nokey_load(const void * __restrict__ p, int type, u64 i, u64 * __restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        out[0] = load_arg_bits(p, type, i);
+}
 
 // any(): the second pass of a block.  Every group's claim word now names the earliest of its rows (all blocks so far); the row a claim
 // names stores its value.  Claims set by earlier blocks name rows of those blocks: no row of this block matches them, the value stays.
@@ -3068,6 +3103,43 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
             u64 * st = &a->host_words[a->word_off[j]];
             if (a->kinds[j] == CHGPU_AGG_COUNT)
                 st[0] += kept;
+            else if (a->kinds[j] == CHGPU_AGG_MIN || a->kinds[j] == CHGPU_AGG_MAX || a->kinds[j] == CHGPU_AGG_ANY)
+            {
+                if (kept == 0 || n == 0)
+                    continue;
+                void * scratch = nullptr;
+                CHGPU_TRY(chgpu_scratch(ctx, 256, &scratch));
+                unsigned long long * dev = (unsigned long long *)scratch;
+                const u8 * cond = filter ? (const u8 *)filter->data : nullptr;
+                u64 v = 0;
+                if (a->kinds[j] != CHGPU_AGG_ANY)
+                {
+                    CHGPU_HIP(hipMemsetAsync(dev, 0, 8, ctx->stream));
+                    hipLaunchKernelGGL(k_nokey_extremum, dim3(chgpu_grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, (const void *)arg_cols[j]->data, a->arg_types[j], row_begin, n, cond,
+                                       a->kinds[j] == CHGPU_AGG_MIN ? 1 : 0, dev);
+                    ctx->counters[6] += 1;
+                    CHGPU_HIP(hipGetLastError());
+                    CHGPU_TRY(chgpu_read_back(ctx, dev, &v, 8));
+                    st[0] = v > st[0] ? v : st[0]; // order keys under an unsigned max (see agg_order_key); zero = no value yet
+                }
+                else if (st[0] == 0) // setIfFirst: only a state without a value takes one
+                {
+                    CHGPU_HIP(hipMemsetAsync(dev, 0xFF, 8, ctx->stream));
+                    hipLaunchKernelGGL(k_nokey_first_row, dim3(chgpu_grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, row_begin, n, cond, dev);
+                    CHGPU_HIP(hipGetLastError());
+                    CHGPU_TRY(chgpu_read_back(ctx, dev, &v, 8));
+                    if (v != ~0ull)
+                    {
+                        hipLaunchKernelGGL(k_nokey_load, dim3(1), dim3(64), 0, ctx->stream, (const void *)arg_cols[j]->data, a->arg_types[j], row_begin + v, (u64 *)dev);
+                        CHGPU_HIP(hipGetLastError());
+                        u64 bits = 0;
+                        CHGPU_TRY(chgpu_read_back(ctx, dev, &bits, 8));
+                        st[0] = ~(a->any_seq + v);
+                        st[1] = bits;
+                    }
+                    ctx->counters[6] += 2;
+                }
+            }
             else
             {
                 if (filter)
@@ -3078,6 +3150,8 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
                     st[1] += kept;
             }
         }
+        a->any_seq += n;
+        a->nokey_kept += kept;
         return CHGPU_OK;
     }
     CHGPU_REQUIRE(key_col, CHGPU_ERR_BAD_ARGUMENTS, "key column is NULL");
@@ -3422,6 +3496,33 @@ static int agg_merge_tuples(chgpu_agg * a, const u64 * src_keys, const u64 * src
     return chgpu_set_error(CHGPU_ERR_LOGICAL, "aggregation merge did not converge after 64 growth rounds");
 }
 
+// one without-key state word of `src_words` folded into dst (mergeWithoutKeyDataImpl, Aggregator.cpp:2584-2628); returns the words consumed
+static u32 agg_merge_host_word(chgpu_agg * dst, u32 w, const u64 * src_words)
+{
+    if ((dst->word_any >> w) & 1)
+    {
+        if (dst->host_words[w] == 0 && src_words[w] != 0) // changeFirstTime: a state that has a value keeps it
+        {
+            dst->host_words[w] = src_words[w];
+            dst->host_words[w + 1] = src_words[w + 1];
+        }
+        return 2;
+    }
+    if ((dst->word_is_f64 >> (16 + w)) & 1)
+        dst->host_words[w] = src_words[w] > dst->host_words[w] ? src_words[w] : dst->host_words[w]; // min / max order keys
+    else if ((dst->word_is_f64 >> w) & 1)
+    {
+        double x, y;
+        memcpy(&x, &dst->host_words[w], 8);
+        memcpy(&y, &src_words[w], 8);
+        x += y;
+        memcpy(&dst->host_words[w], &x, 8);
+    }
+    else
+        dst->host_words[w] += src_words[w];
+    return 1;
+}
+
 static bool agg_same_shape(const chgpu_agg * x, const chgpu_agg * y)
 {
     if (x->key_type != y->key_type || x->n_aggs != y->n_aggs)
@@ -3444,19 +3545,9 @@ extern "C" int chgpu_agg_merge(chgpu_agg * dst, const chgpu_agg * src)
     if (dst->key_type < 0)
     {
         // mergeWithoutKeyDataImpl (Aggregator.cpp:2584-2628)
-        for (u32 w = 0; w < dst->n_words; ++w)
-        {
-            if ((dst->word_is_f64 >> w) & 1)
-            {
-                double x, y;
-                memcpy(&x, &dst->host_words[w], 8);
-                memcpy(&y, &src->host_words[w], 8);
-                x += y;
-                memcpy(&dst->host_words[w], &x, 8);
-            }
-            else
-                dst->host_words[w] += src->host_words[w];
-        }
+        for (u32 w = 0; w < dst->n_words;)
+            w += agg_merge_host_word(dst, w, src->host_words);
+        dst->nokey_kept += src->nokey_kept;
         return CHGPU_OK;
     }
     if (!src->table_mem)
@@ -3529,21 +3620,15 @@ extern "C" int chgpu_agg_merge_states(chgpu_agg * dst, const chgpu_col * key_col
         CHGPU_REQUIRE(rows <= 1, CHGPU_ERR_BAD_ARGUMENTS, "without_key states merge one row at a time");
         if (rows == 0)
             return CHGPU_OK;
+        u64 in[AGG_MAX_WORDS] = {0};
         for (u32 w = 0; w < dst->n_words; ++w)
-        {
-            u64 v;
-            CHGPU_TRY(chgpu_read_back(ctx, state_cols[w]->data, &v, 8));
-            if ((dst->word_is_f64 >> w) & 1)
-            {
-                double x, y;
-                memcpy(&x, &dst->host_words[w], 8);
-                memcpy(&y, &v, 8);
-                x += y;
-                memcpy(&dst->host_words[w], &x, 8);
-            }
-            else
-                dst->host_words[w] += v;
-        }
+            CHGPU_TRY(chgpu_read_back(ctx, state_cols[w]->data, &in[w], 8));
+        bool any_set = false;
+        for (u32 w = 0; w < dst->n_words; ++w)
+            any_set = any_set || in[w] != 0;
+        for (u32 w = 0; w < dst->n_words;)
+            w += agg_merge_host_word(dst, w, in);
+        dst->nokey_kept += any_set ? 1 : 0; // (a partial state of an empty input is all zeros)
         return CHGPU_OK;
     }
     CHGPU_REQUIRE(key_col && key_col->rows >= rows, CHGPU_ERR_SIZES_MISMATCH, "key column shorter than %llu rows", (unsigned long long)rows);
@@ -3864,7 +3949,9 @@ extern "C" int chgpu_agg_finalize(chgpu_agg * a, chgpu_col ** keys_out, chgpu_co
             rc = chgpu_col_new(ctx, a->arg_types[j], n, &r);
             if (rc != CHGPU_OK)
                 break;
-            if (n)
+            if (a->key_type < 0 && a->nokey_kept == 0)
+                CHGPU_HIP(hipMemsetAsync(r->data, 0, chgpu_type_size(a->arg_types[j]), ctx->stream)); // a state without a value: the type's default
+            else if (n)
             {
                 // (any: the value word, as loaded -- no order key to undo)
                 hipLaunchKernelGGL(k_extremum_decode, dim3(chgpu_grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream,

@@ -67,12 +67,12 @@ enum { CHGPU_EQ = 0, CHGPU_NE = 1, CHGPU_LT = 2, CHGPU_GT = 3, CHGPU_LE = 4, CHG
 /* ---- aggregate functions with POD states the device can hold (src/AggregateFunctions/) ---- */
 enum { CHGPU_AGG_COUNT = 0, CHGPU_AGG_SUM = 1, CHGPU_AGG_AVG = 2,
        /* min / max over a numeric argument, result in the argument's type (AggregateFunctionsMinMax.cpp, SingleValueDataFixed: SingleValueData.cpp:
-          219-262); with a GROUP BY key only (without key: chgpu_expr_filter_minmax_node).  The 8-byte state word is an order key: merge /
+          219-262); with a GROUP BY key (hash table states) or without (one reduction per block).  The 8-byte state word is an order key: merge /
           export / import as for the sums, but never through the wire serialisation of chgpu_agg_serialize_states. */
        CHGPU_AGG_MIN = 3, CHGPU_AGG_MAX = 4,
        /* any(x): the value of the group's FIRST row in the order the blocks were added (AggregateFunctionAny.cpp: setIfFirst; merges keep the
           state that already has a value -- changeFirstTime).  Two 8-byte state words {claim, value}: the claim names the earliest row, so the
-          result does not depend on the order the hardware serves the rows in.  With a GROUP BY key only. */
+          result does not depend on the order the hardware serves the rows in. */
        CHGPU_AGG_ANY = 5 };
 
 /* ---- JoinKind / JoinStrictness subset (src/Core/Joins.h) ---- */

@@ -1293,6 +1293,12 @@ int cho_agg_execute_on_block(cho_agg * a, const void * keys, const void * const 
                 case CHO_AGG_AVG: *(uint64_t *)(st + 8) += row_end - row_begin;   /* Avg.h:264-285 */
                     __attribute__((fallthrough));
                 case CHO_AGG_SUM: cho_sum_add_many(a->arg_types[j], st, args[j], row_begin, row_end); break;
+                case CHO_AGG_MIN:
+                case CHO_AGG_MAX:
+                case CHO_AGG_ANY: /* the default addBatchSinglePlace: add() row by row (IAggregateFunction.h:224-260) */
+                    for (size_t i = row_begin; i < row_end; ++i)
+                        agg_add_row(a, j, a->without_key, args[j], i);
+                    break;
                 default: return -1;
             }
         }

@@ -847,9 +847,32 @@ def test_any_is_the_first_row_of_the_group_like_the_oracle(ch, ctx, oracle_mod, 
     fk, (fa, fc, fm) = F.convert_to_block()
     got = dict(zip(fk.tolist(), fa.tolist()))
     assert all(got[k] == 7 for k in range(1000)) and all(got[int(k)] == v for k, v in zip(gk.tolist(), ga.tolist()) if k >= 1000)
-    with pytest.raises(ch.ChgpuError) as e:
-        ch.Aggregator(None, [(ch.AGG_ANY, dt)], ctx=ctx)
-    assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED
+    # without key (executeWithoutKeyImpl): one state, fed block by block with a WHERE mask, merged, exported
+    aggs0 = [(ch.AGG_ANY, dt), (ch.AGG_MIN, dt), (ch.AGG_MAX, dt), (ch.AGG_COUNT, None)]
+    W, W2, OW, OW2 = ch.Aggregator(None, aggs0, ctx=ctx), ch.Aggregator(None, aggs0, ctx=ctx), O.Aggregator(None, aggs0), O.Aggregator(None, aggs0)
+    m2 = mask.copy()
+    m2[:70_000] = 0                                          # the first block passes nothing: any() must wait for the second
+    for g_, o_, lo, hi in ((W, OW, 0, h), (W2, OW2, h, n)):
+        for b in range(lo, hi, 65409):
+            e = min(hi, b + 65409)
+            g_.execute_on_block(None, [vals[b:e], vals[b:e], vals[b:e], None], filter=m2[b:e])
+            kept = m2[b:e] != 0
+            if kept.any():
+                o_.execute_on_block(None, [vals[b:e][kept], vals[b:e][kept], vals[b:e][kept], None])
+    W.merge(W2)
+    OW.merge(OW2)
+    _, gw = W.convert_to_block()
+    _, ow = OW.convert_to_block()
+    assert [x.tobytes() for x in gw] == [x.tobytes() for x in ow] and gw[0].dtype == np.dtype(dt)
+    _, words, rows = W.export_state_columns()
+    X = ch.Aggregator(None, aggs0, ctx=ctx)
+    X.merge_states(None, words, 1)
+    _, gx = X.convert_to_block()
+    assert [x.tobytes() for x in gx] == [x.tobytes() for x in gw]
+    Z = ch.Aggregator(None, aggs0, ctx=ctx)                 # an empty input: the defaults (insertResultInto of a state without value)
+    Z.execute_on_block(None, [vals[:0], vals[:0], vals[:0], None])
+    _, gz = Z.convert_to_block()
+    assert [float(x[0]) for x in gz] == [0.0, 0.0, 0.0, 0.0]
 
 
 def test_min_max_with_where_mask_and_table_growth(ch, ctx, oracle_mod):
@@ -869,9 +892,10 @@ def test_min_max_with_where_mask_and_table_growth(ch, ctx, oracle_mod):
     ok, (omx, omn) = OA.convert_to_block()
     i, j = np.argsort(gk), np.argsort(ok)
     assert np.array_equal(gk[i], ok[j]) and np.array_equal(gmx[i], omx[j]) and np.array_equal(gmn[i], omn[j])
-    with pytest.raises(ch.ChgpuError) as e:              # without key: the generated kernel route (chgpu_expr_filter_minmax_node)
-        ch.Aggregator(None, [(ch.AGG_MIN, np.int64)], ctx=ctx)
-    assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED
+    W = ch.Aggregator(None, [(ch.AGG_MIN, np.int64), (ch.AGG_MAX, np.int64)], ctx=ctx)   # without key: one reduction per block
+    W.execute_on_block(None, [vals, vals], filter=mask)
+    _, (wmn, wmx) = W.convert_to_block()
+    assert (int(wmn[0]), int(wmx[0])) == (int(vals[m].min()), int(vals[m].max()))
 
 
 # ---- round 3: ASOF joins (JoinStrictness::Asof; RowRefs.cpp SortedLookupVector) ---------------------------------------------------------------
