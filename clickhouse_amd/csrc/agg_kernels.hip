@@ -2107,9 +2107,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_agg_any_resolve(AggTable t, Agg
 __global__ __launch_bounds__(256) void k_fx_exp_stats(const void * __restrict__ p, int type, u64 row_begin, u64 n, u32 * __restrict__ out)
 {
     u32 emax = 0, emin_c = 0, bad = 0;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
-    {
-        const u64 bits = load_arg_bits(p, type, row_begin + i);
+    auto take = [&](u64 bits) {
         u32 e = (u32)(bits >> 52) & 0x7ffu;
         if (e == 0x7ffu)
             bad = 1;
@@ -2119,13 +2117,37 @@ __global__ __launch_bounds__(256) void k_fx_exp_stats(const void * __restrict__ 
             emax = e > emax ? e : emax;
             emin_c = 2047u - e > emin_c ? 2047u - e : emin_c;
         }
+    };
+    const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x, nthreads = (u64)gridDim.x * 256;
+    if (type == CHGPU_F64 && (((uintptr_t)p + row_begin * 8) & 15) == 0)
+    {
+        // a streaming read: two 16-byte nontemporal loads per lane in flight
+        typedef u64 v2q __attribute__((ext_vector_type(2)));
+        const v2q * q = (const v2q *)((const u64 *)p + row_begin);
+        const u64 pairs = n / 2;
+        u64 i = tid;
+        for (; i + nthreads < pairs; i += 2 * nthreads)
+        {
+            const v2q a = __builtin_nontemporal_load(q + i), b = __builtin_nontemporal_load(q + i + nthreads);
+            take(a.x), take(a.y), take(b.x), take(b.y);
+        }
+        for (; i < pairs; i += nthreads)
+        {
+            const v2q a = __builtin_nontemporal_load(q + i);
+            take(a.x), take(a.y);
+        }
+        if ((n & 1) && tid == 0)
+            take(((const u64 *)p)[row_begin + n - 1]);
     }
+    else
+        for (u64 i = tid; i < n; i += nthreads)
+            take(load_arg_bits(p, type, row_begin + i));
 #pragma unroll
     for (int dlt = 32; dlt >= 1; dlt >>= 1)
     {
-        const u32 o = (u32)__shfl_xor((int)emax, dlt, WAVE), q = (u32)__shfl_xor((int)emin_c, dlt, WAVE);
+        const u32 o = (u32)__shfl_xor((int)emax, dlt, WAVE), q2 = (u32)__shfl_xor((int)emin_c, dlt, WAVE);
         emax = o > emax ? o : emax;
-        emin_c = q > emin_c ? q : emin_c;
+        emin_c = q2 > emin_c ? q2 : emin_c;
     }
     const u64 anybad = __ballot(bad != 0);
     if ((threadIdx.x & 63) == 0)
