@@ -1438,7 +1438,7 @@ public:
         {
             kinds.push_back(a.kind);
             types.push_back(a.argument_type);
-            n_words += a.kind == CHGPU_AGG_AVG ? 2 : 1;
+            n_words += (a.kind == CHGPU_AGG_AVG || a.kind == CHGPU_AGG_ANY) ? 2 : 1; // avg: numerator + denominator; any: claim + value
         }
         check(chgpu_agg_create(ctx->get(), key_type, static_cast<uint32_t>(aggregates.size()), kinds.data(), types.data(), size_hint, &local));
     }
@@ -1535,7 +1535,7 @@ public:
         {
             kinds.push_back(a.kind);
             types.push_back(a.argument_type);
-            n_words += a.kind == CHGPU_AGG_AVG ? 2 : 1;
+            n_words += (a.kind == CHGPU_AGG_AVG || a.kind == CHGPU_AGG_ANY) ? 2 : 1; // avg: numerator + denominator; any: claim + value
         }
     }
 
