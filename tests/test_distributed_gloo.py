@@ -120,6 +120,16 @@ def test_world2_gloo_sharded_groupby_join_and_state_merge():
         assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(world))
 
 
+@pytest.mark.timeout(300)
+def test_world4_gloo_sharded_groupby_join_and_state_merge():
+    """the same orchestration with four ranks (the owner rule, the count exchange and the all-to-all see more than one peer)"""
+    world = 4
+    with tempfile.TemporaryDirectory() as d:
+        init_file = os.path.join(d, "init")
+        mp.spawn(_worker, args=(world, init_file, d), nprocs=world, join=True)
+        assert all(os.path.exists(os.path.join(d, f"ok{r}")) for r in range(world))
+
+
 def test_non_power_of_two_world_is_rejected():
     from clickhouse_amd import distributed as D
     assert D.world_is_power_of_two(8) and not D.world_is_power_of_two(6)
