@@ -125,7 +125,7 @@ static const char * const CHGPU_OPTION_NAMES[] = {
     "tune_gb_no_two_level", "tune_gb_nocnt32", "tune_gb_noops", "tune_gb_nowide", "tune_gb_old_scatter", "tune_gb_s", "tune_gb_scatter_wgs",
     "tune_gb_tile", "tune_gb_unitdiv", "tune_jit_unroll", "tune_jit_wg_map", "tune_jit_wg_sum", "tune_join_cap_shift", "tune_join_eager_build",
     "tune_join_lds_filter_qpt", "tune_join_lds_min_rows", "tune_join_no_dense_prefilter", "tune_join_no_fused_payload", "tune_join_no_lds_filter",
-    "tune_join_no_lds_filter_multi", "tune_join_no_lds_probe", "tune_join_no_prefilter", "tune_join_no_radix", "tune_join_no_regions",
+    "tune_join_no_lds_filter_multi", "tune_join_no_lds_probe", "tune_join_no_prefilter", "tune_join_no_dense_map", "tune_join_no_radix", "tune_join_no_regions",
     "tune_join_no_slice_build", "tune_join_region_kib", "tune_join_region_min_rows", "tune_gb_no_tiled2", "tune_agg_no_det_f64",
 };
 

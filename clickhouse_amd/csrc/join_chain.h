@@ -66,6 +66,7 @@ struct ChainTailStep
     int anti;
     int has_zero;
     int dense;        // pf is an exact bitmap over [0, max_key]
+    const u32 * dense_row; // or NULL: dense_row[key] = the build row of the key (one build block), 0xFFFFFFFF = absent -- instead of kv
 };
 struct ChainTailArgs
 {
@@ -531,7 +532,14 @@ __global__ __launch_bounds__(JT) void k_chain_gather(ChainEmitArgs a, const u64 
         {
             const ChainTailStep & st = a.s[s];
             u64 rid = NO_ROW;
-            if (!st.anti && !(st.null_map && st.null_map[row]))
+            if (!st.anti && !(st.null_map && st.null_map[row]) && st.dense_row)
+            {
+                // dense surrogate keys: the row sits at its key (one 4-byte read in a table the Infinity Cache holds, no hash, no probing)
+                const u64 key = jload_key(st.keys, st.key_type, row);
+                const u32 r = key <= st.max_key ? st.dense_row[key] : 0xFFFFFFFFu;
+                rid = r == 0xFFFFFFFFu ? NO_ROW : (u64)r; // (block 0 << 32 | row)
+            }
+            else if (!st.anti && !(st.null_map && st.null_map[row]))
             {
                 const u64 key = jload_key(st.keys, st.key_type, row);
                 if (key == 0)
@@ -649,6 +657,62 @@ static int join_build_keyset(chgpu_join * j)
     return CHGPU_OK;
 }
 
+// The key set plus the build row of every key: for a chain step that adds right columns over a build side with dense, UNIQUE keys in one
+// block (a dimension table under its surrogate key) the bitmap filters and dm_rows[key] names the matched row -- no hash table is built
+// (SSB's customer side: 0.46 ms of table build, and a 16-byte cell read in a 0.5 GB table per survivor, become 0.1 ms and a 4-byte read
+// in 120 MB).  CHGPU_ERR_NOT_IMPLEMENTED (no error text): not this shape -- build the table.
+__global__ __launch_bounds__(JT) void k_join_dense_fill(u32 * __restrict__ dm, const u64 * __restrict__ keys, const u8 * __restrict__ valid, u64 n, u32 * __restrict__ dup)
+{
+    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+    {
+        if (valid && !valid[i])
+            continue;
+        if (atomicExch(&dm[keys[i]], (u32)i) != 0xFFFFFFFFu)
+            *dup = 1; // a second row with this key: the reference's maps keep both (ALL) or one by a rule (ANY): the table's business
+    }
+}
+static int join_build_dense(chgpu_join * j)
+{
+    if (j->dm_ready)
+        return CHGPU_OK;
+    if (j->blocks.size() != 1 || j->blocks[0].rows >= 0xFFFFFFFFull)
+        return CHGPU_ERR_NOT_IMPLEMENTED;
+    const int krc = join_build_keyset(j);
+    if (krc != CHGPU_OK)
+        return krc;
+    chgpu_ctx * ctx = j->ctx;
+    const u64 cells = j->max_key + 1;
+    void * m = nullptr;
+    size_t mclass = 0;
+    CHGPU_TRY(chgpu_pool_alloc(ctx, cells * 4 + 256, &m, &mclass));
+    void * scratch0 = nullptr;
+    int rc = chgpu_scratch(ctx, 256, &scratch0);
+    hipError_t e = rc == CHGPU_OK ? hipMemsetAsync(m, 0xFF, cells * 4, ctx->stream) : hipSuccess;
+    if (rc == CHGPU_OK && e == hipSuccess)
+        e = hipMemsetAsync(scratch0, 0, 8, ctx->stream);
+    u32 dup = 0;
+    if (rc == CHGPU_OK && e == hipSuccess)
+    {
+        const BuildBlock & b = j->blocks[0];
+        hipLaunchKernelGGL(k_join_dense_fill, dim3(chgpu_grid_for(ctx, b.rows, JT, 8)), dim3(JT), 0, ctx->stream, (u32 *)m, (const u64 *)b.keys, (const u8 *)b.valid, b.rows, (u32 *)scratch0);
+        ctx->counters[6] += 1;
+        e = hipGetLastError();
+        if (e == hipSuccess)
+            rc = chgpu_read_back(ctx, scratch0, &dup, 4);
+    }
+    if (rc != CHGPU_OK || e != hipSuccess || dup)
+    {
+        chgpu_pool_free(ctx, m, mclass);
+        if (e != hipSuccess)
+            return chgpu_set_error(CHGPU_ERR_DEVICE, "dense join map: %s", hipGetErrorString(e));
+        return rc != CHGPU_OK ? rc : CHGPU_ERR_NOT_IMPLEMENTED;
+    }
+    j->dm_rows = (u32 *)m;
+    j->dm_class = mclass;
+    j->dm_ready = true;
+    return CHGPU_OK;
+}
+
 /* See include/chgpu.h. */
 extern "C" int chgpu_join_probe_chain(uint32_t n_steps, chgpu_join * const * joins, const chgpu_col * const * key_cols, const chgpu_col * const * null_maps,
                                       const int * want_right_rows, uint32_t n_carry, const chgpu_col * const * carry_cols, chgpu_col ** indexes_u64,
@@ -690,13 +754,16 @@ extern "C" int chgpu_join_probe_chain(uint32_t n_steps, chgpu_join * const * joi
             int krc = CHGPU_ERR_NOT_IMPLEMENTED;
             if ((j->strictness == CHGPU_STRICT_SEMI || j->strictness == CHGPU_STRICT_ANTI) && !(want_right_rows && want_right_rows[s]))
                 krc = join_build_keyset(j);
+            else if (want_right_rows && want_right_rows[s] && j->strictness != CHGPU_STRICT_ANTI && !chgpu_opt(ctx, "tune_join_no_dense_map", 0))
+                krc = join_build_dense(j); // right rows over dense unique keys: the key set + a direct row map
             if (krc != CHGPU_OK && krc != CHGPU_ERR_NOT_IMPLEMENTED)
                 return krc;
             if (krc != CHGPU_OK)
                 CHGPU_TRY(join_build_table(j));
         }
         // ALL over duplicate build keys replicates left rows: the chain's result is then not a filter
-        CHGPU_REQUIRE(j->strictness != CHGPU_STRICT_ALL || j->unique_keys, CHGPU_ERR_NOT_IMPLEMENTED, "ALL join over duplicate build keys in a chain");
+        CHGPU_REQUIRE(j->strictness != CHGPU_STRICT_ALL || j->unique_keys || (!j->finished && j->dm_ready), CHGPU_ERR_NOT_IMPLEMENTED,
+                      "ALL join over duplicate build keys in a chain");
     }
     for (u32 c = 0; c < n_carry; ++c)
         CHGPU_REQUIRE(carry_cols[c] && carry_cols[c]->rows == n, CHGPU_ERR_SIZES_MISMATCH, "Size of carried column %u doesn't match the chain's", c);
@@ -731,6 +798,7 @@ extern "C" int chgpu_join_probe_chain(uint32_t n_steps, chgpu_join * const * joi
         t.anti = j->strictness == CHGPU_STRICT_ANTI ? 1 : 0;
         t.has_zero = j->has_zero ? 1 : 0;
         t.dense = (j->finished ? (j->t.pf && j->max_key <= j->t.pf_mask) : j->ks_ready) ? 1 : 0;
+        t.dense_row = (!j->finished && j->dm_ready) ? j->dm_rows : nullptr;
     };
     for (u32 s : lds_steps)
     {

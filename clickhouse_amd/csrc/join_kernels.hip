@@ -125,6 +125,11 @@ struct chgpu_join
     size_t ks_class = 0;
     u64 ks_bits = 0;
     bool ks_ready = false;
+    // the same key set with the build ROW of every key beside it (dense surrogate keys, unique, one build block): dm_rows[key] = row or
+    // 0xFFFFFFFF -- what a chain step that adds right columns needs instead of the hash table (join_chain.h, join_build_dense)
+    u32 * dm_rows = nullptr;
+    size_t dm_class = 0;
+    bool dm_ready = false;
 };
 
 // the left-side behaviour of the four kinds: RIGHT probes like INNER, FULL like LEFT (JoinFeatures.h:20-40: add_missing for LEFT / FULL)
@@ -935,6 +940,8 @@ extern "C" int chgpu_join_free(chgpu_join * j)
         chgpu_pool_free(j->ctx, j->block_base_dev, j->base_class);
     if (j->ks_pf)
         chgpu_pool_free(j->ctx, j->ks_pf, j->ks_class);
+    if (j->dm_rows)
+        chgpu_pool_free(j->ctx, j->dm_rows, j->dm_class);
     chgpu_ctx * ctx = j->ctx;
     delete j;
     chgpu_ctx_release(ctx);
