@@ -614,7 +614,7 @@ __global__ __launch_bounds__(JT) void k_join_keyset_fill(u32 * __restrict__ pf, 
 }
 
 // CHGPU_OK: j->ks_* / max_key / has_zero are set.  CHGPU_ERR_NOT_IMPLEMENTED (no error text): the key domain does not fit; build the table.
-static int join_build_keyset(chgpu_join * j)
+static int join_build_keyset(chgpu_join * j, bool fill = true)
 {
     if (j->ks_ready)
         return CHGPU_OK;
@@ -645,7 +645,7 @@ static int join_build_keyset(chgpu_join * j)
     j->ks_bits = bits;
     CHGPU_HIP(hipMemsetAsync(m, 0, bits / 8 + 256, ctx->stream));
     for (const BuildBlock & b : j->blocks)
-        if (b.rows)
+        if (b.rows && fill) // (!fill: the caller derives the bits from its row map, join_build_dense)
         {
             hipLaunchKernelGGL(k_join_keyset_fill, dim3(chgpu_grid_for(ctx, b.rows, JT, 8)), dim3(JT), 0, ctx->stream, j->ks_pf, (const u64 *)b.keys, (const u8 *)b.valid, b.rows);
             ctx->counters[6] += 1;
@@ -671,13 +671,26 @@ __global__ __launch_bounds__(JT) void k_join_dense_fill(u32 * __restrict__ dm, c
             *dup = 1; // a second row with this key: the reference's maps keep both (ALL) or one by a rule (ANY): the table's business
     }
 }
+// bit k of the key set = "dm[k] names a row": a streaming pass with one ballot per 64 cells instead of one atomicOr per build row
+__global__ __launch_bounds__(JT) void k_join_bitmap_from_dense(const u32 * __restrict__ dm, u64 cells, u64 * __restrict__ pf64)
+{
+    const u64 n64 = (cells + 63) / 64;
+    for (u64 w = ((u64)blockIdx.x * JT + threadIdx.x) >> 6; w < n64; w += ((u64)gridDim.x * JT) >> 6)
+    {
+        const u64 c = w * 64 + (threadIdx.x & 63);
+        const u64 b = __ballot(c < cells && dm[c] != 0xFFFFFFFFu);
+        if ((threadIdx.x & 63) == 0)
+            pf64[w] = b;
+    }
+}
 static int join_build_dense(chgpu_join * j)
 {
     if (j->dm_ready)
         return CHGPU_OK;
     if (j->blocks.size() != 1 || j->blocks[0].rows >= 0xFFFFFFFFull)
         return CHGPU_ERR_NOT_IMPLEMENTED;
-    const int krc = join_build_keyset(j);
+    const bool had_keyset = j->ks_ready;
+    const int krc = join_build_keyset(j, /*fill*/ false);
     if (krc != CHGPU_OK)
         return krc;
     chgpu_ctx * ctx = j->ctx;
@@ -700,8 +713,19 @@ static int join_build_dense(chgpu_join * j)
         if (e == hipSuccess)
             rc = chgpu_read_back(ctx, scratch0, &dup, 4);
     }
+    if (rc == CHGPU_OK && e == hipSuccess && !had_keyset)
+    {
+        // the key set's bits (the bitmap is 8-byte aligned and padded: ks_bits is a multiple of 64)
+        hipLaunchKernelGGL(k_join_bitmap_from_dense, dim3(chgpu_grid_for(ctx, cells, JT, 8)), dim3(JT), 0, ctx->stream, (const u32 *)m, cells, (u64 *)j->ks_pf);
+        ctx->counters[6] += 1;
+        e = hipGetLastError();
+    }
     if (rc != CHGPU_OK || e != hipSuccess || dup)
     {
+        if (!had_keyset && rc == CHGPU_OK && e == hipSuccess)
+        {
+            // duplicate keys: the table path takes over; the key set (filled from the map: a set does not mind duplicates) stays valid
+        }
         chgpu_pool_free(ctx, m, mclass);
         if (e != hipSuccess)
             return chgpu_set_error(CHGPU_ERR_DEVICE, "dense join map: %s", hipGetErrorString(e));
