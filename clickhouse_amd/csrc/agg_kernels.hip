@@ -78,6 +78,9 @@ struct AggDesc
     unsigned char fx_hi[AGG_MAX_WORDS];
     int fx_base;
     u64 row_seq; // any(): row i of the argument columns is the (row_seq + i)-th row this aggregation has seen (modulo 2^64)
+    // A pass over a SUBSET of the functions (one argument word at a time through the tile-sorted plan) numbers its state words locally
+    // (0 .. n_words - 1: the LDS cells hold only those) and finds the table's words through this map; the identity otherwise.
+    unsigned char word_map[AGG_MAX_WORDS];
 };
 
 struct AggTable
@@ -370,7 +373,7 @@ __device__ __forceinline__ void add_row_global(const AggTable & t, const AggDesc
     for (u32 j = 0; j < d.n_aggs; ++j)
     {
         const AggArg & a = d.a[j];
-        u64 * w = t.words + (u64)a.word * stride + slot;
+        u64 * w = t.words + (u64)d.word_map[a.word] * stride + slot;
         if (a.kind == CHGPU_AGG_COUNT)
             global_add_word(w, 1, false);
         else if (a.kind == CHGPU_AGG_MIN || a.kind == CHGPU_AGG_MAX)
@@ -383,7 +386,7 @@ __device__ __forceinline__ void add_row_global(const AggTable & t, const AggDesc
         else
         {
             if ((d.word_fx >> a.word) & 1)
-                global_add_fx(w, t.words + (u64)d.fx_hi[a.word] * stride + slot, fx_from_double(load_arg_bits(a.ptr, a.arg_type, i), d.fx_base));
+                global_add_fx(w, t.words + (u64)d.word_map[d.fx_hi[a.word]] * stride + slot, fx_from_double(load_arg_bits(a.ptr, a.arg_type, i), d.fx_base));
             else
                 global_add_word(w, load_arg_bits(a.ptr, a.arg_type, i), a.arg_type == CHGPU_F64 || a.arg_type == CHGPU_F32);
             if (a.kind == CHGPU_AGG_AVG)
@@ -400,13 +403,13 @@ __device__ __forceinline__ void add_vals_global(const AggTable & t, const AggDes
     for (u32 j = 0; j < d.n_aggs; ++j)
     {
         const AggArg & a = d.a[j];
-        u64 * w = t.words + (u64)a.word * stride + slot;
+        u64 * w = t.words + (u64)d.word_map[a.word] * stride + slot;
         if (a.kind == CHGPU_AGG_COUNT)
             global_add_word(w, cnt, false);
         else
         {
             if ((d.word_fx >> a.word) & 1)
-                global_add_fx(w, t.words + (u64)d.fx_hi[a.word] * stride + slot, fx_from_double(a.pre == 0 ? bits0 : bits1, d.fx_base));
+                global_add_fx(w, t.words + (u64)d.word_map[d.fx_hi[a.word]] * stride + slot, fx_from_double(a.pre == 0 ? bits0 : bits1, d.fx_base));
             else
                 global_add_word(w, a.pre == 0 ? bits0 : bits1, a.arg_type == CHGPU_F64 || a.arg_type == CHGPU_F32);
             if (a.kind == CHGPU_AGG_AVG)
@@ -614,12 +617,12 @@ __global__ __launch_bounds__(1024) void k_agg_rows_lds(AggTable t, AggDesc d, co
                 const u32 wh = d.fx_hi[w];
                 const u64 hb = lwords[wh * lstride + s];
                 if (bits | hb)
-                    global_add_fx(t.words + (u64)w * gstride + slot, t.words + (u64)wh * gstride + slot, Fx128{bits, hb});
+                    global_add_fx(t.words + (u64)d.word_map[w] * gstride + slot, t.words + (u64)d.word_map[wh] * gstride + slot, Fx128{bits, hb});
                 continue;
             }
             const bool f = (d.word_is_f64 >> w) & 1;
             if (f ? (__longlong_as_double((long long)bits) != 0.0 || bits != 0) : (bits != 0))
-                global_add_word(t.words + (u64)w * gstride + slot, bits, f);
+                global_add_word(t.words + (u64)d.word_map[w] * gstride + slot, bits, f);
         }
     }
 }
@@ -1301,11 +1304,11 @@ __global__ __launch_bounds__(1024) void k_agg_part_lds(AggTable t, AggDesc d, co
                     const u32 wh = d.fx_hi[w];
                     const u64 hb = ((const u64 *)(lds_raw + L.off(wh)))[s];
                     if (bits | hb)
-                        global_add_fx(t.words + (u64)w * gstride + slot, t.words + (u64)wh * gstride + slot, Fx128{bits, hb});
+                        global_add_fx(t.words + (u64)d.word_map[w] * gstride + slot, t.words + (u64)d.word_map[wh] * gstride + slot, Fx128{bits, hb});
                     continue;
                 }
                 if (bits != 0)
-                    global_add_word(t.words + (u64)w * gstride + slot, bits, (d.word_is_f64 >> w) & 1);
+                    global_add_word(t.words + (u64)d.word_map[w] * gstride + slot, bits, (d.word_is_f64 >> w) & 1);
             }
         }
         __syncthreads();
@@ -1690,11 +1693,11 @@ __global__ __launch_bounds__(1024) void k_agg_tiles_lds(AggTable t, AggDesc d, c
                     const u32 wh = d.fx_hi[w];
                     const u64 hb = ((const u64 *)(lds_raw + L.off(wh)))[s];
                     if (bits | hb)
-                        global_add_fx(t.words + (u64)w * gstride + slot, t.words + (u64)wh * gstride + slot, Fx128{bits, hb});
+                        global_add_fx(t.words + (u64)d.word_map[w] * gstride + slot, t.words + (u64)d.word_map[wh] * gstride + slot, Fx128{bits, hb});
                     continue;
                 }
                 if (bits != 0)
-                    global_add_word(t.words + (u64)w * gstride + slot, bits, (d.word_is_f64 >> w) & 1);
+                    global_add_word(t.words + (u64)d.word_map[w] * gstride + slot, bits, (d.word_is_f64 >> w) & 1);
             }
         }
         __syncthreads();
@@ -2020,6 +2023,8 @@ static void agg_fill_desc(const chgpu_agg * a, const chgpu_col * const * arg_col
     memcpy(d->fx_hi, a->fx_hi, sizeof(d->fx_hi));
     d->fx_base = a->fx_base;
     d->row_seq = 0;
+    for (u32 w = 0; w < AGG_MAX_WORDS; ++w)
+        d->word_map[w] = (unsigned char)w;
     for (u32 j = 0; j < a->n_aggs; ++j)
     {
         d->a[j].ptr = (arg_cols && arg_cols[j]) ? arg_cols[j]->data : nullptr;
@@ -2426,8 +2431,77 @@ static int agg_finish_rounds_aos(chgpu_agg * a, const AggDesc & d, const u32 * r
 // The TILE-SORTED plan of a partitioned executeOnBlock (k_rp_tilesort + k_agg_tiles_lds): one level, one 8-byte argument column
 // (or none besides counts), 4- or 8-byte keys, a compile-time state update.  Two passes over the rows instead of three (no histogram),
 // and the partition pass writes whole lines in row order.  NOT_IMPLEMENTED = the shape does not fit (the caller runs the scatter plan).
+// The descriptor of a pass over a subset of the functions (d->a[0 .. n_aggs) already compacted to them): its state words renumbered
+// 0 .. n-1 in the order of the functions (a fixed-point sum's high half behind the regular words, as in the aggregator), word_map[] back
+// to the table's words, every per-word mask re-expressed in the local numbering; *cnt32 (which words are 32-bit counts in LDS) likewise.
+static void agg_localise_desc(const chgpu_agg * a, AggDesc * d, u32 * cnt32)
+{
+    const u32 g_cnt32 = *cnt32, g_fx = d->word_fx, g_f64 = d->word_is_f64;
+    unsigned char g_hi[AGG_MAX_WORDS];
+    memcpy(g_hi, d->fx_hi, sizeof(g_hi));
+    u32 wl = 0, l_cnt32 = 0, l_fx = 0, l_fx_hi = 0, l_f64 = 0;
+    memset(d->fx_hi, 0, sizeof(d->fx_hi));
+    u32 fx_lo_local[AGG_MAX_AGGS], n_fx = 0;
+    unsigned char fx_hi_global[AGG_MAX_AGGS];
+    for (u32 m = 0; m < d->n_aggs; ++m)
+    {
+        const u32 gw = d->a[m].word, words = (d->a[m].kind == CHGPU_AGG_AVG || d->a[m].kind == CHGPU_AGG_ANY) ? 2 : 1;
+        d->a[m].word = wl;
+        for (u32 x = 0; x < words; ++x)
+        {
+            d->word_map[wl + x] = (unsigned char)(gw + x);
+            l_cnt32 |= ((g_cnt32 >> (gw + x)) & 1u) << (wl + x);
+            l_f64 |= ((g_f64 >> (gw + x)) & 1u) << (wl + x);
+            l_f64 |= ((g_f64 >> (16 + gw + x)) & 1u) << (16 + wl + x);
+        }
+        if ((g_fx >> gw) & 1)
+        {
+            l_fx |= 1u << wl;
+            fx_lo_local[n_fx] = wl;
+            fx_hi_global[n_fx++] = g_hi[gw]; // placed behind the regular words below
+        }
+        wl += words;
+    }
+    for (u32 k = 0; k < n_fx; ++k)
+    {
+        d->word_map[wl] = fx_hi_global[k];
+        d->fx_hi[fx_lo_local[k]] = (unsigned char)wl;
+        l_fx_hi |= 1u << wl;
+        ++wl;
+    }
+    d->n_words = wl;
+    d->word_fx = l_fx;
+    d->word_fx_hi = l_fx_hi;
+    d->word_is_f64 = l_f64;
+    *cnt32 = l_cnt32;
+    (void)a;
+}
+// bytes of the compact LDS cell that holds only the state words of the functions in `agg_mask` (see agg_part_cell_bytes)
+static size_t agg_part_cell_bytes_masked(const chgpu_agg * a, u64 n, u32 agg_mask)
+{
+    const bool key32 = chgpu_type_size(a->key_type) <= 4;
+    const bool c32 = n < (1ull << 32) && !chgpu_opt(a->ctx, "tune_gb_nocnt32", 0);
+    size_t b = key32 ? 4 : 8;
+    for (u32 j = 0; j < a->n_aggs; ++j)
+    {
+        if (!((agg_mask >> j) & 1))
+            continue;
+        if (a->kinds[j] == CHGPU_AGG_COUNT)
+            b += c32 ? 4 : 8;
+        else
+        {
+            b += 8;
+            if ((a->word_fx >> a->word_off[j]) & 1)
+                b += 8;
+            if (a->kinds[j] == CHGPU_AGG_AVG)
+                b += c32 ? 4 : 8;
+        }
+    }
+    return b;
+}
+
 static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols, u64 row_begin, u64 n, u32 P, u32 S, u32 cnt32,
-                               u32 agg_mask, u64 chunk_rows)
+                               u32 agg_mask, u64 chunk_rows, bool probe_only = false)
 {
     chgpu_ctx * ctx = a->ctx;
     const size_t key_w = chgpu_type_size(a->key_type);
@@ -2494,12 +2568,13 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
             if ((agg_mask >> j) & 1)
                 d.a[m++] = d.a[j];
         d.n_aggs = m;
+        agg_localise_desc(a, &d, &cnt32); // the pass's own state words 0 .. n-1 (the caller sized S and P for exactly those)
     }
     // the compile-time update code (see k_agg_part_lds, OPS)
     u32 ops = 0;
     {
         u32 word_op[AGG_MAX_WORDS] = {0};
-        bool ok = a->n_words <= 4;
+        bool ok = d.n_words <= 4;
         for (u32 j = 0; j < d.n_aggs && ok; ++j)
         {
             const u32 w = d.a[j].word;
@@ -2508,13 +2583,13 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
             else
             {
                 word_op[w] = d.a[j].arg_type == CHGPU_F64 ? 3 : 1;
-                if ((a->word_fx >> w) & 1)
-                    word_op[w] = 7, word_op[a->fx_hi[w]] = 9;
+                if ((d.word_fx >> w) & 1)
+                    word_op[w] = 7, word_op[d.fx_hi[w]] = 9;
                 if (d.a[j].kind == CHGPU_AGG_AVG)
                     word_op[w + 1] = ((cnt32 >> (w + 1)) & 1) ? 5 : 6;
             }
         }
-        for (u32 w = 0; w < a->n_words && ok; ++w)
+        for (u32 w = 0; w < d.n_words && ok; ++w)
         {
             ok = ok && word_op[w] != 0;
             ops |= word_op[w] << (4 * w);
@@ -2524,6 +2599,8 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
     }
     if (ops != 0x51 && ops != 0x15 && ops != 0x1 && ops != 0x53 && ops != 0x3 && ops != 0x61 && ops != 0x16 && ops != 0x97 && ops != 0x957 && ops != 0x967)
         return CHGPU_ERR_NOT_IMPLEMENTED;
+    if (probe_only)
+        return CHGPU_OK; // the plan takes this shape (nothing was launched)
     const u32 G = (u32)ctx->num_cus;
     const u64 rows_per_wg = ((n + G - 1) / G + TILE - 1) / TILE * TILE;
     const int tiles_experiment = CHGPU_EXPERIMENT(ctx, "experiment_tiles"); // timing experiments only (wrong results): -DCHGPU_EXPERIMENTS builds
@@ -2564,7 +2641,7 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
     {
         hipLaunchKernelGGL(k_tile_units, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)part_total, P, chunk_rows, n_tiles, unit_list, max_units, unit_qstart, unit_ctr);
         hipLaunchKernelGGL(k_tile_index_transpose, dim3((n_tiles + 63) / 64, (P + 63) / 64), dim3(256), 0, ctx->stream, (const unsigned short *)tidx, n_tiles, P, run_index);
-        const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
+        const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = d.n_words - n4;
         const size_t keys_lds = ((size_t)key_w * (S + 1) + 7) & ~(size_t)7;
         const size_t lds_ag = keys_lds + (size_t)(S + 1) * (8 * n8 + 4 * n4) + 16;
 #define GB_TILES(KT_, OPS_, TILE_, AOS_)                                                                                                              \
@@ -2630,15 +2707,20 @@ static int agg_add_block_tiled(chgpu_agg * a, const chgpu_col * key_col, const c
 // agg_mask: the aggregate functions this call applies (bit j = function j); the caller splits more than GBP_MAX_K argument
 // columns into several calls over the same rows, each partitioning the key column with its own two argument columns.
 static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, const chgpu_col * const * arg_cols, u64 row_begin, u64 n, u32 K,
-                                     int level = 0, size_t scratch_off = 0, u32 agg_mask = ~0u)
+                                     int level = 0, size_t scratch_off = 0, u32 agg_mask = ~0u, int word_pass = 0 /* 1: a per-word local pass, 2: its probe */)
 {
+    const bool probe_only = word_pass == 2;
     chgpu_ctx * ctx = a->ctx;
     // LDS table of the aggregate pass (one 1024-thread workgroup per CU): compact cells -- key as wide as the partition
     // buffer's keys, COUNT words as 32 bits while the call has fewer than 2^32 rows -- and as many cells as fit ~150 KiB
     const bool key32 = chgpu_type_size(a->key_type) <= 4; // 4-byte (or narrower) keys are stored as 4 bytes in the partition buffers
     u32 cnt32 = 0;
-    const size_t cell_b = agg_part_cell_bytes(a, n, &cnt32);
+    size_t cell_b = agg_part_cell_bytes(a, n, &cnt32);
     const u32 n4 = (u32)__builtin_popcount(cnt32), n8 = a->n_words - n4;
+    // a pass over ONE argument word of a subset of the functions goes through the tile-sorted plan with cells that hold only its words
+    const bool local_pass = word_pass != 0 && level == 0 && K == 1 && agg_mask != ~0u;
+    if (local_pass)
+        cell_b = agg_part_cell_bytes_masked(a, n, agg_mask);
     const u32 S = agg_part_max_cells(a->ctx, cell_b);
     // partitions so that a partition's expected groups fill at most 70 % of the LDS table (fewer partitions = longer runs in
     // the scatter: an estimate of 1.25 M groups still gets 256 partitions)
@@ -2688,10 +2770,12 @@ static int agg_add_block_partitioned(chgpu_agg * a, const chgpu_col * key_col, c
     const bool no_tiled = chgpu_opt(ctx, "tune_gb_no_tiled", 0) != 0;
     if (level == 0 && K == 1 && !no_tiled)
     {
-        const int rc_t = agg_add_block_tiled(a, key_col, arg_cols, row_begin, n, P, S, cnt32, agg_mask, chunk_rows);
-        if (rc_t != CHGPU_ERR_NOT_IMPLEMENTED)
+        const int rc_t = agg_add_block_tiled(a, key_col, arg_cols, row_begin, n, P, S, cnt32, agg_mask, chunk_rows, probe_only);
+        if (rc_t != CHGPU_ERR_NOT_IMPLEMENTED || local_pass) // (a local pass was sized for the tile-sorted plan alone: the caller falls back as a whole)
             return rc_t;
     }
+    if (probe_only)
+        return CHGPU_ERR_NOT_IMPLEMENTED;
     const int gmajor_x = CHGPU_EXPERIMENT(ctx, "experiment_gmajor") ? 1 : 0; // timing experiment only (-DCHGPU_EXPERIMENTS builds): the aggregate pass still reads p-major
     // (carried tails measured SLOWER than plain runs -- 8.5 / 7.3 vs 6.4 ms at C3 -- and wrote more, not fewer, bytes (PMC WRITE_SIZE 21 GB
     //  vs 13 GB): a partition's line is then written by two instructions a barrier apart; kept selectable for A/B runs)
@@ -3266,6 +3350,38 @@ static int agg_add_block_impl(chgpu_agg * a, const chgpu_col * key_col, const ch
         for (u32 j = 0; j < a->n_aggs; ++j)
             if (a->kinds[j] != CHGPU_AGG_COUNT)
                 ++n_argwords;
+        // Two or more argument words: ONE PASS PER WORD through the tile-sorted plan (each pass sorts {key, its word} and aggregates into
+        // cells that hold only its own state words; every count() rides in the first) -- 7 ms per word and 1e9 rows, against 22 ms for
+        // the two-word scatter plan, whose 4096-row tiles leave 8-row runs (tools/bench_two_words.py).  A shape the plan does not take
+        // answers NOT_IMPLEMENTED on its first pass, before anything was added: the older routes below take over.
+        if (n_argwords >= 2 && a->size_hint > lds_groups && n >= (4u << 20) && !chgpu_opt(ctx, "agg_no_partition", 0) && !chgpu_opt(ctx, "tune_gb_no_tiled", 0)
+            && !chgpu_opt(ctx, "tune_gb_no_word_passes", 0))
+        {
+            // every pass is asked first whether the plan takes it (nothing may be added before all of them are known to run)
+            int rc = CHGPU_OK;
+            for (int run = 0; run < 2 && rc == CHGPU_OK; ++run)
+            {
+                bool first = true;
+                for (u32 j = 0; j < a->n_aggs && rc == CHGPU_OK; ++j)
+                {
+                    if (a->kinds[j] == CHGPU_AGG_COUNT)
+                        continue;
+                    u32 mask = 1u << j;
+                    if (first)
+                        for (u32 c = 0; c < a->n_aggs; ++c)
+                            if (a->kinds[c] == CHGPU_AGG_COUNT)
+                                mask |= 1u << c;
+                    rc = agg_add_block_partitioned(a, key_col, arg_cols, row_begin, n, 1, 0, 0, mask, /*word_pass*/ run == 0 ? 2 : 1);
+                    if (run == 1 && rc == CHGPU_ERR_NOT_IMPLEMENTED) // (the probe said yes: not reached)
+                        rc = chgpu_set_error(CHGPU_ERR_LOGICAL, "a pass of a per-word GROUP BY was refused after its probe");
+                    if (run == 1 && !first && rc == CHGPU_OK)
+                        ctx->counters[5] -= n; // rows were counted once per pass
+                    first = false;
+                }
+            }
+            if (rc != CHGPU_ERR_NOT_IMPLEMENTED)
+                return rc;
+        }
         if (a->size_hint > lds_groups && n >= (4u << 20) && n_argwords <= GBP_MAX_K && !chgpu_opt(ctx, "agg_no_partition", 0))
         {
             int rc = agg_add_block_partitioned(a, key_col, arg_cols, row_begin, n, n_argwords);

@@ -121,7 +121,7 @@ static std::map<std::string, long long> g_opt_defaults;
 static const char * const CHGPU_OPTION_NAMES[] = {
     "agg_no_partition", "debug", "deterministic_float_sums", "experiment_gmajor", "experiment_join_lds", "experiment_tiles", "test_keydict_weak_tags", "tune_agg_lds_threads",
     "tune_agg_no_ranged", "tune_agg_ranged_s", "tune_cmp_wg", "tune_expr_wg", "tune_exprn_wg", "tune_fcount_wg", "tune_filter_no_multi",
-    "tune_filter_no_staged", "tune_fs2_wg", "tune_fs_wg", "tune_fscatter_wg", "tune_gb_carry", "tune_gb_kib", "tune_gb_no_aos", "tune_gb_no_tiled",
+    "tune_filter_no_staged", "tune_fs2_wg", "tune_fs_wg", "tune_fscatter_wg", "tune_gb_carry", "tune_gb_kib", "tune_gb_no_aos", "tune_gb_no_tiled", "tune_gb_no_word_passes",
     "tune_gb_no_two_level", "tune_gb_nocnt32", "tune_gb_noops", "tune_gb_nowide", "tune_gb_old_scatter", "tune_gb_s", "tune_gb_scatter_wgs",
     "tune_gb_tile", "tune_gb_unitdiv", "tune_jit_unroll", "tune_jit_wg_map", "tune_jit_wg_sum", "tune_join_cap_shift", "tune_join_eager_build",
     "tune_join_lds_filter_qpt", "tune_join_lds_min_rows", "tune_join_no_dense_prefilter", "tune_join_no_fused_payload", "tune_join_no_lds_filter",

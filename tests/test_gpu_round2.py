@@ -706,3 +706,45 @@ def test_fixed_string_reference_rows_00134_and_00128(ch, ctx):
     with pytest.raises(ch.ChgpuError) as e:
         ch.FixedStringAggregator(33, [(ch.AGG_COUNT, None)], ctx=ctx)
     assert e.value.code == ch._capi.ERR_NOT_IMPLEMENTED
+
+
+# ---- round 3: two and more argument words = one tile-sorted pass per word (agg_kernels.hip, agg_localise_desc) -------------------------------
+@pytest.mark.parametrize("key_dtype", [np.uint32, np.uint64])
+@pytest.mark.parametrize("shape", ["sum_sum_count", "avg_sum", "sum_avg", "avg_avg_count", "f64sum_i32sum_count", "three_sums", "count_sum_sum"])
+def test_groupby_several_argument_words_pass_per_word(ch, ctx, oracle_mod, key_dtype, shape):
+    """sum(a), sum(b), count() and friends over enough rows and groups for the partitioned strategy: every argument word takes its own
+    tile-sorted pass into LDS cells that hold only its state words (numbered locally, mapped back to the table's words); counts ride in the
+    first pass.  Against the oracle: integers bit-exact, Float64 sums exact (fixed-point states)."""
+    O = oracle_mod
+    rng = np.random.Generator(np.random.PCG64(len(shape) + np.dtype(key_dtype).itemsize))
+    n, groups = 6_300_001, 400_000
+    k = rng.integers(0, groups, size=n).astype(key_dtype)
+    k[::101] = 0
+    a64 = rng.integers(-2**40, 2**40, size=n, dtype=np.int64)
+    b64 = rng.integers(-2**40, 2**40, size=n, dtype=np.int64)
+    c64 = rng.integers(0, 2**30, size=n, dtype=np.int64).astype(np.uint64)
+    f = (rng.random(n) * 1e4 - 5e3)
+    i32 = rng.integers(-2**31, 2**31, size=n, dtype=np.int64).astype(np.int32)
+    aggs, args = {
+        "sum_sum_count": ([(ch.AGG_SUM, np.int64), (ch.AGG_SUM, np.int64), (ch.AGG_COUNT, None)], [a64, b64, None]),
+        "avg_sum": ([(ch.AGG_AVG, np.int64), (ch.AGG_SUM, np.int64)], [a64, b64]),
+        "sum_avg": ([(ch.AGG_SUM, np.int64), (ch.AGG_AVG, np.int64)], [a64, b64]),
+        "avg_avg_count": ([(ch.AGG_AVG, np.int64), (ch.AGG_AVG, np.uint64), (ch.AGG_COUNT, None)], [a64, c64, None]),
+        "f64sum_i32sum_count": ([(ch.AGG_SUM, np.float64), (ch.AGG_SUM, np.int32), (ch.AGG_COUNT, None)], [f, i32, None]),
+        "three_sums": ([(ch.AGG_SUM, np.int64), (ch.AGG_SUM, np.uint64), (ch.AGG_SUM, np.int64)], [a64, c64, b64]),
+        "count_sum_sum": ([(ch.AGG_COUNT, None), (ch.AGG_SUM, np.int64), (ch.AGG_SUM, np.int64)], [None, a64, b64]),
+    }[shape]
+    G = ch.Aggregator(key_dtype, aggs, size_hint=groups, ctx=ctx)
+    R = O.Aggregator(key_dtype, aggs)
+    for lo, hi in ((0, n - 1_000_000), (n - 1_000_000, n)):           # a big block (the passes) and a small one (another strategy) into the same table
+        G.execute_on_block(ctx.upload(k[lo:hi]), [ctx.upload(x[lo:hi]) if x is not None else None for x in args])
+        R.execute_on_block(k[lo:hi], [x[lo:hi] if x is not None else None for x in args])
+    gk, gres = G.convert_to_block()
+    ok, ores = R.convert_to_block()
+    i, j = np.argsort(gk), np.argsort(ok)
+    assert np.array_equal(gk[i], ok[j])
+    for (kind, t), g, o in zip(aggs, gres, ores):
+        if g.dtype.kind == "f":
+            assert np.allclose(g[i], o[j], rtol=1e-9, atol=0)
+        else:
+            assert np.array_equal(g[i], o[j])
