@@ -573,36 +573,9 @@ __global__ __launch_bounds__(JT) void k_chain_gather(ChainEmitArgs a, const u64 
 // ---------------------------------------------------------------------------------------------
 // Key set without a hash table.  A SEMI / ANTI step only asks whether the key is present; for a build side of <= 4-byte keys whose
 // largest key is below 2^25 the exact bitmap answers that, and building it costs one pass over the build keys instead of the table's
-// claim / finalise passes (SSB's supplier and part sides: 0.2-0.3 ms each for the tables, ~0.03 ms for the bitmaps).
+// claim / finalise passes (SSB's supplier and part sides: 0.2-0.3 ms each for the tables, ~0.03 ms for the bitmaps).  The largest key and
+// the zero key's presence come from the staging pass of addBlockToJoin (k_join_stage_keys).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(JT) void k_join_keyset_scan(const u64 * __restrict__ keys, const u8 * __restrict__ valid, u64 n, unsigned long long * __restrict__ out)
-{
-    u64 m = 0;
-    u32 zero = 0;
-    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
-    {
-        if (valid && !valid[i])
-            continue;
-        const u64 k = keys[i];
-        m = k > m ? k : m;
-        zero |= k == 0 ? 1u : 0u;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-    {
-        const u64 x = __shfl_xor(m, o);
-        m = x > m ? x : m;
-        zero |= __shfl_xor(zero, o);
-    }
-    if ((threadIdx.x & 63) == 0)
-    {
-        if (m)
-            atomicMax(out, (unsigned long long)m);
-        if (zero)
-            atomicOr(out + 1, 1ull);
-    }
-}
-
 __global__ __launch_bounds__(JT) void k_join_keyset_fill(u32 * __restrict__ pf, const u64 * __restrict__ keys, const u8 * __restrict__ valid, u64 n)
 {
     for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
@@ -622,18 +595,10 @@ static int join_build_keyset(chgpu_join * j, bool fill = true)
         return CHGPU_ERR_NOT_IMPLEMENTED;
     chgpu_ctx * ctx = j->ctx;
     j->build_closed = true;
-    void * scratch0 = nullptr;
-    CHGPU_TRY(chgpu_scratch(ctx, 256, &scratch0));
-    CHGPU_HIP(hipMemsetAsync(scratch0, 0, 16, ctx->stream));
-    for (const BuildBlock & b : j->blocks)
-        if (b.rows)
-        {
-            hipLaunchKernelGGL(k_join_keyset_scan, dim3(chgpu_grid_for(ctx, b.rows, JT, 4)), dim3(JT), 0, ctx->stream, (const u64 *)b.keys, (const u8 *)b.valid, b.rows,
-                               (unsigned long long *)scratch0);
-            ctx->counters[6] += 1;
-        }
+    // the largest key and the zero key's presence were gathered while the keys were staged (k_join_stage_keys)
     u64 r[2] = {0, 0};
-    CHGPU_TRY(chgpu_read_back(ctx, scratch0, r, sizeof(r)));
+    if (j->key_stats)
+        CHGPU_TRY(chgpu_read_back(ctx, j->key_stats, r, sizeof(r)));
     if (r[0] >= (1ull << 25))
         return CHGPU_ERR_NOT_IMPLEMENTED;
     u64 bits = 1ull << 16;

@@ -130,6 +130,8 @@ struct chgpu_join
     u32 * dm_rows = nullptr;
     size_t dm_class = 0;
     bool dm_ready = false;
+    unsigned long long * key_stats = nullptr; // device: {largest inserted key, zero key inserted}, kept up to date by k_join_stage_keys
+    size_t key_stats_class = 0;
 };
 
 // the left-side behaviour of the four kinds: RIGHT probes like INNER, FULL like LEFT (JoinFeatures.h:20-40: add_missing for LEFT / FULL)
@@ -160,14 +162,79 @@ __device__ __forceinline__ u64 jload_key(const void * keys, int type, u64 i)
     }
 }
 
+// stats[0] = the largest inserted key, stats[1] = 1 when the zero key is inserted: what the key-set / row-map builds of join_chain.h size
+// themselves by, gathered while the keys pass through anyway.  One atomic per WORKGROUP at most, and only when it would change the
+// word (thousands of waves on two addresses cost more than the pass itself).  4-byte keys whose column and staging buffer are 16-byte
+// aligned move four rows per lane (the dimension tables of a star join: 30 M customer keys at the rate of a copy).
 __global__ __launch_bounds__(JT) void k_join_stage_keys(const void * __restrict__ keys, int type, const u8 * __restrict__ null_map,
-                                                        const u8 * __restrict__ join_mask, u64 n, u64 * __restrict__ out_keys, u8 * __restrict__ out_valid)
+                                                        const u8 * __restrict__ join_mask, u64 n, u64 * __restrict__ out_keys, u8 * __restrict__ out_valid,
+                                                        unsigned long long * __restrict__ stats)
 {
-    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
-    {
-        out_keys[i] = jload_key(keys, type, i);
+    u64 m = 0;
+    u32 zero = 0;
+    auto row = [&](u64 i, u64 k) {
+        const bool valid = !(null_map && null_map[i]) && !(join_mask && !join_mask[i]); // HashJoinMethodsImpl.h:261-272
         if (out_valid)
-            out_valid[i] = !(null_map && null_map[i]) && !(join_mask && !join_mask[i]); // HashJoinMethodsImpl.h:261-272
+            out_valid[i] = valid;
+        if (valid)
+        {
+            m = k > m ? k : m;
+            zero |= k == 0 ? 1u : 0u;
+        }
+    };
+    const bool wide = (type == CHGPU_U32 || type == CHGPU_I32) && (((uintptr_t)keys | (uintptr_t)out_keys) & 15) == 0;
+    if (wide)
+    {
+        typedef u32 v4d __attribute__((ext_vector_type(4)));
+        typedef u64 v2q __attribute__((ext_vector_type(2)));
+        const u64 quads = n / 4;
+        for (u64 q = (u64)blockIdx.x * JT + threadIdx.x; q < quads; q += (u64)gridDim.x * JT)
+        {
+            const v4d k4 = __builtin_nontemporal_load((const v4d *)keys + q);
+            __builtin_nontemporal_store(v2q{k4.x, k4.y}, (v2q *)out_keys + 2 * q);
+            __builtin_nontemporal_store(v2q{k4.z, k4.w}, (v2q *)out_keys + 2 * q + 1);
+            row(4 * q, k4.x), row(4 * q + 1, k4.y), row(4 * q + 2, k4.z), row(4 * q + 3, k4.w);
+        }
+        for (u64 i = quads * 4 + (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+        {
+            const u64 k = ((const u32 *)keys)[i];
+            out_keys[i] = k;
+            row(i, k);
+        }
+    }
+    else
+        for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+        {
+            const u64 k = jload_key(keys, type, i);
+            out_keys[i] = k;
+            row(i, k);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        const u64 x = __shfl_xor(m, o);
+        m = x > m ? x : m;
+        zero |= __shfl_xor(zero, o);
+    }
+    __shared__ unsigned long long s_m;
+    __shared__ u32 s_zero;
+    if (threadIdx.x == 0)
+        s_m = 0, s_zero = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+    {
+        if (m)
+            atomicMax(&s_m, (unsigned long long)m);
+        if (zero)
+            atomicOr(&s_zero, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        if (s_m > __hip_atomic_load(stats, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(stats, s_m);
+        if (s_zero && !__hip_atomic_load(stats + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicOr(stats + 1, 1ull);
     }
 }
 
@@ -942,6 +1009,8 @@ extern "C" int chgpu_join_free(chgpu_join * j)
         chgpu_pool_free(j->ctx, j->ks_pf, j->ks_class);
     if (j->dm_rows)
         chgpu_pool_free(j->ctx, j->dm_rows, j->dm_class);
+    if (j->key_stats)
+        chgpu_pool_free(j->ctx, j->key_stats, j->key_stats_class);
     chgpu_ctx * ctx = j->ctx;
     delete j;
     chgpu_ctx_release(ctx);
@@ -978,8 +1047,21 @@ extern "C" int chgpu_join_add_block(chgpu_join * j, const chgpu_col * key_col, c
                 return rc;
             }
         }
+        if (!j->key_stats)
+        {
+            int rc = chgpu_pool_alloc(ctx, 256, (void **)&j->key_stats, &j->key_stats_class);
+            if (rc == CHGPU_OK && hipMemsetAsync(j->key_stats, 0, 16, ctx->stream) != hipSuccess)
+                rc = chgpu_set_error(CHGPU_ERR_DEVICE, "memset failed");
+            if (rc != CHGPU_OK)
+            {
+                chgpu_pool_free(ctx, b.keys, b.keys_class);
+                if (b.valid)
+                    chgpu_pool_free(ctx, b.valid, b.valid_class);
+                return rc;
+            }
+        }
         hipLaunchKernelGGL(k_join_stage_keys, dim3(chgpu_grid_for(ctx, b.rows, JT, 8)), dim3(JT), 0, ctx->stream, (const void *)key_col->data, key_col->type,
-                           null_map ? (const u8 *)null_map->data : nullptr, join_mask ? (const u8 *)join_mask->data : nullptr, b.rows, b.keys, b.valid);
+                           null_map ? (const u8 *)null_map->data : nullptr, join_mask ? (const u8 *)join_mask->data : nullptr, b.rows, b.keys, b.valid, j->key_stats);
         ctx->counters[6] += 1;
         // the caller may free its columns right after this call returns.  Columns that own pool memory go back to this context's pool, whose
         // reuse is ordered on this stream behind the staging kernel; anything else (wrapped caller memory, views) may be released or

@@ -77,20 +77,29 @@ def q41_gpu(ch, ctx, dims, lo, group_by=None):
     up = lambda x: x if isinstance(x, ch.Column) else ctx.upload(x)
     # ---- right sides: filtered dimension tables -> hash tables (FillingRightJoinSideTransform) ----
     c_region, c_custkey, c_nation = up(dims["c_region"]), up(dims["c_custkey"]), up(dims["c_nation"])
-    cm = ch.cmp_const(c_region, ch.EQ, AMERICA)
-    ck, cn = ch.filter_columns([c_custkey, c_nation], cm)
-    j_c = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, key_dtype=np.uint32, ctx=ctx)
-    j_c.add_block(ck)
-    sm = ch.cmp_const(up(dims["s_region"]), ch.EQ, AMERICA)
-    # the supplier join is probed in its ANTI form: its filter (1 = no supplier of the region) is handed to the part join as the null map
-    # of lo_partkey -- a row with a NULL key matches nothing -- so the two semi joins yield ONE filter and the fact columns are compacted
-    # once, at 8 %, instead of five columns at 20 % and four more at 40 % of that
     chain = not os.environ.get("SSB_PLAN_PER_JOIN") and not os.environ.get("SSB_PLAN_TWO_FILTERS")
-    j_s = ch.HashJoin(ch.JOIN_LEFT, ch.STRICT_SEMI if (chain or os.environ.get("SSB_PLAN_TWO_FILTERS")) else ch.STRICT_ANTI, key_dtype=np.uint32, ctx=ctx)
-    j_s.add_block(up(dims["s_suppkey"]).filter(sm))
+    cm = ch.cmp_const(c_region, ch.EQ, AMERICA)
+    sm = ch.cmp_const(up(dims["s_region"]), ch.EQ, AMERICA)
     pm = ch.cmp_const(up(dims["p_mfgr"]), ch.LE, 2)
+    j_c = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, key_dtype=np.uint32, ctx=ctx)
+    # the supplier join is probed in its ANTI form in the per-join plan: its filter (1 = no supplier of the region) is handed to the part join
+    # as the null map of lo_partkey -- a row with a NULL key matches nothing -- so the two semi joins yield ONE filter and the fact columns
+    # are compacted once, at 8 %, instead of five columns at 20 % and four more at 40 % of that
+    j_s = ch.HashJoin(ch.JOIN_LEFT, ch.STRICT_SEMI if (chain or os.environ.get("SSB_PLAN_TWO_FILTERS")) else ch.STRICT_ANTI, key_dtype=np.uint32, ctx=ctx)
     j_p = ch.HashJoin(ch.JOIN_LEFT, ch.STRICT_SEMI, key_dtype=np.uint32, ctx=ctx)
-    j_p.add_block(up(dims["p_partkey"]).filter(pm))
+    if chain:
+        # the dimension predicates as the joins' ON masks (`... JOIN customer ON lo_custkey = c_custkey AND c_region = 'AMERICA'`: rows whose
+        # mask is 0 are not inserted, HashJoinMethodsImpl.h:261-272): no filtered copy of a dimension, no row count to wait for, and the
+        # right row ids index the dimension's own columns
+        j_c.add_block(c_custkey, join_mask=cm)
+        j_s.add_block(up(dims["s_suppkey"]), join_mask=sm)
+        j_p.add_block(up(dims["p_partkey"]), join_mask=pm)
+        cn = c_nation
+    else:
+        ck, cn = ch.filter_columns([c_custkey, c_nation], cm)
+        j_c.add_block(ck)
+        j_s.add_block(up(dims["s_suppkey"]).filter(sm))
+        j_p.add_block(up(dims["p_partkey"]).filter(pm))
     d_year = up(dims["d_year"])
     j_d = ch.HashJoin(ch.JOIN_INNER, ch.STRICT_ALL, key_dtype=np.uint32, ctx=ctx)
     j_d.add_block(up(dims["d_datekey"]))
