@@ -111,6 +111,7 @@ SIGNATURES = {
     "chgpu_city_hash128": (_i, [_vp, _u64, _pu64]),
     "chgpu_native_walk_block": (_i, [_vp, _u64, _u64, _u32, _vp, C.POINTER(_u32), _pu64, C.POINTER(C.c_int32), C.POINTER(_i), _pu64]),
     "chgpu_native_read_strings": (_i, [_vp, _vp, _u64, _u64, _pp, _pp]),
+    "chgpu_col_download_many": (_i, [_vp, _u32, _vp, _vp]),
     "chgpu_asof_create": (_i, [_vp, _i, _i, _i, _i, _pp]),
     "chgpu_asof_add_block": (_i, [_vp, _vp, _vp, _vp, _vp, _pu64]),
     "chgpu_asof_total_rows": (_i, [_vp, _pu64]),

@@ -102,7 +102,8 @@ class Aggregator:
     def convert_to_block(self):
         """Aggregator::convertToBlocks(final=true) downloaded: (keys ndarray or None, [result ndarrays])."""
         keys, res = self.finalize_columns()
-        return (keys.numpy() if keys is not None else None), [r.numpy() for r in res]
+        got = Column.numpy_many(([keys] if keys is not None else []) + res)   # one wait for the whole result Block
+        return (got[0] if keys is not None else None), got[(1 if keys is not None else 0):]
 
 
 def serialize_states(ctx: Context, kind: int, word0: Column, word1: Column | None = None):

@@ -178,6 +178,18 @@ class Column:
         K.check(K.lib().chgpu_col_download(self.ctx._h, self._h, out.ctypes.data_as(C.c_void_p), rows))
         return out
 
+    @staticmethod
+    def numpy_many(cols) -> list:
+        """every column of a result Block downloaded with one wait (chgpu_col_download_many)"""
+        cols = list(cols)
+        if not cols:
+            return []
+        outs = [np.empty(c.size(), dtype=c.dtype) for c in cols]
+        hs = (C.c_void_p * len(cols))(*[c._h for c in cols])
+        ps = (C.c_void_p * len(cols))(*[o.ctypes.data for o in outs])
+        K.check(K.lib().chgpu_col_download_many(cols[0].ctx._h, len(cols), hs, ps))
+        return outs
+
     def cut(self, start: int, length: int) -> "Column":
         """IColumn::cut (IColumn.h:118-121) as a non-owning view."""
         h = C.c_void_p()

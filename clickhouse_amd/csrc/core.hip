@@ -499,6 +499,25 @@ extern "C" int chgpu_col_download(chgpu_ctx * ctx, const chgpu_col * col, void *
     return CHGPU_OK;
 }
 
+extern "C" int chgpu_col_download_many(chgpu_ctx * ctx, uint32_t n, const chgpu_col * const * cols, void * const * host_ptrs)
+{
+    ChgpuDeviceGuard _dev_guard(ctx);
+    CHGPU_REQUIRE(ctx && (n == 0 || (cols && host_ptrs)), CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
+    bool any = false;
+    for (u32 c = 0; c < n; ++c)
+    {
+        CHGPU_REQUIRE(cols[c] && (host_ptrs[c] || cols[c]->rows == 0), CHGPU_ERR_BAD_ARGUMENTS, "NULL column or host buffer %u", c);
+        if (cols[c]->rows)
+        {
+            CHGPU_HIP(hipMemcpyAsync(host_ptrs[c], cols[c]->data, cols[c]->rows * chgpu_type_size(cols[c]->type), hipMemcpyDeviceToHost, ctx->stream));
+            any = true;
+        }
+    }
+    if (any)
+        CHGPU_HIP(hipStreamSynchronize(ctx->stream)); // ONE wait for the whole Block (a result of a few rows is all latency)
+    return CHGPU_OK;
+}
+
 extern "C" uint64_t chgpu_col_rows(const chgpu_col * col) { return col ? col->rows : 0; }
 extern "C" int chgpu_col_type(const chgpu_col * col) { return col ? col->type : -1; }
 extern "C" void * chgpu_col_device_ptr(const chgpu_col * col) { return col ? col->data : nullptr; }

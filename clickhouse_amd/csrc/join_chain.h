@@ -596,8 +596,8 @@ static int join_build_keyset(chgpu_join * j, bool fill = true)
     chgpu_ctx * ctx = j->ctx;
     j->build_closed = true;
     // the largest key and the zero key's presence were gathered while the keys were staged (k_join_stage_keys)
-    u64 r[2] = {0, 0};
-    if (j->key_stats)
+    u64 r[2] = {j->stats_host[0], j->stats_host[1]};
+    if (j->key_stats && !j->stats_known)
         CHGPU_TRY(chgpu_read_back(ctx, j->key_stats, r, sizeof(r)));
     if (r[0] >= (1ull << 25))
         return CHGPU_ERR_NOT_IMPLEMENTED;
@@ -648,11 +648,30 @@ __global__ __launch_bounds__(JT) void k_join_bitmap_from_dense(const u32 * __res
             pf64[w] = b;
     }
 }
-static int join_build_dense(chgpu_join * j)
+// the duplicate flag of a pending row map is known: the map becomes usable, or (a second row for some key) goes away -- NOT_IMPLEMENTED
+// then, no error text: the table path takes over (the key set stays valid)
+static int join_finish_dense(chgpu_join * j, u32 dup)
 {
-    if (j->dm_ready)
+    if (!j->dm_pending)
+        return j->dm_ready ? CHGPU_OK : CHGPU_ERR_NOT_IMPLEMENTED;
+    j->dm_pending = false;
+    if (dup)
+    {
+        chgpu_pool_free(j->ctx, j->dm_rows, j->dm_class);
+        j->dm_rows = nullptr;
+        return CHGPU_ERR_NOT_IMPLEMENTED;
+    }
+    j->dm_ready = true;
+    return CHGPU_OK;
+}
+
+// defer_dup: the duplicate flag (key_stats[2]) is left on the device and the map marked pending -- a chain looks at the flags of all its
+// joins with one read-back (join_finish_dense)
+static int join_build_dense(chgpu_join * j, bool defer_dup = false)
+{
+    if (j->dm_ready || j->dm_pending)
         return CHGPU_OK;
-    if (j->blocks.size() != 1 || j->blocks[0].rows >= 0xFFFFFFFFull)
+    if (j->blocks.size() != 1 || j->blocks[0].rows >= 0xFFFFFFFFull || !j->key_stats)
         return CHGPU_ERR_NOT_IMPLEMENTED;
     const bool had_keyset = j->ks_ready;
     const int krc = join_build_keyset(j, /*fill*/ false);
@@ -663,43 +682,36 @@ static int join_build_dense(chgpu_join * j)
     void * m = nullptr;
     size_t mclass = 0;
     CHGPU_TRY(chgpu_pool_alloc(ctx, cells * 4 + 256, &m, &mclass));
-    void * scratch0 = nullptr;
-    int rc = chgpu_scratch(ctx, 256, &scratch0);
-    hipError_t e = rc == CHGPU_OK ? hipMemsetAsync(m, 0xFF, cells * 4, ctx->stream) : hipSuccess;
-    if (rc == CHGPU_OK && e == hipSuccess)
-        e = hipMemsetAsync(scratch0, 0, 8, ctx->stream);
-    u32 dup = 0;
-    if (rc == CHGPU_OK && e == hipSuccess)
+    u32 * dup_dev = (u32 *)(j->key_stats + 2);
+    hipError_t e = hipMemsetAsync(m, 0xFF, cells * 4, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(dup_dev, 0, 8, ctx->stream);
+    if (e == hipSuccess)
     {
         const BuildBlock & b = j->blocks[0];
-        hipLaunchKernelGGL(k_join_dense_fill, dim3(chgpu_grid_for(ctx, b.rows, JT, 8)), dim3(JT), 0, ctx->stream, (u32 *)m, (const u64 *)b.keys, (const u8 *)b.valid, b.rows, (u32 *)scratch0);
+        hipLaunchKernelGGL(k_join_dense_fill, dim3(chgpu_grid_for(ctx, b.rows, JT, 8)), dim3(JT), 0, ctx->stream, (u32 *)m, (const u64 *)b.keys, (const u8 *)b.valid, b.rows, dup_dev);
         ctx->counters[6] += 1;
-        e = hipGetLastError();
-        if (e == hipSuccess)
-            rc = chgpu_read_back(ctx, scratch0, &dup, 4);
-    }
-    if (rc == CHGPU_OK && e == hipSuccess && !had_keyset)
-    {
-        // the key set's bits (the bitmap is 8-byte aligned and padded: ks_bits is a multiple of 64)
-        hipLaunchKernelGGL(k_join_bitmap_from_dense, dim3(chgpu_grid_for(ctx, cells, JT, 8)), dim3(JT), 0, ctx->stream, (const u32 *)m, cells, (u64 *)j->ks_pf);
-        ctx->counters[6] += 1;
-        e = hipGetLastError();
-    }
-    if (rc != CHGPU_OK || e != hipSuccess || dup)
-    {
-        if (!had_keyset && rc == CHGPU_OK && e == hipSuccess)
+        if (!had_keyset)
         {
-            // duplicate keys: the table path takes over; the key set (filled from the map: a set does not mind duplicates) stays valid
+            // the key set's bits (the bitmap is 8-byte aligned and padded: ks_bits is a multiple of 64); a set does not mind duplicate keys
+            hipLaunchKernelGGL(k_join_bitmap_from_dense, dim3(chgpu_grid_for(ctx, cells, JT, 8)), dim3(JT), 0, ctx->stream, (const u32 *)m, cells, (u64 *)j->ks_pf);
+            ctx->counters[6] += 1;
         }
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess)
+    {
         chgpu_pool_free(ctx, m, mclass);
-        if (e != hipSuccess)
-            return chgpu_set_error(CHGPU_ERR_DEVICE, "dense join map: %s", hipGetErrorString(e));
-        return rc != CHGPU_OK ? rc : CHGPU_ERR_NOT_IMPLEMENTED;
+        return chgpu_set_error(CHGPU_ERR_DEVICE, "dense join map: %s", hipGetErrorString(e));
     }
     j->dm_rows = (u32 *)m;
     j->dm_class = mclass;
-    j->dm_ready = true;
-    return CHGPU_OK;
+    j->dm_pending = true;
+    if (defer_dup)
+        return CHGPU_OK;
+    u32 dup = 0;
+    CHGPU_TRY(chgpu_read_back(ctx, dup_dev, &dup, 4));
+    return join_finish_dense(j, dup);
 }
 
 /* See include/chgpu.h. */
@@ -737,17 +749,86 @@ extern "C" int chgpu_join_probe_chain(uint32_t n_steps, chgpu_join * const * joi
         CHGPU_REQUIRE(!(j->kind == CHGPU_JOIN_INNER && j->strictness == CHGPU_STRICT_ANY), CHGPU_ERR_NOT_IMPLEMENTED, "INNER ANY in a chain");
         if (want_right_rows && want_right_rows[s])
             CHGPU_REQUIRE(right_rowid_u64, CHGPU_ERR_BAD_ARGUMENTS, "right row ids wanted but right_rowid_u64 is NULL");
+    }
+    // The right sides that still have to be built.  Their key statistics (gathered while the keys were staged) come over in ONE read-back,
+    // the builds are queued, and the duplicate flags of the row maps come over in a second one: two waits for the whole chain instead of
+    // one or two per join.
+    {
+        chgpu_join * need[JC_MAX_STEPS];
+        u32 n_need = 0;
+        for (u32 s = 0; s < n_steps; ++s)
+        {
+            chgpu_join * j = joins[s];
+            bool seen = false;
+            for (u32 q = 0; q < n_need; ++q)
+                seen = seen || need[q] == j;
+            if (!seen && !j->finished && !j->ks_ready && !j->stats_known && j->key_stats)
+                need[n_need++] = j;
+        }
+        if (n_need)
+        {
+            void * stage = nullptr;
+            CHGPU_TRY(chgpu_pinned(ctx, 16 * JC_MAX_STEPS, &stage));
+            for (u32 q = 0; q < n_need; ++q)
+                CHGPU_HIP(hipMemcpyAsync((char *)stage + 16 * q, need[q]->key_stats, 16, hipMemcpyDeviceToHost, ctx->stream));
+            CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+            for (u32 q = 0; q < n_need; ++q)
+            {
+                memcpy(need[q]->stats_host, (char *)stage + 16 * q, 16);
+                need[q]->stats_known = true;
+            }
+        }
+    }
+    bool to_table[JC_MAX_STEPS] = {false};
+    for (u32 s = 0; s < n_steps; ++s)
+    {
+        chgpu_join * j = joins[s];
+        if (j->finished)
+            continue;
+        // a SEMI / ANTI step that adds no column only needs the key SET: the exact bitmap, without the hash table
+        int krc = CHGPU_ERR_NOT_IMPLEMENTED;
+        if ((j->strictness == CHGPU_STRICT_SEMI || j->strictness == CHGPU_STRICT_ANTI) && !(want_right_rows && want_right_rows[s]))
+            krc = join_build_keyset(j);
+        else if (want_right_rows && want_right_rows[s] && j->strictness != CHGPU_STRICT_ANTI && !chgpu_opt(ctx, "tune_join_no_dense_map", 0))
+            krc = join_build_dense(j, /*defer_dup*/ true); // right rows over dense unique keys: the key set + a direct row map
+        if (krc != CHGPU_OK && krc != CHGPU_ERR_NOT_IMPLEMENTED)
+            return krc;
+        to_table[s] = krc != CHGPU_OK;
+    }
+    {
+        chgpu_join * pend[JC_MAX_STEPS];
+        u32 n_pend = 0;
+        for (u32 s = 0; s < n_steps; ++s)
+        {
+            bool seen = false;
+            for (u32 q = 0; q < n_pend; ++q)
+                seen = seen || pend[q] == joins[s];
+            if (!seen && joins[s]->dm_pending)
+                pend[n_pend++] = joins[s];
+        }
+        if (n_pend)
+        {
+            void * stage = nullptr;
+            CHGPU_TRY(chgpu_pinned(ctx, 16 * JC_MAX_STEPS, &stage));
+            for (u32 q = 0; q < n_pend; ++q)
+                CHGPU_HIP(hipMemcpyAsync((char *)stage + 16 * q, pend[q]->key_stats + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+            CHGPU_HIP(hipStreamSynchronize(ctx->stream));
+            for (u32 q = 0; q < n_pend; ++q)
+            {
+                u32 dup = 0;
+                memcpy(&dup, (char *)stage + 16 * q, 4);
+                (void)join_finish_dense(pend[q], dup); // (a duplicate key: dm_ready stays false, the table is built below)
+            }
+        }
+    }
+    for (u32 s = 0; s < n_steps; ++s)
+    {
+        chgpu_join * j = joins[s];
         if (!j->finished)
         {
-            // a SEMI / ANTI step that adds no column only needs the key SET: the exact bitmap, without the hash table
-            int krc = CHGPU_ERR_NOT_IMPLEMENTED;
-            if ((j->strictness == CHGPU_STRICT_SEMI || j->strictness == CHGPU_STRICT_ANTI) && !(want_right_rows && want_right_rows[s]))
-                krc = join_build_keyset(j);
-            else if (want_right_rows && want_right_rows[s] && j->strictness != CHGPU_STRICT_ANTI && !chgpu_opt(ctx, "tune_join_no_dense_map", 0))
-                krc = join_build_dense(j); // right rows over dense unique keys: the key set + a direct row map
-            if (krc != CHGPU_OK && krc != CHGPU_ERR_NOT_IMPLEMENTED)
-                return krc;
-            if (krc != CHGPU_OK)
+            const bool wants_rows = want_right_rows && want_right_rows[s];
+            const bool have = wants_rows ? j->dm_ready : (j->ks_ready && (j->strictness == CHGPU_STRICT_SEMI || j->strictness == CHGPU_STRICT_ANTI));
+            if (to_table[s] || !have)
                 CHGPU_TRY(join_build_table(j));
         }
         // ALL over duplicate build keys replicates left rows: the chain's result is then not a filter

@@ -130,8 +130,12 @@ struct chgpu_join
     u32 * dm_rows = nullptr;
     size_t dm_class = 0;
     bool dm_ready = false;
-    unsigned long long * key_stats = nullptr; // device: {largest inserted key, zero key inserted}, kept up to date by k_join_stage_keys
+    unsigned long long * key_stats = nullptr; // device: {largest inserted key, zero key inserted}, kept up to date by k_join_stage_keys;
+                                              // word [2]: the duplicate-key flag of a row-map build (k_join_dense_fill)
     size_t key_stats_class = 0;
+    u64 stats_host[2] = {0, 0}; // the two words on the host, when a caller has fetched them for several joins at once (a chain)
+    bool stats_known = false;
+    bool dm_pending = false;    // the row map is filled but its duplicate flag has not been looked at yet
 };
 
 // the left-side behaviour of the four kinds: RIGHT probes like INNER, FULL like LEFT (JoinFeatures.h:20-40: add_missing for LEFT / FULL)
@@ -1050,7 +1054,7 @@ extern "C" int chgpu_join_add_block(chgpu_join * j, const chgpu_col * key_col, c
         if (!j->key_stats)
         {
             int rc = chgpu_pool_alloc(ctx, 256, (void **)&j->key_stats, &j->key_stats_class);
-            if (rc == CHGPU_OK && hipMemsetAsync(j->key_stats, 0, 16, ctx->stream) != hipSuccess)
+            if (rc == CHGPU_OK && hipMemsetAsync(j->key_stats, 0, 32, ctx->stream) != hipSuccess)
                 rc = chgpu_set_error(CHGPU_ERR_DEVICE, "memset failed");
             if (rc != CHGPU_OK)
             {

@@ -134,6 +134,8 @@ int chgpu_col_slice(chgpu_ctx * ctx, const chgpu_col * col, uint64_t start, uint
    src/Columns/ColumnVector.cpp:511-526) */
 int chgpu_col_concat(chgpu_ctx * ctx, uint32_t n, const chgpu_col * const * cols, chgpu_col ** out);
 int chgpu_col_download(chgpu_ctx * ctx, const chgpu_col * col, void * host_ptr, uint64_t rows);
+/* every column of a (result) Block to host memory with ONE wait: host_ptrs[c] receives all rows of cols[c] */
+int chgpu_col_download_many(chgpu_ctx * ctx, uint32_t n, const chgpu_col * const * cols, void * const * host_ptrs);
 uint64_t chgpu_col_rows(const chgpu_col * col);
 int chgpu_col_type(const chgpu_col * col);
 void * chgpu_col_device_ptr(const chgpu_col * col);
