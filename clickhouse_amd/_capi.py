@@ -140,6 +140,7 @@ SIGNATURES = {
     "chgpu_all_reduce_u64_host": (_i, [_vp, _pu64, _u32]),
     "chgpu_comm_barrier": (_i, [_vp]),
     "chgpu_join_probe_chain": (_i, [_u32, _pp, _pp, _pp, C.POINTER(_i), _u32, _pp, _pp, _pp, _pp, _pp, _pu64]),
+    "chgpu_join_probe_chain_columns": (_i, [_u32, _pp, _pp, _pp, C.POINTER(_i), _pp, _u32, _pp, _pp, _pp, _pp, _pp, _pu64]),
     "chgpu_join_flatten_rowids": (_i, [_vp, _vp, _pp]),
     "chgpu_join_non_joined_rows": (_i, [_vp, _pp, _pu64]),
     "chgpu_join_free": (_i, [_vp]),

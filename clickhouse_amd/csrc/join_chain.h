@@ -441,6 +441,11 @@ struct ChainEmitArgs
 {
     ChainTailStep s[JC_MAX_STEPS]; // the steps whose matched right row is wanted
     u64 * rowid_out[JC_MAX_STEPS];
+    // or, instead of the row id, the value of one right column at the matched row (one build block: row = the id's low 32 bits; a miss
+    // gives the type's default 0, insertDefault): payload_in != NULL
+    const void * payload_in[JC_MAX_STEPS];
+    void * payload_out[JC_MAX_STEPS];
+    u32 payload_size[JC_MAX_STEPS];
     const void * carry_in[JC_MAX_CARRY];
     void * carry_out[JC_MAX_CARRY];
     u32 carry_size[JC_MAX_CARRY];  // element bytes: 1, 2, 4, 8
@@ -565,7 +570,19 @@ __global__ __launch_bounds__(JT) void k_chain_gather(ChainEmitArgs a, const u64 
                     }
                 }
             }
-            a.rowid_out[s][o] = rid;
+            if (a.payload_in[s])
+            {
+                const u64 r = rid == NO_ROW ? 0 : (rid & 0xFFFFFFFFull);
+                switch (a.payload_size[s])
+                {
+                    case 1: ((u8 *)a.payload_out[s])[o] = rid == NO_ROW ? (u8)0 : ((const u8 *)a.payload_in[s])[r]; break;
+                    case 2: ((u16 *)a.payload_out[s])[o] = rid == NO_ROW ? (u16)0 : ((const u16 *)a.payload_in[s])[r]; break;
+                    case 4: ((u32 *)a.payload_out[s])[o] = rid == NO_ROW ? 0u : ((const u32 *)a.payload_in[s])[r]; break;
+                    default: ((u64 *)a.payload_out[s])[o] = rid == NO_ROW ? 0ull : ((const u64 *)a.payload_in[s])[r]; break;
+                }
+            }
+            else
+                a.rowid_out[s][o] = rid;
         }
     }
 }
@@ -714,10 +731,11 @@ static int join_build_dense(chgpu_join * j, bool defer_dup = false)
     return join_finish_dense(j, dup);
 }
 
-/* See include/chgpu.h. */
-extern "C" int chgpu_join_probe_chain(uint32_t n_steps, chgpu_join * const * joins, const chgpu_col * const * key_cols, const chgpu_col * const * null_maps,
-                                      const int * want_right_rows, uint32_t n_carry, const chgpu_col * const * carry_cols, chgpu_col ** indexes_u64,
-                                      chgpu_col ** right_rowid_u64, chgpu_col ** carry_out, chgpu_col ** filter_u8, uint64_t * n_kept)
+/* See include/chgpu.h.  right_payload_cols[s] != NULL (with want_right_rows[s]): right_rowid_u64[s] receives that column's values at the matched
+   rows instead of the row ids. */
+static int join_chain_impl(uint32_t n_steps, chgpu_join * const * joins, const chgpu_col * const * key_cols, const chgpu_col * const * null_maps,
+                           const int * want_right_rows, const chgpu_col * const * right_payload_cols, uint32_t n_carry, const chgpu_col * const * carry_cols,
+                           chgpu_col ** indexes_u64, chgpu_col ** right_rowid_u64, chgpu_col ** carry_out, chgpu_col ** filter_u8, uint64_t * n_kept)
 {
     CHGPU_REQUIRE(n_steps >= 1 && joins && key_cols && n_kept, CHGPU_ERR_BAD_ARGUMENTS, "NULL argument");
     CHGPU_REQUIRE(n_steps <= JC_MAX_STEPS, CHGPU_ERR_NOT_IMPLEMENTED, "a join chain of %u steps (at most %u)", n_steps, JC_MAX_STEPS);
@@ -749,6 +767,12 @@ extern "C" int chgpu_join_probe_chain(uint32_t n_steps, chgpu_join * const * joi
         CHGPU_REQUIRE(!(j->kind == CHGPU_JOIN_INNER && j->strictness == CHGPU_STRICT_ANY), CHGPU_ERR_NOT_IMPLEMENTED, "INNER ANY in a chain");
         if (want_right_rows && want_right_rows[s])
             CHGPU_REQUIRE(right_rowid_u64, CHGPU_ERR_BAD_ARGUMENTS, "right row ids wanted but right_rowid_u64 is NULL");
+        if (right_payload_cols && right_payload_cols[s])
+        {
+            CHGPU_REQUIRE(want_right_rows && want_right_rows[s], CHGPU_ERR_BAD_ARGUMENTS, "a right column for step %u, which adds no right rows", s);
+            CHGPU_REQUIRE(j->blocks.size() == 1, CHGPU_ERR_NOT_IMPLEMENTED, "right columns are gathered inside the chain for one-block build sides: take the row ids");
+            CHGPU_REQUIRE(right_payload_cols[s]->rows == j->blocks[0].rows, CHGPU_ERR_SIZES_MISMATCH, "Size of the right column of step %u doesn't match the build block", s);
+        }
     }
     // The right sides that still have to be built.  Their key statistics (gathered while the keys were staged) come over in ONE read-back,
     // the builds are queued, and the duplicate flags of the row maps come over in a second one: two waits for the whole chain instead of
@@ -945,10 +969,14 @@ extern "C" int chgpu_join_probe_chain(uint32_t n_steps, chgpu_join * const * joi
     for (u32 s = 0; s < n_steps; ++s)
         if (want_right_rows && want_right_rows[s])
         {
-            if ((rc = chgpu_col_new(ctx, CHGPU_U64, kept, &rid[s])) != CHGPU_OK)
+            const chgpu_col * pay = right_payload_cols ? right_payload_cols[s] : nullptr;
+            if ((rc = chgpu_col_new(ctx, pay ? pay->type : CHGPU_U64, kept, &rid[s])) != CHGPU_OK)
                 return fail(rc);
             fill_tail(ea.s[ea.n_rowid], s);
-            ea.rowid_out[ea.n_rowid] = (u64 *)rid[s]->data;
+            ea.rowid_out[ea.n_rowid] = pay ? nullptr : (u64 *)rid[s]->data;
+            ea.payload_in[ea.n_rowid] = pay ? pay->data : nullptr;
+            ea.payload_out[ea.n_rowid] = pay ? rid[s]->data : nullptr;
+            ea.payload_size[ea.n_rowid] = pay ? (u32)chgpu_type_size(pay->type) : 0;
             ++ea.n_rowid;
         }
     for (u32 c = 0; c < n_carry; ++c)
@@ -997,4 +1025,18 @@ extern "C" int chgpu_join_probe_chain(uint32_t n_steps, chgpu_join * const * joi
     ctx->counters[3] += n * n_steps;
     ctx->counters[4] += kept;
     return CHGPU_OK;
+}
+
+extern "C" int chgpu_join_probe_chain(uint32_t n_steps, chgpu_join * const * joins, const chgpu_col * const * key_cols, const chgpu_col * const * null_maps,
+                                      const int * want_right_rows, uint32_t n_carry, const chgpu_col * const * carry_cols, chgpu_col ** indexes_u64,
+                                      chgpu_col ** right_rowid_u64, chgpu_col ** carry_out, chgpu_col ** filter_u8, uint64_t * n_kept)
+{
+    return join_chain_impl(n_steps, joins, key_cols, null_maps, want_right_rows, nullptr, n_carry, carry_cols, indexes_u64, right_rowid_u64, carry_out, filter_u8, n_kept);
+}
+
+extern "C" int chgpu_join_probe_chain_columns(uint32_t n_steps, chgpu_join * const * joins, const chgpu_col * const * key_cols, const chgpu_col * const * null_maps,
+                                              const int * want_right_rows, const chgpu_col * const * right_cols, uint32_t n_carry, const chgpu_col * const * carry_cols,
+                                              chgpu_col ** indexes_u64, chgpu_col ** right_out, chgpu_col ** carry_out, chgpu_col ** filter_u8, uint64_t * n_kept)
+{
+    return join_chain_impl(n_steps, joins, key_cols, null_maps, want_right_rows, right_cols, n_carry, carry_cols, indexes_u64, right_out, carry_out, filter_u8, n_kept);
 }

@@ -145,11 +145,13 @@ class HashJoin:
         return left, r["added_block"], r["added_row"], c
 
 
-def join_probe_chain(joins, keys, null_maps=None, right_rows=None, carry=None, want_indexes=True, want_filter=False):
+def join_probe_chain(joins, keys, null_maps=None, right_rows=None, carry=None, want_indexes=True, want_filter=False, right_cols=None):
     """A chain of filter-form JoiningTransforms (LEFT SEMI / LEFT ANTI / ALL over unique build keys) answered in one sweep over the left
     key columns, before any left column is copied (chgpu_join_probe_chain): keys[s] is probed against joins[s].
     right_rows[s] truthy: also return joins[s]'s matched build row per survivor; carry: left Columns to gather at the survivors.
-    -> dict(kept, indexes, right_rowid=[Column | None per step], carry=[Column ...], filter)"""
+    right_cols[s] (a Column of joins[s]'s one build block): return that column's values at the matched rows instead of the row ids
+    (chgpu_join_probe_chain_columns).
+    -> dict(kept, indexes, right_rowid=[Column | None per step: row ids, or the right column's values], carry=[Column ...], filter)"""
     assert len(joins) == len(keys) and len(joins) >= 1
     ctx = joins[0].ctx
     n = len(joins)
@@ -166,9 +168,15 @@ def join_probe_chain(joins, keys, null_maps=None, right_rows=None, carry=None, w
     ch_out = (C.c_void_p * max(nc, 1))()
     ih, fh = C.c_void_p(), C.c_void_p()
     kept = C.c_uint64(0)
-    K.check(K.lib().chgpu_join_probe_chain(n, jh, kh, nh if null_maps is not None else None, want, nc, ch_in if nc else None,
-                                           C.byref(ih) if want_indexes else None, rh, ch_out if nc else None,
-                                           C.byref(fh) if want_filter else None, C.byref(kept)))
+    if right_cols is not None and any(c is not None for c in right_cols):
+        ph = (C.c_void_p * n)(*[(c._h if c is not None else None) for c in right_cols])
+        K.check(K.lib().chgpu_join_probe_chain_columns(n, jh, kh, nh if null_maps is not None else None, want, ph, nc, ch_in if nc else None,
+                                                       C.byref(ih) if want_indexes else None, rh, ch_out if nc else None,
+                                                       C.byref(fh) if want_filter else None, C.byref(kept)))
+    else:
+        K.check(K.lib().chgpu_join_probe_chain(n, jh, kh, nh if null_maps is not None else None, want, nc, ch_in if nc else None,
+                                               C.byref(ih) if want_indexes else None, rh, ch_out if nc else None,
+                                               C.byref(fh) if want_filter else None, C.byref(kept)))
     return dict(kept=int(kept.value), indexes=Column(ctx, ih) if want_indexes else None,
                 right_rowid=[Column(ctx, C.c_void_p(rh[s])) if rh[s] else None for s in range(n)],
                 carry=[Column(ctx, C.c_void_p(ch_out[c])) for c in range(nc)],

@@ -572,6 +572,12 @@ int chgpu_join_probe_agg(chgpu_join * j, const chgpu_col * key_col, const chgpu_
 int chgpu_join_probe_chain(uint32_t n_steps, chgpu_join * const * joins, const chgpu_col * const * key_cols, const chgpu_col * const * null_maps,
                            const int * want_right_rows, uint32_t n_carry, const chgpu_col * const * carry_cols, chgpu_col ** indexes_u64,
                            chgpu_col ** right_rowid_u64, chgpu_col ** carry_out, chgpu_col ** filter_u8, uint64_t * n_kept);
+/* The same with ONE right column per payload step gathered inside the call (AddedColumns' lazy columns, AddedColumns.cpp:39-131): right_cols[s]
+   != NULL (a step with want_right_rows[s], over a one-block build side) makes right_out[s] that column's values at the matched rows -- a miss
+   gives the type's default -- instead of the row ids; steps with right_cols[s] == NULL still return row ids in right_out[s]. */
+int chgpu_join_probe_chain_columns(uint32_t n_steps, chgpu_join * const * joins, const chgpu_col * const * key_cols, const chgpu_col * const * null_maps,
+                                   const int * want_right_rows, const chgpu_col * const * right_cols, uint32_t n_carry, const chgpu_col * const * carry_cols,
+                                   chgpu_col ** indexes_u64, chgpu_col ** right_out, chgpu_col ** carry_out, chgpu_col ** filter_u8, uint64_t * n_kept);
 /* (block_index << 32 | row) ids -> running ordinal of the row over all right blocks in insertion order (all-ones stays
    all-ones): the index into payload columns concatenated with chgpu_col_concat, i.e. fillFromBlocksAndRowNumbers
    (src/Columns/IColumn.cpp:515-526) for many right Blocks */

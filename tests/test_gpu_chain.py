@@ -60,6 +60,18 @@ def run_chain(ch, O, ctx, rows, steps, seed):
         want_rid = np.where(o["added_row"] < 0, np.uint64(0xFFFFFFFFFFFFFFFF),
                             (o["added_block"].astype(np.uint64) << np.uint64(32)) | o["added_row"].astype(np.uint64))
         assert np.array_equal(r["right_rowid"][s].numpy(), want_rid), s
+    # the same chain with one right column per step gathered inside the call: the column's value at the matched row, the default at a miss
+    pay_dt = [np.uint8, np.uint32, np.uint64, np.uint16]
+    pays = [((np.arange(h[2].shape[0], dtype=np.uint64) * 2654435761 + 7) % 251).astype(pay_dt[s % 4]) for s, h in enumerate(host)]
+    r3 = ch.join_probe_chain(joins, keys, nms if any(m is not None for m in nms) else None, right_rows=[True] * len(joins),
+                             right_cols=[ctx.upload(p) for p in pays], want_indexes=False)
+    assert r3["kept"] == r["kept"]
+    for s in range(len(joins)):
+        rid = r["right_rowid"][s].numpy()
+        miss = rid == np.uint64(0xFFFFFFFFFFFFFFFF)
+        want_pay = np.where(miss, 0, pays[s][np.where(miss, 0, rid & np.uint64(0xFFFFFFFF)).astype(np.int64)]).astype(pays[s].dtype) if rid.shape[0] else pays[s][:0]
+        got_pay = r3["right_rowid"][s].numpy()
+        assert got_pay.dtype == pays[s].dtype and np.array_equal(got_pay, want_pay), s
     # the same chain asked for nothing but the count
     r2 = ch.join_probe_chain(joins, keys, nms if any(m is not None for m in nms) else None, want_indexes=False)
     assert r2["kept"] == r["kept"] and r2["indexes"] is None and r2["filter"] is None

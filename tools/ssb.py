@@ -107,11 +107,12 @@ def q41_gpu(ch, ctx, dims, lo, group_by=None):
         j.finish_build()
     # ---- the fact table through the joins (JoiningTransform x4), most selective first ----
     if chain:
+        # (the two right columns the query reads -- c_nation, d_year -- are gathered inside the call: AddedColumns' lazy gather over the survivors)
         r = ch.join_probe_chain([j_s, j_p, j_c, j_d], [lo["lo_suppkey"], lo["lo_partkey"], lo["lo_custkey"], lo["lo_orderdate"]],
-                                right_rows=[False, False, True, True], carry=[lo["lo_revenue"], lo["lo_supplycost"]], want_indexes=False)
+                                right_rows=[False, False, True, True], right_cols=[None, None, cn, d_year],
+                                carry=[lo["lo_revenue"], lo["lo_supplycost"]], want_indexes=False)
         rev, cost = r["carry"]
-        nation = cn.index(r["right_rowid"][2], default_for_missing=True)   # AddedColumns' lazy gather over the survivors
-        year = d_year.index(r["right_rowid"][3], default_for_missing=True)
+        nation, year = r["right_rowid"][2], r["right_rowid"][3]
         return _q41_group_by(ch, ctx, year, nation, rev, cost, group_by)
     r = j_s.probe_columns(lo["lo_suppkey"], need_right_rows=False)   # semi joins: the dimension contributes no column
     f = r["filter"]
