@@ -296,7 +296,8 @@ def sharded_configs(args, ctx, ch, torch, np, dev, stream, rank, world, dist):
         return float(t[0].item())
 
     torch.cuda.synchronize()
-    comm = D.Comm.from_env(ctx, rank, world, bcast)
+    rehearsal = dist.get_backend() != "nccl"
+    comm = _HostStagedComm(ctx, rank, world, dist, torch, np) if rehearsal else D.Comm.from_env(ctx, rank, world, bcast)
     eng = D.LocalEngine(ctx, comm)
     res = {}
 
@@ -437,9 +438,57 @@ def sharded_configs(args, ctx, ch, torch, np, dev, stream, rank, world, dist):
                              "parity": "35 groups, each owned by exactly one rank; count and profit totals equal to the all-reduced totals of every rank's own "
                                        "one-GPU plan over its rows"}
         del lo, lo_t, dims_dev
-    res["transport"] = f"chgpu_all_to_all_multi / chgpu_all_reduce_u64 over RCCL (C ABI), world {world}"
+    res["transport"] = (f"REHEARSAL, not a measurement: the exchange staged through host memory and gloo, world {world} (ranks may share a GPU)" if rehearsal
+                        else f"chgpu_all_to_all_multi / chgpu_all_reduce_u64 over RCCL (C ABI), world {world}")
     comm.close()
     return res
+
+
+class _HostStagedComm:
+    """--backend gloo only: clickhouse_amd.distributed.Comm's surface with every exchange staged through host memory and gloo, so that the
+    N>1 orchestration of `sharded_configs` (device partition / merge / join kernels, the ownership and total checks) can be rehearsed with
+    several ranks on ONE GPU, where RCCL refuses two ranks on one device.  Its timings mean nothing; the measured transport is D.Comm."""
+
+    def __init__(self, ctx, rank, world, dist, torch, np):
+        self.ctx, self.rank, self.world, self.dist, self.torch, self.np = ctx, rank, world, dist, torch, np
+        self._sent = self._recv = self._n = 0
+
+    def all_to_all_counts(self, send_counts):
+        t = self.torch.tensor([int(x) for x in send_counts], dtype=self.torch.int64)
+        r = self.torch.empty_like(t)
+        self.dist.all_to_all_single(r, t)
+        return [int(x) for x in r.tolist()]
+
+    def all_to_all(self, col, send_counts, recv_counts):
+        np, torch = self.np, self.torch
+        dt = np.dtype(col.dtype)
+        host = col.numpy()
+        assert host.shape[0] == sum(send_counts), (host.shape, send_counts)
+        snd = torch.from_numpy(np.ascontiguousarray(host).view(np.uint8).copy())
+        rcv = torch.empty(int(sum(recv_counts)) * dt.itemsize, dtype=torch.uint8)
+        self.dist.all_to_all_single(rcv, snd, [int(c) * dt.itemsize for c in recv_counts], [int(c) * dt.itemsize for c in send_counts])
+        self._sent += snd.numel()
+        self._recv += rcv.numel()
+        self._n += 1
+        return self.ctx.upload(rcv.numpy().view(dt))
+
+    def all_to_all_multi(self, cols, send_counts):
+        recv_counts = self.all_to_all_counts(send_counts)
+        return [self.all_to_all(c, send_counts, recv_counts) for c in cols], recv_counts
+
+    def all_reduce_u64(self, values):
+        t = self.torch.from_numpy(self.np.array([int(v) % 2**64 for v in values], dtype=self.np.uint64).view(self.np.int64).copy())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)  # two's complement: the sum mod 2^64
+        return [int(x) for x in t.numpy().view(self.np.uint64)]
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def stats(self):
+        return dict(bytes_sent=self._sent, bytes_received=self._recv, collectives=self._n)
+
+    def close(self):
+        pass
 
 
 def config_q11(args, ctx, ch, torch, np, dev, stream, with_cpu, _headline_cpu):
