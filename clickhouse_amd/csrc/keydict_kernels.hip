@@ -9,14 +9,21 @@
 //
 // Design (not a translation).  The 8-byte-key operators of this library (GROUP BY strategies, join build / probe, sharding) stay as
 // they are; wide keys are first turned into dense 32-bit ids by a device-resident, exact dictionary:
-//   table  tags u64[cap] (a 64-bit hash of the packed key, low bit forced to 1; 0 = empty) + ids u32[cap]
-//   store  W x u64[store_cap]: the packed key of id k, written once by the row that claimed its cell
-// One row = one probe walk over `tags` (8 bytes per cell: a cache line holds 8 cells, not 2-4 wide keys).  A row that finds an empty
+//   table  cells {u64 tag, u64 id + 1}[cap]: tag = a 64-bit hash of the packed key, low bit forced to 1 (0 = empty); a 64-byte line holds 4 cells
+//   store  u64[store_cap][W]: the packed key of id k, written once by the row that claimed its cell
+// One row = one probe walk over the cells, a line (4 cells) per look.  A row that finds an empty
 // cell claims it with ONE compare-and-swap on the tag, takes the next id (one atomic per wave) and writes its key to the store; a
 // row that finds its own tag is a candidate and is verified against the stored key by the NEXT kernel -- nobody ever waits for another
 // lane inside a kernel, so the protocol cannot deadlock a lock-step wave.  Two different keys with one tag (2^-64 per pair) fail
 // the verification and walk on in a further round; the result is exact.  Ids are stable for the dictionary's lifetime (a grown
 // table re-inserts (tag, id) pairs, the store is append-only), so partial aggregation states keyed by id survive growth and blocks.
+//
+// Two things keep the table small enough to stay in the L2 / Infinity Cache instead of being sized for "every row is a new key":
+//   * a key inserted by an EARLIER kernel (its id is below the count the host read back before this launch) is compared in place --
+//     its tag, id and stored bytes are all visible -- so in the steady state (and always on the find side) no row needs the second kernel;
+//   * the table is sized for the keys it holds, not for the rows of the chunk: a row that would insert beyond `limit` (half the cells)
+//     defers instead; the host grows the table fourfold and runs the deferred rows again.  Between a lane's look at the counter and its
+//     claim at most one grid of lanes can slip through, so cells and store hold `limit` + one grid's worth of lanes (kd_reserve).
 #include "chgpu_internal.h"
 
 #include <cstdlib>
@@ -26,7 +33,8 @@
 static constexpr u32 KD_T = 256;
 static constexpr u32 KD_MAX_COLS = 16;
 static constexpr u32 KD_NO_ID = 0xFFFFFFFFu;
-static constexpr u64 KD_CHUNK_ROWS = 64ull << 20; // rows encoded per pass: bounds the capacity the table must guarantee up front
+static constexpr u64 KD_CHUNK_ROWS = 64ull << 20; // rows encoded per pass (bounds the scratch: 16 bytes per row)
+static constexpr u64 KD_FIRST_CHUNK_ROWS = 4ull << 20;
 
 struct KdCols
 {
@@ -39,18 +47,23 @@ struct KdCols
 struct KdCtrl
 {
     u32 n_ids;
-    u32 retry;
-    u32 pad[2];
+    u32 retry;       // bit 0: a row walks on in a further round (another key under its tag); bit 1: rows deferred, the table must grow
+    u32 need_verify; // some row met a tag claimed in this very kernel: k_kd_verify has work
+    u32 pad;
 };
+
+static constexpr u64 KD_SETTLED = ~0ull;
+static constexpr u64 KD_DEFERRED = ~0ull - 1; // cand[i]: the row found an empty cell while the dictionary was at its limit
 
 struct KdTable
 {
-    u64 * tags;
-    u32 * ids;
+    ulonglong2 * cells; // .x = tag (0: empty), .y = id + 1 (0: the claimer has not written it yet)
     u64 capacity; // power of two
-    u64 * store;  // [W][store_cap]
+    u64 * store;  // [store_cap][W]: the packed key of id k, one 16- or 32-byte line
     u64 store_cap;
     u32 W;
+    u32 ids_before; // keys inserted by earlier kernels: ids below this are compared in place
+    u64 limit;      // inserts stop (rows defer) once n_ids reaches this
     KdCtrl * ctrl;
 };
 
@@ -70,30 +83,28 @@ struct chgpu_keydict
     int weak_tags = 0; // test hook: 20-bit tags, so that the collision rounds run
 };
 
-// packFixed (AggregationCommon.h:91-158): column j's element of row i copied to bytes [offset_j, offset_j + size_j) of the key
-__global__ __launch_bounds__(KD_T) void k_kd_pack(KdCols c, u64 row_begin, u64 n, u32 W, u64 * __restrict__ out /* [W][n] */)
+// packFixed (AggregationCommon.h:91-158): column j's element of row r copied to bytes [offset_j, offset_j + size_j) of the key.  The
+// packed key is never written out: k_kd_claim and k_kd_verify assemble it from the key columns where they need it.
+__device__ __forceinline__ void kd_pack_row(const KdCols & c, u64 r, u64 (&w)[4])
 {
-    for (u64 i = (u64)blockIdx.x * KD_T + threadIdx.x; i < n; i += (u64)gridDim.x * KD_T)
+    w[0] = w[1] = w[2] = w[3] = 0;
+    for (u32 j = 0; j < c.n; ++j)
     {
-        u64 w[4] = {0, 0, 0, 0};
-        for (u32 j = 0; j < c.n; ++j)
+        u64 v;
+        switch (c.size[j])
         {
-            u64 v;
-            const u64 r = row_begin + i;
-            switch (c.size[j])
-            {
-                case 1: v = ((const u8 *)c.ptr[j])[r]; break;
-                case 2: v = ((const u16 *)c.ptr[j])[r]; break;
-                case 4: v = ((const u32 *)c.ptr[j])[r]; break;
-                default: v = ((const u64 *)c.ptr[j])[r]; break;
-            }
-            const u32 word = c.offset[j] >> 3, shift = (c.offset[j] & 7) * 8;
-            w[word] |= v << shift;
-            if (shift && shift + c.size[j] * 8 > 64)
-                w[word + 1] |= v >> (64 - shift);
+            case 1: v = ((const u8 *)c.ptr[j])[r]; break;
+            case 2: v = ((const u16 *)c.ptr[j])[r]; break;
+            case 4: v = ((const u32 *)c.ptr[j])[r]; break;
+            default: v = ((const u64 *)c.ptr[j])[r]; break;
         }
-        for (u32 q = 0; q < W; ++q)
-            out[(u64)q * n + i] = w[q];
+        const u32 word = c.offset[j] >> 3, shift = (c.offset[j] & 7) * 8;
+        // static indexes only: a run-time index into w[] would put it in scratch memory
+        const u64 lo = v << shift, hi = shift && shift + c.size[j] * 8 > 64 ? v >> (64 - shift) : 0;
+        w[0] |= word == 0 ? lo : 0;
+        w[1] |= word == 1 ? lo : word == 0 ? hi : 0;
+        w[2] |= word == 2 ? lo : word == 1 ? hi : 0;
+        w[3] |= word == 3 ? lo : word == 2 ? hi : 0;
     }
 }
 
@@ -108,35 +119,63 @@ __device__ __forceinline__ u64 kd_tag(const u64 * w, u32 W, int weak)
 }
 
 // mode: 1 = emplace (GROUP BY, join build), 0 = find (join probe: an absent key gets KD_NO_ID).
-// round 0: every row; later rounds: the rows whose verification failed, continuing their walk at resume[i].
-// cand[i] = the cell whose tag equals the row's (verified by k_kd_verify), or ~0 when the row is settled.
-__global__ __launch_bounds__(KD_T) void k_kd_claim(KdTable t, const u64 * __restrict__ pk, u64 n, int mode, int round, int weak, u32 * __restrict__ rid, u64 * __restrict__ cand,
-                                                   u64 * __restrict__ resume)
+// round 0: every row; later rounds: the rows that are not settled -- a row whose verification failed continues its walk at resume[i], a
+// deferred row (and every unsettled row after the table has grown: `restart`) starts again at its home cell.
+// cand[i] = the cell whose tag equals the row's and whose key this kernel cannot see yet (k_kd_verify compares), KD_DEFERRED, or KD_SETTLED.
+__global__ __launch_bounds__(KD_T) void k_kd_claim(KdTable t, KdCols kc, u64 row_begin, u64 n, int mode, int round, int restart, int weak, u32 * __restrict__ rid,
+                                                   u64 * __restrict__ cand, u64 * __restrict__ resume)
 {
     const u64 mask = t.capacity - 1;
     const u64 stride = (u64)gridDim.x * KD_T;
+    u32 flags = 0, verify = 0;
+    // what this wave knows of the id counter: the host's count at launch, then whatever its own claims returned.  A wave claims with a
+    // stale count at most once (the claim tells it the true one), so all waves together pass the limit by at most one grid of lanes
+    u32 known_ids = t.ids_before;
     for (u64 i0 = (u64)blockIdx.x * KD_T; i0 < n; i0 += stride)
     {
         const u64 i = i0 + threadIdx.x;
-        bool active = i < n && (round == 0 || cand[i] != ~0ull);
+        const u64 was = round != 0 && i < n ? cand[i] : 0;
+        bool active = i < n && (round == 0 || was != KD_SETTLED);
         u64 w[4] = {0, 0, 0, 0};
         u64 tag = 1, slot = 0;
         if (active)
         {
-            for (u32 q = 0; q < t.W; ++q)
-                w[q] = pk[(u64)q * n + i];
+            kd_pack_row(kc, row_begin + i, w);
             tag = kd_tag(w, t.W, weak);
-            slot = round == 0 ? ((tag >> 1) * 0x9E3779B97F4A7C15ull >> 20) & mask : resume[i];
-            cand[i] = ~0ull;
+            slot = (round == 0 || restart || was == KD_DEFERRED) ? ((tag >> 1) * 0x9E3779B97F4A7C15ull >> 20) & mask : resume[i];
         }
+        u64 state = KD_SETTLED;
         // wave-synchronous walk: every iteration each unsettled lane looks at one cell; the lanes that claimed a cell in this iteration
         // take their ids with one atomic for the whole wave
         for (u64 step = 0; step <= t.capacity && __any(active); ++step)
         {
             bool claimed = false;
+            // linear probing, looked at one 64-byte line (4 cells) at a time: the first cell at or after `slot` that is empty or holds the
+            // row's tag is where the cell-by-cell walk would stop; a line without one is skipped whole.  (A stale line can only show an
+            // empty cell where a tag has landed since -- the compare-and-swap below then returns the tag.)
+            bool at_cell = false;
+            u64 cur = 0, idp1 = 0;
             if (active)
             {
-                u64 cur = t.tags[slot];
+                const u64 line = slot & ~3ull;
+                const ulonglong2 * lp = t.cells + line;
+                const ulonglong2 c0 = lp[0], c1 = lp[1], c2 = lp[2], c3 = lp[3];
+                const u32 same = (u32)(c0.x == tag) | (u32)(c1.x == tag) << 1 | (u32)(c2.x == tag) << 2 | (u32)(c3.x == tag) << 3;
+                const u32 empty = (u32)(c0.x == 0) | (u32)(c1.x == 0) << 1 | (u32)(c2.x == 0) << 2 | (u32)(c3.x == 0) << 3;
+                const u32 ev = (same | empty) & (0xFu << (slot & 3));
+                if (ev)
+                {
+                    const u32 k = (u32)__ffs((int)ev) - 1;
+                    slot = line + k;
+                    cur = (same >> k) & 1 ? tag : 0;
+                    idp1 = k == 0 ? c0.y : k == 1 ? c1.y : k == 2 ? c2.y : c3.y;
+                    at_cell = true;
+                }
+                else
+                    slot = (line + 4) & mask;
+            }
+            if (at_cell)
+            {
                 if (cur == 0)
                 {
                     if (!mode)
@@ -144,18 +183,45 @@ __global__ __launch_bounds__(KD_T) void k_kd_claim(KdTable t, const u64 * __rest
                         rid[i] = KD_NO_ID; // findKey: not there
                         active = false;
                     }
+                    else if (known_ids >= t.limit)
+                    {
+                        state = KD_DEFERRED; // the table grows first
+                        flags |= 2;
+                        active = false;
+                    }
                     else
                     {
-                        cur = atomicCAS((unsigned long long *)&t.tags[slot], 0ull, (unsigned long long)tag);
+                        cur = atomicCAS((unsigned long long *)&t.cells[slot].x, 0ull, (unsigned long long)tag);
                         claimed = cur == 0;
+                        idp1 = 0; // if the cell was taken meanwhile its id is not known here
                     }
                 }
                 if (active && !claimed)
                 {
                     if (cur == tag)
                     {
-                        cand[i] = slot; // same tag: my key, or (2^-64) another one -- the next kernel compares the bytes
-                        active = false;
+                        // same tag: my key, or (2^-64) another one.  A key of an earlier kernel is compared here; one claimed in this
+                        // kernel (its id or bytes may not be visible yet) by k_kd_verify
+                        const u64 id = idp1 - 1; // 2^64 - 1 while the id is not visible
+                        if (id < t.ids_before)
+                        {
+                            bool same = true;
+                            for (u32 q = 0; q < t.W; ++q)
+                                same = same && t.store[id * t.W + q] == w[q];
+                            if (same)
+                            {
+                                rid[i] = (u32)id;
+                                active = false;
+                            }
+                            else
+                                slot = (slot + 1) & mask;
+                        }
+                        else
+                        {
+                            state = slot;
+                            verify = 1;
+                            active = false;
+                        }
                     }
                     else
                         slot = (slot + 1) & mask;
@@ -170,37 +236,56 @@ __global__ __launch_bounds__(KD_T) void k_kd_claim(KdTable t, const u64 * __rest
                 if (lane == leader)
                     base = atomicAdd(&t.ctrl->n_ids, (u32)__popcll(claimers));
                 base = __shfl(base, (int)leader, 64);
+                known_ids = base + (u32)__popcll(claimers);
                 if (claimed)
                 {
                     const u32 id = base + mbcnt(claimers);
-                    t.ids[slot] = id;
-                    for (u32 q = 0; q < t.W; ++q)
-                        t.store[(u64)q * t.store_cap + id] = w[q];
+                    t.cells[slot].y = (u64)id + 1;
+                    if (id < t.store_cap)
+                        for (u32 q = 0; q < t.W; ++q)
+                            t.store[(u64)id * t.W + q] = w[q];
+                    else
+                        flags |= 4; // cannot happen while kd_reserve's bound holds; never write past the store
                     rid[i] = id;
                     active = false;
                 }
             }
         }
+        if (i < n && (round == 0 || was != KD_SETTLED))
+            cand[i] = state;
     }
+    if (__any(flags != 0))
+    {
+        for (int o = 32; o > 0; o >>= 1)
+            flags |= __shfl_xor(flags, o, 64);
+        if (lane_id() == 0)
+            atomicOr(&t.ctrl->retry, flags);
+    }
+    if (__any(verify != 0) && lane_id() == 0)
+        atomicOr(&t.ctrl->need_verify, 1u);
 }
 
-__global__ __launch_bounds__(KD_T) void k_kd_verify(KdTable t, const u64 * __restrict__ pk, u64 n, u32 * __restrict__ rid, u64 * __restrict__ cand, u64 * __restrict__ resume)
+__global__ __launch_bounds__(KD_T) void k_kd_verify(KdTable t, KdCols kc, u64 row_begin, u64 n, u32 * __restrict__ rid, u64 * __restrict__ cand, u64 * __restrict__ resume)
 {
+    if (!t.ctrl->need_verify) // written by the kernel before this one
+        return;
     const u64 mask = t.capacity - 1;
     bool any_retry = false;
     for (u64 i = (u64)blockIdx.x * KD_T + threadIdx.x; i < n; i += (u64)gridDim.x * KD_T)
     {
         const u64 slot = cand[i];
-        if (slot == ~0ull)
+        if (slot == KD_SETTLED || slot == KD_DEFERRED)
             continue;
-        const u32 id = t.ids[slot];
+        const u64 id = t.cells[slot].y - 1;
+        u64 w[4];
+        kd_pack_row(kc, row_begin + i, w);
         bool same = true;
         for (u32 q = 0; q < t.W; ++q)
-            same = same && t.store[(u64)q * t.store_cap + id] == pk[(u64)q * n + i];
+            same = same && t.store[id * t.W + q] == w[q];
         if (same)
         {
-            rid[i] = id;
-            cand[i] = ~0ull;
+            rid[i] = (u32)id;
+            cand[i] = KD_SETTLED;
         }
         else
         {
@@ -213,20 +298,20 @@ __global__ __launch_bounds__(KD_T) void k_kd_verify(KdTable t, const u64 * __res
 }
 
 // growth: every (tag, id) pair of the old table into the new one (all keys are distinct: first empty cell, no comparison)
-__global__ __launch_bounds__(KD_T) void k_kd_rehash(const u64 * __restrict__ old_tags, const u32 * __restrict__ old_ids, u64 old_cap, KdTable t)
+__global__ __launch_bounds__(KD_T) void k_kd_rehash(const ulonglong2 * __restrict__ old_cells, u64 old_cap, KdTable t)
 {
     const u64 mask = t.capacity - 1;
     for (u64 s = (u64)blockIdx.x * KD_T + threadIdx.x; s < old_cap; s += (u64)gridDim.x * KD_T)
     {
-        const u64 tag = old_tags[s];
-        if (tag == 0)
+        const ulonglong2 c = old_cells[s];
+        if (c.x == 0)
             continue;
-        u64 slot = ((tag >> 1) * 0x9E3779B97F4A7C15ull >> 20) & mask;
+        u64 slot = ((c.x >> 1) * 0x9E3779B97F4A7C15ull >> 20) & mask;
         for (u64 step = 0; step <= t.capacity; ++step)
         {
-            if (t.tags[slot] == 0 && atomicCAS((unsigned long long *)&t.tags[slot], 0ull, (unsigned long long)tag) == 0)
+            if (t.cells[slot].x == 0 && atomicCAS((unsigned long long *)&t.cells[slot].x, 0ull, (unsigned long long)c.x) == 0)
             {
-                t.ids[slot] = old_ids[s];
+                t.cells[slot].y = c.y;
                 break;
             }
             slot = (slot + 1) & mask;
@@ -244,9 +329,9 @@ __global__ __launch_bounds__(KD_T) void k_kd_key_column(KdTable t, const u32 * _
         if (id != KD_NO_ID)
         {
             const u32 word = offset >> 3, shift = (offset & 7) * 8;
-            v = t.store[(u64)word * t.store_cap + id] >> shift;
+            v = t.store[(u64)id * t.W + word] >> shift;
             if (shift && shift + size * 8 > 64)
-                v |= t.store[(u64)(word + 1) * t.store_cap + id] << (64 - shift);
+                v |= t.store[(u64)id * t.W + word + 1] << (64 - shift);
         }
         switch (size)
         {
@@ -272,7 +357,7 @@ __global__ __launch_bounds__(KD_T) void k_kd_selector(KdTable t, const u32 * __r
         u32 crc = 0xFFFFFFFFu;
         for (u32 q = 0; q < t.W; ++q)
         {
-            const u64 x = id != KD_NO_ID ? t.store[(u64)q * t.store_cap + id] : 0;
+            const u64 x = id != KD_NO_ID ? t.store[(u64)id * t.W + q] : 0;
             // crc(seed, x) = crc(seed, 0) ^ crc(0, x): the table part is linear in x, the seed part is eight zero bytes pushed through
             crc = dev_crc32c_zero8(crc) ^ dev_crc32c_tab(slut, x);
         }
@@ -285,49 +370,33 @@ __global__ __launch_bounds__(KD_T) void k_kd_selector(KdTable t, const u32 * __r
 // ---------------------------------------------------------------------------------------------
 static int kd_alloc_table(chgpu_keydict * d, u64 cap, KdTable * t, void ** mem, size_t * cls)
 {
-    const size_t tags_b = (cap * 8 + 255) / 256 * 256;
-    CHGPU_TRY(chgpu_pool_alloc(d->ctx, tags_b + cap * 4 + 256, mem, cls));
-    t->tags = (u64 *)*mem;
-    t->ids = (u32 *)((char *)*mem + tags_b);
+    CHGPU_TRY(chgpu_pool_alloc(d->ctx, cap * 16 + 256, mem, cls));
+    t->cells = (ulonglong2 *)*mem;
     t->capacity = cap;
-    CHGPU_HIP(hipMemsetAsync(t->tags, 0, cap * 8, d->ctx->stream));
+    t->limit = cap / 2;
+    CHGPU_HIP(hipMemsetAsync(t->cells, 0, cap * 16, d->ctx->stream));
     return CHGPU_OK;
 }
 
-// room for `extra` more keys: table at most half full, store large enough
-static int kd_ensure(chgpu_keydict * d, u64 extra)
+// Cells and store for `want` keys.  Inserts stop at limit = capacity / 2; `overshoot` = the lanes of one k_kd_claim grid, which may pass
+// the limit check together before any of them has counted itself: cells stay at most 3/4 full, the store holds limit + overshoot keys.
+static int kd_reserve(chgpu_keydict * d, u64 want, u64 overshoot)
 {
     chgpu_ctx * ctx = d->ctx;
-    const u64 need = d->n_ids + extra;
-    CHGPU_REQUIRE(need < KD_NO_ID, CHGPU_ERR_NOT_IMPLEMENTED, "more than 2^32 - 1 distinct wide keys: CPU path");
+    if (want < d->n_ids)
+        want = d->n_ids;
     if (!d->ctrl_mem)
     {
         CHGPU_TRY(chgpu_pool_alloc(ctx, 256, &d->ctrl_mem, &d->ctrl_class));
         CHGPU_HIP(hipMemsetAsync(d->ctrl_mem, 0, 256, ctx->stream));
         d->t.ctrl = (KdCtrl *)d->ctrl_mem;
     }
-    if (need > d->t.store_cap)
+    u64 cap = d->t.capacity ? d->t.capacity : 2048;
+    while (cap < 2 * want || cap < 4 * overshoot)
+        cap *= 2;
+    CHGPU_REQUIRE(cap / 2 + overshoot < KD_NO_ID, CHGPU_ERR_NOT_IMPLEMENTED, "more than 2^32 - 1 distinct wide keys: CPU path");
+    if (cap > d->t.capacity)
     {
-        u64 cap = d->t.store_cap ? d->t.store_cap : 1024;
-        while (cap < need)
-            cap *= 2;
-        void * m = nullptr;
-        size_t cls = 0;
-        CHGPU_TRY(chgpu_pool_alloc(ctx, (size_t)cap * 8 * d->W, &m, &cls));
-        for (u32 q = 0; q < d->W && d->n_ids; ++q)
-            CHGPU_HIP(hipMemcpyAsync((u64 *)m + (u64)q * cap, d->t.store + (u64)q * d->t.store_cap, d->n_ids * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        if (d->store_mem)
-            chgpu_pool_free(ctx, d->store_mem, d->store_class); // reuse is ordered behind the copies above (same stream)
-        d->store_mem = m;
-        d->store_class = cls;
-        d->t.store = (u64 *)m;
-        d->t.store_cap = cap;
-    }
-    if (2 * need > d->t.capacity)
-    {
-        u64 cap = d->t.capacity ? d->t.capacity : 2048;
-        while (cap < 2 * need)
-            cap *= 2;
         KdTable nt = d->t;
         void * m = nullptr;
         size_t cls = 0;
@@ -336,8 +405,7 @@ static int kd_ensure(chgpu_keydict * d, u64 extra)
         {
             if (d->n_ids)
             {
-                hipLaunchKernelGGL(k_kd_rehash, dim3(chgpu_grid_for(ctx, d->t.capacity, KD_T, 8)), dim3(KD_T), 0, ctx->stream, (const u64 *)d->t.tags, (const u32 *)d->t.ids,
-                                   d->t.capacity, nt);
+                hipLaunchKernelGGL(k_kd_rehash, dim3(chgpu_grid_for(ctx, d->t.capacity, KD_T, 8)), dim3(KD_T), 0, ctx->stream, (const ulonglong2 *)d->t.cells, d->t.capacity, nt);
                 ctx->counters[6] += 1;
                 ctx->counters[7] += 1;
             }
@@ -346,6 +414,24 @@ static int kd_ensure(chgpu_keydict * d, u64 extra)
         d->table_mem = m;
         d->table_class = cls;
         d->t = nt;
+    }
+    const u64 need = d->t.limit + overshoot;
+    if (need > d->t.store_cap)
+    {
+        u64 scap = d->t.store_cap ? d->t.store_cap : 1024;
+        while (scap < need)
+            scap *= 2;
+        void * m = nullptr;
+        size_t cls = 0;
+        CHGPU_TRY(chgpu_pool_alloc(ctx, (size_t)scap * 8 * d->W, &m, &cls));
+        if (d->n_ids)
+            CHGPU_HIP(hipMemcpyAsync(m, d->t.store, d->n_ids * 8 * d->W, hipMemcpyDeviceToDevice, ctx->stream));
+        if (d->store_mem)
+            chgpu_pool_free(ctx, d->store_mem, d->store_class); // reuse is ordered behind the copy above (same stream)
+        d->store_mem = m;
+        d->store_class = cls;
+        d->t.store = (u64 *)m;
+        d->t.store_cap = scap;
     }
     return CHGPU_OK;
 }
@@ -362,7 +448,7 @@ extern "C" int chgpu_keydict_create(chgpu_ctx * ctx, uint32_t key_bytes, uint64_
     d->t.W = d->W;
     d->weak_tags = chgpu_opt(ctx, "test_keydict_weak_tags", 0) ? 1 : 0; // test hook: 20-bit tags, so that tag collisions happen
     chgpu_ctx_retain(ctx);
-    const int rc = kd_ensure(d, size_hint ? size_hint : 1024);
+    const int rc = kd_reserve(d, size_hint ? size_hint : 1024, 0);
     if (rc != CHGPU_OK)
     {
         chgpu_keydict_free(d);
@@ -423,38 +509,58 @@ extern "C" int chgpu_keydict_encode(chgpu_keydict * d, uint32_t n_cols, const ch
         return code;
     };
     int rc = CHGPU_OK;
-    for (u64 c0 = 0; c0 < n && rc == CHGPU_OK; c0 += KD_CHUNK_ROWS)
+    // emplace: a short first chunk, then longer ones -- a key met in an earlier chunk is compared in place by k_kd_claim, only rows that meet
+    // a key claimed in their own chunk go through k_kd_verify, and most keys of a block show up in its first few million rows
+    u64 chunk = insert ? KD_FIRST_CHUNK_ROWS : KD_CHUNK_ROWS;
+    for (u64 c0 = 0, m = 0; c0 < n && rc == CHGPU_OK; c0 += m, chunk = chunk * 4 < KD_CHUNK_ROWS ? chunk * 4 : KD_CHUNK_ROWS)
     {
-        const u64 m = n - c0 < KD_CHUNK_ROWS ? n - c0 : KD_CHUNK_ROWS;
-        if (insert && (rc = kd_ensure(d, m)) != CHGPU_OK)
+        m = n - c0 < chunk + chunk / 2 ? n - c0 : chunk; // a short tail joins the last chunk
+        const u32 grid = chgpu_grid_for(ctx, m, KD_T, 8);
+        if (insert && (rc = kd_reserve(d, d->n_ids, (u64)grid * KD_T)) != CHGPU_OK)
             break;
         auto al = [](size_t b) { return (b + 255) / 256 * 256; };
         void * scratch = nullptr;
-        if ((rc = chgpu_scratch(ctx, al(m * 8 * d->W) + 2 * al(m * 8), &scratch)) != CHGPU_OK)
+        if ((rc = chgpu_scratch(ctx, 2 * al(m * 8), &scratch)) != CHGPU_OK)
             break;
-        u64 * pk = (u64 *)scratch;
-        u64 * cand = (u64 *)((char *)scratch + al(m * 8 * d->W));
+        u64 * cand = (u64 *)scratch;
         u64 * resume = (u64 *)((char *)cand + al(m * 8));
         u32 * rid = (u32 *)out->data + c0;
-        const u32 grid = chgpu_grid_for(ctx, m, KD_T, 8);
-        hipLaunchKernelGGL(k_kd_pack, dim3(grid), dim3(KD_T), 0, ctx->stream, kc, row_begin + c0, m, d->W, pk);
-        ctx->counters[6] += 1;
-        for (int round = 0; round < 64; ++round)
+        int restart = 0;
+        for (int round = 0; round < 96; ++round)
         {
-            hipLaunchKernelGGL(k_kd_claim, dim3(grid), dim3(KD_T), 0, ctx->stream, d->t, (const u64 *)pk, m, insert ? 1 : 0, round, d->weak_tags, rid, cand, resume);
-            hipLaunchKernelGGL(k_kd_verify, dim3(grid), dim3(KD_T), 0, ctx->stream, d->t, (const u64 *)pk, m, rid, cand, resume);
+            d->t.ids_before = (u32)d->n_ids;
+            hipLaunchKernelGGL(k_kd_claim, dim3(grid), dim3(KD_T), 0, ctx->stream, d->t, kc, row_begin + c0, m, insert ? 1 : 0, round, restart, d->weak_tags, rid, cand, resume);
+            hipLaunchKernelGGL(k_kd_verify, dim3(grid), dim3(KD_T), 0, ctx->stream, d->t, kc, row_begin + c0, m, rid, cand, resume);
             ctx->counters[6] += 2;
             KdCtrl c;
             if ((rc = chgpu_read_back(ctx, d->t.ctrl, &c, sizeof(c))) != CHGPU_OK)
                 break;
             d->n_ids = c.n_ids;
-            if (!c.retry)
+            if (c.retry & 4)
+            {
+                rc = chgpu_set_error(CHGPU_ERR_LOGICAL, "wide-key dictionary: ids ran past the store");
                 break;
-            // some rows met another key under their tag: they walk on from the next cell
-            if (hipMemsetAsync(&d->t.ctrl->retry, 0, 4, ctx->stream) != hipSuccess)
+            }
+            if (!c.retry)
+            {
+                if (c.need_verify && hipMemsetAsync(&d->t.ctrl->need_verify, 0, 4, ctx->stream) != hipSuccess)
+                    rc = CHGPU_ERR_DEVICE;
+                break;
+            }
+            // bit 0: some rows met another key under their tag and walk on from the next cell; bit 1: rows deferred at the limit -- the
+            // table grows fourfold and every unsettled row starts its walk again in the new cells
+            if (hipMemsetAsync(&d->t.ctrl->retry, 0, 8, ctx->stream) != hipSuccess)
                 rc = CHGPU_ERR_DEVICE;
-            if (round == 63)
-                rc = chgpu_set_error(CHGPU_ERR_LOGICAL, "wide-key dictionary did not settle in 64 rounds");
+            restart = 0;
+            if (rc == CHGPU_OK && (c.retry & 2))
+            {
+                rc = kd_reserve(d, 4 * d->t.limit, (u64)grid * KD_T);
+                restart = 1;
+            }
+            if (rc == CHGPU_OK && round == 95)
+                rc = chgpu_set_error(CHGPU_ERR_LOGICAL, "wide-key dictionary did not settle in 96 rounds");
+            if (rc != CHGPU_OK)
+                break;
         }
     }
     if (rc == CHGPU_OK && hipGetLastError() != hipSuccess)

@@ -536,6 +536,30 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_keys_fixed_dictionary_grows_when_rows_defer_at_its_limit(ch, ctx):
+    """the table is sized for the keys it holds, not for the rows of a chunk: 3 M distinct keys into a dictionary made for 1024 run past
+    limit = capacity / 2 twice (rows defer, the table grows fourfold, the deferred rows run again); ids stay dense, stable and exact"""
+    rng = np.random.Generator(np.random.PCG64(21))
+    n = 3_000_000
+    a = rng.permutation(n).astype(np.uint64) * np.uint64(2654435761)
+    b = (np.arange(n, dtype=np.uint64) * np.uint64(40503)) ^ np.uint64(0xDEADBEEF)
+    d = ch.KeyDict([np.uint64, np.uint64], ctx)
+    ids = d.encode([a, b]).numpy()
+    assert len(d) == n and np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))          # dense: every id exactly once
+    k0, k1 = [c.numpy() for c in d.key_columns(ctx.upload(ids))]
+    assert np.array_equal(k0, a) and np.array_equal(k1, b)
+    # a second block: old keys (compared in place, no second kernel), new keys and repeats of the new keys inside the block
+    a2 = np.concatenate([a[::7], a[:1000] + np.uint64(1), a[:1000] + np.uint64(1)])
+    b2 = np.concatenate([b[::7], b[:1000], b[:1000]])
+    ids2 = d.encode([a2, b2]).numpy()
+    m = a[::7].shape[0]
+    assert np.array_equal(ids2[:m], ids[::7]) and len(d) == n + 1000
+    assert np.array_equal(ids2[m:m + 1000], ids2[m + 1000:]) and np.array_equal(np.sort(ids2[m:m + 1000]), np.arange(n, n + 1000, dtype=np.uint32))
+    # findKey: present keys keep their ids, absent ones get NO_ID
+    probe = d.encode([np.concatenate([a[:500], a[:500] + np.uint64(3)]), np.concatenate([b[:500], b[:500]])], insert=False).numpy()
+    assert np.array_equal(probe[:500], ids[:500]) and (probe[500:] == 0xFFFFFFFF).all() and len(d) == n + 1000
+
+
 # ---- partial states on the wire ------------------------------------------------------------------------------------------------------
 def test_state_bytes_match_reference_vectors_and_round_trip(ch, ctx, golden):
     import json
