@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured configuration) or gloo (rehearsal of the N>1 code path on one GPU)")
     args = ap.parse_args()
 
+    # the hosts of this pool only support dmabuf IPC: without it RCCL's peer buffers fail with hipIpcGetMemHandle: invalid argument.
+    # Exported by the launch environment already; set before HIP starts in case a launcher drops it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
     import numpy as np
     import torch
 
