@@ -42,6 +42,7 @@ struct KdCols
     const void * ptr[KD_MAX_COLS];
     u32 size[KD_MAX_COLS];   // bytes per element: 1, 2, 4, 8
     u32 offset[KD_MAX_COLS]; // byte offset inside the packed key
+    u32 words8;              // every key column is 8 bytes wide: column j IS word j of the key
 };
 
 struct KdCtrl
@@ -87,6 +88,14 @@ struct chgpu_keydict
 // packed key is never written out: k_kd_claim and k_kd_verify assemble it from the key columns where they need it.
 __device__ __forceinline__ void kd_pack_row(const KdCols & c, u64 r, u64 (&w)[4])
 {
+    if (c.words8)
+    {
+        w[0] = ((const u64 *)c.ptr[0])[r];
+        w[1] = c.n > 1 ? ((const u64 *)c.ptr[1])[r] : 0;
+        w[2] = c.n > 2 ? ((const u64 *)c.ptr[2])[r] : 0;
+        w[3] = c.n > 3 ? ((const u64 *)c.ptr[3])[r] : 0;
+        return;
+    }
     w[0] = w[1] = w[2] = w[3] = 0;
     for (u32 j = 0; j < c.n; ++j)
     {
@@ -110,9 +119,15 @@ __device__ __forceinline__ void kd_pack_row(const KdCols & c, u64 r, u64 (&w)[4]
 
 __device__ __forceinline__ u64 kd_tag(const u64 * w, u32 W, int weak)
 {
-    u64 h = dev_intHash64(w[0] ^ 0x9E3779B97F4A7C15ull);
+    // the dictionary's own tag, not one of the reference's hashes: one multiply + xor-shift per word (every step a bijection of the
+    // running value, so two keys share a tag only by a 2^-64 accident of the mixing, and then k_kd_verify tells them apart)
+    u64 h = (w[0] ^ 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 31;
     for (u32 q = 1; q < W; ++q)
-        h = dev_intHash64(h ^ w[q]);
+    {
+        h = (h ^ w[q]) * 0x94D049BB133111EBull;
+        h ^= h >> 29;
+    }
     if (weak)
         h &= 0xFFFFF; // test hook: 20-bit tags, so that different keys do share tags and the verification rounds run
     return h | 1ull;
@@ -499,6 +514,9 @@ extern "C" int chgpu_keydict_encode(chgpu_keydict * d, uint32_t n_cols, const ch
         kc.offset[j] = off; // packFixed: consecutively, no alignment padding
         off += kc.size[j];
     }
+    kc.words8 = n_cols <= 4;
+    for (u32 j = 0; j < n_cols; ++j)
+        kc.words8 = kc.words8 && kc.size[j] == 8;
     CHGPU_REQUIRE(off <= d->key_bytes, CHGPU_ERR_BAD_ARGUMENTS, "the key columns take %u bytes, the dictionary packs %u", off, d->key_bytes);
     CHGPU_REQUIRE(row_begin <= row_end && row_end <= cols[0]->rows, CHGPU_ERR_BAD_ARGUMENTS, "row range out of bounds");
     const u64 n = row_end - row_begin;
