@@ -50,7 +50,7 @@ struct KdCtrl
     u32 n_ids;
     u32 retry;       // bit 0: a row walks on in a further round (another key under its tag); bit 1: rows deferred, the table must grow
     u32 need_verify; // some row met a tag claimed in this very kernel: k_kd_verify has work
-    u32 pad;
+    u32 need_walk;   // k_kd_lookup left rows for k_kd_claim
 };
 
 static constexpr u64 KD_SETTLED = ~0ull;
@@ -133,13 +133,84 @@ __device__ __forceinline__ u64 kd_tag(const u64 * w, u32 W, int weak)
     return h | 1ull;
 }
 
+// The dictionary as it stood before this chunk, looked up with no loop and no atomics: U rows per lane, every load unconditional, so a
+// lane has U key loads, then U cell loads, then U stored keys in flight (k_kd_claim's walk has one -- it spends 72 % of its wave cycles
+// parked on s_waitcnt, profiles/r03_keys128.json).  A row is settled when its HOME cell holds its key (or, on the find side, is empty);
+// every other row -- a new key, a displaced one -- is left to k_kd_claim as a deferred row.  Used while the cells are sparse (kd_encode).
+template <u32 WW, u32 U>
+__global__ __launch_bounds__(KD_T) void k_kd_lookup(KdTable t, KdCols kc, u64 row_begin, u64 n, int mode, int weak, u32 * __restrict__ rid, u64 * __restrict__ cand)
+{
+    const u64 mask = t.capacity - 1;
+    const u64 stride = (u64)gridDim.x * KD_T;
+    u32 walk = 0;
+    for (u64 i0 = (u64)blockIdx.x * KD_T + threadIdx.x; i0 < n; i0 += stride * U)
+    {
+        u64 w[U][4];
+        u64 tag[U];
+        ulonglong2 c[U];
+#pragma unroll
+        for (u32 u = 0; u < U; ++u)
+        {
+            const u64 i = i0 + u * stride;
+            kd_pack_row(kc, row_begin + (i < n ? i : n - 1), w[u]);
+        }
+#pragma unroll
+        for (u32 u = 0; u < U; ++u)
+        {
+            tag[u] = kd_tag(w[u], WW, weak);
+            c[u] = t.cells[((tag[u] >> 1) * 0x9E3779B97F4A7C15ull >> 20) & mask];
+        }
+        u64 sv[U][WW];
+        bool hit[U];
+#pragma unroll
+        for (u32 u = 0; u < U; ++u)
+        {
+            hit[u] = c[u].x == tag[u] && c[u].y - 1 < t.ids_before;
+            const u64 id = hit[u] ? c[u].y - 1 : 0;
+#pragma unroll
+            for (u32 q = 0; q < WW; ++q)
+                sv[u][q] = t.store[id * WW + q];
+        }
+#pragma unroll
+        for (u32 u = 0; u < U; ++u)
+        {
+            const u64 i = i0 + u * stride;
+            if (i >= n)
+                continue;
+            bool same = hit[u];
+#pragma unroll
+            for (u32 q = 0; q < WW; ++q)
+                same = same && sv[u][q] == w[u][q];
+            if (same)
+            {
+                rid[i] = (u32)(c[u].y - 1);
+                cand[i] = KD_SETTLED;
+            }
+            else if (!mode && c[u].x == 0)
+            {
+                rid[i] = KD_NO_ID; // findKey: the home cell is empty
+                cand[i] = KD_SETTLED;
+            }
+            else
+            {
+                cand[i] = KD_DEFERRED;
+                walk = 1;
+            }
+        }
+    }
+    if (__any(walk != 0) && lane_id() == 0)
+        atomicOr(&t.ctrl->need_walk, 1u);
+}
+
 // mode: 1 = emplace (GROUP BY, join build), 0 = find (join probe: an absent key gets KD_NO_ID).
 // round 0: every row; later rounds: the rows that are not settled -- a row whose verification failed continues its walk at resume[i], a
 // deferred row (and every unsettled row after the table has grown: `restart`) starts again at its home cell.
 // cand[i] = the cell whose tag equals the row's and whose key this kernel cannot see yet (k_kd_verify compares), KD_DEFERRED, or KD_SETTLED.
-__global__ __launch_bounds__(KD_T) void k_kd_claim(KdTable t, KdCols kc, u64 row_begin, u64 n, int mode, int round, int restart, int weak, u32 * __restrict__ rid,
+__global__ __launch_bounds__(KD_T) void k_kd_claim(KdTable t, KdCols kc, u64 row_begin, u64 n, int mode, int round, int restart, int weak, int gated, u32 * __restrict__ rid,
                                                    u64 * __restrict__ cand, u64 * __restrict__ resume)
 {
+    if (gated && !t.ctrl->need_walk) // right behind k_kd_lookup, which settled every row
+        return;
     const u64 mask = t.capacity - 1;
     const u64 stride = (u64)gridDim.x * KD_T;
     u32 flags = 0, verify = 0;
@@ -544,10 +615,23 @@ extern "C" int chgpu_keydict_encode(chgpu_keydict * d, uint32_t n_cols, const ch
         u64 * resume = (u64 *)((char *)cand + al(m * 8));
         u32 * rid = (u32 *)out->data + c0;
         int restart = 0;
+        // cells at most 1/8 full and a dictionary that holds something: most rows find their key in their home cell -- the loop-free
+        // look-up settles those, k_kd_claim then sees the chunk as a later round does (only the rows left over; none: it returns at once)
+        const bool lookup_first = d->n_ids != 0 && d->n_ids * 8 <= d->t.capacity;
+        if (lookup_first)
+        {
+            d->t.ids_before = (u32)d->n_ids;
+            if (d->W == 2)
+                hipLaunchKernelGGL((k_kd_lookup<2, 4>), dim3(grid), dim3(KD_T), 0, ctx->stream, d->t, kc, row_begin + c0, m, insert ? 1 : 0, d->weak_tags, rid, cand);
+            else
+                hipLaunchKernelGGL((k_kd_lookup<4, 2>), dim3(grid), dim3(KD_T), 0, ctx->stream, d->t, kc, row_begin + c0, m, insert ? 1 : 0, d->weak_tags, rid, cand);
+            ctx->counters[6] += 1;
+        }
         for (int round = 0; round < 96; ++round)
         {
             d->t.ids_before = (u32)d->n_ids;
-            hipLaunchKernelGGL(k_kd_claim, dim3(grid), dim3(KD_T), 0, ctx->stream, d->t, kc, row_begin + c0, m, insert ? 1 : 0, round, restart, d->weak_tags, rid, cand, resume);
+            hipLaunchKernelGGL(k_kd_claim, dim3(grid), dim3(KD_T), 0, ctx->stream, d->t, kc, row_begin + c0, m, insert ? 1 : 0, round + (lookup_first ? 1 : 0), restart, d->weak_tags,
+                               lookup_first && round == 0 ? 1 : 0, rid, cand, resume);
             hipLaunchKernelGGL(k_kd_verify, dim3(grid), dim3(KD_T), 0, ctx->stream, d->t, kc, row_begin + c0, m, rid, cand, resume);
             ctx->counters[6] += 2;
             KdCtrl c;
@@ -561,13 +645,13 @@ extern "C" int chgpu_keydict_encode(chgpu_keydict * d, uint32_t n_cols, const ch
             }
             if (!c.retry)
             {
-                if (c.need_verify && hipMemsetAsync(&d->t.ctrl->need_verify, 0, 4, ctx->stream) != hipSuccess)
+                if ((c.need_verify || c.need_walk) && hipMemsetAsync(&d->t.ctrl->need_verify, 0, 8, ctx->stream) != hipSuccess)
                     rc = CHGPU_ERR_DEVICE;
                 break;
             }
             // bit 0: some rows met another key under their tag and walk on from the next cell; bit 1: rows deferred at the limit -- the
             // table grows fourfold and every unsettled row starts its walk again in the new cells
-            if (hipMemsetAsync(&d->t.ctrl->retry, 0, 8, ctx->stream) != hipSuccess)
+            if (hipMemsetAsync(&d->t.ctrl->retry, 0, 12, ctx->stream) != hipSuccess)
                 rc = CHGPU_ERR_DEVICE;
             restart = 0;
             if (rc == CHGPU_OK && (c.retry & 2))
