@@ -514,8 +514,13 @@ __global__ __launch_bounds__(JT) void k_join_probe_bid(JoinTable t, const void *
     }
 }
 
-// probe pass 1: per left row, how many right rows get appended (and the filter byte).  A hit costs two random reads (the
-// key cell and its packed value word); the value is kept per left row so the emit pass streams instead of re-probing.
+// probe pass 1: per left row, how many right rows get appended (and the filter byte).  A hit costs one random read (the 16-byte cell holds
+// the key and its packed value word); the value is kept per left row so the emit pass streams instead of re-probing.
+// Four rows per lane, stage by stage, every load of a stage unconditional (a row that is not looked up reads word / cell 0): a lane has four
+// key loads, then four prefilter words, then four home cells in flight.  One row per lane and a probe loop per row left the kernel
+// parked on s_waitcnt (2.55 ms for 1e8 probes of a 1e6-key table that needs 0.5 ms of traffic); only a row whose home cell holds
+// another key walks on, by itself.
+typedef u64 jpc_v2 __attribute__((ext_vector_type(2)));
 template <bool PF>
 __global__ __launch_bounds__(JT) void k_join_probe_count(JoinTable t, int variant, const void * __restrict__ keys, int key_type,
                                                          const u8 * __restrict__ null_map, u64 n, u64 seq_base, int slots_known,
@@ -525,47 +530,154 @@ __global__ __launch_bounds__(JT) void k_join_probe_count(JoinTable t, int varian
     PfView pf{};
     if constexpr (PF)
         pf = jt_pf_view(t);
-    for (u64 i = (u64)blockIdx.x * JT + threadIdx.x; i < n; i += (u64)gridDim.x * JT)
+#ifndef JPC_R
+#define JPC_R 4
+#endif
+    constexpr int R = JPC_R;
+    const u64 stride = (u64)gridDim.x * JT;
+    const u64 mask = t.capacity - 1;
+    for (u64 i0 = (u64)blockIdx.x * JT + threadIdx.x; i0 < n; i0 += stride * R)
     {
-        u32 slot;
-        if (slots_known)
-            slot = slot_of_left[i];
-        else
+        u64 key[R], val[R];
+        u32 slot[R];
+        bool in[R], look[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q)
         {
-            slot = NO_SLOT;
-            if (!(null_map && null_map[i])) // HashJoinMethodsImpl.h:451-452
-                slot = jt_find<PF>(t, pf, jload_key(keys, key_type, i));
-        }
-        const bool found = slot != NO_SLOT;
-        const u64 v = found ? t.kv[2 * (u64)slot + 1] : NO_ROW;
-        u32 rows_here = 0; // RowRefList::rows of the matched cell
-        if (found)
-        {
-            if (!(v & JV_MULTI))
-                rows_here = 1;
+            const u64 i = i0 + (u64)q * stride;
+            in[q] = i < n;
+            const u64 ic = in[q] ? i : n - 1;
+            key[q] = 0;
+            slot[q] = NO_SLOT;
+            if (slots_known)
+                slot[q] = slot_of_left[ic];
             else
+                key[q] = jload_key(keys, key_type, ic);
+            const bool is_null = null_map && null_map[ic]; // HashJoinMethodsImpl.h:451-452
+            look[q] = in[q] && !slots_known && !is_null;
+        }
+        if (!slots_known)
+        {
+            bool zero[R];
+            u64 home[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q)
             {
-                const u64 c = (v >> 40) & JV_CNT_SAT;
-                rows_here = c < JV_CNT_SAT ? (u32)c : t.cnt[slot];
+                zero[q] = look[q] && key[q] == 0; // the zero key lives out of line (HashTable.h:874-898)
+                look[q] = look[q] && key[q] != 0;
+            }
+            if constexpr (PF)
+            {
+                u32 pw[R];
+                u64 pos[R];
+#pragma unroll
+                for (int q = 0; q < R; ++q)
+                {
+                    look[q] = look[q] && !(pf.dense && key[q] > pf.mask);
+                    pos[q] = look[q] ? jt_pf_pos(pf, key[q]) : 0;
+                    pw[q] = pf.words[pos[q] >> 5];
+                }
+#pragma unroll
+                for (int q = 0; q < R; ++q)
+                    look[q] = look[q] && ((pw[q] >> (pos[q] & 31)) & 1u);
+            }
+            jpc_v2 c[R], c2[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q)
+            {
+                home[q] = dev_intHash64(key[q]) & mask;
+                c[q] = *(const jpc_v2 *)(t.kv + 2 * (look[q] ? home[q] : 0));
+                c2[q] = *(const jpc_v2 *)(t.kv + 2 * (look[q] ? (home[q] + 1) & mask : 0)); // the next cell too: nearly always the same 64-byte sector
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q)
+            {
+                val[q] = NO_ROW;
+                if (look[q])
+                {
+                    if (c[q].x == key[q])
+                    {
+                        slot[q] = (u32)home[q];
+                        val[q] = c[q].y;
+                    }
+                    else if (c[q].x == 0)
+                        ;
+                    else if (c2[q].x == key[q])
+                    {
+                        slot[q] = (u32)((home[q] + 1) & mask);
+                        val[q] = c2[q].y;
+                    }
+                    else if (c2[q].x != 0)
+                    {
+                        u64 sl = (home[q] + 2) & mask; // other keys in both cells: the rest of the walk
+                        for (u64 step = 2; step < t.capacity; ++step)
+                        {
+                            const jpc_v2 cc = *(const jpc_v2 *)(t.kv + 2 * sl);
+                            if (cc.x == key[q])
+                            {
+                                slot[q] = (u32)sl;
+                                val[q] = cc.y;
+                                break;
+                            }
+                            if (cc.x == 0)
+                                break;
+                            sl = (sl + 1) & mask;
+                        }
+                    }
+                }
+                else if (zero[q] && t.ctrl->has_zero)
+                {
+                    slot[q] = (u32)t.capacity;
+                    val[q] = t.kv[2 * t.capacity + 1];
+                }
             }
         }
-        u32 c = 0;
-        u8 f = 0;
-        switch (variant)
+        else
         {
-            case PV_ALL_INNER: c = rows_here; break;
-            case PV_ALL_LEFT: c = found ? rows_here : 1; break;                   // addNotFoundRow<add_missing>: ++current_offset
-            case PV_ANY_LEFT: c = 1; break;                                       // found row or default row
-            case PV_SEMI_LEFT: c = found ? 1 : 0; f = found; break;
-            case PV_ANTI_LEFT: c = found ? 0 : 1; f = !found; break;              // :515-519, :535-536
-            case PV_ANY_INNER: c = (found && t.used_by[slot] == seq_base + i) ? 1 : 0; f = (u8)c; break; // setUsedOnce, :498-510
-            case PV_ONCE_RIGHT: c = (found && t.used_by[slot] == seq_base + i) ? rows_here : 0; break;     // RIGHT ANY / SEMI: setUsedOnce + addFoundRowAll, :487-497
-            case PV_ANTI_RIGHT: c = 0; f = 0; break;                              // RIGHT ANTI: found rows only set the flags (:515-519), nothing is emitted
+#pragma unroll
+            for (int q = 0; q < R; ++q)
+            {
+                const u64 v = t.kv[2 * (u64)(slot[q] != NO_SLOT ? slot[q] : 0) + 1];
+                val[q] = slot[q] != NO_SLOT ? v : NO_ROW;
+            }
         }
-        counts[i] = c;
-        val_of_left[i] = v;
-        if (filter)
-            filter[i] = f;
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+        {
+            if (!in[q])
+                continue;
+            const u64 i = i0 + (u64)q * stride;
+            const bool found = slot[q] != NO_SLOT;
+            const u64 v = val[q];
+            u32 rows_here = 0; // RowRefList::rows of the matched cell
+            if (found)
+            {
+                if (!(v & JV_MULTI))
+                    rows_here = 1;
+                else
+                {
+                    const u64 cn = (v >> 40) & JV_CNT_SAT;
+                    rows_here = cn < JV_CNT_SAT ? (u32)cn : t.cnt[slot[q]];
+                }
+            }
+            u32 c = 0;
+            u8 f = 0;
+            switch (variant)
+            {
+                case PV_ALL_INNER: c = rows_here; break;
+                case PV_ALL_LEFT: c = found ? rows_here : 1; break;                   // addNotFoundRow<add_missing>: ++current_offset
+                case PV_ANY_LEFT: c = 1; break;                                       // found row or default row
+                case PV_SEMI_LEFT: c = found ? 1 : 0; f = found; break;
+                case PV_ANTI_LEFT: c = found ? 0 : 1; f = !found; break;              // :515-519, :535-536
+                case PV_ANY_INNER: c = (found && t.used_by[slot[q]] == seq_base + i) ? 1 : 0; f = (u8)c; break; // setUsedOnce, :498-510
+                case PV_ONCE_RIGHT: c = (found && t.used_by[slot[q]] == seq_base + i) ? rows_here : 0; break;     // RIGHT ANY / SEMI: setUsedOnce + addFoundRowAll, :487-497
+                case PV_ANTI_RIGHT: c = 0; f = 0; break;                              // RIGHT ANTI: found rows only set the flags (:515-519), nothing is emitted
+            }
+            counts[i] = c;
+            val_of_left[i] = v;
+            if (filter)
+                filter[i] = f;
+        }
     }
 }
 
