@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """joinBlock's joinRightColumns through the ordered path (chgpu_join_probe: counts -> offsets -> emitted right row ids), the shape a
 JoiningTransform meets with a dimension table on the right: probe rows x build rows of unique keys, half of the probe keys present.
-usage: python tools/bench_joinblock.py [probe_rows] [build_rows] [kind: inner|left] [key: u64|u32]"""
+usage: python tools/bench_joinblock.py [probe_rows] [build_rows] [kind: inner|left|semi] [key: u64|u32]"""
 import json
 import os
 import sys
@@ -26,14 +26,14 @@ pk = torch.where(torch.rand(n_probe, device=dev, generator=g) < 0.5, bk[torch.ra
 ctx = ch.Context(0)
 bkc = ctx.wrap(bk.data_ptr(), ndt, n_build, keepalive=bk)
 pkc = ctx.wrap(pk.data_ptr(), ndt, n_probe, keepalive=pk)
-j = ch.HashJoin(ch.JOIN_INNER if kind == "inner" else ch.JOIN_LEFT, ch.STRICT_ALL, key_dtype=ndt, ctx=ctx)
+j = ch.HashJoin(ch.JOIN_INNER if kind == "inner" else ch.JOIN_LEFT, ch.STRICT_SEMI if kind == "semi" else ch.STRICT_ALL, key_dtype=ndt, ctx=ctx)
 j.add_block(bkc)
 j.finish_build()
 best = 1e9
 for it in range(4):
     ctx.synchronize()
     t0 = time.perf_counter()
-    r = j.probe_columns(pkc)
+    r = j.probe_columns(pkc, need_right_rows=kind != "semi")  # semi: the filter-only probe (k_join_probe_filter)
     ctx.synchronize()
     best = min(best, (time.perf_counter() - t0) * 1e3)
     n_out = r["n_out"]
@@ -41,5 +41,5 @@ for it in range(4):
 sbk, _ = torch.sort(bk)
 pos = torch.searchsorted(sbk, pk).clamp_(max=n_build - 1)
 hits = int((sbk[pos] == pk).sum().item())
-assert n_out == (hits if kind == "inner" else n_probe), (n_out, hits)
+assert n_out == (n_probe if kind == "left" else hits), (n_out, hits)
 print(json.dumps({"probe_rows": n_probe, "build_rows": n_build, "kind": kind, "key": key, "n_out": n_out, "ms": round(best, 3), "probe_rows_per_s": round(n_probe / best * 1e3)}))
