@@ -58,7 +58,8 @@ static constexpr u64 KD_DEFERRED = ~0ull - 1; // cand[i]: the row found an empty
 
 struct KdTable
 {
-    ulonglong2 * cells; // .x = tag (0: empty), .y = id + 1 (0: the claimer has not written it yet)
+    ulonglong2 * cells; // cell = cs x 16 bytes: {tag (0: empty), id + 1 (0: the claimer has not written it yet)}, then the packed key itself
+    u32 cs;             // 16-byte units per cell: 1 + W / 2 (keys128: 32-byte cells, two per 64-byte line; keys256: 48 bytes)
     u64 capacity; // power of two
     u64 * store;  // [store_cap][W]: the packed key of id k, one 16- or 32-byte line
     u64 store_cap;
@@ -145,9 +146,10 @@ __global__ __launch_bounds__(KD_T) void k_kd_lookup(KdTable t, KdCols kc, u64 ro
     u32 walk = 0;
     for (u64 i0 = (u64)blockIdx.x * KD_T + threadIdx.x; i0 < n; i0 += stride * U)
     {
+        constexpr u32 CS = 1 + WW / 2;
         u64 w[U][4];
         u64 tag[U];
-        ulonglong2 c[U];
+        ulonglong2 c[U][CS];
 #pragma unroll
         for (u32 u = 0; u < U; ++u)
         {
@@ -158,18 +160,10 @@ __global__ __launch_bounds__(KD_T) void k_kd_lookup(KdTable t, KdCols kc, u64 ro
         for (u32 u = 0; u < U; ++u)
         {
             tag[u] = kd_tag(w[u], WW, weak);
-            c[u] = t.cells[((tag[u] >> 1) * 0x9E3779B97F4A7C15ull >> 20) & mask];
-        }
-        u64 sv[U][WW];
-        bool hit[U];
+            const ulonglong2 * cp = t.cells + (((tag[u] >> 1) * 0x9E3779B97F4A7C15ull >> 20) & mask) * CS;
 #pragma unroll
-        for (u32 u = 0; u < U; ++u)
-        {
-            hit[u] = c[u].x == tag[u] && c[u].y - 1 < t.ids_before;
-            const u64 id = hit[u] ? c[u].y - 1 : 0;
-#pragma unroll
-            for (u32 q = 0; q < WW; ++q)
-                sv[u][q] = t.store[id * WW + q];
+            for (u32 q = 0; q < CS; ++q)
+                c[u][q] = cp[q];
         }
 #pragma unroll
         for (u32 u = 0; u < U; ++u)
@@ -177,16 +171,16 @@ __global__ __launch_bounds__(KD_T) void k_kd_lookup(KdTable t, KdCols kc, u64 ro
             const u64 i = i0 + u * stride;
             if (i >= n)
                 continue;
-            bool same = hit[u];
+            bool same = c[u][0].x == tag[u] && c[u][0].y - 1 < t.ids_before;
 #pragma unroll
-            for (u32 q = 0; q < WW; ++q)
-                same = same && sv[u][q] == w[u][q];
+            for (u32 q = 1; q < CS; ++q)
+                same = same && c[u][q].x == w[u][2 * q - 2] && c[u][q].y == w[u][2 * q - 1];
             if (same)
             {
-                rid[i] = (u32)(c[u].y - 1);
+                rid[i] = (u32)(c[u][0].y - 1);
                 cand[i] = KD_SETTLED;
             }
-            else if (!mode && c[u].x == 0)
+            else if (!mode && c[u][0].x == 0)
             {
                 rid[i] = KD_NO_ID; // findKey: the home cell is empty
                 cand[i] = KD_SETTLED;
@@ -236,29 +230,49 @@ __global__ __launch_bounds__(KD_T) void k_kd_claim(KdTable t, KdCols kc, u64 row
         for (u64 step = 0; step <= t.capacity && __any(active); ++step)
         {
             bool claimed = false;
-            // linear probing, looked at one 64-byte line (4 cells) at a time: the first cell at or after `slot` that is empty or holds the
-            // row's tag is where the cell-by-cell walk would stop; a line without one is skipped whole.  (A stale line can only show an
-            // empty cell where a tag has landed since -- the compare-and-swap below then returns the tag.)
+            // linear probing; keys128 looks at a 64-byte line (its two cells) at a time: the first cell at or after `slot` that is empty or
+            // holds the row's tag is where the cell-by-cell walk would stop.  (A stale line can only show an empty cell where a tag has
+            // landed since -- the compare-and-swap below then returns the tag.)  The cell carries the key: a hit is ONE random read.
             bool at_cell = false;
             u64 cur = 0, idp1 = 0;
-            if (active)
+            u64 kw[4] = {0, 0, 0, 0}; // the key stored in the cell looked at
+            if (active && t.W == 2)
             {
-                const u64 line = slot & ~3ull;
-                const ulonglong2 * lp = t.cells + line;
-                const ulonglong2 c0 = lp[0], c1 = lp[1], c2 = lp[2], c3 = lp[3];
-                const u32 same = (u32)(c0.x == tag) | (u32)(c1.x == tag) << 1 | (u32)(c2.x == tag) << 2 | (u32)(c3.x == tag) << 3;
-                const u32 empty = (u32)(c0.x == 0) | (u32)(c1.x == 0) << 1 | (u32)(c2.x == 0) << 2 | (u32)(c3.x == 0) << 3;
-                const u32 ev = (same | empty) & (0xFu << (slot & 3));
+                const u64 line = slot & ~1ull;
+                const ulonglong2 * lp = t.cells + line * 2;
+                const ulonglong2 a0 = lp[0], a1 = lp[1], b0 = lp[2], b1 = lp[3];
+                const u32 same = (u32)(a0.x == tag) | (u32)(b0.x == tag) << 1;
+                const u32 empty = (u32)(a0.x == 0) | (u32)(b0.x == 0) << 1;
+                const u32 ev = (same | empty) & (3u << (slot & 1));
                 if (ev)
                 {
                     const u32 k = (u32)__ffs((int)ev) - 1;
                     slot = line + k;
                     cur = (same >> k) & 1 ? tag : 0;
-                    idp1 = k == 0 ? c0.y : k == 1 ? c1.y : k == 2 ? c2.y : c3.y;
+                    idp1 = k ? b0.y : a0.y;
+                    kw[0] = k ? b1.x : a1.x;
+                    kw[1] = k ? b1.y : a1.y;
                     at_cell = true;
                 }
                 else
-                    slot = (line + 4) & mask;
+                    slot = (line + 2) & mask;
+            }
+            else if (active)
+            {
+                const ulonglong2 * lp = t.cells + slot * 3;
+                const ulonglong2 a0 = lp[0], a1 = lp[1], a2 = lp[2];
+                if (a0.x == tag || a0.x == 0)
+                {
+                    cur = a0.x;
+                    idp1 = a0.y;
+                    kw[0] = a1.x;
+                    kw[1] = a1.y;
+                    kw[2] = a2.x;
+                    kw[3] = a2.y;
+                    at_cell = true;
+                }
+                else
+                    slot = (slot + 1) & mask;
             }
             if (at_cell)
             {
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(KD_T) void k_kd_claim(KdTable t, KdCols kc, u64 row
                     }
                     else
                     {
-                        cur = atomicCAS((unsigned long long *)&t.cells[slot].x, 0ull, (unsigned long long)tag);
+                        cur = atomicCAS((unsigned long long *)&t.cells[slot * t.cs].x, 0ull, (unsigned long long)tag);
                         claimed = cur == 0;
                         idp1 = 0; // if the cell was taken meanwhile its id is not known here
                     }
@@ -291,9 +305,7 @@ __global__ __launch_bounds__(KD_T) void k_kd_claim(KdTable t, KdCols kc, u64 row
                         const u64 id = idp1 - 1; // 2^64 - 1 while the id is not visible
                         if (id < t.ids_before)
                         {
-                            bool same = true;
-                            for (u32 q = 0; q < t.W; ++q)
-                                same = same && t.store[id * t.W + q] == w[q];
+                            const bool same = kw[0] == w[0] && kw[1] == w[1] && kw[2] == w[2] && kw[3] == w[3]; // (words past W are 0 on both sides)
                             if (same)
                             {
                                 rid[i] = (u32)id;
@@ -326,7 +338,11 @@ __global__ __launch_bounds__(KD_T) void k_kd_claim(KdTable t, KdCols kc, u64 row
                 if (claimed)
                 {
                     const u32 id = base + mbcnt(claimers);
-                    t.cells[slot].y = (u64)id + 1;
+                    ulonglong2 * cp = t.cells + slot * t.cs;
+                    cp[0].y = (u64)id + 1;
+                    cp[1] = make_ulonglong2(w[0], w[1]);
+                    if (t.W == 4)
+                        cp[2] = make_ulonglong2(w[2], w[3]);
                     if (id < t.store_cap)
                         for (u32 q = 0; q < t.W; ++q)
                             t.store[(u64)id * t.W + q] = w[q];
@@ -362,12 +378,17 @@ __global__ __launch_bounds__(KD_T) void k_kd_verify(KdTable t, KdCols kc, u64 ro
         const u64 slot = cand[i];
         if (slot == KD_SETTLED || slot == KD_DEFERRED)
             continue;
-        const u64 id = t.cells[slot].y - 1;
+        const ulonglong2 * cp = t.cells + slot * t.cs;
+        const u64 id = cp[0].y - 1;
         u64 w[4];
         kd_pack_row(kc, row_begin + i, w);
-        bool same = true;
-        for (u32 q = 0; q < t.W; ++q)
-            same = same && t.store[id * t.W + q] == w[q];
+        const ulonglong2 k01 = cp[1];
+        bool same = k01.x == w[0] && k01.y == w[1];
+        if (t.W == 4)
+        {
+            const ulonglong2 k23 = cp[2];
+            same = same && k23.x == w[2] && k23.y == w[3];
+        }
         if (same)
         {
             rid[i] = (u32)id;
@@ -389,15 +410,19 @@ __global__ __launch_bounds__(KD_T) void k_kd_rehash(const ulonglong2 * __restric
     const u64 mask = t.capacity - 1;
     for (u64 s = (u64)blockIdx.x * KD_T + threadIdx.x; s < old_cap; s += (u64)gridDim.x * KD_T)
     {
-        const ulonglong2 c = old_cells[s];
+        const ulonglong2 * oc = old_cells + s * t.cs;
+        const ulonglong2 c = oc[0];
         if (c.x == 0)
             continue;
         u64 slot = ((c.x >> 1) * 0x9E3779B97F4A7C15ull >> 20) & mask;
         for (u64 step = 0; step <= t.capacity; ++step)
         {
-            if (t.cells[slot].x == 0 && atomicCAS((unsigned long long *)&t.cells[slot].x, 0ull, (unsigned long long)c.x) == 0)
+            ulonglong2 * nc = t.cells + slot * t.cs;
+            if (nc[0].x == 0 && atomicCAS((unsigned long long *)&nc[0].x, 0ull, (unsigned long long)c.x) == 0)
             {
-                t.cells[slot].y = c.y;
+                nc[0].y = c.y;
+                for (u32 q = 1; q < t.cs; ++q)
+                    nc[q] = oc[q];
                 break;
             }
             slot = (slot + 1) & mask;
@@ -456,11 +481,12 @@ __global__ __launch_bounds__(KD_T) void k_kd_selector(KdTable t, const u32 * __r
 // ---------------------------------------------------------------------------------------------
 static int kd_alloc_table(chgpu_keydict * d, u64 cap, KdTable * t, void ** mem, size_t * cls)
 {
-    CHGPU_TRY(chgpu_pool_alloc(d->ctx, cap * 16 + 256, mem, cls));
+    t->cs = 1 + d->W / 2;
+    CHGPU_TRY(chgpu_pool_alloc(d->ctx, cap * 16 * t->cs + 256, mem, cls));
     t->cells = (ulonglong2 *)*mem;
     t->capacity = cap;
     t->limit = cap / 2;
-    CHGPU_HIP(hipMemsetAsync(t->cells, 0, cap * 16, d->ctx->stream));
+    CHGPU_HIP(hipMemsetAsync(t->cells, 0, cap * 16 * t->cs, d->ctx->stream));
     return CHGPU_OK;
 }
 
